@@ -1,0 +1,201 @@
+"""Pins the CPU oracle's linear algebra against the reference's own fixtures and identities.
+
+Mirrors /root/reference/test/inverse_hessian.jl:8-44 (literal S0/Y0 fixture + explicit dense Byrd
+formula, four history layouts) and /root/reference/test/woodbury.jl:18-404 (every factor operation
+against dense algebra, including n < m), plus an independent LAPACK check of the Householder
+convention through SciPy (dgeqrf, the convention Julia's `qr` uses).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.linalg as sla
+
+from oracle import pf_oracle as po
+
+
+def explicit_byrd(alpha, S, Y):
+    """lbfgs_inverse_hessian_explicit, test/inverse_hessian.jl:8-14"""
+    H0 = np.diag(alpha)
+    B = np.hstack([H0 @ Y, S])
+    R = np.triu(S.T @ Y)
+    E = np.diag(np.diag(R))
+    Rinv = np.linalg.inv(R)
+    j = S.shape[1]
+    D = np.block([[np.zeros((j, j)), -Rinv], [-Rinv.T, Rinv.T @ (E + Y.T @ H0 @ Y) @ Rinv]])
+    return H0 + B @ D @ B.T
+
+
+@pytest.fixture(scope="module")
+def s0y0(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "lbfgs_S0Y0.json")))
+    S = np.array(g["S0_columns"]).T.copy()
+    Y = np.array(g["Y0_columns"]).T.copy()
+    return S, Y
+
+
+def test_byrd_compact_matches_explicit_on_reference_fixture(s0y0):
+    S, Y = s0y0
+    n, J = S.shape
+    rng = np.random.default_rng(0)
+    alpha = rng.uniform(0.1, 1.0, n)
+    # empty history (test/inverse_hessian.jl:28)
+    B, D = po.lbfgs_inverse_hessian(alpha, S[:, :0], Y[:, :0])
+    assert B.shape == (n, 0) and D.shape == (0, 0)
+    # partial history (:30-32)
+    B, D = po.lbfgs_inverse_hessian(alpha, S[:, :3], Y[:, :3])
+    H = np.diag(alpha) + B @ D @ B.T
+    np.testing.assert_allclose(H, explicit_byrd(alpha, S[:, :3], Y[:, :3]), rtol=1e-12, atol=1e-13)
+    # full history (:41-43)
+    B, D = po.lbfgs_inverse_hessian(alpha, S, Y)
+    np.testing.assert_allclose(np.diag(alpha) + B @ D @ B.T, explicit_byrd(alpha, S, Y), rtol=1e-11, atol=1e-12)
+    assert B.shape == (n, 2 * J)
+    np.testing.assert_allclose(B[:, :J], alpha[:, None] * Y)
+    np.testing.assert_allclose(B[:, J:], S)
+    np.testing.assert_allclose(D[:J, :J], 0)
+    np.testing.assert_allclose(D, D.T, atol=1e-9 * np.abs(D).max())
+
+
+def test_ring_rotated_history_is_reordered_oldest_first(s0y0):
+    """test/inverse_hessian.jl:34-39: a rotated ring buffer gives the same H.  We drive the
+    trace walk (src/inverse_hessian.jl:43-63) so that the ring wraps and check hist_src."""
+    S, Y = s0y0
+    n, nh = S.shape
+    # build a synthetic trace whose steps are exactly S0 columns / Y0 columns
+    theta = np.zeros((nh + 1, n))
+    grad = np.zeros((nh + 1, n))
+    for l in range(nh):
+        theta[l + 1] = theta[l] + S[:, l]
+        grad[l + 1] = grad[l] - Y[:, l]
+    J = 3
+    alpha_all, hist_len, hist_src, rej = po.lbfgs_history(theta, grad, J)
+    assert rej == 0
+    assert list(hist_len) == [0, 1, 2, 3, 3, 3]
+    assert list(hist_src[3, :3]) == [0, 1, 2]
+    assert list(hist_src[4, :3]) == [1, 2, 3]      # ring wrapped: oldest first
+    assert list(hist_src[5, :3]) == [2, 3, 4]
+    # alpha recurrence = repeated gilbert_init (src/inverse_hessian.jl:55)
+    a = np.ones(n)
+    for l in range(nh):
+        a = po.gilbert_init(a, S[:, l], Y[:, l])
+        np.testing.assert_allclose(alpha_all[l + 1], a, rtol=1e-14)
+    # H at the last point equals the explicit formula on the last J pairs
+    B, D = po.lbfgs_inverse_hessian(alpha_all[5], S[:, 2:5], Y[:, 2:5])
+    np.testing.assert_allclose(np.diag(alpha_all[5]) + B @ D @ B.T,
+                               explicit_byrd(alpha_all[5], S[:, 2:5], Y[:, 2:5]), rtol=1e-10, atol=1e-12)
+
+
+def test_curvature_rejection_counts_and_keeps_state():
+    """src/inverse_hessian.jl:47-58: y.s <= eps |y|^2 -> rejected, history/alpha unchanged."""
+    rng = np.random.default_rng(3)
+    n = 6
+    theta = rng.normal(size=(4, n))
+    grad = -theta.copy()            # iso normal: y = s  -> accepted
+    grad[2] = grad[1] + (theta[2] - theta[1])   # y = -s on step 2 -> rejected
+    alpha_all, hist_len, hist_src, rej = po.lbfgs_history(theta, grad, 5)
+    assert rej >= 1
+    assert hist_len[2] == hist_len[1]
+    np.testing.assert_array_equal(alpha_all[2], alpha_all[1])
+
+
+def test_gilbert_init_formula():
+    rng = np.random.default_rng(1)
+    a, s, y = rng.uniform(0.5, 2, 7), rng.normal(size=7), rng.normal(size=7)
+    aa = np.sum(y * a * y); b = y @ s; c = np.sum(s * s / a)
+    exp = b / (aa / a + y**2 - (aa / c) * (s / a) ** 2)
+    np.testing.assert_allclose(po.gilbert_init(a, s, y), exp, rtol=1e-14)
+
+
+@pytest.mark.parametrize("n,m", [(10, 8), (5, 8), (8, 8), (30, 12), (3, 12)])
+def test_householder_matches_lapack_dgeqrf(n, m):
+    rng = np.random.default_rng(n * 100 + m)
+    A = rng.normal(size=(n, m))
+    QR, tau = po.householder_qr(A)
+    (qr_raw, tau_l), _ = sla.qr(A, mode="raw")
+    np.testing.assert_allclose(QR, qr_raw, rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(tau, tau_l, rtol=1e-12, atol=1e-14)
+
+
+def rand_pd(rng, n):
+    Q, _ = np.linalg.qr(rng.normal(size=(n, n)))
+    return (Q * rng.uniform(0.05, 1.0, n)) @ Q.T
+
+
+@pytest.mark.parametrize("n", [5, 10])
+def test_woodbury_factor_identities(n):
+    """test/woodbury.jl:18-115,217-273,311-402 with m = 8 (n = 5 covers n < m, k = min(n, m))."""
+    m = 8
+    rng = np.random.default_rng(n)
+    alpha = rng.uniform(0.1, 1.0, n)
+    B = rng.normal(size=(n, m))
+    D = rand_pd(rng, m)
+    F = po.Factor(alpha, B, D)
+    assert F.status == 0 and F.k == min(n, m)
+    W = np.diag(alpha) + B @ D @ B.T
+    I = np.eye(n)
+    Rm = F.lmul_R(I)                      # Matrix(R) = lmul!(R, I)  (src/woodbury.jl:104-106)
+    Lm = F.lmul_L(I)
+    np.testing.assert_allclose(Lm, Rm.T, rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(Rm.T @ Rm, W, rtol=1e-11, atol=1e-12)          # W = R'R
+    np.testing.assert_allclose(F.ldiv_R(Rm), I, atol=1e-11)                   # R \ R
+    np.testing.assert_allclose(F.ldiv_L(Lm), I, atol=1e-11)
+    X = rng.normal(size=(n, 7))
+    np.testing.assert_allclose(F.lmul_R(X), Rm @ X, rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(F.lmul_L(X), Lm @ X, rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(F.ldiv_R(X), np.linalg.solve(Rm, X), rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(F.ldiv_L(X), np.linalg.solve(Lm, X), rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(F.mul_W(X), W @ X, rtol=1e-11, atol=1e-12)     # mul!(y, W, x)
+    x = rng.normal(size=n)
+    np.testing.assert_allclose(F.mul_W(x), W @ x, rtol=1e-11, atol=1e-12)
+    sign, ld = np.linalg.slogdet(W)
+    assert sign > 0
+    assert abs(F.logdet - ld) < 1e-10                                          # logdet :217-222
+    # invquad / quad (:367-402)
+    np.testing.assert_allclose(np.sum(F.ldiv_L(X) ** 2, axis=0), np.einsum("ij,ij->j", X, np.linalg.solve(W, X)),
+                               rtol=1e-9)
+    np.testing.assert_allclose(np.sum(F.lmul_R(X) ** 2, axis=0), np.einsum("ij,ij->j", X, W @ X), rtol=1e-10)
+
+
+def test_factor_matches_scipy_pipeline():
+    """pdfactorize (src/woodbury.jl:201-207) step by step through SciPy/LAPACK."""
+    rng = np.random.default_rng(11)
+    n, m = 12, 6
+    alpha = rng.uniform(0.2, 2.0, n)
+    B = rng.normal(size=(n, m))
+    D = rand_pd(rng, m)
+    F = po.Factor(alpha, B, D)
+    U = np.sqrt(alpha)
+    (qr_raw, tau), R = sla.qr(B / U[:, None], mode="raw")
+    np.testing.assert_allclose(F.QR, qr_raw, rtol=1e-12, atol=1e-13)
+    Cm = np.eye(m) + np.triu(qr_raw[:m]) @ D @ np.triu(qr_raw[:m]).T
+    V = sla.cholesky(Cm, lower=False)
+    np.testing.assert_allclose(F.V, V, rtol=1e-11, atol=1e-12)
+    # lmul!(Q, x) through dormqr
+    x = rng.normal(size=(n, 3))
+    Qx, = sla.lapack.dormqr("L", "N", qr_raw, tau, np.asfortranarray(x), 3 * n)[:1]
+    z = x.copy(order="F")
+    po.lib().pfo_apply_q(n, m, po._p(F.QR), po._p(F.tau), 0, po._p(z), 3)
+    np.testing.assert_allclose(z, Qx, rtol=1e-12, atol=1e-13)
+
+
+def test_not_pd_status():
+    n, m = 6, 2
+    alpha = np.ones(n); alpha[2] = -1.0
+    F = po.Factor(alpha, np.zeros((n, m)), np.zeros((m, m)))
+    assert F.status == 1                                  # A not PD  (src/woodbury.jl:202)
+    B = np.zeros((n, m)); B[0, 0] = 1.0; B[1, 1] = 1.0
+    D = -5.0 * np.eye(m)
+    F = po.Factor(np.ones(n), B, D)
+    assert F.status == 2                                  # C = I + R D R' not PD (:205)
+
+
+def test_fit_mean_is_theta_plus_sigma_grad():
+    """test/mvnormal.jl:28: mu = theta + Sigma * grad."""
+    rng = np.random.default_rng(5)
+    n, m = 9, 4
+    alpha = rng.uniform(0.2, 2.0, n)
+    B = rng.normal(size=(n, m)); D = rand_pd(rng, m)
+    F = po.Factor(alpha, B, D)
+    th, g = rng.normal(size=n), rng.normal(size=n)
+    np.testing.assert_allclose(F.fit_mean(th, g), th + F.dense() @ g, rtol=1e-11, atol=1e-12)
