@@ -1,0 +1,181 @@
+/*
+ * pfmi.h -- C ABI of libpfmi.so: the MI355X-native (gfx950, HIP) engine for the ELBO / sampling /
+ * inverse-Hessian / PSIS-resampling hot path of Pathfinder.
+ *
+ * The reference (mlcolab/Pathfinder.jl v0.10.7) has no FFI boundary; the seam this library fills is
+ * the four Julia call sites of the hot path:
+ *     fit_mvnormals(points, gradients; history_length)            src/singlepath.jl:301-303
+ *     maximize_elbo(rng, logp, fit_distributions[2:end], N, ntasks) src/singlepath.jl:306-308
+ *     _compute_psis_result(logp, fit_distributions, draws)        src/multipath.jl:221, src/resample.jl:35
+ *     _resample(rng, draws_per_component, psis_result, ndraws)    src/multipath.jl:225, src/resample.jl:42-44
+ * Each entry point below cites the reference function it replaces.  INTEGRATION.md shows the
+ * Julia `ccall` stubs a maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in any signature; every pointer is a HOST pointer unless the
+ *     function name ends in `_dev` (then it is a device pointer on the ctx's GPU);
+ *   - all matrices are column-major Float64 (Julia's layout); trace points are stored point-major:
+ *     theta[p*d + i] is coordinate i of point p (== hcat(points...) in Julia memory);
+ *   - indices are 0-based here (the Julia wrapper adds 1);
+ *   - the caller owns every host buffer; the library owns device memory inside the ctx and keeps
+ *     no host pointer after a call returns; callbacks run on the calling thread during the call;
+ *   - return value 0 = ok, < 0 = error (message: pfmi_last_error()); per-fit numerical failures
+ *     (src/woodbury.jl:202,205 PosDefException) are reported in status[] and as NaN ELBOs, never
+ *     as a process abort;
+ *   - one ctx per host thread; a ctx owns one HIP stream on one GPU.
+ */
+#ifndef PFMI_H
+#define PFMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pfmi_ctx pfmi_ctx;
+
+/* return codes */
+#define PFMI_OK 0
+#define PFMI_ERR_ARG (-1)
+#define PFMI_ERR_HIP (-2)
+#define PFMI_ERR_STATE (-3)
+#define PFMI_ERR_UNSUPPORTED (-4)
+#define PFMI_ERR_NUMERIC (-5)
+
+/* per-fit status (src/woodbury.jl:189-190, 202, 205) */
+#define PFMI_FIT_OK 0
+#define PFMI_FIT_A_NOT_PD 1
+#define PFMI_FIT_C_NOT_PD 2
+#define PFMI_FIT_NONFINITE 3
+
+/* target kinds: the hot path only ever sees logp(x) = -f(x) (src/singlepath.jl:186, src/multipath.jl:159) */
+#define PFMI_TARGET_GAUSS 0          /* offset - 1/2 [ sum a_i e_i^2 - || G Wd' e ||^2 ], e = x - mean  */
+#define PFMI_TARGET_FUNNEL 1         /* docs/src/examples/quickstart.md:229-234                         */
+#define PFMI_TARGET_HOST_CALLBACK 2  /* arbitrary host closure, evaluated on a host copy of the draws    */
+
+/* host callback: X is d x n column-major, out[n] receives logp of every column (src/elbo.jl:15) */
+typedef void (*pfmi_logp_fn)(const double *X, int32_t d, int64_t n, double *out, void *user);
+
+typedef struct {
+    int32_t kind;        /* PFMI_TARGET_*                                      */
+    int32_t d;           /* dimension                                          */
+    int32_t r;           /* GAUSS: rank of the low-rank part (0 = diagonal)    */
+    int32_t reserved;
+    const double *mean;  /* GAUSS: d                                           */
+    const double *a;     /* GAUSS: d, diagonal precision part                  */
+    const double *Wd;    /* GAUSS: d x r column-major (NULL if r == 0)         */
+    const double *G;     /* GAUSS: r x r column-major, lower triangular        */
+    double offset;       /* GAUSS: additive constant                           */
+    pfmi_logp_fn fn;     /* HOST_CALLBACK                                      */
+    void *user;          /* HOST_CALLBACK                                      */
+} pfmi_target;
+
+/* ---- library / context ----------------------------------------------------------------------- */
+const char *pfmi_last_error(void);
+int32_t pfmi_version(void);
+int32_t pfmi_device_count(int32_t *count);
+int32_t pfmi_create(int32_t device, pfmi_ctx **out);
+int32_t pfmi_destroy(pfmi_ctx *ctx);
+int32_t pfmi_sync(pfmi_ctx *ctx);
+
+/* device-time instrumentation (hipEvents on the ctx stream).  pfmi_timer_* bracket any sequence of
+ * calls; pfmi_kernel_time returns accumulated time and launch count of one named kernel family
+ * ("history", "fit", "elbo_draws", "elbo_reduce", "psis", "resample") since pfmi_profile(ctx, 1). */
+int32_t pfmi_timer_start(pfmi_ctx *ctx);
+int32_t pfmi_timer_stop(pfmi_ctx *ctx, double *milliseconds);
+int32_t pfmi_profile(pfmi_ctx *ctx, int32_t enable);
+int32_t pfmi_kernel_time(pfmi_ctx *ctx, const char *name, double *milliseconds, int64_t *launches);
+
+/* ---- inputs ------------------------------------------------------------------------------------ */
+/* The target log density (what `logp` is in src/elbo.jl:12-20 and src/resample.jl:81-95). */
+int32_t pfmi_set_target(pfmi_ctx *ctx, const pfmi_target *target);
+
+/* K optimisation traces (OptimizationTrace.points / .gradients, src/optimize.jl:110-114), path k
+ * has npoints[k] = L_k + 1 points; theta/grad hold all P = sum npoints points, point-major. */
+int32_t pfmi_set_traces(pfmi_ctx *ctx, int32_t K, const int64_t *npoints, int32_t d,
+                        const double *theta, const double *grad);
+
+/* ---- fit_mvnormals / lbfgs_inverse_hessians / pdfactorize --------------------------------------- */
+/* replaces fit_mvnormals (src/mvnormal.jl:14-21) = lbfgs_inverse_hessians (src/inverse_hessian.jl:25-66)
+ * + lbfgs_inverse_hessian (:98-133) + WoodburyPDMat/pdfactorize (src/woodbury.jl:259-263, 201-207)
+ * + mu = theta + Sigma*grad, for every point of every trace, batched on the GPU. */
+int32_t pfmi_fit_batch(pfmi_ctx *ctx, int32_t history_length, double eps);
+
+/* status[P], j_eff[P] (effective history length), logdet[P], n_rejected[K]; any may be NULL */
+int32_t pfmi_get_fit_status(pfmi_ctx *ctx, int32_t *status, int32_t *j_eff, double *logdet,
+                            int64_t *n_rejected);
+
+/* Materialise one fitted MvNormal{WoodburyPDMat} (so the host can build Sigma.A/.B/.D/.F.{U,Q,V}):
+ * alpha[d]; B[d*2j]; D[2j*2j]; qr_factors[d*2j] + T[k*k] = QRCompactWY of U' \ B (Householder
+ * vectors below the diagonal, R above; T upper triangular); V[k*k] upper Cholesky; mu[d]; k = min(d,2j).
+ * Any output may be NULL. */
+int32_t pfmi_get_fit(pfmi_ctx *ctx, int64_t point, double *alpha, double *B, double *D,
+                     double *qr_factors, double *T, double *V, double *mu, double *logdet);
+
+/* ---- maximize_elbo / elbo_and_samples / rand_and_logpdf ------------------------------------------ */
+/* replaces maximize_elbo (src/elbo.jl:1-10) over fit_distributions[2:end] of every path:
+ * for each point p that is not the first of its path: N draws x = mu + L u (src/mvnormal.jl:24-39),
+ * logq, logp, ELBO mean and standard error (src/elbo.jl:12-20); then the NaN-skipping first-max
+ * argmax per path (src/utils.jl:55-72).
+ * seeds[P]: per-fit UInt64 seed (src/elbo.jl:2), keys the counter-based generator;
+ * u_host: NULL (production: normals generated in-kernel) or P*d*N doubles, block p = the d x N
+ *         standard normals of fit p (parity mode; blocks of first points are ignored);
+ * elbo[P], se[P] (NaN for first points / failed fits), best_iter[K] (1-based iteration index
+ * like the reference's fit_iteration; 0 when the path has no iterations). */
+int32_t pfmi_elbo_batch(pfmi_ctx *ctx, int64_t N, const uint64_t *seeds, const double *u_host,
+                        double *elbo, double *se, int64_t *best_iter);
+
+/* per-draw log densities of one fit from the last pfmi_elbo_batch: logp[N], logq[N] */
+int32_t pfmi_get_elbo_logs(pfmi_ctx *ctx, int64_t point, double *logp, double *logq);
+
+/* draws n0 .. n0+N-1 of fit `point` (ELBOEstimate.draws, src/elbo.jl:19; also rand(rng, dist, n),
+ * src/singlepath.jl:226-233): X[d*N], logp[N], logq[N]; u_host NULL or d*N normals. */
+int32_t pfmi_draws(pfmi_ctx *ctx, int64_t point, uint64_t seed, int64_t n0, int64_t N,
+                   const double *u_host, double *X, double *logp, double *logq);
+
+/* Distributions.logpdf(MvNormal(mu_p, Sigma_p), X) for arbitrary X[d*N] through the factor
+ * (src/resample.jl:85-89 -> src/woodbury.jl:378-382,158-165) */
+int32_t pfmi_logpdf(pfmi_ctx *ctx, int64_t point, int64_t N, const double *X, double *out);
+
+/* ---- pooling, _compute_psis_result, _resample ---------------------------------------------------- */
+/* draws_per_component = stack(draws) (src/multipath.jl:217): for path k take N_r draws of fit
+ * `points[k]` with seed seeds[k] into the device-resident pool (d, N_r, K) and
+ * log_ratios[k*N_r + n] = logp - logq (src/resample.jl:81-95; n fastest, k slowest). */
+int32_t pfmi_pool_build(pfmi_ctx *ctx, int64_t N_r, const int64_t *points, const uint64_t *seeds);
+int32_t pfmi_pool_get(pfmi_ctx *ctx, double *draws, double *log_ratios);
+/* device pointer to the local log-ratio shard (K_local * N_r doubles) for the RCCL all-gather */
+int32_t pfmi_pool_log_ratios_dev(pfmi_ctx *ctx, void **dev_ptr, int64_t *count);
+
+/* PSIS.psis(log_ratios) (src/resample.jl:78): log_ratios_dev is a DEVICE buffer of S doubles (the
+ * all-gathered pool), weights are kept device-resident; host outputs may be NULL. */
+int32_t pfmi_psis_dev(pfmi_ctx *ctx, const void *log_ratios_dev, int64_t S, double *weights,
+                      double *log_weights, double *pareto_k, int64_t *tail_len);
+int32_t pfmi_psis(pfmi_ctx *ctx, const double *log_ratios, int64_t S, double *weights,
+                  double *log_weights, double *pareto_k, int64_t *tail_len);
+
+/* _resample index selection (src/resample.jl:58-66): ndraws indices into 0..S-1.
+ * importance != 0: weighted by the ctx's current PSIS weights; == 0: uniform (psis_result === nothing).
+ * replace: with / without replacement.  uniforms: NULL (Philox(seed)) or ndraws doubles in [0,1). */
+int32_t pfmi_resample_indices(pfmi_ctx *ctx, int64_t S, int64_t ndraws, int32_t importance,
+                              int32_t replace, uint64_t seed, const double *uniforms, int64_t *idx);
+
+/* draws = draws_all[:, inds] for the columns of idx owned by this ctx's pool: global pool column
+ * g = k_global*N_r + n is owned iff col_offset <= g < col_offset + K_local*N_r; columns not owned are
+ * written as zeros (multi-GPU: sum the per-rank results).  draws[d*ndraws]. */
+int32_t pfmi_pool_gather(pfmi_ctx *ctx, int64_t ndraws, const int64_t *idx, int64_t col_offset,
+                         double *draws);
+/* same, into a device buffer (for the xGMI all-reduce) */
+int32_t pfmi_pool_gather_dev(pfmi_ctx *ctx, int64_t ndraws, const int64_t *idx, int64_t col_offset,
+                             void *draws_dev);
+
+/* ---- device utilities for hosts that keep buffers on the GPU (bench, multi-GPU) ---------------- */
+int32_t pfmi_malloc_dev(pfmi_ctx *ctx, int64_t bytes, void **dev_ptr);
+int32_t pfmi_free_dev(pfmi_ctx *ctx, void *dev_ptr);
+int32_t pfmi_memcpy_h2d(pfmi_ctx *ctx, void *dev_dst, const void *host_src, int64_t bytes);
+int32_t pfmi_memcpy_d2h(pfmi_ctx *ctx, void *host_dst, const void *dev_src, int64_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFMI_H */

@@ -1,0 +1,427 @@
+// elbo_kernels.hip -- Monte Carlo ELBO over batches of fitted MvNormals (gfx950).
+//
+//   pf_elbo_draws_kernel : the dominant kernel.  rand_and_logpdf (reference src/mvnormal.jl:24-39)
+//       fused with the target evaluation of elbo_and_samples (src/elbo.jl:12-16):
+//         u ~ N(0, I) (counter-based Philox, or read from HBM in parity mode), |u|^2,
+//         x = mu + U' Q [V'u_1; u_2]   (unwhiten!, src/woodbury.jl:401-406,136-143), logq, logp(x).
+//       Mapping: one LANE per draw, rows of the d-vector walked sequentially.  Every coefficient of a
+//       row (Householder row, sqrt(alpha_i), mu_i, target row) is wave-uniform -> scalar loads, the
+//       per-draw state (Q'z accumulators, target accumulators) lives in VGPRs, and there is no
+//       cross-lane reduction at all.  Q is applied in compact-WY form Q z = z - Vh (T (Vh' z)): pass 1
+//       accumulates w = Vh' z, pass 2 regenerates z from the counter-based generator (nothing is
+//       spilled to HBM) and emits x row by row.  Draws are written only when asked for (the winning
+//       fit of a path); the ELBO scan over all iterations keeps them in registers.
+//   pf_elbo_reduce_kernel : mean and corrected standard error of logp - logq per fit
+//       (src/elbo.jl:16-18), fixed reduction tree.
+//   pf_elbo_argmax_kernel : _findmax_skipnan per path (src/utils.jl:55-72).
+//   pf_logpdf_kernel      : Distributions.logpdf of arbitrary points through the factor
+//       (src/resample.jl:85-89 -> invquad, src/woodbury.jl:378-382,158-165).
+#include "pfmi_common.h"
+
+#define ELBO_THREADS 256
+
+struct ElboArgs {
+    int d;
+    const int32_t *points;     // [nfits] trace point (= fit) per slot
+    const uint64_t *seeds;     // [nfits]
+    int64_t n0, N;             // draws n0 .. n0+N-1
+    const double *vh, *tmat, *vchol, *sqrt_alpha, *mu, *logdet;
+    const int32_t *status;
+    const double *u;           // parity mode: slot s reads u + s*u_stride, d x N column-major
+    int64_t u_stride;
+    double *x;                 // optional: slot s writes x + s*x_stride, d x N column-major
+    int64_t x_stride;
+    double *logp, *logq;       // slot s writes + s*log_stride
+    int64_t log_stride;
+    int by_point;              // != 0: u / logp / logq blocks are indexed by the trace point, not the slot
+    // target
+    const double *t_mean, *t_a, *t_wd, *t_g;
+    double t_offset;
+};
+
+// TGT: 0 none (host callback evaluates later), 1 Gaussian family with RPAD low-rank columns, 2 funnel
+template <int TGT, int RPAD>
+struct TargetAcc {
+    double q = 0.0, tau = 0.0;
+    double tr[RPAD > 0 ? RPAD : 1];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int j = 0; j < (RPAD > 0 ? RPAD : 1); ++j) tr[j] = 0.0;
+    }
+    __device__ __forceinline__ void row(const ElboArgs &A, int i, double x) {
+        if (TGT == 1) {
+            const double e = x - A.t_mean[i];
+            q += A.t_a[i] * e * e;
+            if (RPAD > 0) {
+                const double *wr = A.t_wd + (size_t)i * RPAD;
+#pragma unroll
+                for (int j = 0; j < RPAD; ++j) tr[j] += wr[j] * e;
+            }
+        } else if (TGT == 2) {
+            if (i == 0) tau = x; else q += x * x;
+        }
+    }
+    __device__ __forceinline__ double finish(const ElboArgs &A) {
+        if (TGT == 1) {
+            double corr = 0.0;
+            if (RPAD > 0) {
+#pragma unroll
+                for (int j = 0; j < RPAD; ++j) {
+                    double g = 0.0;
+#pragma unroll
+                    for (int l = 0; l <= j; ++l) g += A.t_g[j * RPAD + l] * tr[l];
+                    corr += g * g;
+                }
+            }
+            return A.t_offset - 0.5 * (q - corr);
+        } else if (TGT == 2) {
+            const double t3 = tau / 3.0;
+            return (t3 * t3 + (double)(A.d - 1) * tau + q * exp(-tau)) / -2.0;
+        }
+        return NAN;
+    }
+};
+
+template <int KPAD, int TGT, int RPAD, bool MEM>
+__global__ __launch_bounds__(ELBO_THREADS) void pf_elbo_draws_kernel(ElboArgs A) {
+    const int slot = blockIdx.y;
+    const int p = A.points[slot];
+    const int64_t nl = (int64_t)blockIdx.x * ELBO_THREADS + threadIdx.x;
+    if (nl >= A.N) return;
+    const int d = A.d;
+    const size_t blk = A.by_point ? (size_t)p : (size_t)slot;
+    double *out_lp = A.logp + blk * A.log_stride + nl;
+    double *out_lq = A.logq + blk * A.log_stride + nl;
+    if (A.status[p] != PFMI_FIT_OK) { *out_lp = NAN; *out_lq = NAN; return; }
+
+    const double *__restrict__ Vh = A.vh + (size_t)p * d * KPAD;
+    const double *__restrict__ T = A.tmat + (size_t)p * KPAD * KPAD;
+    const double *__restrict__ Vc = A.vchol + (size_t)p * KPAD * KPAD;
+    const double *__restrict__ sqa = A.sqrt_alpha + (size_t)p * d;
+    const double *__restrict__ mu = A.mu + (size_t)p * d;
+    const uint64_t seed = A.seeds[slot];
+    const uint32_t n = (uint32_t)(A.n0 + nl);
+    const double *U = MEM ? (A.u + blk * A.u_stride + (size_t)nl * d) : nullptr;
+    double *X = A.x ? (A.x + (size_t)slot * A.x_stride + (size_t)nl * d) : nullptr;
+    const int ngroups = (d + 3) >> 2;
+
+    auto gen4 = [&](int g, double (&z)[4]) {
+        if (MEM) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) z[t] = (4 * g + t < d) ? U[4 * g + t] : 0.0;
+        } else {
+            pf_randn4(seed, (uint32_t)g, n, 0u, z);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) if (4 * g + t >= d) z[t] = 0.0;
+        }
+    };
+
+    // ---- head rows 0..KPAD-1: z_head = V' u_head (lmul!(V', x[1:k]), src/woodbury.jl:139; V is
+    //      identity-padded beyond k), kept in registers for pass 2
+    double zh[KPAD], w[KPAD];
+    double usq = 0.0;
+#pragma unroll
+    for (int g = 0; g < KPAD / 4; ++g) {
+        double z4[4];
+        if (g < ngroups) gen4(g, z4); else { z4[0] = z4[1] = z4[2] = z4[3] = 0.0; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { zh[4 * g + t] = z4[t]; usq += z4[t] * z4[t]; }   // src/mvnormal.jl:31
+    }
+#pragma unroll
+    for (int a = KPAD - 1; a >= 0; --a) {
+        double s = 0.0;
+#pragma unroll
+        for (int b = 0; b <= a; ++b) s += Vc[b * KPAD + a] * zh[b];
+        zh[a] = s;
+    }
+#pragma unroll
+    for (int j = 0; j < KPAD; ++j) w[j] = 0.0;
+#pragma unroll
+    for (int i = 0; i < KPAD; ++i) {
+        if (i < d) {
+            const double *row = Vh + (size_t)i * KPAD;
+#pragma unroll
+            for (int j = 0; j < KPAD; ++j) w[j] += row[j] * zh[i];
+        }
+    }
+    // ---- pass 1 over the remaining rows: |u|^2 and w = Vh' z
+    for (int g = KPAD / 4; g < ngroups; ++g) {
+        double z4[4];
+        gen4(g, z4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int i = 4 * g + t;
+            if (i < d) {
+                usq += z4[t] * z4[t];
+                const double *row = Vh + (size_t)i * KPAD;
+#pragma unroll
+                for (int j = 0; j < KPAD; ++j) w[j] += row[j] * z4[t];
+            }
+        }
+    }
+    // ---- tv = T w  (Q = I - Vh T Vh')
+    double tv[KPAD];
+#pragma unroll
+    for (int a = 0; a < KPAD; ++a) {
+        double s = 0.0;
+#pragma unroll
+        for (int b = a; b < KPAD; ++b) s += T[a * KPAD + b] * w[b];
+        tv[a] = s;
+    }
+    // ---- pass 2: x_i = mu_i + sqrt(alpha_i) (z_i - Vh[i,:] tv)   (lmul!(Q), lmul!(U'), .+= mu)
+    TargetAcc<TGT, RPAD> tg;
+    tg.init();
+#pragma unroll
+    for (int i = 0; i < KPAD; ++i) {
+        if (i < d) {
+            const double *row = Vh + (size_t)i * KPAD;
+            double v = zh[i];
+#pragma unroll
+            for (int j = 0; j < KPAD; ++j) v -= row[j] * tv[j];
+            const double xi = mu[i] + sqa[i] * v;
+            tg.row(A, i, xi);
+            if (X) X[i] = xi;
+        }
+    }
+    for (int g = KPAD / 4; g < ngroups; ++g) {
+        double z4[4];
+        gen4(g, z4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int i = 4 * g + t;
+            if (i < d) {
+                const double *row = Vh + (size_t)i * KPAD;
+                double v = z4[t];
+#pragma unroll
+                for (int j = 0; j < KPAD; ++j) v -= row[j] * tv[j];
+                const double xi = mu[i] + sqa[i] * v;
+                tg.row(A, i, xi);
+                if (X) X[i] = xi;
+            }
+        }
+    }
+    *out_lq = ((double)d * PF_LOG2PI + A.logdet[p] + usq) / -2.0;       // src/mvnormal.jl:36
+    *out_lp = tg.finish(A);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// mean(logr), sqrt(var(logr; corrected) / N)  per fit.  Grid = P points.   src/elbo.jl:16-18
+__global__ __launch_bounds__(256) void pf_elbo_reduce_kernel(int64_t N, const int64_t *__restrict__ off,
+                                                             const int32_t *__restrict__ path_of,
+                                                             const int32_t *__restrict__ status,
+                                                             const double *__restrict__ logp,
+                                                             const double *__restrict__ logq,
+                                                             double *__restrict__ elbo, double *__restrict__ se) {
+    const int p = blockIdx.x, tid = threadIdx.x;
+    __shared__ double red[8];
+    const bool first = ((int64_t)p == off[path_of[p]]);
+    if (first || status[p] != PFMI_FIT_OK || N <= 0) {
+        if (tid == 0) { elbo[p] = NAN; se[p] = NAN; }
+        return;
+    }
+    const double *lp = logp + (size_t)p * N, *lq = logq + (size_t)p * N;
+    double s = 0.0;
+    for (int64_t n = tid; n < N; n += 256) s += lp[n] - lq[n];
+    s = pf_block_sum1(s, red);
+    const double mean = s / (double)N;
+    double v = 0.0;
+    for (int64_t n = tid; n < N; n += 256) { const double r = (lp[n] - lq[n]) - mean; v += r * r; }
+    v = pf_block_sum1(v, red);
+    if (tid == 0) {
+        elbo[p] = mean;
+        se[p] = sqrt((v / (double)(N - 1)) / (double)N);
+    }
+}
+
+// _findmax_skipnan over the iterations 1..L of each path (first element seeds the state even if NaN,
+// later NaNs are skipped, strict > so the first maximum wins).  1-based result, 0 when L == 0.
+__global__ void pf_elbo_argmax_kernel(int K, const int64_t *__restrict__ off, const double *__restrict__ elbo,
+                                      int64_t *__restrict__ best_iter) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const int64_t p0 = off[k];
+    const int L = (int)(off[k + 1] - p0 - 1);
+    if (L <= 0) { best_iter[k] = 0; return; }
+    double xmax = elbo[p0 + 1];
+    int64_t imax = 1;
+    for (int l = 2; l <= L; ++l) {
+        const double xi = elbo[p0 + l];
+        if (isnan(xi)) continue;
+        if (isnan(xmax) || xi > xmax) { xmax = xi; imax = l; }
+    }
+    best_iter[k] = imax;
+}
+
+// log_ratios = logp - logq
+__global__ void pf_logratio_kernel(int64_t n, const double *__restrict__ lp, const double *__restrict__ lq,
+                                   double *__restrict__ lr) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) lr[i] = lp[i] - lq[i];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// logpdf(MvNormal(mu, W), x) = -(d log2pi + logdet)/2 - |L \ (x - mu)|^2 / 2, one lane per column.
+// ldiv!(L): z = U'^{-1}(x - mu); z <- Q'z = z - Vh T'(Vh' z); z[1:k] <- V'^{-1} z[1:k]  (src/woodbury.jl:158-165)
+template <int KPAD>
+__global__ __launch_bounds__(ELBO_THREADS) void pf_logpdf_kernel(int d, int p, int64_t N, const double *__restrict__ Xall,
+                                                                const double *__restrict__ vh, const double *__restrict__ tmat,
+                                                                const double *__restrict__ vchol, const double *__restrict__ sqrt_alpha,
+                                                                const double *__restrict__ mu_all, const double *__restrict__ logdet,
+                                                                const int32_t *__restrict__ status, double *__restrict__ out) {
+    const int64_t n = (int64_t)blockIdx.x * ELBO_THREADS + threadIdx.x;
+    if (n >= N) return;
+    if (status[p] != PFMI_FIT_OK) { out[n] = NAN; return; }
+    const double *Vh = vh + (size_t)p * d * KPAD, *T = tmat + (size_t)p * KPAD * KPAD, *Vc = vchol + (size_t)p * KPAD * KPAD;
+    const double *sqa = sqrt_alpha + (size_t)p * d, *mu = mu_all + (size_t)p * d;
+    const double *X = Xall + (size_t)n * d;
+    double w[KPAD], tv[KPAD], zh[KPAD];
+#pragma unroll
+    for (int j = 0; j < KPAD; ++j) w[j] = 0.0;
+    for (int i = 0; i < d; ++i) {
+        const double e = (X[i] - mu[i]) / sqa[i];
+        const double *row = Vh + (size_t)i * KPAD;
+#pragma unroll
+        for (int j = 0; j < KPAD; ++j) w[j] += row[j] * e;
+    }
+#pragma unroll
+    for (int a = 0; a < KPAD; ++a) {   // tv = T' w
+        double s = 0.0;
+#pragma unroll
+        for (int b = 0; b <= a; ++b) s += T[b * KPAD + a] * w[b];
+        tv[a] = s;
+    }
+    double ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < KPAD; ++i) {
+        zh[i] = 0.0;
+        if (i < d) {
+            const double *row = Vh + (size_t)i * KPAD;
+            double v = (X[i] - mu[i]) / sqa[i];
+#pragma unroll
+            for (int j = 0; j < KPAD; ++j) v -= row[j] * tv[j];
+            zh[i] = v;
+        }
+    }
+    for (int i = KPAD; i < d; ++i) {
+        const double *row = Vh + (size_t)i * KPAD;
+        double v = (X[i] - mu[i]) / sqa[i];
+#pragma unroll
+        for (int j = 0; j < KPAD; ++j) v -= row[j] * tv[j];
+        ss += v * v;
+    }
+#pragma unroll
+    for (int a = 0; a < KPAD; ++a) {   // forward substitution V' y = zh (identity padded)
+        double v = zh[a];
+#pragma unroll
+        for (int b = 0; b < a; ++b) v -= Vc[b * KPAD + a] * zh[b];
+        zh[a] = v / Vc[a * KPAD + a];
+        ss += zh[a] * zh[a];
+    }
+    out[n] = -((double)d * PF_LOG2PI + logdet[p]) / 2.0 - ss / 2.0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <int KPAD, int TGT, int RPAD>
+static void launch_draws_tm(const ElboArgs &a, dim3 grid, hipStream_t s, bool mem) {
+    if (mem) hipLaunchKernelGGL((pf_elbo_draws_kernel<KPAD, TGT, RPAD, true>), grid, dim3(ELBO_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((pf_elbo_draws_kernel<KPAD, TGT, RPAD, false>), grid, dim3(ELBO_THREADS), 0, s, a);
+}
+template <int KPAD>
+static int32_t launch_draws_k(const ElboArgs &a, dim3 grid, hipStream_t s, bool mem, int tgt, int rpad) {
+    if (tgt == 0) launch_draws_tm<KPAD, 0, 0>(a, grid, s, mem);
+    else if (tgt == 2) launch_draws_tm<KPAD, 2, 0>(a, grid, s, mem);
+    else if (rpad == 0) launch_draws_tm<KPAD, 1, 0>(a, grid, s, mem);
+    else if (rpad == 8) launch_draws_tm<KPAD, 1, 8>(a, grid, s, mem);
+    else if (rpad == 16) launch_draws_tm<KPAD, 1, 16>(a, grid, s, mem);
+    else { pf_set_error("unsupported target rank padding %d", rpad); return PFMI_ERR_UNSUPPORTED; }
+    return PFMI_OK;
+}
+
+int32_t pf_launch_elbo_draws(pfmi_ctx *c, const int32_t *d_points, const uint64_t *d_seeds, int64_t nfits,
+                             int64_t n0, int64_t N, const double *d_u, int64_t u_stride, double *d_x,
+                             int64_t x_stride, double *d_logp, double *d_logq, int64_t log_stride,
+                             bool with_target, bool by_point) {
+    if (nfits <= 0 || N <= 0) return PFMI_OK;
+    ElboArgs a;
+    a.d = c->d; a.points = d_points; a.seeds = d_seeds; a.n0 = n0; a.N = N;
+    a.vh = c->vh.as<double>(); a.tmat = c->tmat.as<double>(); a.vchol = c->vchol.as<double>();
+    a.sqrt_alpha = c->sqrt_alpha.as<double>(); a.mu = c->mu.as<double>(); a.logdet = c->logdet.as<double>();
+    a.status = c->status.as<int32_t>();
+    a.u = d_u; a.u_stride = u_stride; a.x = d_x; a.x_stride = x_stride;
+    a.logp = d_logp; a.logq = d_logq; a.log_stride = log_stride; a.by_point = by_point ? 1 : 0;
+    const TargetDev &t = c->target;
+    a.t_mean = t.mean.as<double>(); a.t_a = t.a.as<double>(); a.t_wd = t.wd.as<double>(); a.t_g = t.g.as<double>();
+    a.t_offset = t.offset;
+    int tgt = 0, rpad = 0;
+    if (with_target) {
+        if (t.kind == PFMI_TARGET_GAUSS) { tgt = 1; rpad = t.rpad; }
+        else if (t.kind == PFMI_TARGET_FUNNEL) tgt = 2;
+    }
+    const int64_t gx = (N + ELBO_THREADS - 1) / ELBO_THREADS;
+    const bool mem = d_u != nullptr;
+    // gridDim.y is limited to 65535: chunk the fit list
+    for (int64_t s0 = 0; s0 < nfits; s0 += 32768) {
+        const int64_t ns = (nfits - s0 < 32768) ? (nfits - s0) : 32768;
+        ElboArgs b = a;
+        b.points = d_points + s0; b.seeds = d_seeds + s0;
+        if (b.u && !by_point) b.u += s0 * u_stride;
+        if (b.x) b.x += s0 * x_stride;
+        if (!by_point) { b.logp += s0 * log_stride; b.logq += s0 * log_stride; }
+        dim3 grid((unsigned)gx, (unsigned)ns);
+        pf_kernel_begin(c);
+        int32_t rc = PFMI_OK;
+        switch (c->kpad) {
+            case 4: rc = launch_draws_k<4>(b, grid, c->stream, mem, tgt, rpad); break;
+            case 8: rc = launch_draws_k<8>(b, grid, c->stream, mem, tgt, rpad); break;
+            case 12: rc = launch_draws_k<12>(b, grid, c->stream, mem, tgt, rpad); break;
+            case 20: rc = launch_draws_k<20>(b, grid, c->stream, mem, tgt, rpad); break;
+            case 32: rc = launch_draws_k<32>(b, grid, c->stream, mem, tgt, rpad); break;
+            default: pf_set_error("unsupported kpad %d", c->kpad); rc = PFMI_ERR_UNSUPPORTED;
+        }
+        pf_kernel_end(c, "elbo_draws");
+        PF_TRY(rc);
+        PF_HIP(hipGetLastError());
+    }
+    return PFMI_OK;
+}
+
+int32_t pf_launch_elbo_reduce(pfmi_ctx *c) {
+    pf_kernel_begin(c);
+    hipLaunchKernelGGL(pf_elbo_reduce_kernel, dim3((unsigned)c->P), dim3(256), 0, c->stream, c->N_e,
+                       c->d_off.as<int64_t>(), c->d_path_of.as<int32_t>(), c->status.as<int32_t>(),
+                       c->logp.as<double>(), c->logq.as<double>(), c->elbo.as<double>(), c->se.as<double>());
+    hipLaunchKernelGGL(pf_elbo_argmax_kernel, dim3((unsigned)((c->K + 63) / 64)), dim3(64), 0, c->stream, c->K,
+                       c->d_off.as<int64_t>(), c->elbo.as<double>(), c->best_iter.as<int64_t>());
+    pf_kernel_end(c, "elbo_reduce");
+    PF_HIP(hipGetLastError());
+    return PFMI_OK;
+}
+
+int32_t pf_launch_logratio(pfmi_ctx *c, int64_t n) {
+    if (n <= 0) return PFMI_OK;
+    hipLaunchKernelGGL(pf_logratio_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n,
+                       c->pool_lp.as<double>(), c->pool_lq.as<double>(), c->pool_lr.as<double>());
+    PF_HIP(hipGetLastError());
+    return PFMI_OK;
+}
+
+int32_t pf_launch_logpdf(pfmi_ctx *c, int64_t point, int64_t N, const double *d_x, double *d_out) {
+    if (N <= 0) return PFMI_OK;
+    dim3 grid((unsigned)((N + ELBO_THREADS - 1) / ELBO_THREADS));
+#define PF_LPDF(KP)                                                                                         \
+    hipLaunchKernelGGL(pf_logpdf_kernel<KP>, grid, dim3(ELBO_THREADS), 0, c->stream, c->d, (int)point, N, d_x, \
+                       c->vh.as<double>(), c->tmat.as<double>(), c->vchol.as<double>(),                     \
+                       c->sqrt_alpha.as<double>(), c->mu.as<double>(), c->logdet.as<double>(),              \
+                       c->status.as<int32_t>(), d_out)
+    switch (c->kpad) {
+        case 4: PF_LPDF(4); break;
+        case 8: PF_LPDF(8); break;
+        case 12: PF_LPDF(12); break;
+        case 20: PF_LPDF(20); break;
+        case 32: PF_LPDF(32); break;
+        default: PF_CHECK(false, PFMI_ERR_UNSUPPORTED, "unsupported kpad %d", c->kpad);
+    }
+#undef PF_LPDF
+    PF_HIP(hipGetLastError());
+    return PFMI_OK;
+}

@@ -1,0 +1,441 @@
+// fit_kernels.hip -- batched L-BFGS inverse-Hessian reconstruction + Woodbury factorisation (gfx950).
+//
+//   pf_history_kernel : one workgroup per PATH.  Sequential walk over the trace
+//                       (lbfgs_inverse_hessians, reference src/inverse_hessian.jl:25-66): s, y,
+//                       curvature test, ring-buffer bookkeeping, gilbert_init recurrence (:5-10).
+//   pf_fit_kernel     : one workgroup per trace POINT (= per fitted MvNormal), all points of all
+//                       paths in one launch.  Byrd compact form (src/inverse_hessian.jl:98-133),
+//                       pdfactorize (src/woodbury.jl:201-207): U = sqrt(alpha), Householder QR of
+//                       U'\B in LAPACK convention (so that draws match the reference's lmul!(Q, .)),
+//                       compact-WY T, C = I + R D R', Cholesky V, logdet (:76-80) and
+//                       mu = theta + Sigma*grad through the factor (src/mvnormal.jl:14-21).
+//
+// Data layout: the scaled history block B~ = U'\[alpha.Y  S] lives row-major [d][KPAD] in HBM and is
+// factored in place, so one row (KPAD doubles, 96 B at J = 6) is one contiguous coalesced read
+// and is what the draw kernel later scalar-loads per row.  Column padding (zeros) sits at the END of
+// the column list only (a zero column in the middle would shift later pivots).
+#include "pfmi_common.h"
+
+#define HIST_THREADS 256
+#define FIT_THREADS 256
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(HIST_THREADS) void pf_history_kernel(
+    int d, int J, double eps, const int64_t *__restrict__ off, const double *__restrict__ theta,
+    const double *__restrict__ grad, double *alpha_all, int *__restrict__ hist_len,
+    int *__restrict__ hist_src, int *__restrict__ n_rej) {
+    const int k = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int64_t p0 = off[k];
+    const int L = (int)(off[k + 1] - p0 - 1);
+    __shared__ double red[4 * (HIST_THREADS / 64)];
+    __shared__ int s_slot[64];
+    __shared__ int s_ind, s_eff, s_rej;
+
+    for (int i = tid; i < d; i += nt) alpha_all[(size_t)p0 * d + i] = 1.0;   // H0 = I  (:38-39)
+    if (tid == 0) { hist_len[p0] = 0; s_ind = 0; s_eff = 0; s_rej = 0; }
+    __syncthreads();
+    for (int l = 1; l <= L; ++l) {                                              // :43
+        const double *th0 = theta + (size_t)(p0 + l - 1) * d, *th1 = theta + (size_t)(p0 + l) * d;
+        const double *g0 = grad + (size_t)(p0 + l - 1) * d, *g1 = grad + (size_t)(p0 + l) * d;
+        const double *a0 = alpha_all + (size_t)(p0 + l - 1) * d;
+        double *a1 = alpha_all + (size_t)(p0 + l) * d;
+        double v[4] = {0.0, 0.0, 0.0, 0.0};   // y.s, y.y, y'diag(a)y, s'diag(1/a)s
+        for (int i = tid; i < d; i += nt) {
+            double s = th1[i] - th0[i], y = g0[i] - g1[i], al = a0[i];       // :45-46
+            v[0] += y * s;
+            v[1] += y * y;
+            v[2] += y * al * y;
+            v[3] += s * (1.0 / al) * s;
+        }
+        pf_block_sum<4>(v, red);
+        const bool accept = v[0] > eps * v[1];                                  // :47
+        if (accept) {                                                           // gilbert_init :5-10
+            const double a = v[2], b = v[0], c = v[3];
+            for (int i = tid; i < d; i += nt) {
+                double s = th1[i] - th0[i], y = g0[i] - g1[i], al = a0[i];
+                double sa = s / al;
+                a1[i] = b / (a / al + y * y - (a / c) * sa * sa);
+            }
+        } else {
+            for (int i = tid; i < d; i += nt) a1[i] = a0[i];
+        }
+        if (tid == 0) {
+            if (accept) {
+                s_ind = (s_ind % J) + 1;                                        // mod1 :49
+                if (s_ind > s_eff) s_eff = s_ind;                               // :50
+                s_slot[s_ind - 1] = l - 1;
+            } else {
+                s_rej += 1;                                                     // :57
+            }
+            hist_len[p0 + l] = s_eff;
+            int c = 0;                                                          // hist_inds :105
+            for (int t = s_ind + 1; t <= s_eff; ++t) hist_src[(size_t)(p0 + l) * J + c++] = s_slot[t - 1];
+            for (int t = 1; t <= s_ind; ++t) hist_src[(size_t)(p0 + l) * J + c++] = s_slot[t - 1];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) n_rej[k] = s_rej;
+}
+
+// ---------------------------------------------------------------------------------------------------
+struct FitArgs {
+    int d, J;
+    const int64_t *off;
+    const int32_t *path_of;
+    const double *theta, *grad, *alpha_all;
+    const int32_t *hist_len, *hist_src;
+    double *vh, *tmat, *vchol, *rq, *dmat, *sqrt_alpha, *mu, *logdet;
+    int32_t *status;
+};
+
+// acc[cc] = sum_{i >= i0} M[i][c] * M[i][cc]  for all cc (block-wide, every thread gets the result)
+template <int KPAD>
+__device__ __forceinline__ void pf_multi_dot(const double *M, int d, int i0, int c, double (&acc)[KPAD],
+                                             double *red) {
+#pragma unroll
+    for (int cc = 0; cc < KPAD; ++cc) acc[cc] = 0.0;
+    for (int i = i0 + (int)threadIdx.x; i < d; i += (int)blockDim.x) {
+        const double *row = M + (size_t)i * KPAD;
+        const double xc = row[c];
+#pragma unroll
+        for (int cc = 0; cc < KPAD; ++cc) acc[cc] += xc * row[cc];
+    }
+    pf_block_sum<KPAD>(acc, red);
+}
+// acc[cc] = sum_i x_i * M[i][cc], x_i produced by f(i)
+template <int KPAD, typename F>
+__device__ __forceinline__ void pf_vec_dot(const double *M, int d, F f, double (&acc)[KPAD], double *red) {
+#pragma unroll
+    for (int cc = 0; cc < KPAD; ++cc) acc[cc] = 0.0;
+    for (int i = (int)threadIdx.x; i < d; i += (int)blockDim.x) {
+        const double *row = M + (size_t)i * KPAD;
+        const double x = f(i, row);
+#pragma unroll
+        for (int cc = 0; cc < KPAD; ++cc) acc[cc] += x * row[cc];
+    }
+    pf_block_sum<KPAD>(acc, red);
+}
+
+template <int KPAD>
+__global__ __launch_bounds__(FIT_THREADS) void pf_fit_kernel(FitArgs A) {
+    const int p = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int d = A.d, J = A.J;
+    const int path = A.path_of[p];
+    const int64_t p0 = A.off[path];
+    const int j = A.hist_len[p], m = 2 * j, k = d < m ? d : m;
+    const double *alpha = A.alpha_all + (size_t)p * d;
+    double *Vh = A.vh + (size_t)p * d * KPAD;
+    double *sqa = A.sqrt_alpha + (size_t)p * d;
+    double *mu = A.mu + (size_t)p * d;
+    const double *theta_p = A.theta + (size_t)p * d, *grad_p = A.grad + (size_t)p * d;
+
+    __shared__ double red[(FIT_THREADS / 64) * KPAD];
+    __shared__ double sP[KPAD], sW[KPAD], sHead[KPAD], sTau[KPAD];
+    __shared__ double sD[KPAD * KPAD], sR[KPAD * KPAD], sT[KPAD * KPAD], sV[KPAD * KPAD], sG[KPAD * KPAD];
+    __shared__ double sScal, sBeta, sLogdetV;
+    __shared__ int sStatus;
+
+    // ---- U = sqrt(alpha), A positive definite?  (src/woodbury.jl:202-203)
+    double bad = 0.0, ldu = 0.0;
+    for (int i = tid; i < d; i += nt) {
+        const double al = alpha[i];
+        if (!(al > 0.0) || !isfinite(al)) bad = 1.0;
+        const double s = sqrt(al);
+        sqa[i] = s;
+        ldu += log(s);
+    }
+    {
+        double v[2] = {bad, ldu};
+        pf_block_sum<2>(v, red);
+        bad = v[0]; ldu = v[1];
+    }
+    if (tid == 0) sStatus = (bad > 0.0) ? PFMI_FIT_A_NOT_PD : PFMI_FIT_OK;
+    for (int t = tid; t < KPAD * KPAD; t += nt) { sD[t] = 0.0; sR[t] = 0.0; sT[t] = 0.0; sV[t] = 0.0; sG[t] = 0.0; }
+    __syncthreads();
+    if (sStatus != PFMI_FIT_OK) {
+        for (int i = tid; i < d; i += nt) {
+            mu[i] = NAN;
+            for (int c = 0; c < KPAD; ++c) Vh[(size_t)i * KPAD + c] = 0.0;
+        }
+        for (int t = tid; t < KPAD * KPAD; t += nt) {
+            A.tmat[(size_t)p * KPAD * KPAD + t] = 0.0; A.vchol[(size_t)p * KPAD * KPAD + t] = 0.0;
+            A.rq[(size_t)p * KPAD * KPAD + t] = 0.0; A.dmat[(size_t)p * KPAD * KPAD + t] = 0.0;
+        }
+        if (tid == 0) { A.status[p] = sStatus; A.logdet[p] = NAN; }
+        return;
+    }
+
+    // ---- rows of B~ = U' \ [alpha.Y  S]   (src/inverse_hessian.jl:117-118, src/woodbury.jl:204)
+    for (int i = tid; i < d; i += nt) {
+        double *row = Vh + (size_t)i * KPAD;
+        const double al = alpha[i], sa = sqa[i];
+        for (int c = 0; c < j; ++c) {
+            const int src = A.hist_src[(size_t)p * J + c];
+            const size_t q0 = (size_t)(p0 + src) * d + i, q1 = (size_t)(p0 + src + 1) * d + i;
+            const double y = A.grad[q0] - A.grad[q1];     // y = grad_l - grad_{l+1}   :46
+            const double s = A.theta[q1] - A.theta[q0];   // s = theta_{l+1} - theta_l :45
+            row[c] = (al * y) / sa;
+            row[j + c] = s / sa;
+        }
+        for (int c = m; c < KPAD; ++c) row[c] = 0.0;
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    double acc[KPAD];
+    // ---- Gram matrix G = B~'B~ : G[c][b] (c < j, b < j) = Y'alpha Y ; G[j+a][b] = S'Y
+    for (int c = 0; c < m; ++c) {
+        pf_multi_dot<KPAD>(Vh, d, 0, c, acc, red);
+        if (tid == 0) {
+#pragma unroll
+            for (int cc = 0; cc < KPAD; ++cc) sG[c * KPAD + cc] = acc[cc];
+        }
+    }
+    __syncthreads();
+    // ---- D (m x m)   (src/inverse_hessian.jl:119-130), thread 0; sT/sV used as scratch
+    if (tid == 0 && j > 0) {
+        double *R = sT, *nRinv = sV, *Mm = sR;   // j x j each, row-major with stride KPAD
+        for (int a = 0; a < j; ++a)
+            for (int b = 0; b < j; ++b) {
+                R[a * KPAD + b] = (b >= a) ? sG[(j + a) * KPAD + b] : 0.0;     // triu(S'Y)   :119-121
+                nRinv[a * KPAD + b] = 0.0;
+            }
+        for (int c = 0; c < j; ++c)                                              // -R^{-1}     :122-124
+            for (int r = c; r >= 0; --r) {
+                double rhs = (r == c) ? -1.0 : 0.0;
+                for (int t = r + 1; t <= c; ++t) rhs -= R[r * KPAD + t] * nRinv[t * KPAD + c];
+                nRinv[r * KPAD + c] = rhs / R[r * KPAD + r];
+            }
+        for (int a = 0; a < j; ++a)
+            for (int b = 0; b < j; ++b) {
+                sD[a * KPAD + (j + b)] = nRinv[a * KPAD + b];                    // D12         :122
+                sD[(j + a) * KPAD + b] = nRinv[b * KPAD + a];                    // D21         :125
+                double v = (a <= b) ? sG[a * KPAD + b] : sG[b * KPAD + a];       // Y'alpha Y   :127-128
+                if (a == b) v += R[a * KPAD + a];                                // + diag(R)   :126
+                Mm[a * KPAD + b] = v;
+            }
+        // D22 = nRinv' (M nRinv)                                                   :129-130
+        for (int a = 0; a < j; ++a)
+            for (int b = 0; b < j; ++b) {
+                double v = 0.0;
+                for (int t = 0; t <= b; ++t) v += Mm[a * KPAD + t] * nRinv[t * KPAD + b];
+                sG[a * KPAD + b] = v;   // G no longer needed
+            }
+        for (int a = 0; a < j; ++a)
+            for (int b = 0; b < j; ++b) {
+                double v = 0.0;
+                for (int t = 0; t <= a; ++t) v += nRinv[t * KPAD + a] * sG[t * KPAD + b];
+                sD[(j + a) * KPAD + (j + b)] = v;
+            }
+        for (int t = 0; t < KPAD * KPAD; ++t) { sT[t] = 0.0; sV[t] = 0.0; sR[t] = 0.0; }
+    }
+    __syncthreads();
+
+    // ---- Householder QR of B~ (d x m), dgeqr2/dlarfg convention, + compact-WY T (dlarft)
+    for (int c = 0; c < k; ++c) {
+        pf_multi_dot<KPAD>(Vh, d, c + 1, c, acc, red);
+        if (tid == 0) {
+            const double *rowc = Vh + (size_t)c * KPAD;
+            double xn2 = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < KPAD; ++cc) if (cc == c) xn2 = acc[cc];
+            const double alpha_c = rowc[c];
+            const double xnorm = sqrt(xn2);
+            double tau, scal, beta;
+            if (xnorm == 0.0) { tau = 0.0; scal = 0.0; beta = alpha_c; }
+            else {
+                beta = -copysign(hypot(alpha_c, xnorm), alpha_c);
+                tau = (beta - alpha_c) / beta;
+                scal = 1.0 / (alpha_c - beta);
+            }
+            sTau[c] = tau; sScal = scal; sBeta = beta;
+#pragma unroll
+            for (int cc = 0; cc < KPAD; ++cc) {
+                const double vdot = rowc[cc] + scal * acc[cc];   // v_c . column cc
+                sP[cc] = (cc > c) ? tau * vdot : vdot;
+            }
+            sT[c * KPAD + c] = tau;                              // T[0:c, c] = -tau T[0:c,0:c] (Vh' v_c)
+            for (int a = 0; a < c; ++a) {
+                double v = 0.0;
+                for (int b = a; b < c; ++b) v += sT[a * KPAD + b] * sP[b];
+                sT[a * KPAD + c] = -tau * v;
+            }
+        }
+        __syncthreads();
+        {
+            const double scal = sScal;
+            for (int i = c + 1 + tid; i < d; i += nt) {
+                double *row = Vh + (size_t)i * KPAD;
+                const double v = row[c] * scal;
+                row[c] = v;
+#pragma unroll
+                for (int cc = 0; cc < KPAD; ++cc) if (cc > c) row[cc] -= sP[cc] * v;
+            }
+            if (tid == 0) {
+                double *rowc = Vh + (size_t)c * KPAD;
+                rowc[c] = sBeta;
+#pragma unroll
+                for (int cc = 0; cc < KPAD; ++cc) if (cc > c) rowc[cc] -= sP[cc];
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    // ---- split the in-place factor: R (k x m) -> sR, Householder vectors keep an explicit unit diagonal
+    for (int t = tid; t < k * KPAD; t += nt) {
+        const int a = t / KPAD, b = t % KPAD;
+        if (b >= a) {
+            sR[a * KPAD + b] = (b < m) ? Vh[(size_t)a * KPAD + b] : 0.0;
+            Vh[(size_t)a * KPAD + b] = (b == a) ? 1.0 : 0.0;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- C = I + R D R' (k x k), V = chol(C).U     (src/woodbury.jl:205)
+    if (tid == 0) {
+        int st = PFMI_FIT_OK;
+        double ldv = 0.0;
+        for (int a = 0; a < k; ++a)                       // sG <- R D   (k x m)
+            for (int b = 0; b < m; ++b) {
+                double v = 0.0;
+                for (int t = a; t < m; ++t) v += sR[a * KPAD + t] * sD[t * KPAD + b];
+                sG[a * KPAD + b] = v;
+            }
+        for (int a = 0; a < k; ++a)
+            for (int b = a; b < k; ++b) {
+                double v = (a == b) ? 1.0 : 0.0;
+                for (int t = b; t < m; ++t) v += sG[a * KPAD + t] * sR[b * KPAD + t];
+                sV[a * KPAD + b] = v;
+            }
+        for (int c = 0; c < k && st == PFMI_FIT_OK; ++c) {
+            double diag = sV[c * KPAD + c];
+            for (int t = 0; t < c; ++t) diag -= sV[t * KPAD + c] * sV[t * KPAD + c];
+            if (!(diag > 0.0) || !isfinite(diag)) { st = PFMI_FIT_C_NOT_PD; break; }
+            diag = sqrt(diag);
+            sV[c * KPAD + c] = diag;
+            ldv += log(diag);
+            for (int b = c + 1; b < k; ++b) {
+                double v = sV[c * KPAD + b];
+                for (int t = 0; t < c; ++t) v -= sV[t * KPAD + c] * sV[t * KPAD + b];
+                sV[c * KPAD + b] = v / diag;
+            }
+        }
+        for (int a = k; a < KPAD; ++a) sV[a * KPAD + a] = 1.0;   // identity padding
+        sStatus = st;
+        sLogdetV = ldv;
+    }
+    __syncthreads();
+    const size_t sm = (size_t)p * KPAD * KPAD;
+    for (int t = tid; t < KPAD * KPAD; t += nt) {
+        A.tmat[sm + t] = sT[t]; A.vchol[sm + t] = sV[t]; A.rq[sm + t] = sR[t]; A.dmat[sm + t] = sD[t];
+    }
+    if (sStatus != PFMI_FIT_OK) {
+        for (int i = tid; i < d; i += nt) mu[i] = NAN;
+        if (tid == 0) { A.status[p] = sStatus; A.logdet[p] = NAN; }
+        return;
+    }
+    // ---- mu = theta + Sigma grad,  Sigma g = U' Q [V'V 0;0 I] Q' U g   (src/mvnormal.jl:16-19,
+    //      src/woodbury.jl:64-68,129-143);  Q = I - Vh T Vh',  Q' = I - Vh T' Vh'
+    pf_vec_dot<KPAD>(Vh, d, [&](int i, const double *) { return sqa[i] * grad_p[i]; }, acc, red);
+    if (tid == 0) {
+#pragma unroll
+        for (int cc = 0; cc < KPAD; ++cc) sP[cc] = acc[cc];
+        for (int a = 0; a < KPAD; ++a) {   // t1 = T' w1
+            double v = 0.0;
+            for (int b = 0; b <= a; ++b) v += sT[b * KPAD + a] * sP[b];
+            sW[a] = v;
+        }
+    }
+    __syncthreads();
+    // head rows of b = Q' U g
+    for (int i = tid; i < k; i += nt) {
+        const double *row = Vh + (size_t)i * KPAD;
+        double v = sqa[i] * grad_p[i];
+        for (int cc = 0; cc < KPAD; ++cc) v -= row[cc] * sW[cc];
+        sHead[i] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {   // head <- V'(V head)
+        for (int a = 0; a < k; ++a) {
+            double v = 0.0;
+            for (int b = a; b < k; ++b) v += sV[a * KPAD + b] * sHead[b];
+            sHead[a] = v;
+        }
+        for (int a = k - 1; a >= 0; --a) {
+            double v = 0.0;
+            for (int b = 0; b <= a; ++b) v += sV[b * KPAD + a] * sHead[b];
+            sHead[a] = v;
+        }
+    }
+    __syncthreads();
+    auto bvec = [&](int i, const double *row) {
+        if (i < k) return sHead[i];
+        double v = sqa[i] * grad_p[i];
+#pragma unroll
+        for (int cc = 0; cc < KPAD; ++cc) v -= row[cc] * sW[cc];
+        return v;
+    };
+    pf_vec_dot<KPAD>(Vh, d, bvec, acc, red);
+    if (tid == 0) {
+#pragma unroll
+        for (int cc = 0; cc < KPAD; ++cc) sP[cc] = acc[cc];
+        for (int a = 0; a < KPAD; ++a) {   // t2 = T w2
+            double v = 0.0;
+            for (int b = a; b < KPAD; ++b) v += sT[a * KPAD + b] * sP[b];
+            sTau[a] = v;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < d; i += nt) {
+        const double *row = Vh + (size_t)i * KPAD;
+        double v = bvec(i, row);
+#pragma unroll
+        for (int cc = 0; cc < KPAD; ++cc) v -= row[cc] * sTau[cc];
+        mu[i] = theta_p[i] + sqa[i] * v;
+    }
+    if (tid == 0) {
+        A.status[p] = PFMI_FIT_OK;
+        A.logdet[p] = 2.0 * (ldu + sLogdetV);    // src/woodbury.jl:76-80
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+int32_t pf_launch_history(pfmi_ctx *c, double eps) {
+    PF_CHECK(c->J <= 64, PFMI_ERR_UNSUPPORTED, "history_length %d > 64 unsupported", c->J);
+    pf_kernel_begin(c);
+    hipLaunchKernelGGL(pf_history_kernel, dim3(c->K), dim3(HIST_THREADS), 0, c->stream, c->d, c->J, eps,
+                       c->d_off.as<int64_t>(), c->theta.as<double>(), c->grad.as<double>(),
+                       c->alpha_all.as<double>(), c->hist_len.as<int>(), c->hist_src.as<int>(),
+                       c->n_rej.as<int>());
+    pf_kernel_end(c, "history");
+    PF_HIP(hipGetLastError());
+    return PFMI_OK;
+}
+
+template <int KPAD>
+static void launch_fit_t(pfmi_ctx *c, const FitArgs &a) {
+    hipLaunchKernelGGL(pf_fit_kernel<KPAD>, dim3((unsigned)c->P), dim3(FIT_THREADS), 0, c->stream, a);
+}
+
+int32_t pf_launch_fit(pfmi_ctx *c) {
+    FitArgs a;
+    a.d = c->d; a.J = c->J;
+    a.off = c->d_off.as<int64_t>(); a.path_of = c->d_path_of.as<int32_t>();
+    a.theta = c->theta.as<double>(); a.grad = c->grad.as<double>(); a.alpha_all = c->alpha_all.as<double>();
+    a.hist_len = c->hist_len.as<int32_t>(); a.hist_src = c->hist_src.as<int32_t>();
+    a.vh = c->vh.as<double>(); a.tmat = c->tmat.as<double>(); a.vchol = c->vchol.as<double>();
+    a.rq = c->rq.as<double>(); a.dmat = c->dmat.as<double>(); a.sqrt_alpha = c->sqrt_alpha.as<double>();
+    a.mu = c->mu.as<double>(); a.logdet = c->logdet.as<double>(); a.status = c->status.as<int32_t>();
+    pf_kernel_begin(c);
+    switch (c->kpad) {
+        case 4: launch_fit_t<4>(c, a); break;
+        case 8: launch_fit_t<8>(c, a); break;
+        case 12: launch_fit_t<12>(c, a); break;
+        case 20: launch_fit_t<20>(c, a); break;
+        case 32: launch_fit_t<32>(c, a); break;
+        default: PF_CHECK(false, PFMI_ERR_UNSUPPORTED, "unsupported kpad %d", c->kpad);
+    }
+    pf_kernel_end(c, "fit");
+    PF_HIP(hipGetLastError());
+    return PFMI_OK;
+}

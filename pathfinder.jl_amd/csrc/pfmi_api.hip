@@ -1,0 +1,580 @@
+// pfmi_api.hip -- the extern "C" boundary declared in include/pfmi.h (host side of libpfmi.so).
+#include "pfmi_common.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+
+static thread_local char g_err[1024] = "";
+
+void pf_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+void pf_kernel_begin(pfmi_ctx *c) {
+    if (c->profile) (void)hipEventRecord(c->kev0, c->stream);
+}
+void pf_kernel_end(pfmi_ctx *c, const char *name) {
+    if (!c->profile) return;
+    (void)hipEventRecord(c->kev1, c->stream);
+    (void)hipEventSynchronize(c->kev1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, c->kev0, c->kev1);
+    KernelStat &s = c->kstats[name];
+    s.ms += ms;
+    s.launches += 1;
+}
+
+static int32_t h2d(pfmi_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return PFMI_OK;
+    PF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    PF_HIP(hipStreamSynchronize(c->stream));
+    return PFMI_OK;
+}
+static int32_t d2h(pfmi_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return PFMI_OK;
+    PF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    PF_HIP(hipStreamSynchronize(c->stream));
+    return PFMI_OK;
+}
+#define PF_CTX(c)                                                          \
+    do {                                                                   \
+        PF_CHECK((c) != nullptr, PFMI_ERR_ARG, "null pfmi_ctx");           \
+        PF_HIP(hipSetDevice((c)->device));                                 \
+    } while (0)
+
+extern "C" {
+
+const char *pfmi_last_error(void) { return g_err; }
+int32_t pfmi_version(void) { return 100; }
+
+int32_t pfmi_device_count(int32_t *count) {
+    PF_CHECK(count != nullptr, PFMI_ERR_ARG, "null count");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; pf_set_error("hipGetDeviceCount: %s", hipGetErrorString(e)); return PFMI_ERR_HIP; }
+    *count = n;
+    return PFMI_OK;
+}
+
+int32_t pfmi_create(int32_t device, pfmi_ctx **out) {
+    PF_CHECK(out != nullptr, PFMI_ERR_ARG, "null out");
+    *out = nullptr;
+    int n = 0;
+    PF_HIP(hipGetDeviceCount(&n));
+    PF_CHECK(n > 0, PFMI_ERR_HIP, "no HIP device visible: libpfmi has no CPU fallback");
+    PF_CHECK(device >= 0 && device < n, PFMI_ERR_ARG, "device %d out of range (%d devices)", device, n);
+    hipDeviceProp_t prop;
+    PF_HIP(hipGetDeviceProperties(&prop, device));
+    PF_CHECK(strncmp(prop.gcnArchName, "gfx950", 6) == 0, PFMI_ERR_UNSUPPORTED,
+             "libpfmi is built for gfx950 (MI355X) only; device %d is %s", device, prop.gcnArchName);
+    PF_HIP(hipSetDevice(device));
+    pfmi_ctx *c = new pfmi_ctx();
+    c->device = device;
+    PF_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    PF_HIP(hipEventCreate(&c->ev0));
+    PF_HIP(hipEventCreate(&c->ev1));
+    PF_HIP(hipEventCreate(&c->kev0));
+    PF_HIP(hipEventCreate(&c->kev1));
+    *out = c;
+    return PFMI_OK;
+}
+
+int32_t pfmi_destroy(pfmi_ctx *c) {
+    if (!c) return PFMI_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf *bufs[] = {&c->theta, &c->grad, &c->d_off, &c->d_path_of, &c->target.mean, &c->target.a, &c->target.wd,
+                      &c->target.g, &c->alpha_all, &c->hist_len, &c->hist_src, &c->n_rej, &c->vh, &c->tmat, &c->vchol,
+                      &c->rq, &c->dmat, &c->sqrt_alpha, &c->mu, &c->logdet, &c->status, &c->seeds, &c->logp, &c->logq,
+                      &c->elbo, &c->se, &c->best_iter, &c->fit_list, &c->ubuf, &c->xbuf, &c->scratch, &c->pool,
+                      &c->pool_lr, &c->pool_lp, &c->pool_lq, &c->pool_points, &c->pool_seeds, &c->lw, &c->w,
+                      &c->psis_out, &c->tailbuf, &c->cdf, &c->idx, &c->gbuf};
+    for (DevBuf *b : bufs) b->release();
+    (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
+    (void)hipEventDestroy(c->kev0); (void)hipEventDestroy(c->kev1);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return PFMI_OK;
+}
+
+int32_t pfmi_sync(pfmi_ctx *c) {
+    PF_CTX(c);
+    PF_HIP(hipStreamSynchronize(c->stream));
+    return PFMI_OK;
+}
+
+int32_t pfmi_timer_start(pfmi_ctx *c) {
+    PF_CTX(c);
+    PF_HIP(hipEventRecord(c->ev0, c->stream));
+    return PFMI_OK;
+}
+int32_t pfmi_timer_stop(pfmi_ctx *c, double *ms) {
+    PF_CTX(c);
+    PF_HIP(hipEventRecord(c->ev1, c->stream));
+    PF_HIP(hipEventSynchronize(c->ev1));
+    float f = 0.f;
+    PF_HIP(hipEventElapsedTime(&f, c->ev0, c->ev1));
+    if (ms) *ms = f;
+    return PFMI_OK;
+}
+int32_t pfmi_profile(pfmi_ctx *c, int32_t enable) {
+    PF_CTX(c);
+    c->profile = enable != 0;
+    c->kstats.clear();
+    return PFMI_OK;
+}
+int32_t pfmi_kernel_time(pfmi_ctx *c, const char *name, double *ms, int64_t *launches) {
+    PF_CTX(c);
+    PF_CHECK(name != nullptr, PFMI_ERR_ARG, "null name");
+    auto it = c->kstats.find(name);
+    if (ms) *ms = (it == c->kstats.end()) ? 0.0 : it->second.ms;
+    if (launches) *launches = (it == c->kstats.end()) ? 0 : it->second.launches;
+    return PFMI_OK;
+}
+
+// ---- inputs ------------------------------------------------------------------------------------------
+int32_t pfmi_set_target(pfmi_ctx *c, const pfmi_target *t) {
+    PF_CTX(c);
+    PF_CHECK(t != nullptr, PFMI_ERR_ARG, "null target");
+    PF_CHECK(t->d > 0, PFMI_ERR_ARG, "target dimension must be positive");
+    TargetDev &T = c->target;
+    T.kind = t->kind; T.d = t->d; T.r = 0; T.rpad = 0; T.offset = 0.0; T.fn = nullptr; T.user = nullptr;
+    if (t->kind == PFMI_TARGET_GAUSS) {
+        PF_CHECK(t->mean && t->a, PFMI_ERR_ARG, "GAUSS target needs mean and a");
+        PF_CHECK(t->r >= 0 && t->r <= 16, PFMI_ERR_UNSUPPORTED, "GAUSS target rank %d > 16 unsupported", t->r);
+        PF_CHECK(t->r == 0 || (t->Wd && t->G), PFMI_ERR_ARG, "GAUSS target with r > 0 needs Wd and G");
+        const int d = t->d, r = t->r, rpad = (r == 0) ? 0 : (r <= 8 ? 8 : 16);
+        T.r = r; T.rpad = rpad; T.offset = t->offset;
+        PF_TRY(T.mean.ensure(sizeof(double) * d));
+        PF_TRY(T.a.ensure(sizeof(double) * d));
+        PF_TRY(h2d(c, T.mean.p, t->mean, sizeof(double) * d));
+        PF_TRY(h2d(c, T.a.p, t->a, sizeof(double) * d));
+        if (r > 0) {
+            std::vector<double> wd((size_t)d * rpad, 0.0), g((size_t)rpad * rpad, 0.0);
+            for (int i = 0; i < d; ++i)
+                for (int j = 0; j < r; ++j) wd[(size_t)i * rpad + j] = t->Wd[i + (size_t)d * j];
+            for (int j = 0; j < r; ++j)
+                for (int l = 0; l <= j; ++l) g[(size_t)j * rpad + l] = t->G[j + (size_t)r * l];
+            PF_TRY(T.wd.ensure(sizeof(double) * wd.size()));
+            PF_TRY(T.g.ensure(sizeof(double) * g.size()));
+            PF_TRY(h2d(c, T.wd.p, wd.data(), sizeof(double) * wd.size()));
+            PF_TRY(h2d(c, T.g.p, g.data(), sizeof(double) * g.size()));
+        }
+    } else if (t->kind == PFMI_TARGET_FUNNEL) {
+        /* no parameters */
+    } else if (t->kind == PFMI_TARGET_HOST_CALLBACK) {
+        PF_CHECK(t->fn != nullptr, PFMI_ERR_ARG, "HOST_CALLBACK target needs fn");
+        T.fn = t->fn; T.user = t->user;
+    } else {
+        T.kind = -1;
+        PF_CHECK(false, PFMI_ERR_ARG, "unknown target kind %d", t->kind);
+    }
+    return PFMI_OK;
+}
+
+int32_t pfmi_set_traces(pfmi_ctx *c, int32_t K, const int64_t *npoints, int32_t d, const double *theta,
+                        const double *grad) {
+    PF_CTX(c);
+    PF_CHECK(K > 0 && d > 0 && npoints && theta && grad, PFMI_ERR_ARG, "set_traces: bad arguments");
+    c->off.assign((size_t)K + 1, 0);
+    for (int k = 0; k < K; ++k) {
+        PF_CHECK(npoints[k] >= 1, PFMI_ERR_ARG, "path %d has no points", k);
+        c->off[k + 1] = c->off[k] + npoints[k];
+    }
+    const int64_t P = c->off[K];
+    PF_CHECK(P < (1ll << 31), PFMI_ERR_UNSUPPORTED, "too many trace points");
+    c->path_of.resize((size_t)P);
+    for (int k = 0; k < K; ++k)
+        for (int64_t p = c->off[k]; p < c->off[k + 1]; ++p) c->path_of[(size_t)p] = k;
+    c->K = K; c->d = d; c->P = P;
+    c->fitted = false; c->elbo_done = false; c->pooled = false;
+    const size_t bytes = sizeof(double) * (size_t)P * d;
+    PF_TRY(c->theta.ensure(bytes));
+    PF_TRY(c->grad.ensure(bytes));
+    PF_TRY(c->d_off.ensure(sizeof(int64_t) * (K + 1)));
+    PF_TRY(c->d_path_of.ensure(sizeof(int32_t) * P));
+    PF_TRY(h2d(c, c->theta.p, theta, bytes));
+    PF_TRY(h2d(c, c->grad.p, grad, bytes));
+    PF_TRY(h2d(c, c->d_off.p, c->off.data(), sizeof(int64_t) * (K + 1)));
+    PF_TRY(h2d(c, c->d_path_of.p, c->path_of.data(), sizeof(int32_t) * P));
+    return PFMI_OK;
+}
+
+// ---- fit ----------------------------------------------------------------------------------------------
+int32_t pfmi_fit_batch(pfmi_ctx *c, int32_t J, double eps) {
+    PF_CTX(c);
+    PF_CHECK(c->P > 0, PFMI_ERR_STATE, "fit_batch: no traces set");
+    PF_CHECK(J >= 1, PFMI_ERR_ARG, "history_length must be >= 1");
+    const int m = 2 * J;
+    int kpad = 0;
+    const int opts[] = {4, 8, 12, 20, 32};
+    for (int o : opts) if (m <= o) { kpad = o; break; }
+    PF_CHECK(kpad != 0, PFMI_ERR_UNSUPPORTED, "history_length %d > 16 unsupported", J);
+    c->J = J; c->kpad = kpad;
+    const size_t P = (size_t)c->P, d = (size_t)c->d, kk = (size_t)kpad * kpad;
+    PF_TRY(c->alpha_all.ensure(sizeof(double) * P * d));
+    PF_TRY(c->hist_len.ensure(sizeof(int32_t) * P));
+    PF_TRY(c->hist_src.ensure(sizeof(int32_t) * P * J));
+    PF_TRY(c->n_rej.ensure(sizeof(int32_t) * c->K));
+    PF_TRY(c->vh.ensure(sizeof(double) * P * d * kpad));
+    PF_TRY(c->tmat.ensure(sizeof(double) * P * kk));
+    PF_TRY(c->vchol.ensure(sizeof(double) * P * kk));
+    PF_TRY(c->rq.ensure(sizeof(double) * P * kk));
+    PF_TRY(c->dmat.ensure(sizeof(double) * P * kk));
+    PF_TRY(c->sqrt_alpha.ensure(sizeof(double) * P * d));
+    PF_TRY(c->mu.ensure(sizeof(double) * P * d));
+    PF_TRY(c->logdet.ensure(sizeof(double) * P));
+    PF_TRY(c->status.ensure(sizeof(int32_t) * P));
+    PF_HIP(hipMemsetAsync(c->hist_src.p, 0, sizeof(int32_t) * P * J, c->stream));
+    PF_TRY(pf_launch_history(c, eps));
+    PF_TRY(pf_launch_fit(c));
+    c->fitted = true; c->elbo_done = false; c->pooled = false;
+    return PFMI_OK;
+}
+
+int32_t pfmi_get_fit_status(pfmi_ctx *c, int32_t *status, int32_t *j_eff, double *logdet, int64_t *n_rejected) {
+    PF_CTX(c);
+    PF_CHECK(c->fitted, PFMI_ERR_STATE, "get_fit_status: call pfmi_fit_batch first");
+    if (status) PF_TRY(d2h(c, status, c->status.p, sizeof(int32_t) * c->P));
+    if (j_eff) PF_TRY(d2h(c, j_eff, c->hist_len.p, sizeof(int32_t) * c->P));
+    if (logdet) PF_TRY(d2h(c, logdet, c->logdet.p, sizeof(double) * c->P));
+    if (n_rejected) {
+        std::vector<int32_t> r((size_t)c->K);
+        PF_TRY(d2h(c, r.data(), c->n_rej.p, sizeof(int32_t) * c->K));
+        for (int k = 0; k < c->K; ++k) n_rejected[k] = r[(size_t)k];
+    }
+    return PFMI_OK;
+}
+
+int32_t pfmi_get_fit(pfmi_ctx *c, int64_t p, double *alpha, double *B, double *D, double *qr_factors, double *T,
+                     double *V, double *mu, double *logdet) {
+    PF_CTX(c);
+    PF_CHECK(c->fitted, PFMI_ERR_STATE, "get_fit: call pfmi_fit_batch first");
+    PF_CHECK(p >= 0 && p < c->P, PFMI_ERR_ARG, "get_fit: point %lld out of range", (long long)p);
+    const int d = c->d, J = c->J, kp = c->kpad;
+    int32_t j = 0;
+    PF_TRY(d2h(c, &j, c->hist_len.as<int32_t>() + p, sizeof(int32_t)));
+    const int m = 2 * j, k = d < m ? d : m;
+    std::vector<double> al((size_t)d);
+    PF_TRY(d2h(c, al.data(), c->alpha_all.as<double>() + (size_t)p * d, sizeof(double) * d));
+    if (alpha) memcpy(alpha, al.data(), sizeof(double) * d);
+    if (mu) PF_TRY(d2h(c, mu, c->mu.as<double>() + (size_t)p * d, sizeof(double) * d));
+    if (logdet) PF_TRY(d2h(c, logdet, c->logdet.as<double>() + p, sizeof(double)));
+    const size_t kk = (size_t)kp * kp;
+    std::vector<double> small(kk);
+    if (B && j > 0) {   // B = [alpha .* Y  S], columns oldest -> newest  (src/inverse_hessian.jl:105-118)
+        std::vector<int32_t> src((size_t)J);
+        PF_TRY(d2h(c, src.data(), c->hist_src.as<int32_t>() + (size_t)p * J, sizeof(int32_t) * J));
+        const int64_t p0 = c->off[(size_t)c->path_of[(size_t)p]];
+        std::vector<double> t0((size_t)d), t1((size_t)d), g0((size_t)d), g1((size_t)d);
+        for (int cidx = 0; cidx < j; ++cidx) {
+            const size_t q0 = (size_t)(p0 + src[(size_t)cidx]) * d, q1 = q0 + d;
+            PF_TRY(d2h(c, t0.data(), c->theta.as<double>() + q0, sizeof(double) * d));
+            PF_TRY(d2h(c, t1.data(), c->theta.as<double>() + q1, sizeof(double) * d));
+            PF_TRY(d2h(c, g0.data(), c->grad.as<double>() + q0, sizeof(double) * d));
+            PF_TRY(d2h(c, g1.data(), c->grad.as<double>() + q1, sizeof(double) * d));
+            for (int i = 0; i < d; ++i) {
+                B[i + (size_t)d * cidx] = al[(size_t)i] * (g0[(size_t)i] - g1[(size_t)i]);
+                B[i + (size_t)d * (j + cidx)] = t1[(size_t)i] - t0[(size_t)i];
+            }
+        }
+    }
+    if (D && m > 0) {
+        PF_TRY(d2h(c, small.data(), c->dmat.as<double>() + (size_t)p * kk, sizeof(double) * kk));
+        for (int a = 0; a < m; ++a)
+            for (int b = 0; b < m; ++b) D[a + (size_t)m * b] = small[(size_t)a * kp + b];
+    }
+    if (T && k > 0) {
+        PF_TRY(d2h(c, small.data(), c->tmat.as<double>() + (size_t)p * kk, sizeof(double) * kk));
+        for (int a = 0; a < k; ++a)
+            for (int b = 0; b < k; ++b) T[a + (size_t)k * b] = small[(size_t)a * kp + b];
+    }
+    if (V && k > 0) {
+        PF_TRY(d2h(c, small.data(), c->vchol.as<double>() + (size_t)p * kk, sizeof(double) * kk));
+        for (int a = 0; a < k; ++a)
+            for (int b = 0; b < k; ++b) V[a + (size_t)k * b] = small[(size_t)a * kp + b];
+    }
+    if (qr_factors && m > 0) {
+        std::vector<double> vh((size_t)d * kp);
+        PF_TRY(d2h(c, vh.data(), c->vh.as<double>() + (size_t)p * d * kp, sizeof(double) * d * kp));
+        PF_TRY(d2h(c, small.data(), c->rq.as<double>() + (size_t)p * kk, sizeof(double) * kk));
+        for (int b = 0; b < m; ++b)
+            for (int i = 0; i < d; ++i) {
+                double v;
+                if (i <= b && i < k) v = small[(size_t)i * kp + b];          // R (upper trapezoid)
+                else if (b < k) v = vh[(size_t)i * kp + b];                  // Householder vector
+                else v = 0.0;
+                qr_factors[i + (size_t)d * b] = v;
+            }
+    }
+    return PFMI_OK;
+}
+
+// ---- ELBO ---------------------------------------------------------------------------------------------
+// evaluate the host-callback target on `n` columns stored at device pointer d_x; results to d_lp
+static int32_t callback_logp(pfmi_ctx *c, const double *d_x, int64_t n, double *d_lp) {
+    const TargetDev &T = c->target;
+    std::vector<double> hx((size_t)n * c->d), hl((size_t)n);
+    PF_TRY(d2h(c, hx.data(), d_x, sizeof(double) * hx.size()));
+    T.fn(hx.data(), c->d, n, hl.data(), T.user);
+    PF_TRY(h2d(c, d_lp, hl.data(), sizeof(double) * hl.size()));
+    return PFMI_OK;
+}
+
+int32_t pfmi_elbo_batch(pfmi_ctx *c, int64_t N, const uint64_t *seeds, const double *u_host, double *elbo,
+                        double *se, int64_t *best_iter) {
+    PF_CTX(c);
+    PF_CHECK(c->fitted, PFMI_ERR_STATE, "elbo_batch: call pfmi_fit_batch first");
+    PF_CHECK(c->target.kind >= 0, PFMI_ERR_STATE, "elbo_batch: call pfmi_set_target first");
+    PF_CHECK(c->target.d == c->d, PFMI_ERR_ARG, "target dimension %d != trace dimension %d", c->target.d, c->d);
+    PF_CHECK(N >= 1 && seeds, PFMI_ERR_ARG, "elbo_batch: bad arguments");
+    const int64_t P = c->P;
+    const int d = c->d;
+    c->N_e = N;
+    PF_TRY(c->seeds.ensure(sizeof(uint64_t) * P));
+    PF_TRY(h2d(c, c->seeds.p, seeds, sizeof(uint64_t) * P));
+    PF_TRY(c->logp.ensure(sizeof(double) * P * N));
+    PF_TRY(c->logq.ensure(sizeof(double) * P * N));
+    PF_TRY(c->elbo.ensure(sizeof(double) * P));
+    PF_TRY(c->se.ensure(sizeof(double) * P));
+    PF_TRY(c->best_iter.ensure(sizeof(int64_t) * c->K));
+    // list of fits = every point that is not the first of its path (fit_distributions[2:end])
+    std::vector<int32_t> list;
+    std::vector<uint64_t> lseeds;
+    list.reserve((size_t)P);
+    for (int k = 0; k < c->K; ++k)
+        for (int64_t p = c->off[k] + 1; p < c->off[k + 1]; ++p) { list.push_back((int32_t)p); lseeds.push_back(seeds[p]); }
+    const int64_t nf = (int64_t)list.size();
+    PF_TRY(c->fit_list.ensure(sizeof(int32_t) * (nf > 0 ? nf : 1) + sizeof(uint64_t) * (nf > 0 ? nf : 1) + 16));
+    int32_t *d_list = c->fit_list.as<int32_t>();
+    uint64_t *d_lseeds = reinterpret_cast<uint64_t *>(c->fit_list.as<char>() + ((sizeof(int32_t) * (nf > 0 ? nf : 1) + 7) / 8) * 8);
+    PF_TRY(h2d(c, d_list, list.data(), sizeof(int32_t) * nf));
+    PF_TRY(h2d(c, d_lseeds, lseeds.data(), sizeof(uint64_t) * nf));
+    const double *d_u = nullptr;
+    if (u_host) {
+        PF_TRY(c->ubuf.ensure(sizeof(double) * (size_t)P * d * N));
+        PF_TRY(h2d(c, c->ubuf.p, u_host, sizeof(double) * (size_t)P * d * N));
+        d_u = c->ubuf.as<double>();
+    }
+    const int64_t ustride = (int64_t)d * N;
+    if (c->target.kind != PFMI_TARGET_HOST_CALLBACK) {
+        PF_TRY(pf_launch_elbo_draws(c, d_list, d_lseeds, nf, 0, N, d_u, ustride, nullptr, 0, c->logp.as<double>(),
+                                    c->logq.as<double>(), N, true, true));
+    } else {
+        // host closure: materialise the draws of a chunk of fits, copy to the host, evaluate, upload
+        const int64_t per = (int64_t)d * N;
+        int64_t chunk = (int64_t)((256ll << 20) / (sizeof(double) * (size_t)per));
+        if (chunk < 1) chunk = 1;
+        if (chunk > nf) chunk = nf > 0 ? nf : 1;
+        PF_TRY(c->xbuf.ensure(sizeof(double) * (size_t)chunk * per));
+        PF_TRY(c->scratch.ensure(sizeof(double) * (size_t)chunk * N));
+        for (int64_t s0 = 0; s0 < nf; s0 += chunk) {
+            const int64_t ns = (nf - s0 < chunk) ? nf - s0 : chunk;
+            PF_TRY(pf_launch_elbo_draws(c, d_list + s0, d_lseeds + s0, ns, 0, N, d_u, ustride, c->xbuf.as<double>(), per,
+                                        c->logp.as<double>(), c->logq.as<double>(), N, false, true));
+            PF_TRY(callback_logp(c, c->xbuf.as<double>(), ns * N, c->scratch.as<double>()));
+            for (int64_t s = 0; s < ns; ++s)   // scatter into the point-indexed logp table
+                PF_HIP(hipMemcpyAsync(c->logp.as<double>() + (size_t)list[(size_t)(s0 + s)] * N,
+                                      c->scratch.as<double>() + (size_t)s * N, sizeof(double) * N,
+                                      hipMemcpyDeviceToDevice, c->stream));
+        }
+    }
+    PF_TRY(pf_launch_elbo_reduce(c));
+    c->elbo_done = true;
+    if (elbo) PF_TRY(d2h(c, elbo, c->elbo.p, sizeof(double) * P));
+    if (se) PF_TRY(d2h(c, se, c->se.p, sizeof(double) * P));
+    if (best_iter) PF_TRY(d2h(c, best_iter, c->best_iter.p, sizeof(int64_t) * c->K));
+    PF_HIP(hipStreamSynchronize(c->stream));
+    return PFMI_OK;
+}
+
+int32_t pfmi_get_elbo_logs(pfmi_ctx *c, int64_t p, double *logp, double *logq) {
+    PF_CTX(c);
+    PF_CHECK(c->elbo_done, PFMI_ERR_STATE, "get_elbo_logs: call pfmi_elbo_batch first");
+    PF_CHECK(p >= 0 && p < c->P, PFMI_ERR_ARG, "point out of range");
+    if (logp) PF_TRY(d2h(c, logp, c->logp.as<double>() + (size_t)p * c->N_e, sizeof(double) * c->N_e));
+    if (logq) PF_TRY(d2h(c, logq, c->logq.as<double>() + (size_t)p * c->N_e, sizeof(double) * c->N_e));
+    return PFMI_OK;
+}
+
+int32_t pfmi_draws(pfmi_ctx *c, int64_t p, uint64_t seed, int64_t n0, int64_t N, const double *u_host, double *X,
+                   double *logp, double *logq) {
+    PF_CTX(c);
+    PF_CHECK(c->fitted, PFMI_ERR_STATE, "draws: call pfmi_fit_batch first");
+    PF_CHECK(p >= 0 && p < c->P && N >= 1 && n0 >= 0, PFMI_ERR_ARG, "draws: bad arguments");
+    const int d = c->d;
+    const bool have_t = c->target.kind >= 0 && c->target.d == d;
+    PF_TRY(c->xbuf.ensure(sizeof(double) * (size_t)d * N));
+    PF_TRY(c->scratch.ensure(sizeof(double) * 2 * N + 64));
+    double *d_lp = c->scratch.as<double>(), *d_lq = d_lp + N;
+    int32_t *d_pt = reinterpret_cast<int32_t *>(d_lq + N);
+    uint64_t *d_sd = reinterpret_cast<uint64_t *>(d_lq + N) + 1;
+    const int32_t pt = (int32_t)p;
+    PF_TRY(h2d(c, d_pt, &pt, sizeof(int32_t)));
+    PF_TRY(h2d(c, d_sd, &seed, sizeof(uint64_t)));
+    const double *d_u = nullptr;
+    if (u_host) {
+        PF_TRY(c->ubuf.ensure(sizeof(double) * (size_t)d * N));
+        PF_TRY(h2d(c, c->ubuf.p, u_host, sizeof(double) * (size_t)d * N));
+        d_u = c->ubuf.as<double>();
+    }
+    const bool cb = have_t && c->target.kind == PFMI_TARGET_HOST_CALLBACK;
+    PF_TRY(pf_launch_elbo_draws(c, d_pt, d_sd, 1, n0, N, d_u, 0, c->xbuf.as<double>(), 0, d_lp, d_lq, N,
+                                have_t && !cb, false));
+    if (cb) PF_TRY(callback_logp(c, c->xbuf.as<double>(), N, d_lp));
+    if (X) PF_TRY(d2h(c, X, c->xbuf.p, sizeof(double) * (size_t)d * N));
+    if (logp) PF_TRY(d2h(c, logp, d_lp, sizeof(double) * N));
+    if (logq) PF_TRY(d2h(c, logq, d_lq, sizeof(double) * N));
+    return PFMI_OK;
+}
+
+int32_t pfmi_logpdf(pfmi_ctx *c, int64_t p, int64_t N, const double *X, double *out) {
+    PF_CTX(c);
+    PF_CHECK(c->fitted, PFMI_ERR_STATE, "logpdf: call pfmi_fit_batch first");
+    PF_CHECK(p >= 0 && p < c->P && N >= 1 && X && out, PFMI_ERR_ARG, "logpdf: bad arguments");
+    PF_TRY(c->xbuf.ensure(sizeof(double) * (size_t)c->d * N));
+    PF_TRY(c->scratch.ensure(sizeof(double) * N));
+    PF_TRY(h2d(c, c->xbuf.p, X, sizeof(double) * (size_t)c->d * N));
+    PF_TRY(pf_launch_logpdf(c, p, N, c->xbuf.as<double>(), c->scratch.as<double>()));
+    PF_TRY(d2h(c, out, c->scratch.p, sizeof(double) * N));
+    return PFMI_OK;
+}
+
+// ---- pool / PSIS / resample ---------------------------------------------------------------------------
+int32_t pfmi_pool_build(pfmi_ctx *c, int64_t N_r, const int64_t *points, const uint64_t *seeds) {
+    PF_CTX(c);
+    PF_CHECK(c->fitted, PFMI_ERR_STATE, "pool_build: call pfmi_fit_batch first");
+    PF_CHECK(c->target.kind >= 0, PFMI_ERR_STATE, "pool_build: call pfmi_set_target first");
+    PF_CHECK(N_r >= 1 && points && seeds, PFMI_ERR_ARG, "pool_build: bad arguments");
+    const int K = c->K, d = c->d;
+    std::vector<int32_t> pts((size_t)K);
+    for (int k = 0; k < K; ++k) {
+        PF_CHECK(points[k] >= c->off[k] && points[k] < c->off[k + 1], PFMI_ERR_ARG,
+                 "pool_build: point %lld does not belong to path %d", (long long)points[k], k);
+        pts[(size_t)k] = (int32_t)points[k];
+    }
+    c->N_r = N_r;
+    const size_t S = (size_t)K * N_r;
+    PF_TRY(c->pool.ensure(sizeof(double) * S * d));
+    PF_TRY(c->pool_lr.ensure(sizeof(double) * S));
+    PF_TRY(c->pool_lp.ensure(sizeof(double) * S));
+    PF_TRY(c->pool_lq.ensure(sizeof(double) * S));
+    PF_TRY(c->pool_points.ensure(sizeof(int32_t) * K));
+    PF_TRY(c->pool_seeds.ensure(sizeof(uint64_t) * K));
+    PF_TRY(h2d(c, c->pool_points.p, pts.data(), sizeof(int32_t) * K));
+    PF_TRY(h2d(c, c->pool_seeds.p, seeds, sizeof(uint64_t) * K));
+    const bool cb = c->target.kind == PFMI_TARGET_HOST_CALLBACK;
+    PF_TRY(pf_launch_elbo_draws(c, c->pool_points.as<int32_t>(), c->pool_seeds.as<uint64_t>(), K, 0, N_r, nullptr, 0,
+                                c->pool.as<double>(), (int64_t)N_r * d, c->pool_lp.as<double>(),
+                                c->pool_lq.as<double>(), N_r, !cb, false));
+    if (cb) PF_TRY(callback_logp(c, c->pool.as<double>(), (int64_t)S, c->pool_lp.as<double>()));
+    PF_TRY(pf_launch_logratio(c, (int64_t)S));
+    c->pooled = true;
+    return PFMI_OK;
+}
+
+int32_t pfmi_pool_get(pfmi_ctx *c, double *draws, double *log_ratios) {
+    PF_CTX(c);
+    PF_CHECK(c->pooled, PFMI_ERR_STATE, "pool_get: call pfmi_pool_build first");
+    const size_t S = (size_t)c->K * c->N_r;
+    if (draws) PF_TRY(d2h(c, draws, c->pool.p, sizeof(double) * S * c->d));
+    if (log_ratios) PF_TRY(d2h(c, log_ratios, c->pool_lr.p, sizeof(double) * S));
+    return PFMI_OK;
+}
+
+int32_t pfmi_pool_log_ratios_dev(pfmi_ctx *c, void **dev_ptr, int64_t *count) {
+    PF_CTX(c);
+    PF_CHECK(c->pooled, PFMI_ERR_STATE, "pool_log_ratios_dev: call pfmi_pool_build first");
+    PF_HIP(hipStreamSynchronize(c->stream));
+    if (dev_ptr) *dev_ptr = c->pool_lr.p;
+    if (count) *count = (int64_t)c->K * c->N_r;
+    return PFMI_OK;
+}
+
+int32_t pfmi_psis_dev(pfmi_ctx *c, const void *lr_dev, int64_t S, double *weights, double *log_weights,
+                      double *pareto_k, int64_t *tail_len) {
+    PF_CTX(c);
+    PF_CHECK(lr_dev != nullptr && S > 0, PFMI_ERR_ARG, "psis: bad arguments");
+    PF_TRY(pf_launch_psis(c, reinterpret_cast<const double *>(lr_dev), S));
+    double out[4];
+    PF_TRY(d2h(c, out, c->psis_out.p, sizeof(out)));
+    if (pareto_k) *pareto_k = out[0];
+    if (tail_len) *tail_len = (int64_t)out[1];
+    if (weights) PF_TRY(d2h(c, weights, c->w.p, sizeof(double) * S));
+    if (log_weights) PF_TRY(d2h(c, log_weights, c->lw.p, sizeof(double) * S));
+    return PFMI_OK;
+}
+
+int32_t pfmi_psis(pfmi_ctx *c, const double *lr, int64_t S, double *weights, double *log_weights, double *pareto_k,
+                  int64_t *tail_len) {
+    PF_CTX(c);
+    PF_CHECK(lr != nullptr && S > 0, PFMI_ERR_ARG, "psis: bad arguments");
+    PF_TRY(c->gbuf.ensure(sizeof(double) * S));
+    PF_TRY(h2d(c, c->gbuf.p, lr, sizeof(double) * S));
+    return pfmi_psis_dev(c, c->gbuf.p, S, weights, log_weights, pareto_k, tail_len);
+}
+
+int32_t pfmi_resample_indices(pfmi_ctx *c, int64_t S, int64_t ndraws, int32_t importance, int32_t replace,
+                              uint64_t seed, const double *uniforms, int64_t *idx) {
+    PF_CTX(c);
+    PF_CHECK(S > 0 && ndraws >= 0, PFMI_ERR_ARG, "resample: bad arguments");
+    PF_CHECK(!importance || c->S_w == S, PFMI_ERR_STATE,
+             "resample: importance weights for S=%lld not available (run pfmi_psis first)", (long long)S);
+    const double *d_uni = nullptr;
+    if (uniforms && ndraws > 0) {
+        PF_TRY(c->tailbuf.ensure(sizeof(double) * ndraws));
+        PF_TRY(h2d(c, c->tailbuf.p, uniforms, sizeof(double) * ndraws));
+        d_uni = c->tailbuf.as<double>();
+    }
+    PF_TRY(pf_launch_resample(c, S, ndraws, importance, replace, seed, d_uni));
+    if (idx && ndraws > 0) PF_TRY(d2h(c, idx, c->idx.p, sizeof(int64_t) * ndraws));
+    return PFMI_OK;
+}
+
+int32_t pfmi_pool_gather_dev(pfmi_ctx *c, int64_t ndraws, const int64_t *idx, int64_t col_offset, void *draws_dev) {
+    PF_CTX(c);
+    PF_CHECK(c->pooled, PFMI_ERR_STATE, "pool_gather: call pfmi_pool_build first");
+    PF_CHECK(ndraws >= 0 && idx && draws_dev, PFMI_ERR_ARG, "pool_gather: bad arguments");
+    PF_TRY(c->idx.ensure(sizeof(int64_t) * (ndraws > 0 ? ndraws : 1)));
+    PF_TRY(h2d(c, c->idx.p, idx, sizeof(int64_t) * ndraws));
+    PF_TRY(pf_launch_gather(c, ndraws, c->idx.as<int64_t>(), col_offset, reinterpret_cast<double *>(draws_dev)));
+    PF_HIP(hipStreamSynchronize(c->stream));
+    return PFMI_OK;
+}
+
+int32_t pfmi_pool_gather(pfmi_ctx *c, int64_t ndraws, const int64_t *idx, int64_t col_offset, double *draws) {
+    PF_CTX(c);
+    PF_CHECK(draws != nullptr, PFMI_ERR_ARG, "pool_gather: null output");
+    PF_TRY(c->gbuf.ensure(sizeof(double) * (size_t)(ndraws > 0 ? ndraws : 1) * c->d));
+    PF_TRY(pfmi_pool_gather_dev(c, ndraws, idx, col_offset, c->gbuf.p));
+    PF_TRY(d2h(c, draws, c->gbuf.p, sizeof(double) * (size_t)ndraws * c->d));
+    return PFMI_OK;
+}
+
+// ---- device utilities ----------------------------------------------------------------------------------
+int32_t pfmi_malloc_dev(pfmi_ctx *c, int64_t bytes, void **dev_ptr) {
+    PF_CTX(c);
+    PF_CHECK(dev_ptr != nullptr && bytes > 0, PFMI_ERR_ARG, "malloc_dev: bad arguments");
+    PF_HIP(hipMalloc(dev_ptr, (size_t)bytes));
+    return PFMI_OK;
+}
+int32_t pfmi_free_dev(pfmi_ctx *c, void *dev_ptr) {
+    PF_CTX(c);
+    if (dev_ptr) PF_HIP(hipFree(dev_ptr));
+    return PFMI_OK;
+}
+int32_t pfmi_memcpy_h2d(pfmi_ctx *c, void *dst, const void *src, int64_t bytes) {
+    PF_CTX(c);
+    return h2d(c, dst, src, (size_t)bytes);
+}
+int32_t pfmi_memcpy_d2h(pfmi_ctx *c, void *dst, const void *src, int64_t bytes) {
+    PF_CTX(c);
+    return d2h(c, dst, src, (size_t)bytes);
+}
+
+}  // extern "C"

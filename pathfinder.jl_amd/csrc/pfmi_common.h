@@ -1,0 +1,229 @@
+// pfmi_common.h -- shared declarations of the HIP implementation behind include/pfmi.h (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <map>
+#include <vector>
+
+#include "../../include/pfmi.h"
+
+#define PF_LOG2PI 1.8378770664093454835606594728112352797227949472755668
+
+// ---- error handling ------------------------------------------------------------------------------
+void pf_set_error(const char *fmt, ...);
+#define PF_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e__ = (call);                                                                  \
+        if (e__ != hipSuccess) {                                                                  \
+            pf_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return PFMI_ERR_HIP;                                                                  \
+        }                                                                                         \
+    } while (0)
+#define PF_CHECK(cond, code, ...)                                                                 \
+    do {                                                                                          \
+        if (!(cond)) {                                                                            \
+            pf_set_error(__VA_ARGS__);                                                            \
+            return (code);                                                                        \
+        }                                                                                         \
+    } while (0)
+#define PF_TRY(expr)                                                                              \
+    do {                                                                                          \
+        int32_t rc__ = (expr);                                                                    \
+        if (rc__ != PFMI_OK) return rc__;                                                         \
+    } while (0)
+
+// ---- growable device buffer ------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int32_t ensure(size_t bytes) {
+        if (bytes <= cap) return PFMI_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes < 256 ? 256 : bytes;
+        PF_HIP(hipMalloc(&p, want));
+        cap = want;
+        return PFMI_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct KernelStat { double ms = 0.0; int64_t launches = 0; };
+
+// device-resident target description (Gaussian family rows are stored row-major for scalar loads)
+struct TargetDev {
+    int32_t kind = -1, d = 0, r = 0, rpad = 0;
+    double offset = 0.0;
+    DevBuf mean, a, wd /* [d][rpad] row-major */, g /* [rpad][rpad] row-major, lower */;
+    pfmi_logp_fn fn = nullptr;
+    void *user = nullptr;
+};
+
+struct pfmi_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, kev0 = nullptr, kev1 = nullptr;
+    bool profile = false;
+    std::map<std::string, KernelStat> kstats;
+
+    // traces
+    int32_t K = 0, d = 0;
+    int64_t P = 0;
+    std::vector<int64_t> off;      // K+1 point offsets (host)
+    std::vector<int32_t> path_of;  // P
+    DevBuf theta, grad, d_off /* int64 K+1 */, d_path_of /* int32 P */;
+    TargetDev target;
+
+    // fit state
+    bool fitted = false;
+    int32_t J = 0, kpad = 0;
+    DevBuf alpha_all;   // [P][d]
+    DevBuf hist_len;    // int32 [P]
+    DevBuf hist_src;    // int32 [P][J]
+    DevBuf n_rej;       // int32 [K]
+    DevBuf vh;          // [P][d][kpad] row-major Householder vectors (explicit unit diagonal)
+    DevBuf tmat;        // [P][kpad][kpad] compact-WY T (row-major, upper)
+    DevBuf vchol;       // [P][kpad][kpad] upper Cholesky factor V (row-major), identity padded
+    DevBuf rq;          // [P][kpad][kpad] R factor of the QR (row-major, rows < k)
+    DevBuf dmat;        // [P][kpad][kpad] Byrd D (row-major, m x m block)
+    DevBuf sqrt_alpha;  // [P][d]
+    DevBuf mu;          // [P][d]
+    DevBuf logdet;      // [P]
+    DevBuf status;      // int32 [P]
+
+    // ELBO state
+    bool elbo_done = false;
+    int64_t N_e = 0;
+    DevBuf seeds;       // u64 [P]
+    DevBuf logp, logq;  // [P][N_e]
+    DevBuf elbo, se;    // [P]
+    DevBuf best_iter;   // int64 [K]
+    DevBuf fit_list;    // int32 list of points to process
+    DevBuf ubuf;        // parity-mode normals
+    DevBuf xbuf;        // scratch draws (callback path / pfmi_draws)
+    DevBuf scratch;     // misc
+
+    // pool / PSIS / resample state
+    bool pooled = false;
+    int64_t N_r = 0;
+    DevBuf pool;        // [K][N_r][d]  == column-major (d, N_r, K)
+    DevBuf pool_lr;     // [K*N_r]
+    DevBuf pool_lp, pool_lq;
+    DevBuf pool_points; // int32 [K]
+    DevBuf pool_seeds;  // u64 [K]
+    int64_t S_w = 0;
+    DevBuf lw;          // [S] smoothed, normalised log weights
+    DevBuf w;           // [S] weights
+    DevBuf psis_out;    // [4] pareto_k, tail_len, ...
+    DevBuf tailbuf;     // tail keys / idx
+    DevBuf cdf;         // u64 [S]
+    DevBuf idx;         // int64 [ndraws]
+    DevBuf gbuf;        // gather output
+};
+
+// ---- launch helpers (implemented in the .hip files) ----------------------------------------------
+int32_t pf_launch_history(pfmi_ctx *c, double eps);
+int32_t pf_launch_fit(pfmi_ctx *c);
+int32_t pf_launch_elbo_draws(pfmi_ctx *c, const int32_t *d_points, const uint64_t *d_seeds, int64_t nfits,
+                             int64_t n0, int64_t N, const double *d_u, int64_t u_stride,
+                             double *d_x, int64_t x_stride, double *d_logp, double *d_logq,
+                             int64_t log_stride, bool with_target, bool by_point);
+int32_t pf_launch_elbo_reduce(pfmi_ctx *c);
+int32_t pf_launch_logpdf(pfmi_ctx *c, int64_t point, int64_t N, const double *d_x, double *d_out);
+int32_t pf_launch_psis(pfmi_ctx *c, const double *d_lr, int64_t S);
+int32_t pf_launch_resample(pfmi_ctx *c, int64_t S, int64_t ndraws, int importance, int replace,
+                           uint64_t seed, const double *d_uniforms);
+int32_t pf_launch_gather(pfmi_ctx *c, int64_t ndraws, const int64_t *d_idx, int64_t col_offset, double *d_out);
+int32_t pf_launch_logratio(pfmi_ctx *c, int64_t n);
+
+void pf_kernel_begin(pfmi_ctx *c);
+void pf_kernel_end(pfmi_ctx *c, const char *name);
+
+// ---- device helpers ----------------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+// Philox4x32-10 (Salmon et al. 2011); identical bit stream to oracle/pf_oracle.c:pfo_philox4x32_10
+__device__ __forceinline__ void pf_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                 uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// four standard normals for rows 4g..4g+3 of draw n (Box-Muller on 32-bit uniforms (x+0.5)2^-32)
+__device__ __forceinline__ void pf_randn4(uint64_t seed, uint32_t g, uint32_t n, uint32_t stream, double (&z)[4]) {
+    uint32_t x[4];
+    pf_philox4x32_10(g, n, stream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+    const double S = 2.3283064365386962890625e-10;  // 2^-32
+    double u0 = ((double)x[0] + 0.5) * S, u1 = ((double)x[1] + 0.5) * S;
+    double u2 = ((double)x[2] + 0.5) * S, u3 = ((double)x[3] + 0.5) * S;
+    double r0 = sqrt(-2.0 * log(u0)), r1 = sqrt(-2.0 * log(u2));
+    double s, c;
+    sincospi(2.0 * u1, &s, &c); z[0] = r0 * c; z[1] = r0 * s;
+    sincospi(2.0 * u3, &s, &c); z[2] = r1 * c; z[3] = r1 * s;
+}
+
+__device__ __forceinline__ uint64_t pf_rand_u64(uint64_t seed, uint64_t t, uint32_t stream) {
+    uint32_t x[4];
+    pf_philox4x32_10((uint32_t)t, (uint32_t)(t >> 32), stream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+    return (uint64_t)x[0] | ((uint64_t)x[1] << 32);
+}
+
+// wave64 butterfly sum: every lane ends with the total; fixed order -> deterministic
+__device__ __forceinline__ double pf_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double pf_wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// Block-wide sum of NV values per thread.  `red` is LDS scratch of (blockDim.x/64)*NV doubles.
+// On return every thread holds the totals in v[].  Waves are combined in wave-index order.
+template <int NV>
+__device__ __forceinline__ void pf_block_sum(double (&v)[NV], double *red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = pf_wave_sum(v[i]);
+    __syncthreads();  // protect `red` from a previous use
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) red[wave * NV + i] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double s = red[i];
+        for (int w = 1; w < nw; ++w) s += red[w * NV + i];
+        v[i] = s;
+    }
+}
+__device__ __forceinline__ double pf_block_sum1(double x, double *red) {
+    double v[1] = {x};
+    pf_block_sum<1>(v, red);
+    return v[0];
+}
+__device__ __forceinline__ double pf_block_max1(double x, double *red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    x = pf_wave_max(x);
+    __syncthreads();
+    if (lane == 0) red[wave] = x;
+    __syncthreads();
+    double s = red[0];
+    for (int w = 1; w < nw; ++w) s = fmax(s, red[w]);
+    return s;
+}
+#endif  // __HIPCC__

@@ -1,0 +1,379 @@
+// psis_kernels.hip -- Pareto-smoothed importance sampling + resampling over the pooled draws (gfx950).
+//
+//   pf_psis_kernel     : PSIS.psis(log_ratios) (called at reference src/resample.jl:78; algorithm of
+//                        Vehtari et al. 2024 with the Zhang-Stephens GPD fit, as in PSIS.jl 0.9).
+//                        One 1024-thread workgroup: radix-select of the (M+1) largest log ratios
+//                        ((value, index) composite order -> deterministic under ties), LDS bitonic
+//                        sort of the tail, GPD profile-likelihood grid (one wave per theta), tail
+//                        replacement by GPD quantiles, logsumexp normalisation.
+//   pf_cdf_kernel      : exact fixed-point CDF (u64 prefix sums of floor(w 2^62)); integer arithmetic
+//                        makes the table independent of summation order, launch geometry and GPU count.
+//   pf_sample_kernel   : inverse-CDF index draw (stands in for StatsBase.sample, src/resample.jl:61-66).
+//   pf_norep_kernel    : Efraimidis-Spirakis sampling without replacement (replace = false).
+//   pf_gather_kernel   : draws = draws_all[:, inds] (src/resample.jl:68).
+#include "pfmi_common.h"
+
+#define PSIS_THREADS 1024
+#define TAILCAP 4096
+
+__device__ __forceinline__ uint64_t pf_key_of(double x) {   // order-preserving map double -> u64
+    uint64_t b = (uint64_t)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double pf_val_of(uint64_t k) {
+    uint64_t b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+struct SelectState {
+    unsigned hist[256];
+    unsigned long long prefix;
+    long long remaining;
+    unsigned count;
+};
+
+// Select the R largest elements of vals[0..S) in (value, index) order.  On return (all threads):
+// tkeys/tidx [0..R) hold them sorted ASCENDING (LDS).  Requires R <= TAILCAP, blockDim = PSIS_THREADS.
+__device__ void pf_select_top_sorted(const double *__restrict__ vals, long long S, int R, uint64_t *tkeys,
+                                     uint32_t *tidx, SelectState *st) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    // ---- radix select of the R-th largest key
+    if (tid == 0) { st->prefix = 0ull; st->remaining = R; }
+    __syncthreads();
+    for (int pass = 7; pass >= 0; --pass) {
+        for (int b = tid; b < 256; b += nt) st->hist[b] = 0u;
+        __syncthreads();
+        const unsigned long long prefix = st->prefix;
+        const unsigned long long himask = (pass == 7) ? 0ull : (~0ull << (8 * (pass + 1)));
+        for (long long i = tid; i < S; i += nt) {
+            const uint64_t k = pf_key_of(vals[i]);
+            if ((k & himask) == prefix) atomicAdd(&st->hist[(unsigned)((k >> (8 * pass)) & 0xFF)], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            long long rem = st->remaining;
+            int b = 255;
+            for (; b > 0; --b) {
+                if ((long long)st->hist[b] >= rem) break;
+                rem -= st->hist[b];
+            }
+            st->remaining = rem;
+            st->prefix = prefix | ((unsigned long long)b << (8 * pass));
+        }
+        __syncthreads();
+    }
+    const uint64_t tk = st->prefix;          // threshold key; st->remaining of the equal-key elements are needed
+    const long long need_eq = st->remaining;
+    __syncthreads();
+    // ---- among key == tk take the `need_eq` LARGEST indices: radix select on the index
+    if (tid == 0) { st->prefix = 0ull; st->remaining = need_eq; }
+    __syncthreads();
+    for (int pass = 3; pass >= 0; --pass) {
+        for (int b = tid; b < 256; b += nt) st->hist[b] = 0u;
+        __syncthreads();
+        const unsigned long long prefix = st->prefix;
+        const unsigned long long himask = (pass == 3) ? 0ull : ((~0ull << (8 * (pass + 1))) & 0xFFFFFFFFull);
+        for (long long i = tid; i < S; i += nt) {
+            if (pf_key_of(vals[i]) == tk && (((unsigned long long)i) & himask) == prefix)
+                atomicAdd(&st->hist[(unsigned)((i >> (8 * pass)) & 0xFF)], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            long long rem = st->remaining;
+            int b = 255;
+            for (; b > 0; --b) {
+                if ((long long)st->hist[b] >= rem) break;
+                rem -= st->hist[b];
+            }
+            st->remaining = rem;
+            st->prefix = prefix | ((unsigned long long)b << (8 * pass));
+        }
+        __syncthreads();
+    }
+    const unsigned long long ti = st->prefix;   // index threshold
+    // ---- compact the selected elements into LDS, pad with sentinels, bitonic sort ascending
+    int npow = 1;
+    while (npow < R) npow <<= 1;
+    for (int t = tid; t < npow; t += nt) { tkeys[t] = ~0ull; tidx[t] = 0xFFFFFFFFu; }
+    if (tid == 0) st->count = 0u;
+    __syncthreads();
+    for (long long i = tid; i < S; i += nt) {
+        const uint64_t k = pf_key_of(vals[i]);
+        if (k > tk || (k == tk && (unsigned long long)i >= ti)) {
+            const unsigned slot = atomicAdd(&st->count, 1u);
+            if (slot < (unsigned)TAILCAP) { tkeys[slot] = k; tidx[slot] = (uint32_t)i; }
+        }
+    }
+    __syncthreads();
+    for (int size = 2; size <= npow; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < npow / 2; t += nt) {
+                const int lo = 2 * t - (t & (stride - 1));   // index with bit `stride` clear
+                const int hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const uint64_t ka = tkeys[lo], kb = tkeys[hi];
+                const uint32_t ia = tidx[lo], ib = tidx[hi];
+                const bool a_gt_b = (ka > kb) || (ka == kb && ia > ib);
+                if (a_gt_b == up) { tkeys[lo] = kb; tkeys[hi] = ka; tidx[lo] = ib; tidx[hi] = ia; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// out[0] = pareto_k, out[1] = tail length M, out[2] = sigma (scaled), out[3] = logsumexp
+__global__ __launch_bounds__(PSIS_THREADS) void pf_psis_kernel(long long S, const double *__restrict__ lr,
+                                                               double *__restrict__ lw, double *__restrict__ wout,
+                                                               double *__restrict__ out, int M) {
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    __shared__ uint64_t tkeys[TAILCAP];   // reused as double w[] after the sort
+    __shared__ uint32_t tidx[TAILCAP];
+    __shared__ SelectState st;
+    __shared__ double red[PSIS_THREADS / 64];
+    __shared__ double s_theta[128], s_ll[128];
+    __shared__ double s_k, s_sigma, s_mu, s_lmax;
+    __shared__ int s_ok;
+
+    for (long long i = tid; i < S; i += nt) lw[i] = lr[i];
+    double pareto_k = NAN;
+    if (tid == 0) { s_ok = 0; s_k = NAN; s_sigma = NAN; }
+    __syncthreads();
+    if (M >= 5 && M + 1 <= TAILCAP && (long long)(M + 1) <= S) {
+        pf_select_top_sorted(lr, S, M + 1, tkeys, tidx, &st);
+        // tkeys[0] = cutoff, tkeys[1..M] = the M largest, ascending
+        double *w = reinterpret_cast<double *>(tkeys);
+        const double logu = pf_val_of(tkeys[0]);
+        const double lmax = pf_val_of(tkeys[M]);
+        double bad = 0.0;
+        for (int t = 1 + tid; t <= M; t += nt) if (!isfinite(pf_val_of(tkeys[t]))) bad = 1.0;
+        bad = pf_block_sum1(bad, red);
+        __syncthreads();
+        if (bad == 0.0) {
+            const double mu_s = exp(logu - lmax);
+            double vals[(TAILCAP + PSIS_THREADS - 1) / PSIS_THREADS];
+            double nz = 0.0;
+#pragma unroll
+            for (int q = 0; q < (TAILCAP + PSIS_THREADS - 1) / PSIS_THREADS; ++q) {
+                const int t = tid + q * nt;          // tail element t (0-based) lives at tkeys[t + 1]
+                vals[q] = (t < M) ? (exp(pf_val_of(tkeys[t + 1]) - lmax) - mu_s) : 0.0;
+                if (t < M && vals[q] != 0.0) nz = 1.0;
+            }
+            nz = pf_block_sum1(nz, red);
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < (TAILCAP + PSIS_THREADS - 1) / PSIS_THREADS; ++q) {
+                const int t = tid + q * nt;
+                if (t < M) w[t] = vals[q];           // tail idx t is tidx[t + 1]
+            }
+            __syncthreads();
+            if (nz > 0.0) {
+                // ---- Zhang & Stephens (2009) profile likelihood on a grid of m theta values
+                const int mest = 30 + (int)floor(sqrt((double)M));
+                const double xstar = w[(M + 2) / 4 - 1], xmax = w[M - 1];
+                for (int i = wave; i < mest; i += nw) {
+                    const double p = ((double)(i + 1) - 0.5) / (double)mest;
+                    const double theta = 1.0 / xmax + (1.0 - sqrt(1.0 / p)) / (3.0 * xstar);
+                    double kk = 0.0;
+                    for (int t = lane; t < M; t += 64) kk += log1p(-theta * w[t]);
+                    kk = pf_wave_sum(kk) / (double)M;
+                    if (lane == 0) {
+                        s_theta[i] = theta;
+                        s_ll[i] = (double)M * (log(-theta / kk) - kk - 1.0);
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    double lmx = -INFINITY;
+                    for (int i = 0; i < mest; ++i) if (s_ll[i] > lmx) lmx = s_ll[i];
+                    double ws = 0.0, ts = 0.0;
+                    for (int i = 0; i < mest; ++i) { const double e = exp(s_ll[i] - lmx); ws += e; ts += e * s_theta[i]; }
+                    s_mu = ts / ws;   // posterior-mean theta
+                }
+                __syncthreads();
+                const double th = s_mu;
+                double kk = 0.0;
+                for (int t = tid; t < M; t += nt) kk += log1p(-th * w[t]);
+                kk = pf_block_sum1(kk, red) / (double)M;
+                const double sigma = -kk / th;
+                double kadj = kk;
+                if (isfinite(kk)) kadj = (kk * (double)M + 5.0) / ((double)M + 10.0);   // prior adjustment
+                pareto_k = kadj;
+                if (isfinite(kadj) && isfinite(sigma)) {
+                    for (int t = tid; t < M; t += nt) {
+                        const double p = ((double)(t + 1) - 0.5) / (double)M;
+                        const double nl = -log1p(-p);
+                        const double z = (kadj == 0.0) ? nl : expm1(kadj * nl) / kadj;
+                        double v = log(sigma * z + mu_s);
+                        if (v > 0.0) v = 0.0;
+                        lw[tidx[t + 1]] = v + lmax;
+                    }
+                }
+                if (tid == 0) s_sigma = sigma;
+            }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- log-normalise: lw -= logsumexp(lw); weights = exp(lw)
+    double mx = -INFINITY;
+    for (long long i = tid; i < S; i += nt) mx = fmax(mx, lw[i]);
+    mx = pf_block_max1(mx, red);
+    __syncthreads();
+    double se = 0.0;
+    if (isfinite(mx)) for (long long i = tid; i < S; i += nt) se += exp(lw[i] - mx);
+    se = pf_block_sum1(se, red);
+    const double lse = isfinite(mx) ? mx + log(se) : mx;
+    for (long long i = tid; i < S; i += nt) {
+        const double v = lw[i] - lse;
+        lw[i] = v;
+        wout[i] = exp(v);
+    }
+    if (tid == 0) { out[0] = pareto_k; out[1] = (double)M; out[2] = s_sigma; out[3] = lse; }
+}
+
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t pf_weight_to_fixed(double w) {
+    if (!(w > 0.0)) return 0ull;
+    if (w >= 1.0) return 1ull << 62;
+    return (uint64_t)floor(w * 4611686018427387904.0);   // 2^62
+}
+__device__ __forceinline__ uint64_t pf_uniform_to_bits(double u) {
+    return ((uint64_t)floor(u * 9007199254740992.0)) << 11;
+}
+// single workgroup; uniform != 0 -> every weight is 1 (importance = false)
+__global__ __launch_bounds__(PSIS_THREADS) void pf_cdf_kernel(long long S, const double *__restrict__ w,
+                                                              uint64_t *__restrict__ cdf) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    __shared__ uint64_t part[PSIS_THREADS];
+    const long long chunk = (S + nt - 1) / nt;
+    const long long i0 = (long long)tid * chunk, i1 = (i0 + chunk < S) ? i0 + chunk : S;
+    uint64_t s = 0;
+    for (long long i = i0; i < i1; ++i) s += pf_weight_to_fixed(w[i]);
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        uint64_t acc = 0;
+        for (int t = 0; t < nt; ++t) { const uint64_t v = part[t]; part[t] = acc; acc += v; }
+    }
+    __syncthreads();
+    uint64_t acc = part[tid];
+    for (long long i = i0; i < i1; ++i) { acc += pf_weight_to_fixed(w[i]); cdf[i] = acc; }
+}
+
+__global__ void pf_sample_kernel(long long S, long long ndraws, int weighted, uint64_t seed,
+                                 const double *__restrict__ uniforms, const uint64_t *__restrict__ cdf,
+                                 int64_t *__restrict__ idx, int *__restrict__ err) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ndraws) return;
+    const uint64_t R = uniforms ? pf_uniform_to_bits(uniforms[t]) : pf_rand_u64(seed, (uint64_t)t, 1u);
+    if (!weighted) { idx[t] = (int64_t)__umul64hi(R, (uint64_t)S); return; }
+    const uint64_t Q = cdf[S - 1];
+    if (Q == 0) { if (t == 0) *err = 1; idx[t] = 0; return; }
+    const uint64_t r = __umul64hi(R, Q);
+    long long lo = 0, hi = S - 1;
+    while (lo < hi) { const long long mid = (lo + hi) >> 1; if (cdf[mid] > r) hi = mid; else lo = mid + 1; }
+    idx[t] = lo;
+}
+
+// Efraimidis-Spirakis keys (negated so that the selection of the LARGEST picks the smallest keys)
+__global__ void pf_norep_keys_kernel(long long S, int weighted, uint64_t seed, const double *__restrict__ w,
+                                     double *__restrict__ negkey) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S) return;
+    const uint64_t R = pf_rand_u64(seed, (uint64_t)i, 2u);
+    const double u = ((double)(R >> 11) + 0.5) * 1.1102230246251565404e-16;
+    const double wi = weighted ? w[i] : 1.0;
+    negkey[i] = (wi > 0.0) ? -(-log(u) / wi) : -INFINITY;
+}
+__global__ __launch_bounds__(PSIS_THREADS) void pf_norep_select_kernel(long long S, int ndraws,
+                                                                       const double *__restrict__ negkey,
+                                                                       int64_t *__restrict__ idx, int *__restrict__ err) {
+    __shared__ uint64_t tkeys[TAILCAP];
+    __shared__ uint32_t tidx[TAILCAP];
+    __shared__ SelectState st;
+    pf_select_top_sorted(negkey, S, ndraws, tkeys, tidx, &st);
+    // ascending in -key  ==  descending key; emit in ascending key order (smallest key first)
+    for (int t = threadIdx.x; t < ndraws; t += blockDim.x) {
+        idx[t] = (int64_t)tidx[ndraws - 1 - t];
+        if (!isfinite(pf_val_of(tkeys[ndraws - 1 - t]))) *err = 1;   // not enough positive weights
+    }
+}
+
+// out[:, t] = owned(idx[t]) ? pool[:, idx[t] - col_offset] : 0
+__global__ void pf_gather_kernel(int d, long long ndraws, long long ncols_local, long long col_offset,
+                                 const int64_t *__restrict__ idx, const double *__restrict__ pool,
+                                 double *__restrict__ out) {
+    const long long t = blockIdx.x;
+    const long long g = idx[t] - col_offset;
+    const bool own = (g >= 0 && g < ncols_local);
+    for (int i = threadIdx.x; i < d; i += blockDim.x)
+        out[(size_t)t * d + i] = own ? pool[(size_t)g * d + i] : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+static long long psis_tail_length(long long S) {
+    long long a = (S + 4) / 5;
+    long long b = (long long)ceil(3.0 * sqrt((double)S));
+    return a < b ? a : b;
+}
+
+int32_t pf_launch_psis(pfmi_ctx *c, const double *d_lr, int64_t S) {
+    PF_CHECK(S > 0, PFMI_ERR_ARG, "psis: empty log-ratio vector");
+    PF_CHECK(S < (1ll << 32), PFMI_ERR_UNSUPPORTED, "psis: S too large");
+    const long long M = psis_tail_length(S);
+    PF_CHECK(M + 1 <= TAILCAP, PFMI_ERR_UNSUPPORTED, "psis: tail length %lld exceeds %d", M, TAILCAP - 1);
+    PF_TRY(c->lw.ensure(sizeof(double) * S));
+    PF_TRY(c->w.ensure(sizeof(double) * S));
+    PF_TRY(c->psis_out.ensure(sizeof(double) * 4));
+    pf_kernel_begin(c);
+    hipLaunchKernelGGL(pf_psis_kernel, dim3(1), dim3(PSIS_THREADS), 0, c->stream, (long long)S, d_lr,
+                       c->lw.as<double>(), c->w.as<double>(), c->psis_out.as<double>(), (int)M);
+    pf_kernel_end(c, "psis");
+    PF_HIP(hipGetLastError());
+    c->S_w = S;
+    return PFMI_OK;
+}
+
+int32_t pf_launch_resample(pfmi_ctx *c, int64_t S, int64_t ndraws, int importance, int replace, uint64_t seed,
+                           const double *d_uniforms) {
+    PF_TRY(c->idx.ensure(sizeof(int64_t) * (ndraws > 0 ? ndraws : 1)));
+    PF_TRY(c->scratch.ensure(sizeof(double) * (S > 0 ? S : 1) + 64));
+    int *d_err = reinterpret_cast<int *>(c->scratch.as<char>() + sizeof(double) * (S > 0 ? S : 1));
+    PF_HIP(hipMemsetAsync(d_err, 0, sizeof(int), c->stream));
+    pf_kernel_begin(c);
+    if (replace) {
+        if (importance) {
+            PF_TRY(c->cdf.ensure(sizeof(uint64_t) * S));
+            hipLaunchKernelGGL(pf_cdf_kernel, dim3(1), dim3(PSIS_THREADS), 0, c->stream, (long long)S,
+                               c->w.as<double>(), c->cdf.as<uint64_t>());
+        }
+        hipLaunchKernelGGL(pf_sample_kernel, dim3((unsigned)((ndraws + 255) / 256)), dim3(256), 0, c->stream,
+                           (long long)S, (long long)ndraws, importance, seed, d_uniforms, c->cdf.as<uint64_t>(),
+                           c->idx.as<int64_t>(), d_err);
+    } else {
+        PF_CHECK(ndraws <= S, PFMI_ERR_ARG, "cannot draw %lld without replacement from %lld", (long long)ndraws,
+                 (long long)S);
+        PF_CHECK(ndraws <= TAILCAP, PFMI_ERR_UNSUPPORTED, "replace=false supports at most %d draws", TAILCAP);
+        hipLaunchKernelGGL(pf_norep_keys_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, c->stream,
+                           (long long)S, importance, seed, c->w.as<double>(), c->scratch.as<double>());
+        hipLaunchKernelGGL(pf_norep_select_kernel, dim3(1), dim3(PSIS_THREADS), 0, c->stream, (long long)S,
+                           (int)ndraws, c->scratch.as<double>(), c->idx.as<int64_t>(), d_err);
+    }
+    pf_kernel_end(c, "resample");
+    PF_HIP(hipGetLastError());
+    int err = 0;
+    PF_HIP(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PF_HIP(hipStreamSynchronize(c->stream));
+    PF_CHECK(err == 0, PFMI_ERR_NUMERIC, "resample: weights are all zero / not enough positive weights");
+    return PFMI_OK;
+}
+
+int32_t pf_launch_gather(pfmi_ctx *c, int64_t ndraws, const int64_t *d_idx, int64_t col_offset, double *d_out) {
+    if (ndraws <= 0) return PFMI_OK;
+    pf_kernel_begin(c);
+    hipLaunchKernelGGL(pf_gather_kernel, dim3((unsigned)ndraws), dim3(256), 0, c->stream, c->d, (long long)ndraws,
+                       (long long)(c->K * c->N_r), (long long)col_offset, d_idx, c->pool.as<double>(), d_out);
+    pf_kernel_end(c, "resample");
+    PF_HIP(hipGetLastError());
+    return PFMI_OK;
+}

@@ -1,0 +1,75 @@
+"""ctypes binding of libpfmi.so (include/pfmi.h).  No CPU fallback: if the HIP library is missing
+or no MI355X is visible, every entry point raises."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)                      # pathfinder.jl_amd/
+_SO = os.path.join(_ROOT, "lib", "libpfmi.so")
+_lib = None
+
+
+class PfmiError(RuntimeError):
+    pass
+
+
+class pfmi_target(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("d", C.c_int32), ("r", C.c_int32), ("reserved", C.c_int32),
+                ("mean", C.POINTER(C.c_double)), ("a", C.POINTER(C.c_double)),
+                ("Wd", C.POINTER(C.c_double)), ("G", C.POINTER(C.c_double)), ("offset", C.c_double),
+                ("fn", C.c_void_p), ("user", C.c_void_p)]
+
+
+LOGP_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int32, C.c_int64, C.POINTER(C.c_double), C.c_void_p)
+
+# every symbol include/pfmi.h declares (tests/test_abi.py checks the built library exports them all)
+SYMBOLS = [
+    "pfmi_last_error", "pfmi_version", "pfmi_device_count", "pfmi_create", "pfmi_destroy", "pfmi_sync",
+    "pfmi_timer_start", "pfmi_timer_stop", "pfmi_profile", "pfmi_kernel_time", "pfmi_set_target",
+    "pfmi_set_traces", "pfmi_fit_batch", "pfmi_get_fit_status", "pfmi_get_fit", "pfmi_elbo_batch",
+    "pfmi_get_elbo_logs", "pfmi_draws", "pfmi_logpdf", "pfmi_pool_build", "pfmi_pool_get",
+    "pfmi_pool_log_ratios_dev", "pfmi_psis_dev", "pfmi_psis", "pfmi_resample_indices", "pfmi_pool_gather",
+    "pfmi_pool_gather_dev", "pfmi_malloc_dev", "pfmi_free_dev", "pfmi_memcpy_h2d", "pfmi_memcpy_d2h",
+]
+
+
+def build(force=False):
+    """Compile libpfmi.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    srcs = [os.path.join(_ROOT, "csrc", f) for f in os.listdir(os.path.join(_ROOT, "csrc"))]
+    srcs.append(os.path.join(os.path.dirname(_ROOT), "include", "pfmi.h"))
+    stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if force or stale:
+        if not os.path.exists("/opt/rocm/bin/hipcc"):
+            raise PfmiError("libpfmi.so is missing/stale and hipcc is not available to build it")
+        subprocess.check_call(["make", "-C", _ROOT, "-j8"] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    """Load libpfmi.so.  torch (when installed) is imported FIRST so that the process ends up with a
+    single HIP runtime (torch bundles its own libamdhip64 with the same SONAME)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.environ.get("PFMI_NO_TORCH") and "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover
+            pass
+    if not os.path.exists(_SO):
+        raise PfmiError(f"{_SO} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(there is no CPU fallback)")
+    L = C.CDLL(_SO, mode=C.RTLD_GLOBAL)
+    L.pfmi_last_error.restype = C.c_char_p
+    for s in SYMBOLS:
+        if s != "pfmi_last_error":
+            getattr(L, s).restype = C.c_int32
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise PfmiError(f"libpfmi error {rc}: {lib().pfmi_last_error().decode()}")

@@ -1,0 +1,401 @@
+"""Host-side mirror of the reference's public API for the hot path:
+
+    pathfinder()       reference src/singlepath.jl:142-257
+    multipathfinder()  reference src/multipath.jl:118-245
+    resample()         reference src/resample.jl:20-46
+    fit_mvnormals()    reference src/mvnormal.jl:14-21
+    maximize_elbo()    reference src/elbo.jl:1-10
+
+Same names, argument meaning and failure behaviour; the numerics run in libpfmi.so on the GPU.  Runs
+are batched: the host performs the K optimisations (each with its own seeded rng copy, as
+src/multipath.jl:190-193), then ONE fit_batch / elbo_batch / pool_build covers every path.
+
+(The north-star host language is Julia; no Julia toolchain exists in this image, so the host mirror
+is Python and the Julia `ccall` wrapper lives, untested, in pathfinder.jl_amd/julia/ -- INTEGRATION.md.)
+"""
+import warnings
+from dataclasses import dataclass, field
+from typing import Any, List, Optional
+
+import numpy as np
+
+from .core import Engine
+from .hostrng import HostRNG
+from .optimize import OptimizationTrace, optimize_with_trace
+
+DEFAULT_HISTORY_LENGTH = 6     # src/Pathfinder.jl:24
+DEFAULT_NDRAWS_ELBO = 5        # src/Pathfinder.jl:27
+
+
+class PosDefException(ArithmeticError):
+    """mirrors LinearAlgebra.PosDefException thrown by pdfactorize (src/woodbury.jl:202,205)"""
+
+
+# ---- distribution objects -------------------------------------------------------------------------------
+@dataclass
+class WoodburyPDFactorization:      # src/woodbury.jl:12-21
+    U: np.ndarray                   # diag of the (diagonal) Cholesky factor of A = sqrt(alpha)
+    Q_factors: np.ndarray           # QRCompactWY factors (d x 2j)
+    Q_T: np.ndarray                 # compact-WY T (k x k)
+    V: np.ndarray                   # upper Cholesky factor (k x k)
+
+
+@dataclass
+class WoodburyPDMat:                # src/woodbury.jl:246-257
+    A: np.ndarray                   # diagonal (d,)
+    B: np.ndarray                   # (d, 2j)
+    D: np.ndarray                   # (2j, 2j)
+    F: WoodburyPDFactorization
+    logdet: float
+
+    def dense(self):
+        return np.diag(self.A) + self.B @ self.D @ self.B.T
+
+
+@dataclass
+class MvNormal:
+    mu: np.ndarray
+    Sigma: WoodburyPDMat
+    engine: Any = field(repr=False, default=None)
+    point: int = -1
+
+    def logpdf(self, X):
+        return self.engine.logpdf(self.point, X)
+
+    def rand(self, seed, n, n0=0):
+        return self.engine.draws(self.point, seed, n, n0)[0]
+
+
+@dataclass
+class ELBOEstimate:                 # src/elbo.jl:22-29
+    value: float
+    std_err: float
+    engine: Any = field(repr=False, default=None)
+    point: int = -1
+    seed: int = 0
+    ndraws: int = 0
+    _cache: Any = field(repr=False, default=None)
+
+    def _materialise(self):         # draws are regenerated on demand from the seed
+        if self._cache is None:
+            self._cache = self.engine.draws(self.point, self.seed, self.ndraws)
+        return self._cache
+
+    @property
+    def draws(self): return self._materialise()[0]
+    @property
+    def log_densities_target(self): return self._materialise()[1]
+    @property
+    def log_densities_fit(self): return self._materialise()[2]
+    @property
+    def log_density_ratios(self):
+        x = self._materialise()
+        return x[1] - x[2]
+
+    def __str__(self):
+        return f"ELBO estimate: {self.value:.2f} ± {self.std_err:.2f}"
+
+
+@dataclass
+class PSISResult:
+    weights: np.ndarray
+    log_weights: np.ndarray
+    pareto_shape: float
+    tail_length: int
+
+
+@dataclass
+class PathfinderResult:             # src/singlepath.jl:53-70
+    input: Any
+    rng: Any
+    logp: Any
+    fit_distribution: MvNormal
+    draws: np.ndarray
+    fit_iteration: int
+    num_tries: int
+    optim_trace: OptimizationTrace
+    fit_distributions: List[MvNormal]
+    elbo_estimates: List[ELBOEstimate]
+    num_bfgs_updates_rejected: int
+    success: bool = True
+    draw_seed: int = 0
+
+    @property
+    def fit_distribution_transformed(self): return self.fit_distribution
+    @property
+    def draws_transformed(self): return self.draws
+
+
+@dataclass
+class MultiPathfinderResult:        # src/multipath.jl:31-44
+    input: Any
+    rng: Any
+    logp: Any
+    fit_distribution: List[MvNormal]        # components of the uniform mixture (src/multipath.jl:215-216)
+    draws: np.ndarray
+    draw_component_ids: np.ndarray          # 1-based like the reference
+    pathfinder_results: List[PathfinderResult]
+    psis_result: Optional[PSISResult]
+    engine: Any = field(repr=False, default=None)
+    ndraws_per_run: int = 0
+
+    @property
+    def fit_distribution_transformed(self): return self.fit_distribution
+    @property
+    def draws_transformed(self): return self.draws
+
+
+# ---- helpers --------------------------------------------------------------------------------------------
+_STATUS_MSG = {1: "A = diag(alpha) is not positive definite", 2: "C = I + R D R' is not positive definite",
+               3: "non-finite factor"}
+
+
+def _make_dists(eng, p0, npts, status, jeff, materialise=True):
+    dists = []
+    for l in range(npts):
+        p = p0 + l
+        if not materialise:
+            dists.append(MvNormal(None, None, eng, p))
+            continue
+        f = eng.get_fit(p, int(jeff[p]))
+        F = WoodburyPDFactorization(np.sqrt(f["alpha"]), f["qr_factors"], f["T"], f["V"])
+        W = WoodburyPDMat(f["alpha"], f["B"], f["D"], F, f["logdet"])
+        dists.append(MvNormal(f["mu"], W, eng, p))
+    return dists
+
+
+def fit_mvnormals(points, gradients, history_length=5, engine=None, eps=1e-12):
+    """fit_mvnormals(θs, ∇logpθs; history_length) -> (dists, num_bfgs_updates_rejected)
+    reference src/mvnormal.jl:14-21.  Raises PosDefException like WoodburyPDMat's constructor."""
+    eng = engine or Engine()
+    eng.set_traces([np.asarray(points)], [np.asarray(gradients)])
+    eng.fit_batch(history_length, eps)
+    status, jeff, _, nrej = eng.fit_status()
+    bad = np.nonzero(status)[0]
+    if len(bad):
+        raise PosDefException(f"fit {int(bad[0])}: {_STATUS_MSG.get(int(status[bad[0]]), 'failed')}")
+    return _make_dists(eng, 0, len(points), status, jeff), int(nrej[0])
+
+
+def maximize_elbo(rng, target, dists, ndraws, ntasks=1):
+    """maximize_elbo(rng, logp, dists, ndraws, ntasks) -> (iteration_opt, estimates)
+    reference src/elbo.jl:1-10.  `dists` must be a contiguous slice of one fit_mvnormals result."""
+    if len(dists) == 0:
+        return 0, []                                        # src/elbo.jl:7
+    eng = dists[0].engine
+    seeds_l = rng.rand_u64(len(dists))                      # src/elbo.jl:2
+    seeds = np.zeros(eng.P, dtype=np.uint64)
+    for dist, s in zip(dists, seeds_l):
+        seeds[dist.point] = s
+    eng.set_target(target)
+    elbo, se, _ = eng.elbo_batch(ndraws, seeds)
+    ests = [ELBOEstimate(float(elbo[d.point]), float(se[d.point]), eng, d.point, int(seeds[d.point]), ndraws)
+            for d in dists]
+    return _findmax_skipnan([e.value for e in ests])[1], ests
+
+
+def _findmax_skipnan(xs):
+    """reference src/utils.jl:55-72 (1-based index)"""
+    state = None
+    for i, xi in enumerate(xs, 1):
+        if state is None:
+            state = (xi, i)
+            continue
+        if np.isnan(xi):
+            continue
+        if np.isnan(state[0]) or xi > state[0]:
+            state = (xi, i)
+    return state
+
+
+class UniformSampler:               # src/singlepath.jl:332-344
+    def __init__(self, scale):
+        if not scale > 0:
+            raise ValueError("scale of uniform sampler must be positive.")   # DomainError
+        self.scale = scale
+
+    def __call__(self, rng, point):
+        point[:] = rng.rand(len(point)) * 2 * self.scale - self.scale
+        return point
+
+
+# ---- batched driver shared by pathfinder / multipathfinder ------------------------------------------------
+def _run_paths(eng, target, inits, run_rngs, *, dim, history_length, ndraws_elbo, ntries, init_sampler,
+               optimizer_kwargs, materialise):
+    """Runs every path to success (or ntries), batching the GPU work.  Returns per-path dicts."""
+    K = len(inits)
+    state = [dict(itry=0, done=False) for _ in range(K)]
+    pending = list(range(K))
+    while pending:
+        for k in pending:
+            st = state[k]
+            st["itry"] += 1
+            rng = run_rngs[k]
+            if st["itry"] == 1 and inits[k] is not None:
+                x0 = np.array(inits[k], dtype=np.float64)
+            else:
+                x0 = init_sampler(rng, np.empty(dim))          # src/singlepath.jl:167-168, 277
+            st["trace"] = optimize_with_trace(target, x0, history_length=history_length, **optimizer_kwargs)
+            L = len(st["trace"]) - 1
+            st["seeds"] = np.concatenate([[np.uint64(0)], rng.rand_u64(L)]).astype(np.uint64)  # src/elbo.jl:2
+        # one batched fit + ELBO over every path (finished paths are recomputed identically from their seeds)
+        eng.set_traces([s["trace"].points for s in state], [s["trace"].gradients for s in state])
+        eng.fit_batch(history_length)
+        status, jeff, logdet, nrej = eng.fit_status()
+        seeds = np.concatenate([s["seeds"] for s in state])
+        elbo, se, best = eng.elbo_batch(ndraws_elbo, seeds)
+        new_pending = []
+        for k in range(K):
+            st = state[k]
+            p0, p1 = int(eng.offsets[k]), int(eng.offsets[k + 1])
+            L = p1 - p0 - 1
+            fit_it = int(best[k])
+            ok = L > 0                                           # src/singlepath.jl:299
+            if fit_it > 0:
+                v = elbo[p0 + fit_it]
+                ok = ok and (not np.isnan(v)) and v != -np.inf   # :309-314
+            else:
+                ok = False
+            st.update(p0=p0, L=L, fit_iteration=fit_it, success=ok, status=status[p0:p1], jeff=jeff[p0:p1],
+                      elbo=elbo[p0:p1], se=se[p0:p1], nrej=int(nrej[k]))
+            if not ok and st["itry"] < ntries and not st["done"]:
+                new_pending.append(k)
+            else:
+                st["done"] = True
+        pending = new_pending
+    return state, status, jeff
+
+
+def _assemble_path(eng, target, st, rng, ndraws, ndraws_elbo, input_, status, jeff, materialise, warn=True):
+    p0, L = st["p0"], st["L"]
+    if not st["success"] and warn:
+        warnings.warn(f"Pathfinder failed after {st['itry']} tries. Increase `ntries`, inspect the model for "
+                      "numerical instability, or provide a more suitable `init_sampler`.")
+    if st["nrej"] > 0 and warn:
+        perc = round(st["nrej"] * 100 / (L + 1), 1)
+        warnings.warn(f"{st['nrej']} ({perc}%) updates to the inverse Hessian estimate were rejected to keep it "
+                      "positive definite.")
+    dists = _make_dists(eng, p0, L + 1, status, jeff, materialise)
+    ests = [ELBOEstimate(float(st["elbo"][l]), float(st["se"][l]), eng, p0 + l, int(st["seeds"][l]), ndraws_elbo)
+            for l in range(1, L + 1)]
+    fit_it = st["fit_iteration"]
+    fit_point = p0 + fit_it                                       # fit_distributions[fit_iteration + 1]
+    if st["success"]:
+        draw_seed = int(st["seeds"][fit_it])                      # reuse the ELBO draws, top up if needed
+    else:
+        draw_seed = int(rng.rand_u64(1)[0])                       # rand(rng, fit_distribution, ndraws)
+    return dict(dists=dists, ests=ests, fit_point=fit_point, draw_seed=draw_seed)
+
+
+def pathfinder(target, *, rng=None, init=None, dim=-1, init_scale=2, init_sampler=None, input=None,
+               history_length=DEFAULT_HISTORY_LENGTH, ndraws_elbo=DEFAULT_NDRAWS_ELBO, ndraws=None, ntries=1000,
+               ntasks=1, engine=None, materialise=True, **optimizer_kwargs):
+    """Single-path Pathfinder (reference src/singlepath.jl:142-257)."""
+    rng = rng if rng is not None else HostRNG(0)
+    ndraws = ndraws_elbo if ndraws is None else ndraws
+    init_sampler = init_sampler or UniformSampler(init_scale)
+    if init is None:
+        if dim <= 0:
+            dim = getattr(target, "d", -1)
+        if dim <= 0:
+            raise ValueError("An initial point `init` or dimension `dim` must be provided.")   # :171
+    else:
+        dim = len(init)
+    eng = engine or Engine()
+    eng.set_target(target)
+    state, status, jeff = _run_paths(eng, target, [init], [rng], dim=dim, history_length=history_length,
+                                     ndraws_elbo=ndraws_elbo, ntries=ntries, init_sampler=init_sampler,
+                                     optimizer_kwargs=optimizer_kwargs, materialise=materialise)
+    st = state[0]
+    a = _assemble_path(eng, target, st, rng, ndraws, ndraws_elbo, input, status, jeff, materialise)
+    X = eng.draws(a["fit_point"], a["draw_seed"], ndraws)[0]     # src/singlepath.jl:226-233
+    return PathfinderResult(input if input is not None else target, rng, target.logp,
+                            a["dists"][st["fit_iteration"]], X, st["fit_iteration"], st["itry"], st["trace"],
+                            a["dists"], a["ests"], st["nrej"], st["success"], a["draw_seed"])
+
+
+def multipathfinder(target, ndraws, *, init=None, nruns=-1, ndraws_elbo=DEFAULT_NDRAWS_ELBO, ndraws_per_run=None,
+                    rng=None, history_length=DEFAULT_HISTORY_LENGTH, importance=True, dim=-1, init_scale=2,
+                    init_sampler=None, ntries=1000, ntasks=1, ntasks_per_run=1, input=None, engine=None,
+                    materialise=False, **optimizer_kwargs):
+    """Multi-path Pathfinder (reference src/multipath.jl:118-245)."""
+    if init is None:
+        if nruns <= 0:
+            raise ValueError("A positive `nruns` must be set or `init` must be provided.")     # :148-150
+        inits = [None] * nruns
+    else:
+        inits = list(init)
+    nruns = len(inits)
+    if ndraws_per_run is None:
+        ndraws_per_run = max(ndraws_elbo, -(-ndraws // max(nruns, 1)))                          # :138
+    if ndraws > ndraws_per_run * nruns:
+        warnings.warn("More draws requested than total number of draws across replicas. Draws will not be unique.")
+    rng = rng if rng is not None else HostRNG(0)
+    init_sampler = init_sampler or UniformSampler(init_scale)
+    if dim <= 0:
+        dim = getattr(target, "d", -1) if inits[0] is None else len(inits[0])
+    run_seeds = rng.rand_u64(nruns)                                                             # :162
+    run_rngs = [rng.copy().seed_(int(s)) for s in run_seeds]                                    # :189-193
+    eng = engine or Engine()
+    eng.set_target(target)
+    state, status, jeff = _run_paths(eng, target, inits, run_rngs, dim=dim, history_length=history_length,
+                                     ndraws_elbo=ndraws_elbo, ntries=ntries, init_sampler=init_sampler,
+                                     optimizer_kwargs=optimizer_kwargs, materialise=materialise)
+    parts = [_assemble_path(eng, target, st, r, ndraws_per_run, ndraws_elbo, input, status, jeff, materialise)
+             for st, r in zip(state, run_rngs)]
+    # draws_per_component = stack(draws)   (:217) -- device resident
+    eng.pool_build(ndraws_per_run, [a["fit_point"] for a in parts], [a["draw_seed"] for a in parts])
+    pool, log_ratios = eng.pool_get(draws=True)
+    results = []
+    for k, (st, a) in enumerate(zip(state, parts)):
+        results.append(PathfinderResult(input if input is not None else target, run_rngs[k], target.logp,
+                                        a["dists"][st["fit_iteration"]], pool[:, :, k], st["fit_iteration"],
+                                        st["itry"], st["trace"], a["dists"], a["ests"], st["nrej"], st["success"],
+                                        a["draw_seed"]))
+    S = nruns * ndraws_per_run
+    psis_result = None
+    if importance:                                                                               # :220-224
+        ptr, cnt = eng.pool_log_ratios_dev()
+        psis_result = PSISResult(**eng.psis_dev(ptr, cnt))
+    draws, ids = _resample(rng, eng, S, ndraws_per_run, psis_result, ndraws)                     # :225
+    return MultiPathfinderResult(input if input is not None else target, rng, target.logp,
+                                 [r.fit_distribution for r in results], draws, ids, results, psis_result, eng,
+                                 ndraws_per_run)
+
+
+def _resample(rng, eng, S, ndraws_per_component, psis_result, ndraws, replace=True):
+    """_resample (reference src/resample.jl:58-72): indices on the device, gather, component ids."""
+    seed = int(rng.rand_u64(1)[0])
+    idx = eng.resample_indices(S, ndraws, importance=psis_result is not None, replace=replace, seed=seed)
+    draws = eng.pool_gather(idx)
+    ids = idx // ndraws_per_component + 1                          # cld.(inds, N) with 1-based inds
+    return draws, ids
+
+
+def resample(result, ndraws, *, rng=None, replace=True, importance=True, ndraws_per_run=None, ntasks=1):
+    """resample(result::MultiPathfinderResult, ndraws; ...)  (reference src/resample.jl:20-46)"""
+    rng = rng if rng is not None else result.rng
+    eng = result.engine
+    K = len(result.pathfinder_results)
+    psis_result = result.psis_result
+    if ndraws_per_run is not None:                                  # fresh candidates (:102-109)
+        seeds = rng.rand_u64(K)
+        eng.pool_build(ndraws_per_run, [r.fit_distribution.point for r in result.pathfinder_results], seeds)
+        psis_result = None
+        npr = ndraws_per_run
+    else:                                                           # reuse stored draws (:97-101)
+        npr = result.ndraws_per_run
+        eng.pool_build(npr, [r.fit_distribution.point for r in result.pathfinder_results],
+                       [r.draw_seed for r in result.pathfinder_results])
+    S = K * npr
+    if importance:
+        if psis_result is None or ndraws_per_run is not None:
+            ptr, cnt = eng.pool_log_ratios_dev()
+            psis_result = PSISResult(**eng.psis_dev(ptr, cnt))
+        else:                                                       # stored PSIS weights back onto the device
+            psis_result = PSISResult(**eng.psis_dev(*eng.pool_log_ratios_dev()))
+    else:
+        psis_result = None
+    draws, ids = _resample(rng, eng, S, npr, psis_result, ndraws, replace=replace)
+    return MultiPathfinderResult(result.input, result.rng, result.logp, result.fit_distribution, draws, ids,
+                                 result.pathfinder_results, psis_result, eng, npr)

@@ -1,0 +1,197 @@
+"""Engine: thin Python handle over a pfmi_ctx (one GPU, one stream).  All numerics run in
+libpfmi.so on the MI355X; this file only marshals arrays across the C ABI."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+_dp = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_u64p = C.POINTER(C.c_uint64)
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+class Engine:
+    def __init__(self, device=0):
+        self.L = _lib.lib()
+        self.ctx = C.c_void_p()
+        check(self.L.pfmi_create(C.c_int32(device), C.byref(self.ctx)))
+        self.device = device
+        self.target = None
+        self.K = self.P = self.d = 0
+        self.offsets = None
+        self.J = 0
+
+    def close(self):
+        if getattr(self, "ctx", None) is not None and self.ctx:
+            self.L.pfmi_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- instrumentation -------------------------------------------------------------------------
+    def sync(self):
+        check(self.L.pfmi_sync(self.ctx))
+
+    def timer_start(self):
+        check(self.L.pfmi_timer_start(self.ctx))
+
+    def timer_stop(self):
+        ms = C.c_double()
+        check(self.L.pfmi_timer_stop(self.ctx, C.byref(ms)))
+        return ms.value
+
+    def profile(self, enable=True):
+        check(self.L.pfmi_profile(self.ctx, C.c_int32(1 if enable else 0)))
+
+    def kernel_time(self, name):
+        ms, n = C.c_double(), C.c_int64()
+        check(self.L.pfmi_kernel_time(self.ctx, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # ---- inputs -------------------------------------------------------------------------------------
+    def set_target(self, target):
+        self.target = target                      # keep parameter arrays / callbacks alive
+        desc = target.descriptor()
+        check(self.L.pfmi_set_target(self.ctx, C.byref(desc)))
+
+    def set_traces(self, thetas, grads):
+        """thetas/grads: lists (one per path) of (L_k+1, d) arrays (point-major)."""
+        npts = np.array([len(t) for t in thetas], dtype=np.int64)
+        theta = np.ascontiguousarray(np.concatenate([np.asarray(t, dtype=np.float64) for t in thetas], axis=0))
+        grad = np.ascontiguousarray(np.concatenate([np.asarray(g, dtype=np.float64) for g in grads], axis=0))
+        assert theta.shape == grad.shape and theta.ndim == 2
+        self.K, self.P, self.d = len(npts), int(npts.sum()), theta.shape[1]
+        self.offsets = np.concatenate([[0], np.cumsum(npts)]).astype(np.int64)
+        check(self.L.pfmi_set_traces(self.ctx, C.c_int32(self.K), npts.ctypes.data_as(_i64p), C.c_int32(self.d),
+                                     _d(theta), _d(grad)))
+
+    # ---- fit -------------------------------------------------------------------------------------------
+    def fit_batch(self, history_length=6, eps=1e-12):
+        self.J = history_length
+        check(self.L.pfmi_fit_batch(self.ctx, C.c_int32(history_length), C.c_double(eps)))
+
+    def fit_status(self):
+        status = np.empty(self.P, dtype=np.int32)
+        jeff = np.empty(self.P, dtype=np.int32)
+        logdet = np.empty(self.P)
+        nrej = np.empty(self.K, dtype=np.int64)
+        check(self.L.pfmi_get_fit_status(self.ctx, status.ctypes.data_as(_i32p), jeff.ctypes.data_as(_i32p),
+                                         _d(logdet), nrej.ctypes.data_as(_i64p)))
+        return status, jeff, logdet, nrej
+
+    def get_fit(self, p, j):
+        d, m = self.d, 2 * j
+        k = min(d, m)
+        out = dict(alpha=np.empty(d), B=np.zeros((d, m), order="F"), D=np.zeros((m, m), order="F"),
+                   qr_factors=np.zeros((d, m), order="F"), T=np.zeros((k, k), order="F"),
+                   V=np.zeros((k, k), order="F"), mu=np.empty(d))
+        ld = C.c_double()
+        check(self.L.pfmi_get_fit(self.ctx, C.c_int64(p), _d(out["alpha"]), _d(out["B"]), _d(out["D"]),
+                                  _d(out["qr_factors"]), _d(out["T"]), _d(out["V"]), _d(out["mu"]), C.byref(ld)))
+        out["logdet"] = ld.value
+        out["j"] = j
+        return out
+
+    # ---- ELBO ---------------------------------------------------------------------------------------------
+    def elbo_batch(self, N, seeds, u=None):
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        assert len(seeds) == self.P
+        if u is not None:
+            u = np.ascontiguousarray(u, dtype=np.float64)
+            assert u.size == self.P * self.d * N
+        elbo, se = np.empty(self.P), np.empty(self.P)
+        best = np.empty(self.K, dtype=np.int64)
+        check(self.L.pfmi_elbo_batch(self.ctx, C.c_int64(N), seeds.ctypes.data_as(_u64p), _d(u), _d(elbo), _d(se),
+                                     best.ctypes.data_as(_i64p)))
+        return elbo, se, best
+
+    def elbo_logs(self, p, N):
+        lp, lq = np.empty(N), np.empty(N)
+        check(self.L.pfmi_get_elbo_logs(self.ctx, C.c_int64(p), _d(lp), _d(lq)))
+        return lp, lq
+
+    def draws(self, p, seed, N, n0=0, u=None):
+        """(X (d,N) column-major, logp, logq) of draws n0..n0+N-1 of fit p."""
+        X = np.empty((self.d, N), order="F")
+        lp, lq = np.empty(N), np.empty(N)
+        if u is not None:
+            u = np.asfortranarray(u, dtype=np.float64)
+        check(self.L.pfmi_draws(self.ctx, C.c_int64(p), C.c_uint64(int(seed)), C.c_int64(n0), C.c_int64(N), _d(u),
+                                _d(X), _d(lp), _d(lq)))
+        return X, lp, lq
+
+    def logpdf(self, p, X):
+        X = np.asfortranarray(X, dtype=np.float64)
+        N = X.shape[1]
+        out = np.empty(N)
+        check(self.L.pfmi_logpdf(self.ctx, C.c_int64(p), C.c_int64(N), _d(X), _d(out)))
+        return out
+
+    # ---- pool / PSIS / resample -------------------------------------------------------------------------
+    def pool_build(self, N_r, points, seeds):
+        points = np.ascontiguousarray(points, dtype=np.int64)
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        self.N_r = N_r
+        check(self.L.pfmi_pool_build(self.ctx, C.c_int64(N_r), points.ctypes.data_as(_i64p),
+                                     seeds.ctypes.data_as(_u64p)))
+
+    def pool_get(self, draws=True):
+        S = self.K * self.N_r
+        X = np.empty((self.d, self.N_r, self.K), order="F") if draws else None
+        lr = np.empty(S)
+        check(self.L.pfmi_pool_get(self.ctx, _d(X), _d(lr)))
+        return X, lr
+
+    def pool_log_ratios_dev(self):
+        p, n = C.c_void_p(), C.c_int64()
+        check(self.L.pfmi_pool_log_ratios_dev(self.ctx, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def psis(self, log_ratios, want_weights=True):
+        lr = np.ascontiguousarray(log_ratios, dtype=np.float64)
+        S = len(lr)
+        w = np.empty(S) if want_weights else None
+        lw = np.empty(S) if want_weights else None
+        k, M = C.c_double(), C.c_int64()
+        check(self.L.pfmi_psis(self.ctx, _d(lr), C.c_int64(S), _d(w), _d(lw), C.byref(k), C.byref(M)))
+        return dict(weights=w, log_weights=lw, pareto_shape=k.value, tail_length=M.value)
+
+    def psis_dev(self, dev_ptr, S, want_weights=True):
+        w = np.empty(S) if want_weights else None
+        lw = np.empty(S) if want_weights else None
+        k, M = C.c_double(), C.c_int64()
+        check(self.L.pfmi_psis_dev(self.ctx, C.c_void_p(dev_ptr), C.c_int64(S), _d(w), _d(lw), C.byref(k),
+                                   C.byref(M)))
+        return dict(weights=w, log_weights=lw, pareto_shape=k.value, tail_length=M.value)
+
+    def resample_indices(self, S, ndraws, importance=True, replace=True, seed=0, uniforms=None):
+        idx = np.empty(ndraws, dtype=np.int64)
+        if uniforms is not None:
+            uniforms = np.ascontiguousarray(uniforms, dtype=np.float64)
+        check(self.L.pfmi_resample_indices(self.ctx, C.c_int64(S), C.c_int64(ndraws), C.c_int32(int(importance)),
+                                           C.c_int32(int(replace)), C.c_uint64(int(seed)), _d(uniforms),
+                                           idx.ctypes.data_as(_i64p)))
+        return idx
+
+    def pool_gather(self, idx, col_offset=0):
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        out = np.empty((self.d, len(idx)), order="F")
+        check(self.L.pfmi_pool_gather(self.ctx, C.c_int64(len(idx)), idx.ctypes.data_as(_i64p),
+                                      C.c_int64(col_offset), _d(out)))
+        return out
+
+    def pool_gather_dev(self, idx, col_offset, dev_ptr):
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        check(self.L.pfmi_pool_gather_dev(self.ctx, C.c_int64(len(idx)), idx.ctypes.data_as(_i64p),
+                                          C.c_int64(col_offset), C.c_void_p(dev_ptr)))

@@ -1,0 +1,74 @@
+"""Host-side counter-based RNG (Philox4x32-10, NumPy) for the seed hierarchy and synthetic inputs.
+
+The reference seeds its runs with ``rand!(rng, UInt64[nruns])`` (src/multipath.jl:162) and its fits
+with ``rand!(rng, UInt64[L])`` (src/elbo.jl:2); Julia's Xoshiro stream cannot be reproduced outside
+Julia, so this module provides the same *structure* (master rng -> run seeds -> fit seeds) on the
+generator the device kernels use.  Bit-identical to pf_philox4x32_10 in csrc/pfmi_common.h.
+"""
+import numpy as np
+
+_M0, _M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+_W0, _W1 = 0x9E3779B9, 0xBB67AE85
+_MASK = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(ctr, key):
+    """ctr: (..., 4) uint32, key: (2,) ints -> (..., 4) uint32"""
+    c = np.asarray(ctr, dtype=np.uint64) & _MASK
+    c0, c1, c2, c3 = c[..., 0], c[..., 1], c[..., 2], c[..., 3]
+    k0, k1 = int(key[0]) & 0xFFFFFFFF, int(key[1]) & 0xFFFFFFFF
+    for _ in range(10):
+        p0 = _M0 * c0
+        p1 = _M1 * c2
+        n0 = ((p1 >> np.uint64(32)) ^ c1 ^ np.uint64(k0)) & _MASK
+        n1 = p1 & _MASK
+        n2 = ((p0 >> np.uint64(32)) ^ c3 ^ np.uint64(k1)) & _MASK
+        n3 = p0 & _MASK
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0 = (k0 + _W0) & 0xFFFFFFFF
+        k1 = (k1 + _W1) & 0xFFFFFFFF
+    return np.stack([c0, c1, c2, c3], axis=-1).astype(np.uint32)
+
+
+def rand_u64(seed, t, stream):
+    """64 random bits for counters t (array) of `seed` on `stream` (== pf_rand_u64)."""
+    t = np.atleast_1d(np.asarray(t, dtype=np.uint64))
+    ctr = np.stack([t & _MASK, t >> np.uint64(32), np.full_like(t, stream), np.zeros_like(t)], axis=-1)
+    seed = int(seed)
+    x = philox4x32_10(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)).astype(np.uint64)
+    return x[..., 0] | (x[..., 1] << np.uint64(32))
+
+
+class HostRNG:
+    """Minimal AbstractRNG stand-in: seedable, copyable, counter-based."""
+    STREAM = 7   # host streams never collide with device streams 0 (normals), 1 (resample), 2 (norep)
+
+    def __init__(self, seed=0):
+        self.seed_(seed)
+
+    def seed_(self, seed):
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.counter = 0
+        return self
+
+    def copy(self):
+        r = HostRNG(self.seed)
+        r.counter = self.counter
+        return r
+
+    def rand_u64(self, n):
+        out = rand_u64(self.seed, np.arange(self.counter, self.counter + n, dtype=np.uint64), self.STREAM)
+        self.counter += n
+        return out
+
+    def rand(self, n):
+        """uniform [0,1) doubles (53 bits)"""
+        return (self.rand_u64(n) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+    def randn(self, n):
+        m = (n + 1) // 2
+        u1 = ((self.rand_u64(m) >> np.uint64(11)).astype(np.float64) + 0.5) / 9007199254740992.0
+        u2 = self.rand(m)
+        r = np.sqrt(-2.0 * np.log(u1))
+        z = np.concatenate([r * np.cos(2 * np.pi * u2), r * np.sin(2 * np.pi * u2)])
+        return z[:n]

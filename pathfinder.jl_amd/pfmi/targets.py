@@ -1,0 +1,167 @@
+"""Target log densities.  The hot path only sees ``logp(x) = -f(x)`` (reference
+src/singlepath.jl:186, src/multipath.jl:159); the host optimiser additionally needs the gradient
+(LogDensityProblems.logdensity_and_gradient, src/optimize.jl:1-29).
+
+Built-in targets are evaluated on the device; ``CallbackTarget`` wraps an arbitrary host closure
+(the reference's general case) and is evaluated on a host copy of the draws.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .hostrng import HostRNG
+
+KIND_GAUSS, KIND_FUNNEL, KIND_CALLBACK = 0, 1, 2
+
+
+class GaussTarget:
+    """logp(x) = offset - 1/2 (x-m)' Sigma*^-1 (x-m),  Sigma* = diag(sigma2) + W W'  (W optional)."""
+    kind = KIND_GAUSS
+
+    def __init__(self, mean, sigma2, W=None, offset=0.0):
+        self.mean = np.ascontiguousarray(mean, dtype=np.float64)
+        self.d = len(self.mean)
+        sigma2 = np.broadcast_to(np.asarray(sigma2, dtype=np.float64), (self.d,))
+        self.a = np.ascontiguousarray(1.0 / sigma2)
+        self.offset = float(offset)
+        if W is None or np.asarray(W).size == 0:
+            self.r = 0
+            self.Wd = np.zeros((self.d, 0), order="F")
+            self.G = np.zeros((0, 0), order="F")
+        else:
+            W = np.asarray(W, dtype=np.float64).reshape(self.d, -1)
+            self.r = W.shape[1]
+            self.Wd = np.asfortranarray(W * self.a[:, None])
+            cap = np.eye(self.r) + W.T @ self.Wd                  # capacitance matrix
+            self.G = np.asfortranarray(np.linalg.inv(np.linalg.cholesky(cap)))   # lower triangular
+
+    def logp(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        e = (x.T - self.mean).T if x.ndim == 2 else x - self.mean
+        q = np.einsum("i...,i...->...", e * (self.a[:, None] if x.ndim == 2 else self.a), e)
+        if self.r:
+            g = self.G @ (self.Wd.T @ e)
+            q = q - np.sum(g * g, axis=0)
+        return self.offset - 0.5 * q
+
+    def grad(self, x):
+        e = x - self.mean
+        g = self.a * e
+        if self.r:
+            g = g - self.Wd @ (self.G.T @ (self.G @ (self.Wd.T @ e)))
+        return -g
+
+    def logp_and_grad(self, x):
+        return float(self.logp(x)), self.grad(x)
+
+    def descriptor(self):
+        t = _lib.pfmi_target()
+        t.kind, t.d, t.r, t.offset = KIND_GAUSS, self.d, self.r, self.offset
+        t.mean = self.mean.ctypes.data_as(C.POINTER(C.c_double))
+        t.a = self.a.ctypes.data_as(C.POINTER(C.c_double))
+        if self.r:
+            t.Wd = self.Wd.ctypes.data_as(C.POINTER(C.c_double))
+            t.G = self.G.ctypes.data_as(C.POINTER(C.c_double))
+        return t
+
+
+class FunnelTarget:
+    """reference docs/src/examples/quickstart.md:229-234"""
+    kind = KIND_FUNNEL
+
+    def __init__(self, d):
+        self.d = d
+
+    def logp(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        tau = x[0]
+        ss = np.sum((x[1:] * np.exp(-tau / 2)) ** 2, axis=0)
+        return ((tau / 3) ** 2 + (self.d - 1) * tau + ss) / -2
+
+    def grad(self, x):
+        tau = x[0]
+        e = np.exp(-tau)
+        g = np.empty_like(x)
+        g[0] = -0.5 * (2 * tau / 9 + (self.d - 1) - e * np.sum(x[1:] ** 2))
+        g[1:] = -e * x[1:]
+        return g
+
+    def logp_and_grad(self, x):
+        return float(self.logp(x)), self.grad(x)
+
+    def descriptor(self):
+        t = _lib.pfmi_target()
+        t.kind, t.d = KIND_FUNNEL, self.d
+        return t
+
+
+class CallbackTarget:
+    """Arbitrary host closure, called one column at a time like the reference (src/elbo.jl:15).
+    ``logp(x) -> float``; ``grad(x)`` optional (finite differences otherwise)."""
+    kind = KIND_CALLBACK
+
+    def __init__(self, d, logp, grad=None):
+        self.d = d
+        self._logp = logp
+        self._grad = grad
+
+        def _cb(Xp, d_, n, outp, _user):
+            X = np.ctypeslib.as_array(Xp, shape=(n, d_))
+            out = np.ctypeslib.as_array(outp, shape=(n,))
+            for i in range(n):
+                out[i] = self._logp(X[i])
+
+        self._cfn = _lib.LOGP_FN(_cb)   # keep alive
+
+    def logp(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        if x.ndim == 1:
+            return float(self._logp(x))
+        return np.array([self._logp(x[:, i]) for i in range(x.shape[1])])
+
+    def grad(self, x):
+        if self._grad is not None:
+            return np.asarray(self._grad(x), dtype=np.float64)
+        g = np.empty_like(x)
+        for i in range(len(x)):
+            h = 1e-6 * max(1.0, abs(x[i]))
+            xp, xm = x.copy(), x.copy()
+            xp[i] += h
+            xm[i] -= h
+            g[i] = (self._logp(xp) - self._logp(xm)) / (2 * h)
+        return g
+
+    def logp_and_grad(self, x):
+        return float(self._logp(x)), self.grad(x)
+
+    def descriptor(self):
+        t = _lib.pfmi_target()
+        t.kind, t.d = KIND_CALLBACK, self.d
+        t.fn = C.cast(self._cfn, C.c_void_p)
+        return t
+
+
+# ---- the synthetic targets of SURVEY.md 8(d) ------------------------------------------------------------
+def t_iso(d):
+    """logp = -|x|^2/2  (reference test/singlepath.jl:15)"""
+    return GaussTarget(np.zeros(d), np.ones(d))
+
+
+def t_diag(d, seed=1):
+    rng = HostRNG(seed)
+    m = rng.randn(d)
+    logsig = -1.5 + 3.0 * rng.rand(d)
+    return GaussTarget(m, np.exp(2 * logsig))
+
+
+def t_lowrank(d, r=8, seed=2):
+    rng = HostRNG(seed)
+    logsig = -0.5 + 1.0 * rng.rand(d)
+    W = rng.randn(d * r).reshape(d, r)
+    m = rng.randn(d)
+    return GaussTarget(m, np.exp(2 * logsig), W)
+
+
+def t_funnel(d):
+    return FunnelTarget(d)

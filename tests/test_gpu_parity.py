@@ -1,0 +1,453 @@
+"""GPU parity tests: the HIP path (through the C ABI of libpfmi.so) against the CPU oracle on the same
+seeded inputs, against the reference's own fixtures / known answers, and -- at BASELINE sizes --
+through size-independent properties.  fp64 tolerances are those of SURVEY.md 8(d).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import fit_seeds, make_traces, oracle_target
+from oracle import pf_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pfmi_mod():
+    import pfmi
+    return pfmi
+
+
+@pytest.fixture(scope="module")
+def eng(pfmi_mod):
+    e = pfmi_mod.Engine(0)
+    yield e
+    e.close()
+
+
+def _targets(pfmi):
+    return {
+        "iso10": pfmi.t_iso(10),                 # d < 2J = 12: k = min(d, m) path (reference test/woodbury.jl:21-31)
+        "diag30": pfmi.t_diag(30, seed=1),
+        "lr50": pfmi.t_lowrank(50, r=8, seed=2),
+        "lr64r3": pfmi.t_lowrank(64, r=3, seed=5),
+        "funnel12": pfmi.t_funnel(12),
+    }
+
+
+CASES = [("iso10", 3, 6), ("diag30", 4, 6), ("lr50", 3, 6), ("lr64r3", 2, 2), ("funnel12", 3, 6), ("diag30", 2, 10),
+         ("lr50", 2, 4), ("lr50", 2, 16)]
+
+
+def _setup(pfmi, eng, name, K, J, seed=11):
+    tg = _targets(pfmi)[name]
+    maxit = 25 if name.startswith("funnel") else 1000
+    scale = 2.0
+    traces = make_traces(tg, K, seed, scale=scale, history_length=J, maxiters=maxit)
+    eng.set_target(tg)
+    eng.set_traces([t.points for t in traces], [t.gradients for t in traces])
+    eng.fit_batch(J)
+    return tg, traces
+
+
+@pytest.mark.parametrize("name,K,J", CASES)
+def test_fit_batch_matches_oracle(pfmi_mod, eng, name, K, J):
+    """fit_mvnormals / lbfgs_inverse_hessians / pdfactorize (src/mvnormal.jl:14-21, src/inverse_hessian.jl:25-133,
+    src/woodbury.jl:201-207): status, effective history, rejected updates, logdet, mu, and the dense
+    W = A + B D B' rebuilt from the GPU factors."""
+    tg, traces = _setup(pfmi_mod, eng, name, K, J)
+    status, jeff, logdet, nrej = eng.fit_status()
+    otg = oracle_target(tg)
+    for k, tr in enumerate(traces):
+        p0 = int(eng.offsets[k])
+        P = len(tr)
+        ref = po.path_fit_elbo(tr.points, tr.gradients, J, otg, 0, np.zeros(P, dtype=np.uint64))
+        np.testing.assert_array_equal(status[p0:p0 + P], ref["status"])
+        np.testing.assert_array_equal(jeff[p0:p0 + P], ref["j_eff"])
+        assert nrej[k] == ref["n_rejected"]
+        ok = ref["status"] == 0
+        np.testing.assert_allclose(logdet[p0:p0 + P][ok], ref["logdet"][ok], rtol=0, atol=1e-10 * (1 + np.abs(ref["logdet"][ok]).max()))
+        alpha_all, hl, hs, _ = po.lbfgs_history(tr.points, tr.gradients, J)
+        for l in list(range(min(P, 9))) + [P - 1]:
+            if not ok[l]:
+                continue
+            f = eng.get_fit(p0 + l, int(jeff[p0 + l]))
+            mu_ref = ref["mu"][l]
+            assert np.max(np.abs(f["mu"] - mu_ref)) <= 1e-10 * (1 + np.abs(mu_ref).max())
+            np.testing.assert_allclose(f["alpha"], alpha_all[l], rtol=1e-12)
+            j = int(hl[l])
+            S = np.stack([tr.points[s + 1] - tr.points[s] for s in hs[l, :j]], axis=1) if j else np.zeros((tg.d, 0))
+            Y = np.stack([tr.gradients[s] - tr.gradients[s + 1] for s in hs[l, :j]], axis=1) if j else np.zeros((tg.d, 0))
+            B, D = po.lbfgs_inverse_hessian(alpha_all[l], S, Y)
+            Wref = np.diag(alpha_all[l]) + B @ D @ B.T
+            Wgpu = np.diag(f["alpha"]) + f["B"] @ f["D"] @ f["B"].T
+            assert np.max(np.abs(Wgpu - Wref)) <= 1e-11 * np.abs(Wref).max() * max(1.0, np.linalg.cond(D) ** 0.5 if j else 1.0)
+            assert f["B"].shape == (tg.d, 2 * j)                       # size(Σ.B) == (d, 2j), test/singlepath.jl:41
+            # the factor itself: R = [V 0;0 I] Q' U,  W = R'R   (src/woodbury.jl:178-187)
+            F = po.Factor(alpha_all[l], B, D)
+            kk = min(tg.d, 2 * j)
+            if kk:
+                np.testing.assert_allclose(f["V"], F.V[:kk, :kk], rtol=1e-9, atol=1e-10 * np.abs(F.V).max())
+                np.testing.assert_allclose(f["qr_factors"], F.QR[:, :2 * j], rtol=1e-9, atol=1e-10 * np.abs(F.QR).max())
+                # compact-WY T reproduces Q = H_0 ... H_{k-1}
+                Vh = np.tril(f["qr_factors"][:, :kk], -1) + np.eye(tg.d, kk)
+                Q = np.eye(tg.d) - Vh @ f["T"] @ Vh.T
+                z = np.eye(tg.d, order="F").copy(order="F")
+                po.lib().pfo_apply_q(tg.d, kk, po._p(F.QR), po._p(F.tau), 0, po._p(z), tg.d)
+                np.testing.assert_allclose(Q, z, atol=1e-12)
+
+
+@pytest.mark.parametrize("name,K,J", CASES[:6])
+def test_draws_and_logq_match_oracle_same_u_and_rng(pfmi_mod, eng, name, K, J):
+    """rand_and_logpdf (src/mvnormal.jl:24-39) + target: identical host-supplied u (parity mode) and
+    the in-kernel Philox normals (production mode) against the oracle."""
+    tg, traces = _setup(pfmi_mod, eng, name, K, J)
+    otg = oracle_target(tg)
+    status, jeff, logdet, _ = eng.fit_status()
+    N = 130
+    rng = np.random.default_rng(0)
+    for k, tr in enumerate(traces):
+        p0 = int(eng.offsets[k])
+        alpha_all, hl, hs, _ = po.lbfgs_history(tr.points, tr.gradients, J)
+        for l in sorted({1, min(3, len(tr) - 1), len(tr) - 1}):
+            if status[p0 + l] != 0:
+                continue
+            j = int(hl[l])
+            S = np.stack([tr.points[s + 1] - tr.points[s] for s in hs[l, :j]], axis=1)
+            Y = np.stack([tr.gradients[s] - tr.gradients[s + 1] for s in hs[l, :j]], axis=1)
+            B, D = po.lbfgs_inverse_hessian(alpha_all[l], S, Y)
+            F = po.Factor(alpha_all[l], B, D)
+            mu = F.fit_mean(tr.points[l], tr.gradients[l])
+            seed = 1000 + 17 * l + k
+            for mode in ("mem", "rng"):
+                U = rng.normal(size=(tg.d, N)) if mode == "mem" else po.randn_fill(seed, tg.d, N)
+                Xr, lqr = F.rand_and_logpdf(mu, U)
+                lpr = otg.logp(Xr)
+                X, lp, lq = eng.draws(p0 + l, seed, N, u=U if mode == "mem" else None)
+                scale = 1 + np.abs(Xr).max(axis=0)
+                assert np.max(np.abs(X - Xr) / scale) <= 1e-10, (name, l, mode)
+                assert np.max(np.abs(lq - lqr) / (1 + np.abs(lqr))) <= 1e-9
+                assert np.max(np.abs(lp - lpr) / (1 + np.abs(lpr))) <= 1e-9
+            # counter-based: draws n0.. are a pure function of (seed, n)
+            X2, _, _ = eng.draws(p0 + l, seed, 40, n0=90)
+            np.testing.assert_array_equal(X2, X[:, 90:130])
+            # Distributions.logpdf through the factor (src/resample.jl:85-89) == logq from u
+            lpdf = eng.logpdf(p0 + l, X)
+            assert np.max(np.abs(lpdf - lq) / (1 + np.abs(lq))) <= 1e-9
+            np.testing.assert_allclose(lpdf, F.logpdf(mu, X), rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("name,K,J", CASES)
+def test_elbo_batch_matches_oracle(pfmi_mod, eng, name, K, J):
+    """maximize_elbo (src/elbo.jl:1-20) over every path: ELBO, SE, NaN-skipping argmax."""
+    tg, traces = _setup(pfmi_mod, eng, name, K, J)
+    otg = oracle_target(tg)
+    N = 200
+    seeds = fit_seeds(eng.P, 5)
+    elbo, se, best = eng.elbo_batch(N, seeds)
+    # parity mode with uploaded normals gives the same answers as the in-kernel generator
+    U = np.concatenate([po.randn_fill(int(seeds[p]), tg.d, N).T.ravel() for p in range(eng.P)])
+    elbo_m, se_m, best_m = eng.elbo_batch(N, seeds, u=U)
+    for k, tr in enumerate(traces):
+        p0, p1 = int(eng.offsets[k]), int(eng.offsets[k + 1])
+        ref = po.path_fit_elbo(tr.points, tr.gradients, J, otg, N, seeds[p0:p1])
+        assert np.isnan(elbo[p0]) and np.isnan(se[p0])
+        for a, b in ((elbo, ref["elbo"]), (se, ref["se"]), (elbo_m, ref["elbo"]), (se_m, ref["se"])):
+            x, y = a[p0 + 1:p1], b[1:]
+            fin = np.isfinite(y)
+            np.testing.assert_array_equal(np.isfinite(x), fin)
+            assert np.all(np.abs(x[fin] - y[fin]) <= 1e-9 * (1 + np.abs(y[fin])))
+        vals = ref["elbo"][1:]
+        top = np.sort(vals[np.isfinite(vals)])[-2:] if np.sum(np.isfinite(vals)) >= 2 else None
+        if top is None or top[1] - top[0] > 1e-8 * (1 + abs(top[1])):
+            assert best[k] == ref["best_iter"] == best_m[k]
+        lp, lq = eng.elbo_logs(p0 + int(best[k]), N)
+        v, s, _ = po.elbo_stats(lp, lq)
+        assert abs(v - elbo[p0 + int(best[k])]) <= 1e-10 * (1 + abs(v))
+
+
+def test_reference_fixture_S0Y0_through_gpu(pfmi_mod, eng, golden_dir):
+    """reference test/inverse_hessian.jl:19-44 on the GPU: the literal S0/Y0 history (as a trace whose
+    steps are the fixture columns) reproduces the explicit dense Byrd formula, incl. ring rotation."""
+    g = json.load(open(os.path.join(golden_dir, "lbfgs_S0Y0.json")))
+    S = np.array(g["S0_columns"]).T
+    Y = np.array(g["Y0_columns"]).T
+    n, nh = S.shape
+    theta = np.zeros((nh + 1, n)); grad = np.zeros((nh + 1, n))
+    for l in range(nh):
+        theta[l + 1] = theta[l] + S[:, l]
+        grad[l + 1] = grad[l] - Y[:, l]
+    for J in (3, 5):
+        eng.set_traces([theta], [grad])
+        eng.fit_batch(J)
+        status, jeff, _, nrej = eng.fit_status()
+        assert nrej[0] == 0 and list(jeff) == [min(l, J) for l in range(nh + 1)]
+        for l in range(nh + 1):
+            f = eng.get_fit(l, int(jeff[l]))
+            j = int(jeff[l])
+            if j == 0:
+                np.testing.assert_allclose(f["alpha"], 1.0)
+                continue
+            Sl, Yl = S[:, l - j:l], Y[:, l - j:l]
+            H0 = np.diag(f["alpha"])
+            R = np.triu(Sl.T @ Yl); Rinv = np.linalg.inv(R)
+            Bx = np.hstack([H0 @ Yl, Sl])
+            Dx = np.block([[np.zeros((j, j)), -Rinv], [-Rinv.T, Rinv.T @ (np.diag(np.diag(R)) + Yl.T @ H0 @ Yl) @ Rinv]])
+            Hexp = H0 + Bx @ Dx @ Bx.T
+            Hgpu = H0 + f["B"] @ f["D"] @ f["B"].T
+            np.testing.assert_allclose(Hgpu, Hexp, rtol=1e-9, atol=1e-10 * np.abs(Hexp).max())
+
+
+@pytest.mark.parametrize("sigma", [1e-3, 0.05, 0.8, 1.0, 1.1, 1.2, 5.0, 10.0])
+def test_analytic_elbo_known_answer_on_gpu(pfmi_mod, eng, sigma):
+    """reference test/elbo.jl:7-28 on the GPU: 1-D, ELBO = (1 - r^2)/2 + log r within 3 SE.  A 1-D Normal(0, sigma)
+    is obtained as the fit of a one-step trace on the quadratic with curvature 1/sigma^2."""
+    sigma_t = 0.08
+    tgt = pfmi_mod.GaussTarget(np.zeros(1), np.array([sigma_t**2]), offset=-0.5 * np.log(2 * np.pi) - np.log(sigma_t))
+    th0 = 0.3
+    theta = np.array([[th0], [0.0]])
+    grad = np.array([[-th0 / sigma**2], [0.0]])      # gradient of -x^2/(2 sigma^2): one exact Newton step
+    eng.set_target(tgt)
+    eng.set_traces([theta], [grad])
+    eng.fit_batch(6)
+    f = eng.get_fit(1, 1)
+    Sig = f["alpha"][0] + (f["B"] @ f["D"] @ f["B"].T)[0, 0]
+    assert abs(Sig - sigma**2) < 1e-9 * sigma**2 and abs(f["mu"][0]) < 1e-12
+    N = 400_000
+    elbo, se, best = eng.elbo_batch(N, np.array([0, 4242], dtype=np.uint64))
+    r = sigma / sigma_t
+    assert abs(elbo[1] - ((1 - r * r) / 2 + np.log(r))) <= 3 * se[1] + 1e-12
+    assert best[0] == 1
+
+
+def test_isonormal_exact_after_one_iteration_on_gpu(pfmi_mod, eng):
+    """reference test/singlepath.jl:13-41 (BASELINE config 1 numerics): mu ~ 0, Sigma ~ I, size(B) = (d, 2)."""
+    rng = np.random.default_rng(1)
+    for d in (1, 5, 10, 100):
+        th0 = rng.normal(size=d)
+        eng.set_target(pfmi_mod.t_iso(d))
+        eng.set_traces([np.stack([th0, np.zeros(d)])], [np.stack([-th0, np.zeros(d)])])
+        eng.fit_batch(6)
+        f = eng.get_fit(1, 1)
+        assert f["B"].shape == (d, 2)
+        np.testing.assert_allclose(f["mu"], 0, atol=1e-6)
+        np.testing.assert_allclose(np.diag(f["alpha"]) + f["B"] @ f["D"] @ f["B"].T, np.eye(d), atol=1e-6)
+        elbo, se, best = eng.elbo_batch(100, np.array([1, 2], dtype=np.uint64))
+        assert best[0] == 1 and abs(elbo[1] - d / 2 * np.log(2 * np.pi)) < 1e-9 * d + 1e-9
+
+
+def test_callback_target_equals_builtin(pfmi_mod, eng):
+    """the host-closure target (reference's general logp, src/elbo.jl:15) gives the built-in target's numbers"""
+    tg = pfmi_mod.t_diag(20, seed=3)
+    traces = make_traces(tg, 2, 5)
+    seeds = None
+    out = []
+    for target in (tg, pfmi_mod.CallbackTarget(20, lambda x: float(tg.logp(x)))):
+        eng.set_target(target)
+        eng.set_traces([t.points for t in traces], [t.gradients for t in traces])
+        eng.fit_batch(6)
+        seeds = fit_seeds(eng.P, 3)
+        out.append(eng.elbo_batch(64, seeds))
+        eng.pool_build(70, [int(eng.offsets[k]) + int(out[-1][2][k]) for k in range(2)], [1, 2])
+        out[-1] = out[-1] + eng.pool_get()
+    for a, b in zip(out[0], out[1]):
+        np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-12, equal_nan=True)
+
+
+# ---- PSIS / resampling ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("S,df", [(1000, 3.0), (64000, 5.0), (200, 1.5), (30, 2.0), (512000, 4.0)])
+def test_psis_matches_oracle(pfmi_mod, eng, S, df):
+    import scipy.stats as st
+    lr = st.t(df).rvs(S, random_state=np.random.default_rng(S)) * 1.5 - 3.0
+    res = eng.psis(lr)
+    lw, w, k, M = po.psis(lr)
+    assert res["tail_length"] == M
+    assert abs(res["pareto_shape"] - k) <= 1e-8
+    assert np.max(np.abs(res["log_weights"] - lw)) <= 1e-10 * (1 + np.abs(lw).max())
+    np.testing.assert_allclose(res["weights"], w, rtol=1e-9, atol=1e-300)
+    assert abs(res["weights"].sum() - 1) < 1e-12                       # reference test/resample.jl:108
+
+
+def test_psis_ties_small_and_degenerate(pfmi_mod, eng):
+    lr = np.array([0.1, -0.3, 0.5, 0.0, 1.0, -2.0])                    # M < 5: normalise only
+    res = eng.psis(lr)
+    assert np.isnan(res["pareto_shape"])
+    np.testing.assert_allclose(res["log_weights"], lr - np.logaddexp.reduce(lr), rtol=1e-13)
+    lwm = np.full((10, 4), -1000.0); lwm[:, 0] = 0.0                   # reference test/resample.jl:36-49
+    lr = lwm.T.ravel()
+    res = eng.psis(lr)
+    _, w, k, M = po.psis(lr)
+    np.testing.assert_allclose(res["weights"], w, rtol=1e-12, atol=1e-300)
+    idx = eng.resample_indices(40, 20, seed=3)
+    assert np.all(idx < 10)                                            # all(==(1), component_ids)
+    # heavy ties at the cutoff: (value, index) order must match the oracle's stable sort
+    rng = np.random.default_rng(0)
+    lr = np.round(rng.normal(size=5000), 1)
+    res = eng.psis(lr)
+    lw, w, k, M = po.psis(lr)
+    assert abs(res["pareto_shape"] - k) <= 1e-8
+    assert np.max(np.abs(res["log_weights"] - lw)) <= 1e-10 * (1 + np.abs(lw).max())
+
+
+def test_resample_indices_bit_exact(pfmi_mod, eng):
+    """index selection is bit-exact against the oracle on identical (weights, uniforms) -- SURVEY.md H4"""
+    import scipy.stats as st
+    S = 64000
+    lr = st.t(4).rvs(S, random_state=np.random.default_rng(1))
+    res = eng.psis(lr)
+    w = res["weights"]
+    for nd in (1, 1000, 5000):
+        idx = eng.resample_indices(S, nd, seed=99)
+        np.testing.assert_array_equal(idx, po.sample_weighted(w, nd, seed=99))
+        u = np.random.default_rng(nd).random(nd)
+        np.testing.assert_array_equal(eng.resample_indices(S, nd, uniforms=u), po.sample_weighted(w, nd, uniforms=u))
+    np.testing.assert_array_equal(eng.resample_indices(S, 300, importance=False, seed=5), po.sample_uniform(S, 300, seed=5))
+    # without replacement (reference test/resample.jl:31-34): unique, and equal to the oracle's Efraimidis-Spirakis
+    idx = eng.resample_indices(S, 500, replace=False, seed=7)
+    assert len(set(idx.tolist())) == 500
+    np.testing.assert_array_equal(idx, po.sample_weighted_norep(w, 500, seed=7))
+    idx = eng.resample_indices(S, 50, importance=False, replace=False, seed=8)
+    assert len(set(idx.tolist())) == 50
+
+
+def test_pool_log_ratio_ordering_and_gather(pfmi_mod, eng):
+    """reference test/resample.jl:62-89: ratios[(k-1)N + n] = logp(x_nk) - logpdf(comp_k, x_nk); and
+    draws = draws_all[:, inds] (src/resample.jl:68)"""
+    tg, traces = _setup(pfmi_mod, eng, "lr50", 3, 6)
+    seeds = fit_seeds(eng.P, 1)
+    elbo, se, best = eng.elbo_batch(50, seeds)
+    pts = [int(eng.offsets[k]) + int(best[k]) for k in range(3)]
+    N_r = 80                                                           # > N_e: top-up draws (src/singlepath.jl:229-230)
+    eng.pool_build(N_r, pts, seeds[pts])
+    pool, lr = eng.pool_get()
+    assert pool.shape == (tg.d, N_r, 3)
+    for k in range(3):
+        X, lp, lq = eng.draws(pts[k], seeds[pts[k]], N_r)
+        np.testing.assert_array_equal(pool[:, :, k], X)
+        np.testing.assert_array_equal(lr[k * N_r:(k + 1) * N_r], lp - lq)
+        np.testing.assert_allclose(lr[k * N_r:(k + 1) * N_r], tg.logp(X) - eng.logpdf(pts[k], X), rtol=1e-9, atol=1e-9)
+        Xe, _, _ = eng.draws(pts[k], seeds[pts[k]], 50)                # the first N_e columns ARE the ELBO draws
+        np.testing.assert_array_equal(pool[:, :50, k], Xe)
+    idx = np.array([0, 79, 80, 239, 100, 100])
+    g = eng.pool_gather(idx)
+    np.testing.assert_array_equal(g, pool.reshape(tg.d, -1, order="F")[:, idx])
+    # ownership window (multi-GPU): columns outside [col_offset, col_offset + K*N_r) come back as zeros
+    g2 = eng.pool_gather(idx + 1000, col_offset=1000)
+    np.testing.assert_array_equal(g2, g)
+    g3 = eng.pool_gather(idx, col_offset=100)
+    assert np.all(g3[:, :3] == 0) and np.array_equal(g3[:, 3], pool.reshape(tg.d, -1, order="F")[:, 139])
+
+
+def test_not_pd_fit_reports_status_and_nan_elbo(pfmi_mod, eng):
+    """src/woodbury.jl:202,205: a non-PD fit is a per-fit status + NaN ELBO, never an abort; other paths proceed."""
+    d = 8
+    tg = pfmi_mod.t_iso(d)
+    good = make_traces(tg, 1, 3)[0]
+    theta = np.array([np.ones(d), np.zeros(d), -np.ones(d) * 0.5])
+    grad = -theta.copy(); grad[2] = grad[1] * 0 + 1e-3 * np.arange(1, d + 1)   # inconsistent curvature on step 2
+    eng.set_target(tg)
+    eng.set_traces([theta, good.points], [grad, good.gradients])
+    eng.fit_batch(6)
+    status, jeff, logdet, nrej = eng.fit_status()
+    ref = po.path_fit_elbo(theta, grad, 6, oracle_target(tg), 0, np.zeros(3, dtype=np.uint64))
+    np.testing.assert_array_equal(status[:3], ref["status"])
+    assert nrej[0] == ref["n_rejected"]
+    elbo, se, best = eng.elbo_batch(32, fit_seeds(eng.P, 2))
+    assert np.all(np.isfinite(elbo[4:]))
+    if np.any(status[:3] != 0):
+        assert np.all(np.isnan(elbo[:3][status[:3] != 0]))
+        with pytest.raises(pfmi_mod.PosDefException):
+            pfmi_mod.fit_mvnormals(theta, grad, history_length=6, engine=eng)
+
+
+# ---- properties at BASELINE sizes (config 3: d = 1000, J = 6, N = 1000) ------------------------------------
+def test_full_size_properties_config3(pfmi_mod, eng):
+    tg = pfmi_mod.t_lowrank(1000, r=8, seed=2)
+    traces = make_traces(tg, 4, 20260928)
+    eng.set_target(tg)
+    eng.set_traces([t.points for t in traces], [t.gradients for t in traces])
+    eng.fit_batch(6)
+    status, jeff, logdet, nrej = eng.fit_status()
+    assert np.all(status == 0) and jeff.max() == 6
+    N = 1000
+    seeds = fit_seeds(eng.P, 77)
+    elbo, se, best = eng.elbo_batch(N, seeds)
+    for k in range(4):
+        p0, p1 = int(eng.offsets[k]), int(eng.offsets[k + 1])
+        assert np.all(np.isfinite(elbo[p0 + 1:p1]))
+        p = p0 + int(best[k])
+        X, lp, lq = eng.draws(p, seeds[p], N)
+        # unwhiten -> whiten round trip: logpdf(x) recomputed through L \ (x - mu) equals logq from |u|^2
+        assert np.max(np.abs(eng.logpdf(p, X) - lq)) <= 1e-8 * (1 + np.abs(lq).max())
+        # target evaluation against the NumPy formula
+        np.testing.assert_allclose(lp, tg.logp(X), rtol=1e-9, atol=1e-7)
+        # the Gaussian target is fitted essentially exactly at convergence: closed-form ELBO of the last fit
+        # = -1/2 [tr(P Sigma) + (mu-m)'P(mu-m)] + 1/2 logdet(2 pi e Sigma)  
+        pl = p1 - 1
+        f = eng.get_fit(pl, int(jeff[pl]))
+        Sig = np.diag(f["alpha"]) + f["B"] @ f["D"] @ f["B"].T
+        Pm = np.diag(tg.a) - tg.Wd @ (tg.G.T @ tg.G) @ tg.Wd.T
+        e = f["mu"] - tg.mean
+        closed = -0.5 * (np.sum(Pm * Sig) + e @ Pm @ e) + 0.5 * (f["logdet"] + 1000 * (1 + np.log(2 * np.pi)))
+        assert abs(elbo[pl] - closed) <= 5 * se[pl] + 1e-6
+        # oracle parity on one full-size fit (same Philox normals)
+        ref = po.path_fit_elbo(traces[k].points[:12], traces[k].gradients[:12], 6, oracle_target(tg), N, seeds[p0:p0 + 12])
+        x, y = elbo[p0 + 1:p0 + 12], ref["elbo"][1:]
+        assert np.all(np.abs(x - y) <= 1e-9 * (1 + np.abs(y)))
+
+
+# ---- end to end -----------------------------------------------------------------------------------------
+def test_multipathfinder_end_to_end(pfmi_mod):
+    """reference test/multipath.jl:12-85: d = 10 correlated normal, 20 runs; mean / covariance of the draws within
+    Monte Carlo tolerance; reseeding reproduces draws and component ids (:63-69)."""
+    rng0 = np.random.default_rng(3)
+    d, nruns, ndraws = 10, 20, 20000
+    A = rng0.normal(size=(d, d)); Sigma = A @ A.T / d + np.eye(d) * 0.3
+    mean = rng0.normal(size=d)
+    w, Vv = np.linalg.eigh(Sigma)
+    tgt = pfmi_mod.CallbackTarget(d, lambda x: float(-0.5 * (x - mean) @ np.linalg.solve(Sigma, x - mean)),
+                                  grad=lambda x: -np.linalg.solve(Sigma, x - mean))
+    res = pfmi_mod.multipathfinder(tgt, ndraws, nruns=nruns, ndraws_elbo=25, ndraws_per_run=2000, rng=pfmi_mod.HostRNG(42))
+    assert res.draws.shape == (d, ndraws) and res.draw_component_ids.shape == (ndraws,)
+    assert res.draw_component_ids.min() >= 1 and res.draw_component_ids.max() <= nruns
+    assert len(res.pathfinder_results) == nruns and abs(res.psis_result.weights.sum() - 1) < 1e-10
+    tol = 15 / np.sqrt(ndraws)
+    assert np.all(np.abs(res.draws.mean(1) - mean) < tol * np.sqrt(np.diag(Sigma)))
+    C = np.cov(res.draws)
+    assert np.max(np.abs(C - Sigma)) < tol * np.max(np.diag(Sigma)) * 1.5
+    res2 = pfmi_mod.multipathfinder(tgt, ndraws, nruns=nruns, ndraws_elbo=25, ndraws_per_run=2000, rng=pfmi_mod.HostRNG(42))
+    np.testing.assert_array_equal(res.draws, res2.draws)
+    np.testing.assert_array_equal(res.draw_component_ids, res2.draw_component_ids)
+    # every drawn column is a pool column of the component it claims (reference test/resample.jl:51-59)
+    for t in range(0, ndraws, 997):
+        k = res.draw_component_ids[t] - 1
+        assert np.any(np.all(res.pathfinder_results[k].draws == res.draws[:, [t]], axis=0))
+    # resample(): stored draws, fresh candidates, no importance, without replacement (src/resample.jl:20-46)
+    r3 = pfmi_mod.resample(res, 500)
+    assert r3.draws.shape == (d, 500)
+    r4 = pfmi_mod.resample(res, 300, ndraws_per_run=100, rng=pfmi_mod.HostRNG(1))
+    assert r4.draws.shape == (d, 300) and len(r4.psis_result.weights) == 100 * nruns
+    r5 = pfmi_mod.resample(res, 50, importance=False, replace=False)
+    assert r5.psis_result is None and len({tuple(c) for c in r5.draws.T}) == 50
+
+
+def test_pathfinder_single_path_plumbing(pfmi_mod):
+    """BASELINE config 1 (reference test/singlepath.jl:13-66): d = 10 iso normal, history 6, ndraws = 100."""
+    tg = pfmi_mod.t_iso(10)
+    init = np.random.default_rng(0).normal(size=10)
+    res = pfmi_mod.pathfinder(tg, init=init, ndraws=100, rng=pfmi_mod.HostRNG(42))
+    assert res.success and res.draws.shape == (10, 100)
+    np.testing.assert_allclose(res.fit_distribution.mu, 0, atol=1e-6)
+    np.testing.assert_allclose(res.fit_distribution.Sigma.dense(), np.eye(10), atol=1e-6)
+    assert len(res.fit_distributions) == len(res.optim_trace)
+    vals = [e.value for e in res.elbo_estimates]
+    assert res.fit_iteration == int(np.nanargmax(vals)) + 1
+    np.testing.assert_array_equal(res.draws[:, :5], res.elbo_estimates[res.fit_iteration - 1].draws)  # ELBO draws reused
+    res2 = pfmi_mod.pathfinder(tg, init=init, ndraws=100, rng=pfmi_mod.HostRNG(42))
+    np.testing.assert_array_equal(res.draws, res2.draws)
+    assert [e.value for e in res2.elbo_estimates] == vals
+    assert pfmi_mod.pathfinder(tg, init=init, ndraws=2).draws.shape == (10, 2)
+    with pytest.raises(ValueError):
+        pfmi_mod.pathfinder(pfmi_mod.CallbackTarget(0, lambda x: 0.0))

@@ -1,0 +1,72 @@
+"""CPU tests of the host-side logic (no GPU): seed hierarchy RNG, trace driver, target formulas,
+_findmax_skipnan mirror, argument errors of the public API."""
+import numpy as np
+import pytest
+
+from oracle import pf_oracle as po
+
+
+def test_host_philox_matches_oracle_and_kat():
+    from pfmi import hostrng
+    out = hostrng.philox4x32_10(np.array([[0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344]], dtype=np.uint32),
+                                (0xA4093822, 0x299F31D0))
+    assert [int(v) for v in out[0]] == [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+    for seed, t, stream in [(1, 0, 1), (2**63 + 12345, 2**33 + 7, 2), (987654321987654321, 99, 9)]:
+        assert int(hostrng.rand_u64(seed, [t], stream)[0]) == po.rand_u64(seed, t, stream)
+    r = hostrng.HostRNG(5)
+    a = r.rand_u64(4)
+    r2 = hostrng.HostRNG(5)
+    assert np.array_equal(np.concatenate([r2.rand_u64(1), r2.rand_u64(3)]), a)       # counter based
+    c = r.copy()
+    assert np.array_equal(c.rand_u64(3), r.rand_u64(3))
+    z = hostrng.HostRNG(1).randn(20001)
+    assert abs(z.mean()) < 0.05 and abs(z.std() - 1) < 0.05
+
+
+def test_targets_match_oracle_and_gradients():
+    import pfmi
+    from helpers import oracle_target
+    rng = np.random.default_rng(0)
+    for tg in (pfmi.t_iso(7), pfmi.t_diag(9), pfmi.t_lowrank(12, r=3), pfmi.t_funnel(6)):
+        X = rng.normal(size=(tg.d, 5))
+        np.testing.assert_allclose(tg.logp(X), oracle_target(tg).logp(X), rtol=1e-12, atol=1e-12)
+        x = rng.normal(size=tg.d)
+        g = tg.grad(x)
+        for i in range(tg.d):
+            h = 1e-6
+            xp, xm = x.copy(), x.copy(); xp[i] += h; xm[i] -= h
+            assert abs((tg.logp(xp) - tg.logp(xm)) / (2 * h) - g[i]) < 1e-5 * (1 + abs(g[i]))
+    cb = pfmi.CallbackTarget(3, lambda x: -0.5 * float(x @ x))
+    np.testing.assert_allclose(cb.grad(np.array([1.0, -2.0, 0.5])), [-1.0, 2.0, -0.5], atol=1e-6)
+
+
+def test_trace_driver_converges_and_records_log_density_gradients():
+    import pfmi
+    tg = pfmi.t_lowrank(40, r=4, seed=3)
+    tr = pfmi.optimize_with_trace(tg, pfmi.HostRNG(1).rand(40) * 4 - 2)
+    L = len(tr) - 1
+    assert L > 3 and np.max(np.abs(tr.gradients[-1])) <= 1e-8
+    assert tr.points.shape == (L + 1, 40) and tr.gradients.shape == (L + 1, 40)
+    np.testing.assert_allclose(tr.log_densities, [float(tg.logp(p)) for p in tr.points], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(tr.gradients[2], tg.grad(tr.points[2]), rtol=1e-12, atol=1e-12)
+    assert np.all(np.diff(tr.log_densities) > -1e-12)          # monotone ascent of logp
+    # every step of an L-BFGS run on a convex quadratic has positive curvature -> no rejected updates
+    _, hl, _, rej = po.lbfgs_history(tr.points, tr.gradients, 6)
+    assert rej == 0 and hl.max() == min(6, L)
+
+
+def test_findmax_mirror_and_api_errors():
+    import pfmi
+    from pfmi.api import _findmax_skipnan
+    assert _findmax_skipnan([np.nan, 3.0, 1.0]) == (3.0, 2)
+    v, i = _findmax_skipnan([np.nan, np.nan])
+    assert np.isnan(v) and i == 1
+    assert _findmax_skipnan([2.0, np.nan, 4.0]) == (4.0, 3)
+    for xs in ([1.0, 5.0, 5.0], [np.nan, 2.0, np.nan, 2.0]):
+        assert _findmax_skipnan(xs)[1] == po.findmax_skipnan(xs)[1]
+    with pytest.raises(ValueError):
+        pfmi.UniformSampler(0)                                   # DomainError, reference src/singlepath.jl:335
+    with pytest.raises(ValueError):
+        pfmi.multipathfinder(pfmi.t_iso(3), 10)                  # ArgumentError, reference src/multipath.jl:148-150
+    assert pfmi.maximize_elbo(pfmi.HostRNG(0), pfmi.t_iso(3), [], 10) == (0, [])   # reference src/elbo.jl:7
+    assert pfmi.DEFAULT_HISTORY_LENGTH == 6 and pfmi.DEFAULT_NDRAWS_ELBO == 5
