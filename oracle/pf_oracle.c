@@ -485,7 +485,7 @@ void pfo_logp_funnel(int d, long N, const double *X, double *out) {
 /* ------------------------------------------------------------------------------------------ */
 /* Counter-based RNG (this repo's replacement for Random.randn!, src/mvnormal.jl:30).          */
 /* Philox4x32-10 (Salmon et al. 2011), key = 64-bit per-fit seed.  Normal number for           */
-/* (row i, draw n): counter = (i/4, n, stream, 0) -> 4 x u32 -> u = (x + 0.5) 2^-32 ->          */
+/* (row i, draw n): counter = (n, i/4, stream, 0) -> 4 x u32 -> u = (x + 0.5) 2^-32 ->          */
 /* Box-Muller pairs (x0,x1) -> rows 4g, 4g+1 ; (x2,x3) -> rows 4g+2, 4g+3.                     */
 /* ------------------------------------------------------------------------------------------ */
 static inline void philox_round(uint32_t c[4], const uint32_t k[2]) {
@@ -522,7 +522,7 @@ static void sincos2pi(double u, double *s, double *c) {
     }
 }
 void pfo_randn4(uint64_t seed, uint32_t g, uint32_t n, uint32_t stream, double z[4]) {
-    uint32_t ctr[4] = {g, n, stream, 0u};
+    uint32_t ctr[4] = {n, g, stream, 0u};
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     uint32_t x[4];
     pfo_philox4x32_10(ctr, key, x);

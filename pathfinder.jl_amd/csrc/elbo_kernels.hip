@@ -18,27 +18,11 @@
 //       (src/resample.jl:85-89 -> invquad, src/woodbury.jl:378-382,158-165).
 #include "pfmi_common.h"
 #include "pfmi_fastmath.h"
+#include "elbo_args.h"
+#include <stdlib.h>
 
 #define ELBO_THREADS 256
 
-struct ElboArgs {
-    int d;
-    const int32_t *points;     // [nfits] trace point (= fit) per slot
-    const uint64_t *seeds;     // [nfits]
-    int64_t n0, N;             // draws n0 .. n0+N-1
-    const double *vh, *tmat, *vchol, *sqrt_alpha, *mu, *logdet;
-    const int32_t *status;
-    const double *u;           // parity mode: slot s reads u + s*u_stride, d x N column-major
-    int64_t u_stride;
-    double *x;                 // optional: slot s writes x + s*x_stride, d x N column-major
-    int64_t x_stride;
-    double *logp, *logq;       // slot s writes + s*log_stride
-    int64_t log_stride;
-    int by_point;              // != 0: u / logp / logq blocks are indexed by the trace point, not the slot
-    // target
-    const double *t_mean, *t_a, *t_wd, *t_g;
-    double t_offset;
-};
 
 // TGT: 0 none (host callback evaluates later), 1 Gaussian family with RPAD low-rank columns, 2 funnel
 template <int TGT, int RPAD>
@@ -356,7 +340,7 @@ int32_t pf_launch_elbo_draws(pfmi_ctx *c, const int32_t *d_points, const uint64_
     a.u = d_u; a.u_stride = u_stride; a.x = d_x; a.x_stride = x_stride;
     a.logp = d_logp; a.logq = d_logq; a.log_stride = log_stride; a.by_point = by_point ? 1 : 0;
     const TargetDev &t = c->target;
-    a.t_mean = t.mean.as<double>(); a.t_a = t.a.as<double>(); a.t_wd = t.wd.as<double>(); a.t_g = t.g.as<double>();
+    a.t_mean = t.mean.as<double>(); a.t_a = t.a.as<double>(); a.t_wd = t.wd.as<double>(); a.t_g = t.g.as<double>(); a.t_wd16 = t.wd16.as<double>();
     a.t_offset = t.offset;
     int tgt = 0, rpad = 0;
     if (with_target) {
@@ -365,6 +349,20 @@ int32_t pf_launch_elbo_draws(pfmi_ctx *c, const int32_t *d_points, const uint64_
     }
     const int64_t gx = (N + ELBO_THREADS - 1) / ELBO_THREADS;
     const bool mem = d_u != nullptr;
+    // production (in-kernel RNG) path: MFMA kernel with register-resident normals when the shape allows;
+    // PFMI_ELBO_KERNEL=lane forces the general lane-per-draw kernel (used by the tests to cross-check)
+    const char *force = getenv("PFMI_ELBO_KERNEL");
+    if (!mem && !(force && force[0] == 'l')) {
+        bool handled = false;
+        pf_kernel_begin(c);
+        int32_t rc = pf_launch_elbo_mfma(c, a, nfits, tgt, rpad, &handled);
+        if (handled) {
+            pf_kernel_end(c, "elbo_draws");
+            PF_TRY(rc);
+            PF_HIP(hipGetLastError());
+            return PFMI_OK;
+        }
+    }
     // gridDim.y is limited to 65535: chunk the fit list
     for (int64_t s0 = 0; s0 < nfits; s0 += 32768) {
         const int64_t ns = (nfits - s0 < 32768) ? (nfits - s0) : 32768;
@@ -380,6 +378,7 @@ int32_t pf_launch_elbo_draws(pfmi_ctx *c, const int32_t *d_points, const uint64_
             case 4: rc = launch_draws_k<4>(b, grid, c->stream, mem, tgt, rpad); break;
             case 8: rc = launch_draws_k<8>(b, grid, c->stream, mem, tgt, rpad); break;
             case 12: rc = launch_draws_k<12>(b, grid, c->stream, mem, tgt, rpad); break;
+            case 16: rc = launch_draws_k<16>(b, grid, c->stream, mem, tgt, rpad); break;
             case 20: rc = launch_draws_k<20>(b, grid, c->stream, mem, tgt, rpad); break;
             case 32: rc = launch_draws_k<32>(b, grid, c->stream, mem, tgt, rpad); break;
             default: pf_set_error("unsupported kpad %d", c->kpad); rc = PFMI_ERR_UNSUPPORTED;
@@ -423,6 +422,7 @@ int32_t pf_launch_logpdf(pfmi_ctx *c, int64_t point, int64_t N, const double *d_
         case 4: PF_LPDF(4); break;
         case 8: PF_LPDF(8); break;
         case 12: PF_LPDF(12); break;
+        case 16: PF_LPDF(16); break;
         case 20: PF_LPDF(20); break;
         case 32: PF_LPDF(32); break;
         default: PF_CHECK(false, PFMI_ERR_UNSUPPORTED, "unsupported kpad %d", c->kpad);

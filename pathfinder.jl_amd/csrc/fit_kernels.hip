@@ -431,6 +431,7 @@ int32_t pf_launch_fit(pfmi_ctx *c) {
         case 4: launch_fit_t<4>(c, a); break;
         case 8: launch_fit_t<8>(c, a); break;
         case 12: launch_fit_t<12>(c, a); break;
+        case 16: launch_fit_t<16>(c, a); break;
         case 20: launch_fit_t<20>(c, a); break;
         case 32: launch_fit_t<32>(c, a); break;
         default: PF_CHECK(false, PFMI_ERR_UNSUPPORTED, "unsupported kpad %d", c->kpad);

@@ -89,7 +89,7 @@ int32_t pfmi_destroy(pfmi_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->theta, &c->grad, &c->d_off, &c->d_path_of, &c->target.mean, &c->target.a, &c->target.wd,
-                      &c->target.g, &c->alpha_all, &c->hist_len, &c->hist_src, &c->n_rej, &c->vh, &c->tmat, &c->vchol,
+                      &c->target.g, &c->target.wd16, &c->alpha_all, &c->hist_len, &c->hist_src, &c->n_rej, &c->vh, &c->tmat, &c->vchol,
                       &c->rq, &c->dmat, &c->sqrt_alpha, &c->mu, &c->logdet, &c->status, &c->seeds, &c->logp, &c->logq,
                       &c->elbo, &c->se, &c->best_iter, &c->fit_list, &c->ubuf, &c->xbuf, &c->scratch, &c->pool,
                       &c->pool_lr, &c->pool_lp, &c->pool_lq, &c->pool_points, &c->pool_seeds, &c->lw, &c->w,
@@ -164,6 +164,12 @@ int32_t pfmi_set_target(pfmi_ctx *c, const pfmi_target *t) {
             PF_TRY(T.g.ensure(sizeof(double) * g.size()));
             PF_TRY(h2d(c, T.wd.p, wd.data(), sizeof(double) * wd.size()));
             PF_TRY(h2d(c, T.g.p, g.data(), sizeof(double) * g.size()));
+            const size_t rows16 = ((size_t)d + 15) / 16 * 16;
+            std::vector<double> w16(rows16 * 16, 0.0);
+            for (int i = 0; i < d; ++i)
+                for (int j = 0; j < r; ++j) w16[(size_t)i * 16 + j] = t->Wd[i + (size_t)d * j];
+            PF_TRY(T.wd16.ensure(sizeof(double) * w16.size()));
+            PF_TRY(h2d(c, T.wd16.p, w16.data(), sizeof(double) * w16.size()));
         }
     } else if (t->kind == PFMI_TARGET_FUNNEL) {
         /* no parameters */
@@ -212,7 +218,7 @@ int32_t pfmi_fit_batch(pfmi_ctx *c, int32_t J, double eps) {
     PF_CHECK(J >= 1, PFMI_ERR_ARG, "history_length must be >= 1");
     const int m = 2 * J;
     int kpad = 0;
-    const int opts[] = {4, 8, 12, 20, 32};
+    const int opts[] = {4, 8, 12, 16, 20, 32};
     for (int o : opts) if (m <= o) { kpad = o; break; }
     PF_CHECK(kpad != 0, PFMI_ERR_UNSUPPORTED, "history_length %d > 16 unsupported", J);
     c->J = J; c->kpad = kpad;

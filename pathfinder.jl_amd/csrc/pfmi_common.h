@@ -56,6 +56,7 @@ struct TargetDev {
     int32_t kind = -1, d = 0, r = 0, rpad = 0;
     double offset = 0.0;
     DevBuf mean, a, wd /* [d][rpad] row-major */, g /* [rpad][rpad] row-major, lower */;
+    DevBuf wd16;   // [ceil(d/16)*16][16] row-major, zero padded: MFMA A-operand source of the low-rank target part
     pfmi_logp_fn fn = nullptr;
     void *user = nullptr;
 };
@@ -163,7 +164,7 @@ __device__ __forceinline__ void pf_philox4x32_10(uint32_t c0, uint32_t c1, uint3
 // four standard normals for rows 4g..4g+3 of draw n (Box-Muller on 32-bit uniforms (x+0.5)2^-32)
 __device__ __forceinline__ void pf_randn4(uint64_t seed, uint32_t g, uint32_t n, uint32_t stream, double (&z)[4]) {
     uint32_t x[4];
-    pf_philox4x32_10(g, n, stream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+    pf_philox4x32_10(n, g, stream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
     const double S = 2.3283064365386962890625e-10;  // 2^-32
     double u0 = ((double)x[0] + 0.5) * S, u1 = ((double)x[1] + 0.5) * S;
     double u2 = ((double)x[2] + 0.5) * S, u3 = ((double)x[3] + 0.5) * S;

@@ -113,7 +113,7 @@ __device__ __forceinline__ void pf_boxmuller4_fast(const uint32_t (&x)[4], const
 __device__ __forceinline__ void pf_randn4_fast(uint64_t seed, uint32_t g, uint32_t n, uint32_t stream,
                                                const double2 *tab, double (&z)[4]) {
     uint32_t x[4];
-    pf_philox4x32_10(g, n, stream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+    pf_philox4x32_10(n, g, stream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
     pf_boxmuller4_fast(x, tab, z);
 }
 #endif
