@@ -100,20 +100,18 @@ def main():
         ptr, cnt = eng.pool_log_ratios_dev()                        # syncs the engine stream
         if G > 1:
             import torch
+            from pfmi.distributed import pooled_psis_resample
             shard = torch.as_tensor(_DevArray(ptr, cnt), device=f"cuda:{local_rank}")
-            dist.all_gather_into_tensor(lr_all, shard)              # the single RCCL collective of the data path
-            torch.cuda.synchronize()
-            res = eng.psis_dev(lr_all.data_ptr(), K * N_r, want_weights=False)
-        else:
-            res = eng.psis_dev(ptr, cnt, want_weights=False)
-        idx = eng.resample_indices(K * N_r, ndraws, seed=master)    # replicated, deterministic
-        if G > 1:
-            import torch
-            eng.pool_gather_dev(idx, k0 * N_r, out_dev.data_ptr())
-            dist.all_reduce(out_dev)                                # each column is owned by exactly one rank
-            torch.cuda.synchronize()
+            res, idx = pooled_psis_resample(                        # one RCCL all-gather + owner all-reduce
+                dist, shard, lr_all, out_dev,
+                psis_fn=lambda t: eng.psis_dev(t.data_ptr(), t.numel(), want_weights=False),
+                sample_fn=lambda S: eng.resample_indices(S, ndraws, seed=master),
+                gather_fn=lambda ix, o: eng.pool_gather_dev(ix, k0 * N_r, o.data_ptr()),
+                sync_fn=torch.cuda.synchronize)
             state["draws"] = out_dev
         else:
+            res = eng.psis_dev(ptr, cnt, want_weights=False)
+            idx = eng.resample_indices(K * N_r, ndraws, seed=master)
             state["draws"] = eng.pool_gather(idx)
         state.update(elbo=elbo, best=best, pareto_k=res["pareto_shape"], idx=idx)
 

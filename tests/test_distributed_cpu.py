@@ -1,0 +1,108 @@
+"""world_size-2 `gloo` test of the multi-GPU orchestration (pfmi/distributed.py) on CPU.
+
+The engine-specific steps (per-path ELBO/draws, PSIS, index draw, column gather) are played by the CPU oracle,
+so what is under test is the sharding + all-gather + replicated PSIS/index selection + owner all-reduce logic
+that bench.py runs over RCCL: the 2-rank result must be IDENTICAL to the single-process result
+(extension of the reference's ntasks invariance, test/multipath.jl:107-140, to the GPU count).
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _pipeline(rank, world, dist):
+    """One rank's share of a small multipath job; returns (draws (d, ndraws), idx, pareto_k)."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "pathfinder.jl_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, ROOT)
+    import pfmi
+    from pfmi.distributed import pooled_psis_resample, shard_paths
+    from helpers import oracle_target
+    from oracle import pf_oracle as po
+
+    K, d, N, J, ndraws = 4, 12, 40, 6, 64
+    tg = pfmi.t_lowrank(d, r=3, seed=4)
+    otg = oracle_target(tg)
+    k0, k1 = shard_paths(K, world, rank)
+    run_seeds = pfmi.hostrng.rand_u64(77, np.arange(K, dtype=np.uint64), 9)    # keyed by the GLOBAL path index
+    pools, lrs = [], []
+    for k in range(k0, k1):
+        tr = pfmi.optimize_with_trace(tg, pfmi.HostRNG(int(run_seeds[k])).rand(d) * 4 - 2, history_length=J)
+        seeds = pfmi.hostrng.rand_u64(int(run_seeds[k]), np.arange(len(tr), dtype=np.uint64), 10)
+        r = po.path_fit_elbo(tr.points, tr.gradients, J, otg, N, seeds, want_draws=True)
+        pools.append(r["draws"])
+        lrs.append(r["logp"] - r["logq"])
+    pool = np.concatenate(pools, axis=1)                       # (d, K_local * N), k-major
+    lr_local = torch.from_numpy(np.concatenate(lrs))
+    lr_all = torch.empty(K * N, dtype=torch.float64)
+    out = torch.zeros(d * ndraws, dtype=torch.float64)
+    state = {}
+
+    def psis_fn(t):
+        lw, w, k, M = po.psis(t.numpy())
+        state["w"] = w
+        return dict(pareto_shape=k, tail_length=M)
+
+    def sample_fn(S):
+        return po.sample_weighted(state["w"], ndraws, seed=123)
+
+    def gather_fn(idx, o):
+        col0 = k0 * N
+        buf = np.zeros((d, ndraws), order="F")
+        own = (idx >= col0) & (idx < col0 + pool.shape[1])
+        buf[:, own] = pool[:, idx[own] - col0]
+        o.copy_(torch.from_numpy(buf.T.ravel().copy()))
+
+    res, idx = pooled_psis_resample(dist if world > 1 else None, lr_local, lr_all, out,
+                                    psis_fn=psis_fn, sample_fn=sample_fn, gather_fn=gather_fn)
+    return out.numpy().reshape(ndraws, d).T.copy(), idx, res["pareto_shape"]
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        draws, idx, k = _pipeline(rank, world, dist)
+        q.put((rank, draws, idx, k))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_equal_single_process():
+    import torch.multiprocessing as mp
+    ref_draws, ref_idx, ref_k = _pipeline(0, 1, None)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, draws, idx, k in got:
+        np.testing.assert_array_equal(idx, ref_idx)            # replicated, deterministic index selection
+        np.testing.assert_array_equal(draws, ref_draws)        # owner all-reduce reassembles the same columns
+        assert k == ref_k
+
+
+def test_shard_paths_contract():
+    from pfmi.distributed import shard_paths
+    assert [shard_paths(64, 8, r) for r in (0, 7)] == [(0, 8), (56, 64)]
+    with pytest.raises(ValueError):
+        shard_paths(10, 4, 0)

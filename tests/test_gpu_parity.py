@@ -495,3 +495,36 @@ def test_pathfinder_single_path_plumbing(pfmi_mod):
     assert pfmi_mod.pathfinder(tg, init=init, ndraws=2).draws.shape == (10, 2)
     with pytest.raises(ValueError):
         pfmi_mod.pathfinder(pfmi_mod.CallbackTarget(0, lambda x: 0.0))
+
+
+def test_torch_interop_for_the_collective_path(pfmi_mod, eng):
+    """the plumbing bench.py uses under RCCL, on one GPU: zero-copy torch view of the engine's log-ratio shard
+    (CUDA array interface), PSIS on a torch-owned device buffer, owner-gather into a torch tensor."""
+    import torch
+    from pfmi.distributed import pooled_psis_resample
+
+    class DevArray:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+    tg, traces = _setup(pfmi_mod, eng, "lr50", 4, 6)
+    seeds = fit_seeds(eng.P, 4)
+    elbo, se, best = eng.elbo_batch(64, seeds)
+    pts = [int(eng.offsets[k]) + int(best[k]) for k in range(4)]
+    eng.pool_build(64, pts, seeds[pts])
+    pool, lr = eng.pool_get()
+    ptr, cnt = eng.pool_log_ratios_dev()
+    shard = torch.as_tensor(DevArray(ptr, cnt), device="cuda:0")
+    np.testing.assert_array_equal(shard.cpu().numpy(), lr)
+    lr_all = shard.clone()                                            # torch-owned device memory
+    out = torch.zeros(tg.d * 32, dtype=torch.float64, device="cuda:0")
+    res, idx = pooled_psis_resample(
+        None, lr_all, lr_all, out,
+        psis_fn=lambda t: eng.psis_dev(t.data_ptr(), t.numel(), want_weights=True),
+        sample_fn=lambda S: eng.resample_indices(S, 32, seed=9),
+        gather_fn=lambda ix, o: eng.pool_gather_dev(ix, 0, o.data_ptr()),
+        sync_fn=torch.cuda.synchronize)
+    ref = eng.psis(lr)
+    np.testing.assert_array_equal(res["weights"], ref["weights"])
+    np.testing.assert_array_equal(idx, po.sample_weighted(ref["weights"], 32, seed=9))
+    np.testing.assert_array_equal(out.cpu().numpy().reshape(32, tg.d).T, pool.reshape(tg.d, -1, order="F")[:, idx])
