@@ -33,7 +33,7 @@ __device__ __forceinline__ d4 pf_mfma(double a, double b, d4 c) {
 }
 
 // TGT: 0 none, 1 Gaussian family (RPAD = 0 or 8 or 16 low-rank columns), 2 funnel
-template <int KC, int NBW, int TGT, int RPAD>
+template <int KC, int NBW, int TGT, int RPAD, bool WX>
 __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, int groups_per_block, int ngroups) {
     extern __shared__ double lds[];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, q = lane >> 4, c = lane & 15;
@@ -61,11 +61,14 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
     double *mu_s = vh_s + (size_t)rows * KC;   // [rows]
     double *sqa_s = mu_s + rows;               // [rows]
     double *tm_s = sqa_s + rows;               // [rows] target mean       (TGT == 1)
-    double *ta_s = tm_s + rows;                // [rows] target diag prec  (TGT == 1)
-    double *t_s = ta_s + rows;                 // [KC][KC] compact-WY T
-    double *red = t_s + KC * KC;               // [8][256] per-wave partial tiles
-    double *wsum = red + MF_WAVES * 256;       // [256]
-    double *red2 = wsum + 256;                 // [8][16][4] per-wave per-draw scalars
+    double *t_s = tm_s + rows;                 // [KC][KC] compact-WY T
+    double *red = t_s + KC * KC;               // [8][64 * KC/4] per-wave partial W tiles (rows j < KC only)
+    double *redb = red + MF_WAVES * 64 * (KC / 4);            // [8][64 * ceil(RPAD/4)] per-wave partial target tiles
+    double *wsum = redb + MF_WAVES * 64 * ((RPAD + 3) / 4);   // [256] summed W tile
+    double *tsum = wsum + 256;                 // [64 * ceil(RPAD/4)] summed target tile
+    double *ssum = tsum + 64 * ((RPAD + 3) / 4);              // [2][16] summed |u|^2 and diagonal quadratic form
+    double *gs = ssum + 32;                    // [RPAD][RPAD] target capacitance factor
+    double *red2 = gs + RPAD * RPAD;           // [8][16][4] per-wave per-draw scalars
     double2 *logtab = reinterpret_cast<double2 *>(red2 + MF_WAVES * 64);   // [128]
     double *zero_s = red2 + MF_WAVES * 64 + 256;                           // [2] zeros (masked A-operand lanes)
 
@@ -76,13 +79,11 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
         for (int i = tid; i < rows; i += MF_THREADS) {
             mu_s[i] = (i < d) ? mu[i] : 0.0;
             sqa_s[i] = (i < d) ? sqa[i] : 0.0;
-            if (TGT == 1) {
-                tm_s[i] = (i < d) ? A.t_mean[i] : 0.0;
-                ta_s[i] = (i < d) ? A.t_a[i] : 0.0;
-            }
+            if (TGT == 1) tm_s[i] = (i < d) ? A.t_mean[i] : 0.0;
         }
         const double *T = A.tmat + (size_t)p * KC * KC;
         for (int i = tid; i < KC * KC; i += MF_THREADS) t_s[i] = T[i];
+        if (TGT == 1 && RPAD > 0) for (int i = tid; i < RPAD * RPAD; i += MF_THREADS) gs[i] = A.t_g[i];
         pf_logtab_load(logtab);
         if (tid < 2) zero_s[tid] = 0.0;
     }
@@ -103,126 +104,248 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
     const double logdet = A.logdet[p];
     __syncthreads();
 
-    for (int grp = g_begin; grp < g_end; ++grp) {
-        // the wave index is made opaque once per group so that nothing derived from the block index is treated
-        // as loop-invariant: otherwise LLVM hoists per-block Philox partial products and addresses out of the
-        // group loop and spills them (the kernel is register-bound: z alone is 8*NBW VGPRs)
-        int wvs = __builtin_amdgcn_readfirstlane(wv);
-        asm volatile("" : "+s"(wvs));
-        const int64_t nl = (int64_t)grp * 16 + c;             // local draw index of this lane's column
-        const bool valid = nl < A.N;
-        const uint32_t n = (uint32_t)(A.n0 + nl);
-        double z[NBW][4];
-        double usq = 0.0;
-        d4 acc = {0.0, 0.0, 0.0, 0.0};
-        // ---------------- pass 1: normals -> registers, W = Vh' z on the matrix cores
+    // ---- software pipeline over draw groups: while group g is finished (pass 2 + target, MFMA heavy), the
+    //      normals of group g+1 are generated (VALU heavy) into the SAME registers block by block, and its pass-1
+    //      contraction is issued.  Every block body is straight-line code mixing ~11 MFMAs with the RNG VALU
+    //      stream so that one wave keeps both pipes busy.
+    constexpr int WR = KC / 4;                                   // registers of the W tile that carry rows j < KC
+    constexpr int TR = (RPAD + 3) / 4;                           // registers of the target tile that carry rows j' < RPAD
+    double z[NBW][4];
+    double usq_next = 0.0;
+    d4 accw = {0.0, 0.0, 0.0, 0.0};
+    double ntv[KC / 4];
+
+    // normals of rows 16 blk + 4q + {0..3} of draw n (+ head transform for block 0) and their pass-1 MFMAs
+    auto pass1_block = [&](const int blk, const uint32_t n, const bool head, double (&zz)[4]) {
+        pf_randn4_fast(seed, (uint32_t)(blk * 4 + q), n, 0u, logtab, zz);
+        const int rowbase = blk * 16 + 4 * q;
 #pragma unroll
-        for (int b = 0; b < NBW; ++b) {
-            const int blk = wvs * NBW + b;
-            if (blk < nblk) {
-                double zz[4];
-                pf_randn4_fast(seed, (uint32_t)(blk * 4 + q), n, 0u, logtab, zz);
-                const int rowbase = blk * 16 + 4 * q;
-                if (blk == nblk - 1) {                                      // rows >= d of the last block do not exist
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (rowbase + r >= d) zz[r] = 0.0;
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) usq += zz[r] * zz[r];           // |u|^2 before the transform
-                if (blk == 0) {                                             // z[1:k] = V' u[1:k]  (src/woodbury.jl:139)
-                    d4 h = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) h = pf_mfma(a_head[r], zz[r], h);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) zz[r] = h[r];
-                }
-                const double *a1p = (c < KC) ? (vh_s + rowbase * KC + c) : zero_s;     // A[i = c][k = q] = Vh[row][c]
-                const int a1s = (c < KC) ? KC : 0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    acc = pf_mfma(a1p[r * a1s], zz[r], acc);
-                    z[b][r] = zz[r];
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) z[b][r] = 0.0;
-            }
-            __builtin_amdgcn_sched_barrier(0);   // keep one block's RNG temporaries live at a time
+        for (int r = 0; r < 4; ++r) {
+            zz[r] = (rowbase + r < d) ? zz[r] : 0.0;                // rows >= d do not exist
+            usq_next += zz[r] * zz[r];                              // |u|^2 before the transform (src/mvnormal.jl:31)
         }
-        // ---------------- W: sum the 8 per-wave tiles, tv = T W  (lane (q,c) needs tv[4s + q][c])
+        if (head) {                                                 // z[1:k] = V' u[1:k]  (src/woodbury.jl:139)
+            d4 h = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) red[wv * 256 + reg * 64 + lane] = acc[reg];   // entry (j = q + 4 reg, c)
-        __syncthreads();
-        if (tid < 256) {
+            for (int r = 0; r < 4; ++r) h = pf_mfma(a_head[r], zz[r], h);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) zz[r] = h[r];
+        }
+    };
+    auto pass1_mfma = [&](const int blk, const double (&zz)[4]) {
+        const int rowbase = blk * 16 + 4 * q;
+        const double *a1p = (c < KC) ? (vh_s + rowbase * KC + c) : zero_s;         // A[i = c][k = q] = Vh[row][c]
+        const int a1s = (c < KC) ? KC : 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accw = pf_mfma(a1p[r * a1s], zz[r], accw);
+    };
+    // W: sum the 8 per-wave tiles, tv = T W  (lane (q,c) needs tv[4s + q][c]); two barriers
+    auto reduce_w = [&]() {
+        if (tid < 64 * WR) {
             double s = red[tid];
 #pragma unroll
-            for (int w = 1; w < MF_WAVES; ++w) s += red[w * 256 + tid];
+            for (int w = 1; w < MF_WAVES; ++w) s += red[w * 64 * WR + tid];
             wsum[tid] = s;
         }
-        __syncthreads();
-        double ntv[KC / 4];
+    };
+    auto compute_ntv = [&]() {
 #pragma unroll
         for (int s = 0; s < KC / 4; ++s) {
             const int jp = 4 * s + q;
             double v = 0.0;
 #pragma unroll
-            for (int j = 0; j < KC; ++j) {
-                // W[j][c] lives at entry (reg = j >> 2, lane = (j & 3) * 16 + c)
+            for (int j = 0; j < KC; ++j)       // W[j][c] lives at entry (reg = j >> 2, lane = (j & 3) * 16 + c)
                 v += t_s[jp * KC + j] * wsum[(j >> 2) * 64 + (j & 3) * 16 + c];
-            }
             ntv[s] = -v;
         }
-        // ---------------- pass 2: x = mu + sqrt(alpha) (z - Vh tv), target, optional store
-        double qd = 0.0, tau = 0.0;
-        d4 acc3 = {0.0, 0.0, 0.0, 0.0};
-        double *X = (A.x && valid) ? (A.x + (size_t)slot * A.x_stride + (size_t)nl * d) : nullptr;
-        double a3n[4] = {0.0, 0.0, 0.0, 0.0};                  // software-prefetched A operands of the target contraction
-        if (TGT == 1 && RPAD > 0 && wvs * NBW < nblk) {
-            const double *w16 = A.t_wd16 + ((size_t)(wvs * NBW) * 16 + 4 * q) * 16 + c;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) a3n[r] = w16[r * 16];
-        }
+    };
+
+    int wvs = __builtin_amdgcn_readfirstlane(wv);
+    asm volatile("" : "+s"(wvs));
+    uint32_t xc[4];                      // Philox output of the NEXT (group, block) pair to be transformed
+    {   // prologue: pass 1 of the first group
+        const uint32_t n = (uint32_t)(A.n0 + (int64_t)g_begin * 16 + c);
 #pragma unroll
         for (int b = 0; b < NBW; ++b) {
             const int blk = wvs * NBW + b;
             if (blk < nblk) {
-                double a3[4];
-                if (TGT == 1 && RPAD > 0) {
+                double zz[4];
+                pass1_block(blk, n, blk == 0, zz);
+                pass1_mfma(blk, zz);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) a3[r] = a3n[r];
-                    if (b + 1 < NBW && blk + 1 < nblk) {
-                        const double *w16 = A.t_wd16 + ((size_t)(blk + 1) * 16 + 4 * q) * 16 + c;   // A[j' = c][k = q]
+                for (int r = 0; r < 4; ++r) z[b][r] = zz[r];
+            } else {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) a3n[r] = w16[r * 16];
-                    }
-                }
-                d4 xa = {z[b][0], z[b][1], z[b][2], z[b][3]};
-                const double *a2p = vh_s + (blk * 16 + rho) * KC + q;                    // A[i'][k = q] = Vh[16 blk + rho(i')][4s + q]
-#pragma unroll
-                for (int s = 0; s < KC / 4; ++s) xa = pf_mfma(a2p[4 * s], ntv[s], xa);
-                const int rowbase = blk * 16 + 4 * q;
-                double e4[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = rowbase + r;
-                    const double xi = mu_s[row] + sqa_s[row] * xa[r];
-                    if (TGT == 1) {
-                        const double e = xi - tm_s[row];
-                        qd += ta_s[row] * e * e;
-                        e4[r] = e;
-                    } else if (TGT == 2) {
-                        if (row == 0) tau = xi; else qd += xi * xi;           // padded rows give xi = 0
-                    }
-                    if (X && row < d) X[row] = xi;
-                }
-                if (TGT == 1 && RPAD > 0) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc3 = pf_mfma(a3[r], e4[r], acc3);
-                }
+                for (int r = 0; r < 4; ++r) z[b][r] = 0.0;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // ---------------- per-draw reductions over q (lanes) and waves (LDS)
+        pf_philox4x32_10(n + 16u, (uint32_t)(wvs * NBW * 4 + q), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), xc);
+#pragma unroll
+        for (int reg = 0; reg < WR; ++reg) red[wv * 64 * WR + reg * 64 + lane] = accw[reg];   // entry (j = q + 4 reg, c)
+        __syncthreads();
+        reduce_w();
+        __syncthreads();
+        compute_ntv();
+    }
+
+    for (int grp = g_begin; grp < g_end; ++grp) {
+        // the wave index is made opaque once per group so that nothing derived from the block index is treated as
+        // loop-invariant (LLVM would hoist per-block Philox partial products / addresses and spill them)
+        wvs = __builtin_amdgcn_readfirstlane(wv);
+        asm volatile("" : "+s"(wvs));
+        const int64_t nl = (int64_t)grp * 16 + c;                 // local draw index of this lane's column
+        const bool valid = nl < A.N;
+        const uint32_t n_next = (uint32_t)(A.n0 + nl + 16);       // the group whose normals are generated in this iteration
+        const double usq_cur = usq_next;
+        usq_next = 0.0;
+        accw = (d4){0.0, 0.0, 0.0, 0.0};
+        double qd = 0.0, tau = 0.0;
+        d4 acc3 = {0.0, 0.0, 0.0, 0.0};
+        double *X = (WX && valid) ? (A.x + (size_t)slot * A.x_stride + (size_t)nl * d) : nullptr;
+        // Block body.  Three INDEPENDENT dependency chains are advanced side by side in each of 11 phases -- the two
+        // Box-Muller pairs of (next group, this block) and the Philox call of the following pair -- and one MFMA is
+        // issued per phase (3 pass-2, 4 pass-1 of the previous block, 4 target), with a scheduling barrier after each
+        // phase: the wave keeps the matrix pipe (64 cycles per f64 MFMA) and the VALU busy at once, and the VALU
+        // always has an independent instruction to issue while a dependent fp64 result is in flight.
+#define PF_PHASE_END() __builtin_amdgcn_sched_barrier(0)
+        // pin a value to the phase that produced it (IR-level sinking would otherwise move the work to its first use
+        // and unbalance the phases); costs no instruction
+#define PF_PIN(x) asm volatile("" : "+v"(x))
+#define PF_PIN_RNG() do { PF_PIN(c0); PF_PIN(c1); PF_PIN(c2); PF_PIN(c3); } while (0)
+        auto body = [&](const int b, const int blk, const bool head) {
+            const int rowbase = blk * 16 + 4 * q;
+            // ---- operand fetch (LDS / L2) for this block, issued up front
+            double a3[4] = {0.0, 0.0, 0.0, 0.0}, ta4[4] = {0.0, 0.0, 0.0, 0.0};
+            if (TGT == 1) {
+                if (RPAD > 0) {
+                    const double *w16 = A.t_wd16 + ((size_t)blk * 16 + 4 * q) * 16 + c;  // A[j' = c][k = q]
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a3[r] = w16[r * 16];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ta4[r] = A.t_a[(rowbase + r < d) ? rowbase + r : d - 1];
+            }
+            const double *a2p = vh_s + (blk * 16 + rho) * KC + q;                       // A[i'][k = q] = Vh[16 blk + rho(i')][4s + q]
+            double a2v[KC / 4];
+#pragma unroll
+            for (int s2 = 0; s2 < KC / 4; ++s2) a2v[s2] = a2p[4 * s2];
+            double a1v[4] = {0.0, 0.0, 0.0, 0.0};
+            if (b > 0) {                                                                // pass-1 operands of the previous block
+                const double *a1p = (c < KC) ? (vh_s + (rowbase - 16) * KC + c) : zero_s;
+                const int a1s = (c < KC) ? KC : 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a1v[r] = a1p[r * a1s];
+            }
+            const double mu4[4] = {mu_s[rowbase], mu_s[rowbase + 1], mu_s[rowbase + 2], mu_s[rowbase + 3]};
+            const double sq4[4] = {sqa_s[rowbase], sqa_s[rowbase + 1], sqa_s[rowbase + 2], sqa_s[rowbase + 3]};
+            const double tm4[4] = {tm_s[rowbase], tm_s[rowbase + 1], tm_s[rowbase + 2], tm_s[rowbase + 3]};
+            d4 xa = {z[b][0], z[b][1], z[b][2], z[b][3]};
+            // Philox state of the FOLLOWING pair: next block of this wave, or block 0 of the group after
+            const bool nbv = (b + 1 < NBW) && (blk + 1 < nblk);
+            uint32_t c0 = nbv ? n_next : n_next + 16u;
+            uint32_t c1 = (uint32_t)((nbv ? blk + 1 : wvs * NBW) * 4 + q), c2 = 0u, c3 = 0u;
+            uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+            PfPair p1, p2;
+            double zz[4], e4[4], xi4[4];
+            // P0
+            xa = pf_mfma(a2v[0], ntv[0], xa);
+            pf_philox_round(c0, c1, c2, c3, k0, k1); p1.s0(xc[0], xc[1]); p2.s0(xc[2], xc[3]);
+            PF_PIN_RNG(); PF_PIN(p1.m); PF_PIN(p1.t4); PF_PIN(p2.m); PF_PIN(p2.t4);
+            PF_PHASE_END();
+            // P1
+            if (KC >= 8) xa = pf_mfma(a2v[KC >= 8 ? 1 : 0], ntv[KC >= 8 ? 1 : 0], xa);
+            pf_philox_round(c0, c1, c2, c3, k0, k1); p1.s1(logtab); p2.s1(logtab);
+            PF_PIN_RNG(); PF_PIN(p1.r); PF_PIN(p1.f); PF_PIN(p2.r); PF_PIN(p2.f);
+            PF_PHASE_END();
+            // P2
+            if (KC >= 12) xa = pf_mfma(a2v[KC >= 12 ? 2 : 0], ntv[KC >= 12 ? 2 : 0], xa);
+            if (KC >= 16) xa = pf_mfma(a2v[KC >= 16 ? 3 : 0], ntv[KC >= 16 ? 3 : 0], xa);
+            pf_philox_round(c0, c1, c2, c3, k0, k1); p1.s2(); p2.s2();
+            PF_PIN_RNG(); PF_PIN(p1.p); PF_PIN(p2.p);
+            PF_PHASE_END();
+            // P3
+            if (b > 0) accw = pf_mfma(a1v[0], z[b > 0 ? b - 1 : 0][0], accw);
+            pf_philox_round(c0, c1, c2, c3, k0, k1); p1.s3(); p2.s3();
+            PF_PIN_RNG(); PF_PIN(p1.g); PF_PIN(p1.h); PF_PIN(p1.f2); PF_PIN(p2.g); PF_PIN(p2.h); PF_PIN(p2.f2);
+            PF_PHASE_END();
+            // P4: first half of the epilogue of the current group: x = mu + sqrt(alpha) x~
+            if (b > 0) accw = pf_mfma(a1v[1], z[b > 0 ? b - 1 : 0][1], accw);
+            pf_philox_round(c0, c1, c2, c3, k0, k1); p1.s4(); p2.s4();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xi4[r] = mu4[r] + sq4[r] * xa[r];
+                e4[r] = xi4[r] - tm4[r];
+            }
+            PF_PIN_RNG(); PF_PIN(p1.rad); PF_PIN(p1.ps); PF_PIN(p2.rad); PF_PIN(p2.ps);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) PF_PIN(e4[r]);
+            PF_PHASE_END();
+            // P5: second half: target accumulation, optional store
+            if (b > 0) accw = pf_mfma(a1v[2], z[b > 0 ? b - 1 : 0][2], accw);
+            pf_philox_round(c0, c1, c2, c3, k0, k1); p1.s5(); p2.s5();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rowbase + r;
+                if (TGT == 1) qd += ta4[r] * e4[r] * e4[r];                             // padded rows: e = 0
+                else if (TGT == 2) { if (row == 0) tau = xi4[r]; else qd += xi4[r] * xi4[r]; }   // padded rows: xi = 0
+                if (WX) { if (X && row < d) X[row] = xi4[r]; }
+            }
+            PF_PIN_RNG(); PF_PIN(p1.ps); PF_PIN(p1.pc); PF_PIN(p2.ps); PF_PIN(p2.pc); PF_PIN(qd);
+            PF_PHASE_END();
+            // P6
+            if (TGT == 1 && RPAD > 0) acc3 = pf_mfma(a3[0], e4[0], acc3);
+            pf_philox_round(c0, c1, c2, c3, k0, k1); p1.s6(); p2.s6();
+            PF_PIN_RNG(); PF_PIN(p1.pc); PF_PIN(p2.pc);
+            PF_PHASE_END();
+            // P7
+            if (TGT == 1 && RPAD > 0) acc3 = pf_mfma(a3[1], e4[1], acc3);
+            pf_philox_round(c0, c1, c2, c3, k0, k1); p1.s7(zz[0], zz[1]); p2.s7(zz[2], zz[3]);
+            PF_PIN_RNG(); PF_PIN(zz[0]); PF_PIN(zz[1]); PF_PIN(zz[2]); PF_PIN(zz[3]);
+            PF_PHASE_END();
+            // P8
+            if (TGT == 1 && RPAD > 0) acc3 = pf_mfma(a3[2], e4[2], acc3);
+            pf_philox_round(c0, c1, c2, c3, k0, k1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                zz[r] = (rowbase + r < d) ? zz[r] : 0.0;                                // rows >= d do not exist
+                usq_next += zz[r] * zz[r];                                              // |u|^2 before the transform
+            }
+            PF_PIN_RNG(); PF_PIN(usq_next);
+            PF_PHASE_END();
+            // P9
+            if (TGT == 1 && RPAD > 0) acc3 = pf_mfma(a3[3], e4[3], acc3);
+            pf_philox_round(c0, c1, c2, c3, k0, k1);
+            if (head) {                                                                 // z[1:k] = V' u[1:k]  (src/woodbury.jl:139)
+                d4 h = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h = pf_mfma(a_head[r], zz[r], h);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) zz[r] = h[r];
+            }
+            PF_PHASE_END();
+            // P10
+            if (b > 0) accw = pf_mfma(a1v[3], z[b > 0 ? b - 1 : 0][3], accw);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[b][r] = zz[r];
+            xc[0] = c0; xc[1] = c1; xc[2] = c2; xc[3] = c3;
+            PF_PHASE_END();
+        };
+#undef PF_PHASE_END
+#undef PF_PIN
+#undef PF_PIN_RNG
+#pragma unroll
+        for (int b = 0; b <= NBW; ++b) {
+            const int blk = wvs * NBW + b;
+            if (b < NBW && blk < nblk) {
+                if (b == 0 && blk == 0) body(b, blk, true);
+                else body(b, blk, false);
+            } else if (b > 0 && blk - 1 < nblk) {
+                pass1_mfma(blk - 1, z[b > 0 ? b - 1 : 0]);             // tail: pass 1 of the last block of this wave
+            }
+        }
+        // ---------------- per-draw reductions over q (lanes) and waves (LDS), W tile of the next group
+        double usq = usq_cur;
         usq += __shfl_xor(usq, 16, 64); usq += __shfl_xor(usq, 32, 64);
         qd += __shfl_xor(qd, 16, 64);   qd += __shfl_xor(qd, 32, 64);
         if (q == 0) {
@@ -232,31 +355,44 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
         }
         if (TGT == 1 && RPAD > 0) {
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) red[wv * 256 + reg * 64 + lane] = acc3[reg];
+            for (int reg = 0; reg < TR; ++reg) redb[wv * 64 * (TR > 0 ? TR : 1) + reg * 64 + lane] = acc3[reg];
+        }
+#pragma unroll
+        for (int reg = 0; reg < WR; ++reg) red[wv * 64 * WR + reg * 64 + lane] = accw[reg];
+        __syncthreads();
+        // stage 1 (parallel, between the barriers): sums over the 8 waves
+        reduce_w();                                                                    // threads 0 .. 64 WR - 1
+        if (TGT == 1 && RPAD > 0 && tid >= 256 && tid < 256 + 64 * TR) {
+            const int e = tid - 256;
+            double sacc = redb[e];
+#pragma unroll
+            for (int w = 1; w < MF_WAVES; ++w) sacc += redb[w * 64 * (TR > 0 ? TR : 1) + e];
+            tsum[e] = sacc;
+        }
+        if (tid >= 448 && tid < 480) {
+            const int cc = (tid - 448) & 15, which = (tid - 448) >> 4;
+            double sacc = 0.0;
+#pragma unroll
+            for (int w = 0; w < MF_WAVES; ++w) sacc += red2[(w * 16 + cc) * 4 + which];
+            ssum[which * 16 + cc] = sacc;
         }
         __syncthreads();
-        if (tid < 16) {
-            const int cc = tid;
-            double us = 0.0, qq = 0.0;
-#pragma unroll
-            for (int w = 0; w < MF_WAVES; ++w) { us += red2[(w * 16 + cc) * 4 + 0]; qq += red2[(w * 16 + cc) * 4 + 1]; }
+        compute_ntv();
+        if (tid >= 256 && tid < 272) {                             // finalise the current group (16 lanes of wave 4)
+            const int cc = tid - 256;
+            const double us = ssum[cc], qq = ssum[16 + cc];
             double lp = NAN;
             if (TGT == 1) {
                 double corr = 0.0;
                 if (RPAD > 0) {
                     double t[RPAD > 0 ? RPAD : 1];
 #pragma unroll
-                    for (int j = 0; j < RPAD; ++j) {
-                        double s = 0.0;
-#pragma unroll
-                        for (int w = 0; w < MF_WAVES; ++w) s += red[w * 256 + (j >> 2) * 64 + (j & 3) * 16 + cc];
-                        t[j] = s;
-                    }
+                    for (int j = 0; j < RPAD; ++j) t[j] = tsum[(j >> 2) * 64 + (j & 3) * 16 + cc];
 #pragma unroll
                     for (int j = 0; j < RPAD; ++j) {
                         double g = 0.0;
 #pragma unroll
-                        for (int l = 0; l <= j; ++l) g += A.t_g[j * RPAD + l] * t[l];
+                        for (int l = 0; l <= j; ++l) g += gs[j * RPAD + l] * t[l];
                         corr += g * g;
                     }
                 }
@@ -271,19 +407,22 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
                 out_lp[no] = lp;
             }
         }
-        __syncthreads();
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <int KC, int NBW, int TGT, int RPAD>
+static size_t mf_lds_bytes(int d, int kc, int rpad) {
+    const size_t rows = (size_t)((d + 15) / 16) * 16;
+    return sizeof(double) * (rows * kc + 3 * rows + (size_t)kc * kc + MF_WAVES * 64 * (kc / 4) +
+                             MF_WAVES * 64 * ((rpad + 3) / 4) + 256 + 64 * ((rpad + 3) / 4) + 32 + (size_t)rpad * rpad +
+                             MF_WAVES * 64 + 256 + 2);
+}
+
+template <int KC, int NBW, int TGT, int RPAD, bool WX>
 static int32_t launch_mf(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
-    const int d = a.d;
-    const int nblk = (d + 15) / 16, rows = nblk * 16;
-    const size_t lds_bytes = sizeof(double) * ((size_t)rows * KC + 4 * (size_t)rows + KC * KC + MF_WAVES * 256 + 256 +
-                                               MF_WAVES * 64 + 256 + 2);
+    const size_t lds_bytes = mf_lds_bytes(a.d, KC, RPAD);
     PF_CHECK(lds_bytes <= 160 * 1024, PFMI_ERR_UNSUPPORTED, "mfma kernel LDS %zu too large", lds_bytes);
-    auto kern = pf_elbo_mfma_kernel<KC, NBW, TGT, RPAD>;
+    auto kern = pf_elbo_mfma_kernel<KC, NBW, TGT, RPAD, WX>;
     static bool attr_set = false;
     if (!attr_set) {
         PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -307,13 +446,19 @@ static int32_t launch_mf(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
     return PFMI_OK;
 }
 
+template <int KC, int NBW, int TGT, int RPAD>
+static int32_t launch_mf_w(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
+    if (a.x) return launch_mf<KC, NBW, TGT, RPAD, true>(c, a, nfits);
+    return launch_mf<KC, NBW, TGT, RPAD, false>(c, a, nfits);
+}
+
 template <int KC, int NBW>
 static int32_t launch_mf_t(pfmi_ctx *c, const ElboArgs &a, int64_t nfits, int tgt, int rpad) {
-    if (tgt == 0) return launch_mf<KC, NBW, 0, 0>(c, a, nfits);
-    if (tgt == 2) return launch_mf<KC, NBW, 2, 0>(c, a, nfits);
-    if (rpad == 0) return launch_mf<KC, NBW, 1, 0>(c, a, nfits);
-    if (rpad == 8) return launch_mf<KC, NBW, 1, 8>(c, a, nfits);
-    return launch_mf<KC, NBW, 1, 16>(c, a, nfits);
+    if (tgt == 0) return launch_mf_w<KC, NBW, 0, 0>(c, a, nfits);
+    if (tgt == 2) return launch_mf_w<KC, NBW, 2, 0>(c, a, nfits);
+    if (rpad == 0) return launch_mf_w<KC, NBW, 1, 0>(c, a, nfits);
+    if (rpad == 8) return launch_mf_w<KC, NBW, 1, 8>(c, a, nfits);
+    return launch_mf_w<KC, NBW, 1, 16>(c, a, nfits);
 }
 
 template <int KC>
@@ -332,10 +477,7 @@ int32_t pf_launch_elbo_mfma(pfmi_ctx *c, const ElboArgs &a, int64_t nfits, int t
     if (a.u != nullptr) return PFMI_OK;                       // parity mode -> lane kernel
     if (!(kc == 4 || kc == 8 || kc == 12 || kc == 16)) return PFMI_OK;
     if (a.d > 1024) return PFMI_OK;
-    const int rows = ((a.d + 15) / 16) * 16;
-    const size_t lds_bytes = sizeof(double) * ((size_t)rows * kc + 4 * (size_t)rows + kc * kc + MF_WAVES * 256 + 256 +
-                                               MF_WAVES * 64 + 256 + 2);
-    if (lds_bytes > 160 * 1024) return PFMI_OK;
+    if (mf_lds_bytes(a.d, kc, tgt == 1 ? rpad : 0) > 160 * 1024) return PFMI_OK;
     *handled = true;
     switch (kc) {
         case 4: return launch_mf_k<4>(c, a, nfits, tgt, rpad);

@@ -15,6 +15,7 @@
 // and is what the draw kernel later scalar-loads per row.  Column padding (zeros) sits at the END of
 // the column list only (a zero column in the middle would shift later pivots).
 #include "pfmi_common.h"
+#include <stdlib.h>
 
 #define HIST_THREADS 256
 #define FIT_THREADS 256
@@ -400,6 +401,377 @@ __global__ __launch_bounds__(FIT_THREADS) void pf_fit_kernel(FitArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Register-resident variant of pf_fit_kernel for d <= 256 * RPT: thread t owns rows {t + 256 i}, the whole
+// d x KC block lives in VGPRs (RPT * KC doubles per thread), so the ~25 sweeps of the Gram / Householder /
+// mean computation touch no memory at all -- only ~27 block reductions remain.  Same operations and the same
+// LAPACK reflector convention as pf_fit_kernel; only the summation order inside the block reductions differs
+// (fp64 roundoff), which the parity tests cover.
+template <int KPAD, int RPT>
+__global__ __launch_bounds__(FIT_THREADS) void pf_fit_reg_kernel(FitArgs A) {
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int d = A.d, J = A.J;
+    const int path = A.path_of[p];
+    const int64_t p0 = A.off[path];
+    const int j = A.hist_len[p], m = 2 * j, k = d < m ? d : m;
+    const double *alpha = A.alpha_all + (size_t)p * d;
+    double *Vh = A.vh + (size_t)p * d * KPAD;
+    double *sqa = A.sqrt_alpha + (size_t)p * d;
+    double *mu = A.mu + (size_t)p * d;
+    const double *theta_p = A.theta + (size_t)p * d, *grad_p = A.grad + (size_t)p * d;
+
+    __shared__ double red[(FIT_THREADS / 64) * KPAD];
+    __shared__ double sRow[KPAD], sHead[KPAD];
+    __shared__ double sD[KPAD * KPAD], sR[KPAD * KPAD], sT[KPAD * KPAD], sV[KPAD * KPAD], sG[KPAD * KPAD];
+    __shared__ double sLogdetV;
+    __shared__ int sStatus;
+
+    double a[RPT][KPAD];       // this thread's rows of B~ (later: Householder vectors)
+    double sq[RPT], ag[RPT];   // sqrt(alpha_i), sqrt(alpha_i) * grad_i
+    double bad = 0.0, ldu = 0.0;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int row = tid + FIT_THREADS * i;
+        sq[i] = 1.0; ag[i] = 0.0;
+        if (row < d) {
+            const double al = alpha[row];
+            if (!(al > 0.0) || !isfinite(al)) bad = 1.0;
+            const double s = sqrt(al);
+            sq[i] = s;
+            sqa[row] = s;
+            ldu += log(s);
+            ag[i] = s * grad_p[row];
+        }
+    }
+    {
+        double v[2] = {bad, ldu};
+        pf_block_sum<2>(v, red);
+        bad = v[0]; ldu = v[1];
+    }
+    for (int t = tid; t < KPAD * KPAD; t += FIT_THREADS) { sD[t] = 0.0; sR[t] = 0.0; sT[t] = 0.0; sV[t] = 0.0; sG[t] = 0.0; }
+    const size_t sm = (size_t)p * KPAD * KPAD;
+    if (bad > 0.0) {                                           // A not positive definite (src/woodbury.jl:202)
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int row = tid + FIT_THREADS * i;
+            if (row < d) {
+                mu[row] = NAN;
+                for (int c = 0; c < KPAD; ++c) Vh[(size_t)row * KPAD + c] = 0.0;
+            }
+        }
+        for (int t = tid; t < KPAD * KPAD; t += FIT_THREADS) { A.tmat[sm + t] = 0.0; A.vchol[sm + t] = 0.0; A.rq[sm + t] = 0.0; A.dmat[sm + t] = 0.0; }
+        if (tid == 0) { A.status[p] = PFMI_FIT_A_NOT_PD; A.logdet[p] = NAN; }
+        return;
+    }
+    // ---- rows of B~ = U' \ [alpha.Y  S]   (src/inverse_hessian.jl:117-118, src/woodbury.jl:204)
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int row = tid + FIT_THREADS * i;
+#pragma unroll
+        for (int c = 0; c < KPAD; ++c) a[i][c] = 0.0;
+        if (row < d) {
+            const double al = alpha[row], sa = sq[i];
+#pragma unroll
+            for (int c = 0; c < KPAD / 2; ++c) {
+                if (c < j) {
+                    const int src = A.hist_src[(size_t)p * J + c];
+                    const size_t q0 = (size_t)(p0 + src) * d + row, q1 = (size_t)(p0 + src + 1) * d + row;
+                    const double y = A.grad[q0] - A.grad[q1];
+                    const double s = A.theta[q1] - A.theta[q0];
+                    const double by = (al * y) / sa, bs = s / sa;
+                    // columns c and j + c (j is runtime: select statically unrolled targets)
+#pragma unroll
+                    for (int cc = 0; cc < KPAD; ++cc) {
+                        if (cc == c) a[i][cc] = by;
+                        if (cc == j + c) a[i][cc] = bs;
+                    }
+                }
+            }
+        }
+    }
+    double acc[KPAD];
+    // ---- Gram matrix G = B~'B~ (row c at a time)
+    for (int c = 0; c < m; ++c) {
+#pragma unroll
+        for (int cc = 0; cc < KPAD; ++cc) acc[cc] = 0.0;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            double xc = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < KPAD; ++cc) if (cc == c) xc = a[i][cc];
+#pragma unroll
+            for (int cc = 0; cc < KPAD; ++cc) acc[cc] += xc * a[i][cc];
+        }
+        pf_block_sum<KPAD>(acc, red);
+        if (tid == 0) {
+#pragma unroll
+            for (int cc = 0; cc < KPAD; ++cc) sG[c * KPAD + cc] = acc[cc];
+        }
+    }
+    __syncthreads();
+    // ---- D (m x m)   (src/inverse_hessian.jl:119-130)
+    if (tid == 0 && j > 0) {
+        double *R = sT, *nRinv = sV;
+        for (int aa = 0; aa < j; ++aa)
+            for (int b = 0; b < j; ++b) {
+                R[aa * KPAD + b] = (b >= aa) ? sG[(j + aa) * KPAD + b] : 0.0;
+                nRinv[aa * KPAD + b] = 0.0;
+            }
+        for (int c = 0; c < j; ++c)
+            for (int r = c; r >= 0; --r) {
+                double rhs = (r == c) ? -1.0 : 0.0;
+                for (int t = r + 1; t <= c; ++t) rhs -= R[r * KPAD + t] * nRinv[t * KPAD + c];
+                nRinv[r * KPAD + c] = rhs / R[r * KPAD + r];
+            }
+    }
+    __syncthreads();
+    if (j > 0) {   // M = Y'alpha Y + diag(R); D12, D21 -- one entry per thread
+        for (int t = tid; t < j * j; t += FIT_THREADS) {
+            const int aa = t / j, b = t % j;
+            sD[aa * KPAD + (j + b)] = sV[aa * KPAD + b];
+            sD[(j + aa) * KPAD + b] = sV[b * KPAD + aa];
+            double v = (aa <= b) ? sG[aa * KPAD + b] : sG[b * KPAD + aa];
+            if (aa == b) v += sT[aa * KPAD + aa];
+            sR[aa * KPAD + b] = v;                                   // M
+        }
+    }
+    __syncthreads();
+    if (j > 0) {   // T1 = M nRinv  -> sG (G is no longer needed)
+        for (int t = tid; t < j * j; t += FIT_THREADS) {
+            const int aa = t / j, b = t % j;
+            double v = 0.0;
+            for (int u = 0; u <= b; ++u) v += sR[aa * KPAD + u] * sV[u * KPAD + b];
+            sG[aa * KPAD + b] = v;
+        }
+    }
+    __syncthreads();
+    if (j > 0) {   // D22 = nRinv' T1
+        for (int t = tid; t < j * j; t += FIT_THREADS) {
+            const int aa = t / j, b = t % j;
+            double v = 0.0;
+            for (int u = 0; u <= aa; ++u) v += sV[u * KPAD + aa] * sG[u * KPAD + b];
+            sD[(j + aa) * KPAD + (j + b)] = v;
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < KPAD * KPAD; t += FIT_THREADS) { sT[t] = 0.0; sV[t] = 0.0; sR[t] = 0.0; }
+    __syncthreads();
+
+    // ---- Householder QR, one block reduction per column
+    for (int c = 0; c < k; ++c) {
+        // row c belongs to thread c (slot 0): publish it
+        if (tid == c) {
+#pragma unroll
+            for (int cc = 0; cc < KPAD; ++cc) sRow[cc] = a[0][cc];
+        }
+#pragma unroll
+        for (int cc = 0; cc < KPAD; ++cc) acc[cc] = 0.0;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int row = tid + FIT_THREADS * i;
+            if (row > c) {
+                double xc = 0.0;
+#pragma unroll
+                for (int cc = 0; cc < KPAD; ++cc) if (cc == c) xc = a[i][cc];
+#pragma unroll
+                for (int cc = 0; cc < KPAD; ++cc) acc[cc] += xc * a[i][cc];
+            }
+        }
+        pf_block_sum<KPAD>(acc, red);       // its barriers also publish sRow
+        double xn2 = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < KPAD; ++cc) if (cc == c) xn2 = acc[cc];
+        const double alpha_c = sRow[c];
+        const double xnorm = sqrt(xn2);
+        double tau, scal, beta;
+        if (xnorm == 0.0) { tau = 0.0; scal = 0.0; beta = alpha_c; }
+        else {
+            beta = -copysign(hypot(alpha_c, xnorm), alpha_c);
+            tau = (beta - alpha_c) / beta;
+            scal = 1.0 / (alpha_c - beta);
+        }
+        double wv[KPAD];                     // cc > c: tau * (v_c . column cc); cc < c: v_c . v_cc
+#pragma unroll
+        for (int cc = 0; cc < KPAD; ++cc) {
+            const double vdot = sRow[cc] + scal * acc[cc];
+            wv[cc] = (cc > c) ? tau * vdot : vdot;
+        }
+        if (tid == 0) {                      // T[0:c, c] = -tau T[0:c,0:c] (Vh' v_c)   (dlarft)
+            double g[KPAD];
+#pragma unroll
+            for (int cc = 0; cc < KPAD; ++cc) g[cc] = wv[cc];
+            sT[c * KPAD + c] = tau;
+            for (int aa = 0; aa < c; ++aa) {
+                double v = 0.0;
+#pragma unroll
+                for (int b = 0; b < KPAD; ++b) if (b >= aa && b < c) v += sT[aa * KPAD + b] * g[b];
+                sT[aa * KPAD + c] = -tau * v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int row = tid + FIT_THREADS * i;
+            if (row > c) {
+                double v = 0.0;
+#pragma unroll
+                for (int cc = 0; cc < KPAD; ++cc) if (cc == c) v = a[i][cc] * scal;
+#pragma unroll
+                for (int cc = 0; cc < KPAD; ++cc) {
+                    if (cc == c) a[i][cc] = v;
+                    else if (cc > c) a[i][cc] -= wv[cc] * v;
+                }
+            } else if (row == c) {
+#pragma unroll
+                for (int cc = 0; cc < KPAD; ++cc) {
+                    if (cc == c) a[i][cc] = beta;
+                    else if (cc > c) a[i][cc] -= wv[cc];
+                }
+            }
+        }
+        __syncthreads();                     // sRow is rewritten by the next column's owner
+    }
+    // ---- split: R (k x m) -> sR; Householder vectors get an explicit unit diagonal
+    if (tid < k) {
+#pragma unroll
+        for (int cc = 0; cc < KPAD; ++cc) {
+            if (cc >= tid) {
+                sR[tid * KPAD + cc] = (cc < m) ? a[0][cc] : 0.0;
+                a[0][cc] = (cc == tid) ? 1.0 : 0.0;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- C = I + R D R' (k x k): RD -> sG, then C -> sV (upper), all threads; Cholesky on one lane
+    for (int t = tid; t < k * m; t += FIT_THREADS) {
+        const int aa = t / m, b = t % m;
+        double v = 0.0;
+        for (int u = aa; u < m; ++u) v += sR[aa * KPAD + u] * sD[u * KPAD + b];
+        sG[aa * KPAD + b] = v;
+    }
+    __syncthreads();
+    for (int t = tid; t < k * k; t += FIT_THREADS) {
+        const int aa = t / k, b = t % k;
+        if (b >= aa) {
+            double v = (aa == b) ? 1.0 : 0.0;
+            for (int u = b; u < m; ++u) v += sG[aa * KPAD + u] * sR[b * KPAD + u];
+            sV[aa * KPAD + b] = v;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int st = PFMI_FIT_OK;
+        double ldv = 0.0;
+        for (int c = 0; c < k && st == PFMI_FIT_OK; ++c) {
+            double diag = sV[c * KPAD + c];
+            for (int t = 0; t < c; ++t) diag -= sV[t * KPAD + c] * sV[t * KPAD + c];
+            if (!(diag > 0.0) || !isfinite(diag)) { st = PFMI_FIT_C_NOT_PD; break; }
+            diag = sqrt(diag);
+            sV[c * KPAD + c] = diag;
+            ldv += log(diag);
+            for (int b = c + 1; b < k; ++b) {
+                double v = sV[c * KPAD + b];
+                for (int t = 0; t < c; ++t) v -= sV[t * KPAD + c] * sV[t * KPAD + b];
+                sV[c * KPAD + b] = v / diag;
+            }
+        }
+        for (int aa = k; aa < KPAD; ++aa) sV[aa * KPAD + aa] = 1.0;
+        sStatus = st;
+        sLogdetV = ldv;
+    }
+    __syncthreads();
+    for (int t = tid; t < KPAD * KPAD; t += FIT_THREADS) {
+        A.tmat[sm + t] = sT[t]; A.vchol[sm + t] = sV[t]; A.rq[sm + t] = sR[t]; A.dmat[sm + t] = sD[t];
+    }
+    // Householder block out (row-major [d][KPAD], 96 B rows)
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int row = tid + FIT_THREADS * i;
+        if (row < d) {
+            double *o = Vh + (size_t)row * KPAD;
+#pragma unroll
+            for (int cc = 0; cc < KPAD; ++cc) o[cc] = a[i][cc];
+        }
+    }
+    if (sStatus != PFMI_FIT_OK) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) { const int row = tid + FIT_THREADS * i; if (row < d) mu[row] = NAN; }
+        if (tid == 0) { A.status[p] = sStatus; A.logdet[p] = NAN; }
+        return;
+    }
+    // ---- mu = theta + U' Q [V'V 0;0 I] Q' U g
+#pragma unroll
+    for (int cc = 0; cc < KPAD; ++cc) acc[cc] = 0.0;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i)
+#pragma unroll
+        for (int cc = 0; cc < KPAD; ++cc) acc[cc] += ag[i] * a[i][cc];
+    pf_block_sum<KPAD>(acc, red);
+    double t1[KPAD];                          // t1 = T' w1 (every thread, from LDS T)
+#pragma unroll
+    for (int aa = 0; aa < KPAD; ++aa) {
+        double v = 0.0;
+#pragma unroll
+        for (int b = 0; b < KPAD; ++b) if (b <= aa) v += sT[b * KPAD + aa] * acc[b];
+        t1[aa] = v;
+    }
+    double bv[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        double v = ag[i];
+#pragma unroll
+        for (int cc = 0; cc < KPAD; ++cc) v -= a[i][cc] * t1[cc];
+        bv[i] = v;
+    }
+    if (tid < k) sHead[tid] = bv[0];
+    __syncthreads();
+    if (tid == 0) {
+        for (int aa = 0; aa < k; ++aa) {
+            double v = 0.0;
+            for (int b = aa; b < k; ++b) v += sV[aa * KPAD + b] * sHead[b];
+            sHead[aa] = v;
+        }
+        for (int aa = k - 1; aa >= 0; --aa) {
+            double v = 0.0;
+            for (int b = 0; b <= aa; ++b) v += sV[b * KPAD + aa] * sHead[b];
+            sHead[aa] = v;
+        }
+    }
+    __syncthreads();
+    if (tid < k) bv[0] = sHead[tid];
+#pragma unroll
+    for (int cc = 0; cc < KPAD; ++cc) acc[cc] = 0.0;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int row = tid + FIT_THREADS * i;
+        if (row < d) {
+#pragma unroll
+            for (int cc = 0; cc < KPAD; ++cc) acc[cc] += bv[i] * a[i][cc];
+        }
+    }
+    pf_block_sum<KPAD>(acc, red);
+#pragma unroll
+    for (int aa = 0; aa < KPAD; ++aa) {       // t2 = T w2
+        double v = 0.0;
+#pragma unroll
+        for (int b = 0; b < KPAD; ++b) if (b >= aa) v += sT[aa * KPAD + b] * acc[b];
+        t1[aa] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int row = tid + FIT_THREADS * i;
+        if (row < d) {
+            double v = bv[i];
+#pragma unroll
+            for (int cc = 0; cc < KPAD; ++cc) v -= a[i][cc] * t1[cc];
+            mu[row] = theta_p[row] + sq[i] * v;
+        }
+    }
+    if (tid == 0) {
+        A.status[p] = PFMI_FIT_OK;
+        A.logdet[p] = 2.0 * (ldu + sLogdetV);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 int32_t pf_launch_history(pfmi_ctx *c, double eps) {
     PF_CHECK(c->J <= 64, PFMI_ERR_UNSUPPORTED, "history_length %d > 64 unsupported", c->J);
     pf_kernel_begin(c);
@@ -414,7 +786,16 @@ int32_t pf_launch_history(pfmi_ctx *c, double eps) {
 
 template <int KPAD>
 static void launch_fit_t(pfmi_ctx *c, const FitArgs &a) {
-    hipLaunchKernelGGL(pf_fit_kernel<KPAD>, dim3((unsigned)c->P), dim3(FIT_THREADS), 0, c->stream, a);
+    const char *force = getenv("PFMI_FIT_KERNEL");            // "mem" forces the general (memory-resident) kernel
+    const bool allow_reg = !(force && force[0] == 'm');
+    const int rpt = (a.d + FIT_THREADS - 1) / FIT_THREADS;
+    dim3 grid((unsigned)c->P), block(FIT_THREADS);
+    if constexpr (KPAD <= 16) {
+        if (allow_reg && rpt <= 1) { hipLaunchKernelGGL((pf_fit_reg_kernel<KPAD, 1>), grid, block, 0, c->stream, a); return; }
+        if (allow_reg && rpt <= 2) { hipLaunchKernelGGL((pf_fit_reg_kernel<KPAD, 2>), grid, block, 0, c->stream, a); return; }
+        if (allow_reg && rpt <= 4) { hipLaunchKernelGGL((pf_fit_reg_kernel<KPAD, 4>), grid, block, 0, c->stream, a); return; }
+    }
+    hipLaunchKernelGGL(pf_fit_kernel<KPAD>, grid, block, 0, c->stream, a);
 }
 
 int32_t pf_launch_fit(pfmi_ctx *c) {

@@ -116,4 +116,167 @@ __device__ __forceinline__ void pf_randn4_fast(uint64_t seed, uint32_t g, uint32
     pf_philox4x32_10(n, g, stream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
     pf_boxmuller4_fast(x, tab, z);
 }
+
+// ---- the same Box-Muller pair, cut into three phases of ~20 fp64 VALU instructions each so that a kernel can
+//      interleave them with MFMA issue (elbo_mfma_kernel.hip).  pf_bm_a/b/c(x_radius, x_angle) == one pair of
+//      pf_boxmuller4_fast, bit for bit.
+struct PfBM {
+    double v;        // -2 ln u_radius
+    double rad;      // sqrt(v)
+    double f, f2;    // half-turn fraction of the angle and its square
+    double ps;       // partial sine polynomial
+    int iq;          // quadrant
+};
+__device__ __forceinline__ void pf_bm_a(uint32_t xr, uint32_t xa, const double2 *tab, PfBM &st) {
+    const double S = 2.3283064365386962890625e-10;  // 2^-32
+    const double ur = ((double)xr + 0.5) * S, ua = ((double)xa + 0.5) * S;
+    st.v = pf_neg2log_fast(ur, tab);
+    const double t4 = 4.0 * ua;
+    const double q = rint(t4);
+    st.f = 0.5 * (t4 - q);
+    st.iq = (int)q;
+}
+__device__ __forceinline__ void pf_bm_b(PfBM &st) {
+    st.rad = pf_sqrt_fast(st.v);
+    const double f2 = st.f * st.f;
+    st.f2 = f2;
+    double ps = -2.1915353447830217e-05;
+    ps = fma(ps, f2, 0.00046630280576761255);
+    ps = fma(ps, f2, -0.0073704309457143504);
+    ps = fma(ps, f2, 0.08214588661112823);
+    st.ps = ps;
+}
+__device__ __forceinline__ void pf_bm_c(const PfBM &st, double &z0, double &z1) {
+    const double f2 = st.f2;
+    double ps = st.ps;
+    ps = fma(ps, f2, -0.5992645293207921);
+    ps = fma(ps, f2, 2.5501640398773455);
+    ps = fma(ps, f2, -5.16771278004997);
+    ps = fma(ps, f2, 3.141592653589793);
+    ps *= st.f;
+    double pc = 4.303069587032947e-06;
+    pc = fma(pc, f2, -0.0001046381049248457);
+    pc = fma(pc, f2, 0.0019295743094039231);
+    pc = fma(pc, f2, -0.02580689139001406);
+    pc = fma(pc, f2, 0.2353306303588932);
+    pc = fma(pc, f2, -1.3352627688545895);
+    pc = fma(pc, f2, 4.0587121264167685);
+    pc = fma(pc, f2, -4.934802200544679);
+    pc = fma(pc, f2, 1.0);
+    const bool swap = (st.iq & 1) != 0;
+    const double ss = swap ? pc : ps;
+    const double cc = swap ? ps : pc;
+    const long long sflip = ((long long)(st.iq & 2)) << 62;
+    const long long cflip = ((long long)((st.iq + 1) & 2)) << 62;
+    const double s = __longlong_as_double(__double_as_longlong(ss) ^ sflip);
+    const double c = __longlong_as_double(__double_as_longlong(cc) ^ cflip);
+    z0 = st.rad * c;
+    z1 = st.rad * s;
+}
+// two Philox4x32 rounds (the generator is split 5 x 2 rounds by the pipelined kernel)
+__device__ __forceinline__ void pf_philox_2rounds(uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3,
+                                                  uint32_t &k0, uint32_t &k1) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+// ---- eight-piece version of one Box-Muller pair (same operations, same order => same bits) for kernels that
+//      interleave several independent chains (two pairs + the next Philox call) inside one scheduling region.
+struct PfPair {
+    double m, t4, r, ty, f, f2, p, v, g, h, rad, ps, pc;
+    int e, idx, iq;
+    __device__ __forceinline__ void s0(uint32_t xr, uint32_t xa) {
+        const double S = 2.3283064365386962890625e-10;  // 2^-32
+        const double ur = ((double)xr + 0.5) * S, ua = ((double)xa + 0.5) * S;
+        const long long bits = __double_as_longlong(ur);
+        e = (int)(bits >> 52) - 1023;
+        idx = (int)(bits >> 45) & 127;
+        m = __longlong_as_double((bits & 0x000FFFFFFFFFFFFFll) | 0x3FF0000000000000ll);
+        t4 = 4.0 * ua;
+    }
+    __device__ __forceinline__ void s1(const double2 *tab) {
+        const double2 t = tab[idx];
+        ty = t.y;
+        r = fma(m, t.x, -1.0);
+        const double qq = rint(t4);
+        f = 0.5 * (t4 - qq);
+        iq = (int)qq;
+    }
+    __device__ __forceinline__ void s2() {
+        double pp = fma(r, -1.0 / 7.0, 1.0 / 6.0);
+        pp = fma(r, pp, -1.0 / 5.0);
+        pp = fma(r, pp, 1.0 / 4.0);
+        pp = fma(r, pp, -1.0 / 3.0);
+        pp = fma(r, pp, 0.5);
+        p = fma(r, pp, -1.0);
+    }
+    __device__ __forceinline__ void s3() {
+        const double l = fma((double)e, 0.6931471805599453094, ty);
+        v = fma(2.0 * r, p, -2.0 * l);
+        const double y = __builtin_amdgcn_rsq(v);
+        g = v * y;
+        h = 0.5 * y;
+        f2 = f * f;
+    }
+    __device__ __forceinline__ void s4() {
+        const double rr = fma(-h, g, 0.5);
+        g = fma(g, rr, g);
+        h = fma(h, rr, h);
+        const double dd = fma(-g, g, v);
+        rad = fma(dd, h, g);
+        double q = -2.1915353447830217e-05;
+        q = fma(q, f2, 0.00046630280576761255);
+        q = fma(q, f2, -0.0073704309457143504);
+        ps = fma(q, f2, 0.08214588661112823);
+    }
+    __device__ __forceinline__ void s5() {
+        double q = fma(ps, f2, -0.5992645293207921);
+        q = fma(q, f2, 2.5501640398773455);
+        q = fma(q, f2, -5.16771278004997);
+        q = fma(q, f2, 3.141592653589793);
+        ps = q * f;
+        double w = 4.303069587032947e-06;
+        w = fma(w, f2, -0.0001046381049248457);
+        w = fma(w, f2, 0.0019295743094039231);
+        pc = fma(w, f2, -0.02580689139001406);
+    }
+    __device__ __forceinline__ void s6() {
+        double w = fma(pc, f2, 0.2353306303588932);
+        w = fma(w, f2, -1.3352627688545895);
+        w = fma(w, f2, 4.0587121264167685);
+        w = fma(w, f2, -4.934802200544679);
+        pc = fma(w, f2, 1.0);
+    }
+    __device__ __forceinline__ void s7(double &z0, double &z1) const {
+        const bool swap = (iq & 1) != 0;
+        const double ss = swap ? pc : ps;
+        const double cc = swap ? ps : pc;
+        const long long sflip = ((long long)(iq & 2)) << 62;
+        const long long cflip = ((long long)((iq + 1) & 2)) << 62;
+        const double sn = __longlong_as_double(__double_as_longlong(ss) ^ sflip);
+        const double cs = __longlong_as_double(__double_as_longlong(cc) ^ cflip);
+        z0 = rad * cs;
+        z1 = rad * sn;
+    }
+};
+__device__ __forceinline__ void pf_philox_round(uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3,
+                                                uint32_t &k0, uint32_t &k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+}
 #endif
