@@ -81,7 +81,8 @@ int32_t pfmi_sync(pfmi_ctx *ctx);
 
 /* device-time instrumentation (hipEvents on the ctx stream).  pfmi_timer_* bracket any sequence of
  * calls; pfmi_kernel_time returns accumulated time and launch count of one named kernel family
- * ("history", "fit", "elbo_draws", "elbo_reduce", "psis", "resample") since pfmi_profile(ctx, 1). */
+ * ("history", "fit", "elbo_draws" = ELBO scan, "elbo_draws_x" = draw launches that also write x, "elbo_reduce",
+ * "psis", "resample") since pfmi_profile(ctx, 1). */
 int32_t pfmi_timer_start(pfmi_ctx *ctx);
 int32_t pfmi_timer_stop(pfmi_ctx *ctx, double *milliseconds);
 int32_t pfmi_profile(pfmi_ctx *ctx, int32_t enable);

@@ -357,7 +357,7 @@ int32_t pf_launch_elbo_draws(pfmi_ctx *c, const int32_t *d_points, const uint64_
         pf_kernel_begin(c);
         int32_t rc = pf_launch_elbo_mfma(c, a, nfits, tgt, rpad, &handled);
         if (handled) {
-            pf_kernel_end(c, "elbo_draws");
+            pf_kernel_end(c, d_x ? "elbo_draws_x" : "elbo_draws");
             PF_TRY(rc);
             PF_HIP(hipGetLastError());
             return PFMI_OK;
@@ -383,7 +383,7 @@ int32_t pf_launch_elbo_draws(pfmi_ctx *c, const int32_t *d_points, const uint64_
             case 32: rc = launch_draws_k<32>(b, grid, c->stream, mem, tgt, rpad); break;
             default: pf_set_error("unsupported kpad %d", c->kpad); rc = PFMI_ERR_UNSUPPORTED;
         }
-        pf_kernel_end(c, "elbo_draws");
+        pf_kernel_end(c, d_x ? "elbo_draws_x" : "elbo_draws");
         PF_TRY(rc);
         PF_HIP(hipGetLastError());
     }

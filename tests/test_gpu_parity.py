@@ -528,3 +528,72 @@ def test_torch_interop_for_the_collective_path(pfmi_mod, eng):
     np.testing.assert_array_equal(res["weights"], ref["weights"])
     np.testing.assert_array_equal(idx, po.sample_weighted(ref["weights"], 32, seed=9))
     np.testing.assert_array_equal(out.cpu().numpy().reshape(32, tg.d).T, pool.reshape(tg.d, -1, order="F")[:, idx])
+
+
+def test_large_d_general_paths(pfmi_mod, eng):
+    """d beyond the MFMA / register kernels (config-5 style: funnel, history_length = 10 -> KC = 20, d = 2500):
+    exercises the lane-per-draw ELBO kernel and the memory-resident fit kernel against the oracle."""
+    d, J = 2500, 10
+    tg = pfmi_mod.t_funnel(d)
+    rng = pfmi_mod.HostRNG(5)
+    traces = [pfmi_mod.optimize_with_trace(tg, rng.rand(d) * 2 - 1, history_length=J, maxiters=14) for _ in range(2)]
+    eng.set_target(tg)
+    eng.set_traces([t.points for t in traces], [t.gradients for t in traces])
+    eng.fit_batch(J)
+    status, jeff, logdet, nrej = eng.fit_status()
+    seeds = fit_seeds(eng.P, 8)
+    N = 64
+    elbo, se, best = eng.elbo_batch(N, seeds)
+    otg = oracle_target(tg)
+    for k, tr in enumerate(traces):
+        p0, p1 = int(eng.offsets[k]), int(eng.offsets[k + 1])
+        ref = po.path_fit_elbo(tr.points, tr.gradients, J, otg, N, seeds[p0:p1])
+        np.testing.assert_array_equal(status[p0:p1], ref["status"])
+        np.testing.assert_array_equal(jeff[p0:p1], ref["j_eff"])
+        ok = ref["status"] == 0
+        assert np.all(np.abs(logdet[p0:p1][ok] - ref["logdet"][ok]) <= 1e-9 * (1 + np.abs(ref["logdet"][ok])))
+        alpha_all, hl, hs, _ = po.lbfgs_history(tr.points, tr.gradients, J)
+        for l in range(1, p1 - p0):
+            if not ok[l]:
+                continue
+            F = _oracle_factor(tr, alpha_all, hl, hs, l, d)
+            if _well_conditioned(F):
+                assert abs(elbo[p0 + l] - ref["elbo"][l]) <= 1e-8 * (1 + abs(ref["elbo"][l])), (k, l)
+            else:
+                assert abs(elbo[p0 + l] - ref["elbo"][l]) <= 8 * max(se[p0 + l], ref["se"][l]) + 1e-8 * (1 + abs(ref["elbo"][l]))
+    p = int(eng.offsets[0]) + 2
+    X, lp, lq = eng.draws(p, seeds[p], 32)
+    np.testing.assert_allclose(lp, tg.logp(X), rtol=1e-9, atol=1e-6)
+    assert np.max(np.abs(eng.logpdf(p, X) - lq)) <= 1e-8 * (1 + np.abs(lq).max())
+
+
+def test_mfma_and_lane_kernels_agree(pfmi_mod):
+    """the two ELBO kernels are interchangeable: same seeds -> same log densities to fp64 roundoff"""
+    import subprocess, sys, json
+    code = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, "tests"); sys.path.insert(0, "pathfinder.jl_amd"); sys.path.insert(0, ".")
+import pfmi
+from helpers import make_traces, fit_seeds
+tg = pfmi.t_lowrank(300, r=8, seed=2)
+traces = make_traces(tg, 2, 3)
+e = pfmi.Engine(0); e.set_target(tg); e.set_traces([t.points for t in traces], [t.gradients for t in traces]); e.fit_batch(6)
+seeds = fit_seeds(e.P, 1)
+elbo, se, best = e.elbo_batch(100, seeds)
+p = int(e.offsets[0]) + int(best[0])
+X, lp, lq = e.draws(p, seeds[p], 100)
+print(json.dumps(dict(elbo=np.nan_to_num(elbo).tolist(), best=best.tolist(), x=X[:, :3].ravel().tolist(), lp=lp.tolist(), lq=lq.tolist())))
+'''
+    outs = []
+    for mode in ("mfma", "lane"):
+        env = dict(os.environ, PFMI_ELBO_KERNEL=mode)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    a, b = outs
+    assert a["best"] == b["best"]
+    for key in ("elbo", "x", "lp", "lq"):
+        x, y = np.array(a[key]), np.array(b[key])
+        assert np.max(np.abs(x - y) / (1 + np.abs(y))) <= 1e-10, key
