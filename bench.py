@@ -186,18 +186,22 @@ def main():
             from oracle import pf_oracle as po
             cores = os.cpu_count() or 1
             otg = oracle_target(tg)
-            # bounded sample: `cores` paths (re-using this rank's traces cyclically), first `nf` fits of each
-            per_fit_s = 0.12
-            nf = max(2, int(args.cpu_seconds / per_fit_s))
-            nf = min(nf, min(len(t) for t in traces) - 1)
+            # bounded sample: `cores` paths (this rank's traces re-used cyclically), first `nf` fits of each; `nf` is
+            # calibrated with a 2-fit probe so that the timed sample costs about args.cpu_seconds of wall-clock
             sel = [traces[i % len(traces)] for i in range(cores)]
-            th = np.concatenate([t.points[:nf + 1] for t in sel])
-            gr = np.concatenate([t.gradients[:nf + 1] for t in sel])
-            off = np.arange(cores + 1, dtype=np.int64) * (nf + 1)
-            sd = np.arange(len(th), dtype=np.uint64) + np.uint64(1)
-            t1 = time.perf_counter()
-            r = po.multipath_fit_elbo(off, th, gr, J, otg, N_e, sd, nthreads=cores)
-            t_cpu = time.perf_counter() - t1
+
+            def run(nf):
+                th = np.concatenate([t.points[:nf + 1] for t in sel])
+                gr = np.concatenate([t.gradients[:nf + 1] for t in sel])
+                off = np.arange(cores + 1, dtype=np.int64) * (nf + 1)
+                sd = np.arange(len(th), dtype=np.uint64) + np.uint64(1)
+                t1 = time.perf_counter()
+                r = po.multipath_fit_elbo(off, th, gr, J, otg, N_e, sd, nthreads=cores)
+                return r, time.perf_counter() - t1
+
+            _, t_probe = run(2)
+            nf = int(max(2, min(args.cpu_seconds / max(t_probe / 2, 1e-3), min(len(t) for t in traces) - 1)))
+            r, t_cpu = run(nf)
             cpu = {"value": round(r["total_draws"] / t_cpu, 1), "unit": "ELBO draws/s", "cores": cores,
                    "kind": "port",
                    "sample": f"{cores} paths x first {nf} fits x {N_e} draws (d={d}, J={J}) = "
