@@ -406,8 +406,8 @@ __global__ __launch_bounds__(FIT_THREADS) void pf_fit_kernel(FitArgs A) {
 // mean computation touch no memory at all -- only ~27 block reductions remain.  Same operations and the same
 // LAPACK reflector convention as pf_fit_kernel; only the summation order inside the block reductions differs
 // (fp64 roundoff), which the parity tests cover.
-template <int KPAD, int RPT>
-__global__ __launch_bounds__(FIT_THREADS) void pf_fit_reg_kernel(FitArgs A) {
+template <int KPAD, int RPT, int NT>
+__global__ __launch_bounds__(NT) void pf_fit_reg_kernel(FitArgs A) {
     const int p = blockIdx.x, tid = threadIdx.x;
     const int d = A.d, J = A.J;
     const int path = A.path_of[p];
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(FIT_THREADS) void pf_fit_reg_kernel(FitArgs A) {
     double *mu = A.mu + (size_t)p * d;
     const double *theta_p = A.theta + (size_t)p * d, *grad_p = A.grad + (size_t)p * d;
 
-    __shared__ double red[(FIT_THREADS / 64) * KPAD];
+    __shared__ double red[(NT / 64) * KPAD];
     __shared__ double sRow[KPAD], sHead[KPAD];
     __shared__ double sD[KPAD * KPAD], sR[KPAD * KPAD], sT[KPAD * KPAD], sV[KPAD * KPAD], sG[KPAD * KPAD];
     __shared__ double sLogdetV;
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(FIT_THREADS) void pf_fit_reg_kernel(FitArgs A) {
     double bad = 0.0, ldu = 0.0;
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
-        const int row = tid + FIT_THREADS * i;
+        const int row = tid + NT * i;
         sq[i] = 1.0; ag[i] = 0.0;
         if (row < d) {
             const double al = alpha[row];
@@ -447,25 +447,25 @@ __global__ __launch_bounds__(FIT_THREADS) void pf_fit_reg_kernel(FitArgs A) {
         pf_block_sum<2>(v, red);
         bad = v[0]; ldu = v[1];
     }
-    for (int t = tid; t < KPAD * KPAD; t += FIT_THREADS) { sD[t] = 0.0; sR[t] = 0.0; sT[t] = 0.0; sV[t] = 0.0; sG[t] = 0.0; }
+    for (int t = tid; t < KPAD * KPAD; t += NT) { sD[t] = 0.0; sR[t] = 0.0; sT[t] = 0.0; sV[t] = 0.0; sG[t] = 0.0; }
     const size_t sm = (size_t)p * KPAD * KPAD;
     if (bad > 0.0) {                                           // A not positive definite (src/woodbury.jl:202)
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
-            const int row = tid + FIT_THREADS * i;
+            const int row = tid + NT * i;
             if (row < d) {
                 mu[row] = NAN;
                 for (int c = 0; c < KPAD; ++c) Vh[(size_t)row * KPAD + c] = 0.0;
             }
         }
-        for (int t = tid; t < KPAD * KPAD; t += FIT_THREADS) { A.tmat[sm + t] = 0.0; A.vchol[sm + t] = 0.0; A.rq[sm + t] = 0.0; A.dmat[sm + t] = 0.0; }
+        for (int t = tid; t < KPAD * KPAD; t += NT) { A.tmat[sm + t] = 0.0; A.vchol[sm + t] = 0.0; A.rq[sm + t] = 0.0; A.dmat[sm + t] = 0.0; }
         if (tid == 0) { A.status[p] = PFMI_FIT_A_NOT_PD; A.logdet[p] = NAN; }
         return;
     }
     // ---- rows of B~ = U' \ [alpha.Y  S]   (src/inverse_hessian.jl:117-118, src/woodbury.jl:204)
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
-        const int row = tid + FIT_THREADS * i;
+        const int row = tid + NT * i;
 #pragma unroll
         for (int c = 0; c < KPAD; ++c) a[i][c] = 0.0;
         if (row < d) {
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(FIT_THREADS) void pf_fit_reg_kernel(FitArgs A) {
     }
     __syncthreads();
     if (j > 0) {   // M = Y'alpha Y + diag(R); D12, D21 -- one entry per thread
-        for (int t = tid; t < j * j; t += FIT_THREADS) {
+        for (int t = tid; t < j * j; t += NT) {
             const int aa = t / j, b = t % j;
             sD[aa * KPAD + (j + b)] = sV[aa * KPAD + b];
             sD[(j + aa) * KPAD + b] = sV[b * KPAD + aa];
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(FIT_THREADS) void pf_fit_reg_kernel(FitArgs A) {
     }
     __syncthreads();
     if (j > 0) {   // T1 = M nRinv  -> sG (G is no longer needed)
-        for (int t = tid; t < j * j; t += FIT_THREADS) {
+        for (int t = tid; t < j * j; t += NT) {
             const int aa = t / j, b = t % j;
             double v = 0.0;
             for (int u = 0; u <= b; ++u) v += sR[aa * KPAD + u] * sV[u * KPAD + b];
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(FIT_THREADS) void pf_fit_reg_kernel(FitArgs A) {
     }
     __syncthreads();
     if (j > 0) {   // D22 = nRinv' T1
-        for (int t = tid; t < j * j; t += FIT_THREADS) {
+        for (int t = tid; t < j * j; t += NT) {
             const int aa = t / j, b = t % j;
             double v = 0.0;
             for (int u = 0; u <= aa; ++u) v += sV[u * KPAD + aa] * sG[u * KPAD + b];
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(FIT_THREADS) void pf_fit_reg_kernel(FitArgs A) {
         }
     }
     __syncthreads();
-    for (int t = tid; t < KPAD * KPAD; t += FIT_THREADS) { sT[t] = 0.0; sV[t] = 0.0; sR[t] = 0.0; }
+    for (int t = tid; t < KPAD * KPAD; t += NT) { sT[t] = 0.0; sV[t] = 0.0; sR[t] = 0.0; }
     __syncthreads();
 
     // ---- Householder QR, one block reduction per column
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(FIT_THREADS) void pf_fit_reg_kernel(FitArgs A) {
         for (int cc = 0; cc < KPAD; ++cc) acc[cc] = 0.0;
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
-            const int row = tid + FIT_THREADS * i;
+            const int row = tid + NT * i;
             if (row > c) {
                 double xc = 0.0;
 #pragma unroll
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(FIT_THREADS) void pf_fit_reg_kernel(FitArgs A) {
         double tau, scal, beta;
         if (xnorm == 0.0) { tau = 0.0; scal = 0.0; beta = alpha_c; }
         else {
-            beta = -copysign(hypot(alpha_c, xnorm), alpha_c);
+            beta = -copysign(sqrt(fma(alpha_c, alpha_c, xn2)), alpha_c);
             tau = (beta - alpha_c) / beta;
             scal = 1.0 / (alpha_c - beta);
         }
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(FIT_THREADS) void pf_fit_reg_kernel(FitArgs A) {
         }
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
-            const int row = tid + FIT_THREADS * i;
+            const int row = tid + NT * i;
             if (row > c) {
                 double v = 0.0;
 #pragma unroll
@@ -641,14 +641,14 @@ __global__ __launch_bounds__(FIT_THREADS) void pf_fit_reg_kernel(FitArgs A) {
     }
     __syncthreads();
     // ---- C = I + R D R' (k x k): RD -> sG, then C -> sV (upper), all threads; Cholesky on one lane
-    for (int t = tid; t < k * m; t += FIT_THREADS) {
+    for (int t = tid; t < k * m; t += NT) {
         const int aa = t / m, b = t % m;
         double v = 0.0;
         for (int u = aa; u < m; ++u) v += sR[aa * KPAD + u] * sD[u * KPAD + b];
         sG[aa * KPAD + b] = v;
     }
     __syncthreads();
-    for (int t = tid; t < k * k; t += FIT_THREADS) {
+    for (int t = tid; t < k * k; t += NT) {
         const int aa = t / k, b = t % k;
         if (b >= aa) {
             double v = (aa == b) ? 1.0 : 0.0;
@@ -678,13 +678,13 @@ __global__ __launch_bounds__(FIT_THREADS) void pf_fit_reg_kernel(FitArgs A) {
         sLogdetV = ldv;
     }
     __syncthreads();
-    for (int t = tid; t < KPAD * KPAD; t += FIT_THREADS) {
+    for (int t = tid; t < KPAD * KPAD; t += NT) {
         A.tmat[sm + t] = sT[t]; A.vchol[sm + t] = sV[t]; A.rq[sm + t] = sR[t]; A.dmat[sm + t] = sD[t];
     }
     // Householder block out (row-major [d][KPAD], 96 B rows)
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
-        const int row = tid + FIT_THREADS * i;
+        const int row = tid + NT * i;
         if (row < d) {
             double *o = Vh + (size_t)row * KPAD;
 #pragma unroll
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(FIT_THREADS) void pf_fit_reg_kernel(FitArgs A) {
     }
     if (sStatus != PFMI_FIT_OK) {
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) { const int row = tid + FIT_THREADS * i; if (row < d) mu[row] = NAN; }
+        for (int i = 0; i < RPT; ++i) { const int row = tid + NT * i; if (row < d) mu[row] = NAN; }
         if (tid == 0) { A.status[p] = sStatus; A.logdet[p] = NAN; }
         return;
     }
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(FIT_THREADS) void pf_fit_reg_kernel(FitArgs A) {
     for (int cc = 0; cc < KPAD; ++cc) acc[cc] = 0.0;
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
-        const int row = tid + FIT_THREADS * i;
+        const int row = tid + NT * i;
         if (row < d) {
 #pragma unroll
             for (int cc = 0; cc < KPAD; ++cc) acc[cc] += bv[i] * a[i][cc];
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(FIT_THREADS) void pf_fit_reg_kernel(FitArgs A) {
     }
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
-        const int row = tid + FIT_THREADS * i;
+        const int row = tid + NT * i;
         if (row < d) {
             double v = bv[i];
 #pragma unroll
@@ -788,12 +788,13 @@ template <int KPAD>
 static void launch_fit_t(pfmi_ctx *c, const FitArgs &a) {
     const char *force = getenv("PFMI_FIT_KERNEL");            // "mem" forces the general (memory-resident) kernel
     const bool allow_reg = !(force && force[0] == 'm');
-    const int rpt = (a.d + FIT_THREADS - 1) / FIT_THREADS;
     dim3 grid((unsigned)c->P), block(FIT_THREADS);
     if constexpr (KPAD <= 16) {
-        if (allow_reg && rpt <= 1) { hipLaunchKernelGGL((pf_fit_reg_kernel<KPAD, 1>), grid, block, 0, c->stream, a); return; }
-        if (allow_reg && rpt <= 2) { hipLaunchKernelGGL((pf_fit_reg_kernel<KPAD, 2>), grid, block, 0, c->stream, a); return; }
-        if (allow_reg && rpt <= 4) { hipLaunchKernelGGL((pf_fit_reg_kernel<KPAD, 4>), grid, block, 0, c->stream, a); return; }
+        // register-resident kernel: 256 threads x RPT rows (measured faster than 512 x 2: the kernel is bound by
+        // block-reduction / serial O(m^3) latency, and 8-wave barriers cost more than the extra occupancy buys)
+        if (allow_reg && a.d <= 256) { hipLaunchKernelGGL((pf_fit_reg_kernel<KPAD, 1, 256>), grid, dim3(256), 0, c->stream, a); return; }
+        if (allow_reg && a.d <= 512) { hipLaunchKernelGGL((pf_fit_reg_kernel<KPAD, 2, 256>), grid, dim3(256), 0, c->stream, a); return; }
+        if (allow_reg && a.d <= 1024) { hipLaunchKernelGGL((pf_fit_reg_kernel<KPAD, 4, 256>), grid, dim3(256), 0, c->stream, a); return; }
     }
     hipLaunchKernelGGL(pf_fit_kernel<KPAD>, grid, block, 0, c->stream, a);
 }

@@ -180,11 +180,26 @@ __device__ __forceinline__ uint64_t pf_rand_u64(uint64_t seed, uint64_t t, uint3
     return (uint64_t)x[0] | ((uint64_t)x[1] << 32);
 }
 
-// wave64 butterfly sum: every lane ends with the total; fixed order -> deterministic
+// wave64 sum on the DPP data path (no LDS traffic): row_shr 1/2/4/8 scan inside each row of 16 lanes, row_bcast15 /
+// row_bcast31 across rows, total read from lane 63 into SGPRs -> every lane gets the same value.  Fixed order ->
+// deterministic.  (fp64 adds have no DPP form: each step moves the two halves with v_mov_b32_dpp and adds.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double pf_dpp_add(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return v + __hiloint2double(hi2, lo2);
+}
 __device__ __forceinline__ double pf_wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v = pf_dpp_add<0x111, 0xf>(v);   // row_shr:1
+    v = pf_dpp_add<0x112, 0xf>(v);   // row_shr:2
+    v = pf_dpp_add<0x114, 0xf>(v);   // row_shr:4
+    v = pf_dpp_add<0x118, 0xf>(v);   // row_shr:8  -> lane 15 of each row holds the row sum
+    v = pf_dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v = pf_dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double pf_wave_max(double v) {
 #pragma unroll
