@@ -69,8 +69,9 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
     double *ssum = tsum + 64 * ((RPAD + 3) / 4);              // [2][16] summed |u|^2 and diagonal quadratic form
     double *gs = ssum + 32;                    // [RPAD][RPAD] target capacitance factor
     double *red2 = gs + RPAD * RPAD;           // [8][16][4] per-wave per-draw scalars
-    double2 *logtab = reinterpret_cast<double2 *>(red2 + MF_WAVES * 64);   // [128]
-    double *zero_s = red2 + MF_WAVES * 64 + 256;                           // [2] zeros (masked A-operand lanes)
+    double2 *logtab = reinterpret_cast<double2 *>(red2 + MF_WAVES * 64);   // [128] log table
+    double2 *sctab = logtab + 128;                                         // [256] {cos, sin} angle table
+    double *zero_s = red2 + MF_WAVES * 64 + 256 + 512;                     // [2] zeros (masked A-operand lanes)
 
     {
         const double *Vh = A.vh + (size_t)p * d * KC;
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
         for (int i = tid; i < KC * KC; i += MF_THREADS) t_s[i] = T[i];
         if (TGT == 1 && RPAD > 0) for (int i = tid; i < RPAD * RPAD; i += MF_THREADS) gs[i] = A.t_g[i];
         pf_logtab_load(logtab);
+        pf_sctab_load(sctab);
         if (tid < 2) zero_s[tid] = 0.0;
     }
     // head transform z_head = V' u_head as 4 MFMAs: A_r[i'][k] = M[rho(i')][4k + r], M = V' (identity padded)
@@ -117,7 +119,13 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
 
     // normals of rows 16 blk + 4q + {0..3} of draw n (+ head transform for block 0) and their pass-1 MFMAs
     auto pass1_block = [&](const int blk, const uint32_t n, const bool head, double (&zz)[4]) {
-        pf_randn4_fast(seed, (uint32_t)(blk * 4 + q), n, 0u, logtab, zz);
+        uint32_t x[4];
+        pf_philox4x32_10(n, (uint32_t)(blk * 4 + q), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+        PfPair p1, p2;                                              // same arithmetic as the pipelined body
+        p1.s0(x[0], x[1]); p2.s0(x[2], x[3]);
+        p1.s1(logtab, sctab); p2.s1(logtab, sctab);
+        p1.s2(); p2.s2(); p1.s3(); p2.s3(); p1.s4(); p2.s4(); p1.s5(); p2.s5();
+        p1.s6(zz[0], zz[1]); p2.s6(zz[2], zz[3]);
         const int rowbase = blk * 16 + 4 * q;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -251,12 +259,12 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
             // P0
             xa = pf_mfma(a2v[0], ntv[0], xa);
             pf_philox_round(c0, c1, c2, c3, k0, k1); p1.s0(xc[0], xc[1]); p2.s0(xc[2], xc[3]);
-            PF_PIN_RNG(); PF_PIN(p1.m); PF_PIN(p1.t4); PF_PIN(p2.m); PF_PIN(p2.t4);
+            PF_PIN_RNG(); PF_PIN(p1.m); PF_PIN(p1.dlt); PF_PIN(p2.m); PF_PIN(p2.dlt);
             PF_PHASE_END();
             // P1
             if (KC >= 8) xa = pf_mfma(a2v[KC >= 8 ? 1 : 0], ntv[KC >= 8 ? 1 : 0], xa);
-            pf_philox_round(c0, c1, c2, c3, k0, k1); p1.s1(logtab); p2.s1(logtab);
-            PF_PIN_RNG(); PF_PIN(p1.r); PF_PIN(p1.f); PF_PIN(p2.r); PF_PIN(p2.f);
+            pf_philox_round(c0, c1, c2, c3, k0, k1); p1.s1(logtab, sctab); p2.s1(logtab, sctab);
+            PF_PIN_RNG(); PF_PIN(p1.r); PF_PIN(p1.d2); PF_PIN(p2.r); PF_PIN(p2.d2);
             PF_PHASE_END();
             // P2
             if (KC >= 12) xa = pf_mfma(a2v[KC >= 12 ? 2 : 0], ntv[KC >= 12 ? 2 : 0], xa);
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
             // P3
             if (b > 0) accw = pf_mfma(a1v[0], z[b > 0 ? b - 1 : 0][0], accw);
             pf_philox_round(c0, c1, c2, c3, k0, k1); p1.s3(); p2.s3();
-            PF_PIN_RNG(); PF_PIN(p1.g); PF_PIN(p1.h); PF_PIN(p1.f2); PF_PIN(p2.g); PF_PIN(p2.h); PF_PIN(p2.f2);
+            PF_PIN_RNG(); PF_PIN(p1.g); PF_PIN(p1.h); PF_PIN(p2.g); PF_PIN(p2.h);
             PF_PHASE_END();
             // P4: first half of the epilogue of the current group: x = mu + sqrt(alpha) x~
             if (b > 0) accw = pf_mfma(a1v[1], z[b > 0 ? b - 1 : 0][1], accw);
@@ -277,7 +285,7 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
                 xi4[r] = mu4[r] + sq4[r] * xa[r];
                 e4[r] = xi4[r] - tm4[r];
             }
-            PF_PIN_RNG(); PF_PIN(p1.rad); PF_PIN(p1.ps); PF_PIN(p2.rad); PF_PIN(p2.ps);
+            PF_PIN_RNG(); PF_PIN(p1.rad); PF_PIN(p1.sd); PF_PIN(p2.rad); PF_PIN(p2.sd);
 #pragma unroll
             for (int r = 0; r < 4; ++r) PF_PIN(e4[r]);
             PF_PHASE_END();
@@ -291,27 +299,28 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
                 else if (TGT == 2) { if (row == 0) tau = xi4[r]; else qd += xi4[r] * xi4[r]; }   // padded rows: xi = 0
                 if (WX) { if (X && row < d) X[row] = xi4[r]; }
             }
-            PF_PIN_RNG(); PF_PIN(p1.ps); PF_PIN(p1.pc); PF_PIN(p2.ps); PF_PIN(p2.pc); PF_PIN(qd);
+            PF_PIN_RNG(); PF_PIN(p1.cs); PF_PIN(p1.sn); PF_PIN(p2.cs); PF_PIN(p2.sn); PF_PIN(qd);
             PF_PHASE_END();
             // P6
             if (TGT == 1 && RPAD > 0) acc3 = pf_mfma(a3[0], e4[0], acc3);
-            pf_philox_round(c0, c1, c2, c3, k0, k1); p1.s6(); p2.s6();
-            PF_PIN_RNG(); PF_PIN(p1.pc); PF_PIN(p2.pc);
+            pf_philox_round(c0, c1, c2, c3, k0, k1); p1.s6(zz[0], zz[1]); p2.s6(zz[2], zz[3]);
+            PF_PIN_RNG(); PF_PIN(zz[0]); PF_PIN(zz[1]); PF_PIN(zz[2]); PF_PIN(zz[3]);
             PF_PHASE_END();
             // P7
             if (TGT == 1 && RPAD > 0) acc3 = pf_mfma(a3[1], e4[1], acc3);
-            pf_philox_round(c0, c1, c2, c3, k0, k1); p1.s7(zz[0], zz[1]); p2.s7(zz[2], zz[3]);
-            PF_PIN_RNG(); PF_PIN(zz[0]); PF_PIN(zz[1]); PF_PIN(zz[2]); PF_PIN(zz[3]);
+            pf_philox_round(c0, c1, c2, c3, k0, k1);
+            if (blk == nblk - 1) {                                                      // rows >= d exist only in the last block
+#pragma unroll
+                for (int r = 0; r < 4; ++r) zz[r] = (rowbase + r < d) ? zz[r] : 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) usq_next += zz[r] * zz[r];                      // |u|^2 before the transform
+            PF_PIN_RNG(); PF_PIN(usq_next);
             PF_PHASE_END();
             // P8
             if (TGT == 1 && RPAD > 0) acc3 = pf_mfma(a3[2], e4[2], acc3);
             pf_philox_round(c0, c1, c2, c3, k0, k1);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                zz[r] = (rowbase + r < d) ? zz[r] : 0.0;                                // rows >= d do not exist
-                usq_next += zz[r] * zz[r];                                              // |u|^2 before the transform
-            }
-            PF_PIN_RNG(); PF_PIN(usq_next);
+            PF_PIN_RNG();
             PF_PHASE_END();
             // P9
             if (TGT == 1 && RPAD > 0) acc3 = pf_mfma(a3[3], e4[3], acc3);
@@ -415,7 +424,7 @@ static size_t mf_lds_bytes(int d, int kc, int rpad) {
     const size_t rows = (size_t)((d + 15) / 16) * 16;
     return sizeof(double) * (rows * kc + 3 * rows + (size_t)kc * kc + MF_WAVES * 64 * (kc / 4) +
                              MF_WAVES * 64 * ((rpad + 3) / 4) + 256 + 64 * ((rpad + 3) / 4) + 32 + (size_t)rpad * rpad +
-                             MF_WAVES * 64 + 256 + 2);
+                             MF_WAVES * 64 + 256 + 512 + 2);
 }
 
 template <int KC, int NBW, int TGT, int RPAD, bool WX>
