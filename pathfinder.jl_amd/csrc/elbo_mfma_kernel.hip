@@ -31,6 +31,17 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ d4 pf_mfma(double a, double b, d4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
+// v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products, 16 cycles.  Lane layout measured on gfx950
+// (tools/probe_mfma4x4.hip, profiles/r01_probe_mfma_f64_4x4x4.txt):
+//   A: lane = 16 k + 4 blk + i     B: lane = 16 k + 4 blk + j     D: lane = 16 i + 4 blk + j
+// With blk = draw quartet (c >> 2), j = c & 3, k = q this is exactly the (q, c) row ownership of this kernel, and a
+// result row i lands in lane (q' = i, c): the same place as register `reg` of the 16x16x4 C/D layout when the
+// instruction index I plays the role of reg (row = q' + 4 I).  Contractions whose output has fewer than 16 rows
+// (pass 1: KC = 12 history columns; target: RPAD = 8) therefore cost KC/4 resp. RPAD/4 quarter-size MFMAs instead
+// of one full 16-row MFMA: 48 resp. 32 cycles per k-step instead of 64.
+__device__ __forceinline__ double pf_mfma4(double a, double b, double c) {
+    return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
 
 // TGT: 0 none, 1 Gaussian family (RPAD = 0 or 8 or 16 low-rank columns), 2 funnel
 template <int KC, int NBW, int TGT, int RPAD, bool WX>
@@ -114,7 +125,9 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
     constexpr int TR = (RPAD + 3) / 4;                           // registers of the target tile that carry rows j' < RPAD
     double z[NBW][4];
     double usq_next = 0.0;
-    d4 accw = {0.0, 0.0, 0.0, 0.0};
+    double accw[KC / 4];                                         // W tile: accw[I] = W[4 I + q][c]
+#pragma unroll
+    for (int I = 0; I < KC / 4; ++I) accw[I] = 0.0;
     double ntv[KC / 4];
 
     // normals of rows 16 blk + 4q + {0..3} of draw n (+ head transform for block 0) and their pass-1 MFMAs
@@ -140,12 +153,15 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
             for (int r = 0; r < 4; ++r) zz[r] = h[r];
         }
     };
-    auto pass1_mfma = [&](const int blk, const double (&zz)[4]) {
-        const int rowbase = blk * 16 + 4 * q;
-        const double *a1p = (c < KC) ? (vh_s + rowbase * KC + c) : zero_s;         // A[i = c][k = q] = Vh[row][c]
-        const int a1s = (c < KC) ? KC : 0;
+    const int l3 = lane & 3;
+    auto pass1_mfma_r = [&](const int blk, const int r, const double zr) {         // one k-step (4 rows) of pass 1
+        const double *ap = vh_s + (blk * 16 + 4 * q + r) * KC + l3;                // A[i][k = q] = Vh[row 4q + r][4 I + i]
 #pragma unroll
-        for (int r = 0; r < 4; ++r) accw = pf_mfma(a1p[r * a1s], zz[r], accw);
+        for (int I = 0; I < KC / 4; ++I) accw[I] = pf_mfma4(ap[4 * I], zr, accw[I]);
+    };
+    auto pass1_mfma = [&](const int blk, const double (&zz)[4]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pass1_mfma_r(blk, r, zz[r]);
     };
     // W: sum the 8 per-wave tiles, tv = T W  (lane (q,c) needs tv[4s + q][c]); two barriers
     auto reduce_w = [&]() {
@@ -207,9 +223,12 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
         const uint32_t n_next = (uint32_t)(A.n0 + nl + 16);       // the group whose normals are generated in this iteration
         const double usq_cur = usq_next;
         usq_next = 0.0;
-        accw = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int I = 0; I < KC / 4; ++I) accw[I] = 0.0;
         double qd = 0.0, tau = 0.0;
-        d4 acc3 = {0.0, 0.0, 0.0, 0.0};
+        double acc3[TR > 0 ? TR : 1];                              // target tile: acc3[I] = t[4 I + q][c]
+#pragma unroll
+        for (int I = 0; I < (TR > 0 ? TR : 1); ++I) acc3[I] = 0.0;
         double *X = (WX && valid) ? (A.x + (size_t)slot * A.x_stride + (size_t)nl * d) : nullptr;
         // Block body.  Three INDEPENDENT dependency chains are advanced side by side in each of 11 phases -- the two
         // Box-Muller pairs of (next group, this block) and the Philox call of the following pair -- and one MFMA is
@@ -224,12 +243,14 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
         auto body = [&](const int b, const int blk, const bool head) {
             const int rowbase = blk * 16 + 4 * q;
             // ---- operand fetch (LDS / L2) for this block, issued up front
-            double a3[4] = {0.0, 0.0, 0.0, 0.0}, ta4[4] = {0.0, 0.0, 0.0, 0.0};
+            double a3[4][TR > 0 ? TR : 1], ta4[4] = {0.0, 0.0, 0.0, 0.0};
             if (TGT == 1) {
                 if (RPAD > 0) {
-                    const double *w16 = A.t_wd16 + ((size_t)blk * 16 + 4 * q) * 16 + c;  // A[j' = c][k = q]
+                    const double *w16 = A.t_wd16 + ((size_t)blk * 16 + 4 * q) * 16 + l3;  // A[i][k = q] = Wd[row 4q + r][4 I + i]
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) a3[r] = w16[r * 16];
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int I = 0; I < TR; ++I) a3[r][I] = w16[r * 16 + 4 * I];
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) ta4[r] = A.t_a[(rowbase + r < d) ? rowbase + r : d - 1];
@@ -238,13 +259,6 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
             double a2v[KC / 4];
 #pragma unroll
             for (int s2 = 0; s2 < KC / 4; ++s2) a2v[s2] = a2p[4 * s2];
-            double a1v[4] = {0.0, 0.0, 0.0, 0.0};
-            if (b > 0) {                                                                // pass-1 operands of the previous block
-                const double *a1p = (c < KC) ? (vh_s + (rowbase - 16) * KC + c) : zero_s;
-                const int a1s = (c < KC) ? KC : 0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) a1v[r] = a1p[r * a1s];
-            }
             const double mu4[4] = {mu_s[rowbase], mu_s[rowbase + 1], mu_s[rowbase + 2], mu_s[rowbase + 3]};
             const double sq4[4] = {sqa_s[rowbase], sqa_s[rowbase + 1], sqa_s[rowbase + 2], sqa_s[rowbase + 3]};
             const double tm4[4] = {tm_s[rowbase], tm_s[rowbase + 1], tm_s[rowbase + 2], tm_s[rowbase + 3]};
@@ -273,12 +287,12 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
             PF_PIN_RNG(); PF_PIN(p1.p); PF_PIN(p2.p);
             PF_PHASE_END();
             // P3
-            if (b > 0) accw = pf_mfma(a1v[0], z[b > 0 ? b - 1 : 0][0], accw);
+            if (b > 0) pass1_mfma_r(blk - 1, 0, z[b > 0 ? b - 1 : 0][0]);
             pf_philox_round(c0, c1, c2, c3, k0, k1); p1.s3(); p2.s3();
             PF_PIN_RNG(); PF_PIN(p1.g); PF_PIN(p1.h); PF_PIN(p2.g); PF_PIN(p2.h);
             PF_PHASE_END();
             // P4: first half of the epilogue of the current group: x = mu + sqrt(alpha) x~
-            if (b > 0) accw = pf_mfma(a1v[1], z[b > 0 ? b - 1 : 0][1], accw);
+            if (b > 0) pass1_mfma_r(blk - 1, 1, z[b > 0 ? b - 1 : 0][1]);
             pf_philox_round(c0, c1, c2, c3, k0, k1); p1.s4(); p2.s4();
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -290,7 +304,7 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
             for (int r = 0; r < 4; ++r) PF_PIN(e4[r]);
             PF_PHASE_END();
             // P5: second half: target accumulation, optional store
-            if (b > 0) accw = pf_mfma(a1v[2], z[b > 0 ? b - 1 : 0][2], accw);
+            if (b > 0) pass1_mfma_r(blk - 1, 2, z[b > 0 ? b - 1 : 0][2]);
             pf_philox_round(c0, c1, c2, c3, k0, k1); p1.s5(); p2.s5();
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -302,12 +316,18 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
             PF_PIN_RNG(); PF_PIN(p1.cs); PF_PIN(p1.sn); PF_PIN(p2.cs); PF_PIN(p2.sn); PF_PIN(qd);
             PF_PHASE_END();
             // P6
-            if (TGT == 1 && RPAD > 0) acc3 = pf_mfma(a3[0], e4[0], acc3);
+            if (TGT == 1 && RPAD > 0) {
+#pragma unroll
+                for (int I = 0; I < TR; ++I) acc3[I] = pf_mfma4(a3[0][I], e4[0], acc3[I]);
+            }
             pf_philox_round(c0, c1, c2, c3, k0, k1); p1.s6(zz[0], zz[1]); p2.s6(zz[2], zz[3]);
             PF_PIN_RNG(); PF_PIN(zz[0]); PF_PIN(zz[1]); PF_PIN(zz[2]); PF_PIN(zz[3]);
             PF_PHASE_END();
             // P7
-            if (TGT == 1 && RPAD > 0) acc3 = pf_mfma(a3[1], e4[1], acc3);
+            if (TGT == 1 && RPAD > 0) {
+#pragma unroll
+                for (int I = 0; I < TR; ++I) acc3[I] = pf_mfma4(a3[1][I], e4[1], acc3[I]);
+            }
             pf_philox_round(c0, c1, c2, c3, k0, k1);
             if (blk == nblk - 1) {                                                      // rows >= d exist only in the last block
 #pragma unroll
@@ -318,12 +338,18 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
             PF_PIN_RNG(); PF_PIN(usq_next);
             PF_PHASE_END();
             // P8
-            if (TGT == 1 && RPAD > 0) acc3 = pf_mfma(a3[2], e4[2], acc3);
+            if (TGT == 1 && RPAD > 0) {
+#pragma unroll
+                for (int I = 0; I < TR; ++I) acc3[I] = pf_mfma4(a3[2][I], e4[2], acc3[I]);
+            }
             pf_philox_round(c0, c1, c2, c3, k0, k1);
             PF_PIN_RNG();
             PF_PHASE_END();
             // P9
-            if (TGT == 1 && RPAD > 0) acc3 = pf_mfma(a3[3], e4[3], acc3);
+            if (TGT == 1 && RPAD > 0) {
+#pragma unroll
+                for (int I = 0; I < TR; ++I) acc3[I] = pf_mfma4(a3[3][I], e4[3], acc3[I]);
+            }
             pf_philox_round(c0, c1, c2, c3, k0, k1);
             if (head) {                                                                 // z[1:k] = V' u[1:k]  (src/woodbury.jl:139)
                 d4 h = {0.0, 0.0, 0.0, 0.0};
@@ -334,7 +360,7 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
             }
             PF_PHASE_END();
             // P10
-            if (b > 0) accw = pf_mfma(a1v[3], z[b > 0 ? b - 1 : 0][3], accw);
+            if (b > 0) pass1_mfma_r(blk - 1, 3, z[b > 0 ? b - 1 : 0][3]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) z[b][r] = zz[r];
             xc[0] = c0; xc[1] = c1; xc[2] = c2; xc[3] = c3;
