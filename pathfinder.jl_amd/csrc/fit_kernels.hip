@@ -419,8 +419,11 @@ __global__ __launch_bounds__(NT) void pf_fit_reg_kernel(FitArgs A) {
     double *mu = A.mu + (size_t)p * d;
     const double *theta_p = A.theta + (size_t)p * d, *grad_p = A.grad + (size_t)p * d;
 
-    __shared__ double red[(NT / 64) * KPAD];
-    __shared__ double sRow[KPAD], sHead[KPAD];
+    constexpr int NP = KPAD * (KPAD + 1) / 2;            // Gram entries (upper triangle)
+    constexpr int CH = NP < 26 ? NP : 26;                // entries per block reduction
+    constexpr int NCH = (NP + CH - 1) / CH;
+    __shared__ double red[(NT / 64) * (CH > KPAD ? CH : KPAD)];
+    __shared__ double sRow[2][KPAD], sHead[KPAD];
     __shared__ double sD[KPAD * KPAD], sR[KPAD * KPAD], sT[KPAD * KPAD], sV[KPAD * KPAD], sG[KPAD * KPAD];
     __shared__ double sLogdetV;
     __shared__ int sStatus;
@@ -489,39 +492,58 @@ __global__ __launch_bounds__(NT) void pf_fit_reg_kernel(FitArgs A) {
         }
     }
     double acc[KPAD];
-    // ---- Gram matrix G = B~'B~ (row c at a time)
-    for (int c = 0; c < m; ++c) {
+    // ---- Gram matrix G = B~'B~: all KPAD(KPAD+1)/2 entries with compile-time column indices (pure FMAs), CH entries
+    //      per block reduction (3 reductions at KPAD = 12 instead of one per row)
 #pragma unroll
-        for (int cc = 0; cc < KPAD; ++cc) acc[cc] = 0.0;
+    for (int ch = 0; ch < NCH; ++ch) {
+        double g2[CH];
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) {
-            double xc = 0.0;
+        for (int e = 0; e < CH; ++e) g2[e] = 0.0;
+        {
+            int e = 0;
 #pragma unroll
-            for (int cc = 0; cc < KPAD; ++cc) if (cc == c) xc = a[i][cc];
+            for (int ca = 0; ca < KPAD; ++ca)
 #pragma unroll
-            for (int cc = 0; cc < KPAD; ++cc) acc[cc] += xc * a[i][cc];
+                for (int cb = ca; cb < KPAD; ++cb) {
+                    if (e / CH == ch) {
+#pragma unroll
+                        for (int i = 0; i < RPT; ++i) g2[e % CH] += a[i][ca] * a[i][cb];
+                    }
+                    ++e;
+                }
         }
-        pf_block_sum<KPAD>(acc, red);
+        pf_block_sum<CH>(g2, red);
         if (tid == 0) {
+            int e = 0;
 #pragma unroll
-            for (int cc = 0; cc < KPAD; ++cc) sG[c * KPAD + cc] = acc[cc];
+            for (int ca = 0; ca < KPAD; ++ca)
+#pragma unroll
+                for (int cb = ca; cb < KPAD; ++cb) {
+                    if (e / CH == ch) { sG[ca * KPAD + cb] = g2[e % CH]; sG[cb * KPAD + ca] = g2[e % CH]; }
+                    ++e;
+                }
         }
     }
     __syncthreads();
     // ---- D (m x m)   (src/inverse_hessian.jl:119-130)
-    if (tid == 0 && j > 0) {
+    if (j > 0) {
         double *R = sT, *nRinv = sV;
-        for (int aa = 0; aa < j; ++aa)
-            for (int b = 0; b < j; ++b) {
-                R[aa * KPAD + b] = (b >= aa) ? sG[(j + aa) * KPAD + b] : 0.0;
-                nRinv[aa * KPAD + b] = 0.0;
-            }
-        for (int c = 0; c < j; ++c)
-            for (int r = c; r >= 0; --r) {
-                double rhs = (r == c) ? -1.0 : 0.0;
-                for (int t = r + 1; t <= c; ++t) rhs -= R[r * KPAD + t] * nRinv[t * KPAD + c];
-                nRinv[r * KPAD + c] = rhs / R[r * KPAD + r];
-            }
+        for (int t = tid; t < j * j; t += NT) {
+            const int aa = t / j, b = t % j;
+            R[aa * KPAD + b] = (b >= aa) ? sG[(j + aa) * KPAD + b] : 0.0;      // triu(S'Y)   :119-121
+            nRinv[aa * KPAD + b] = 0.0;
+        }
+    }
+    __syncthreads();
+    if (tid < j) {                                   // -R^{-1}: lane c solves column c by back substitution :122-124
+        const double *R = sT;
+        double *nRinv = sV;
+        const int c = tid;
+        for (int r = c; r >= 0; --r) {
+            double rhs = (r == c) ? -1.0 : 0.0;
+            for (int t = r + 1; t <= c; ++t) rhs -= R[r * KPAD + t] * nRinv[t * KPAD + c];
+            nRinv[r * KPAD + c] = rhs / R[r * KPAD + r];
+        }
     }
     __syncthreads();
     if (j > 0) {   // M = Y'alpha Y + diag(R); D12, D21 -- one entry per thread
@@ -556,12 +578,16 @@ __global__ __launch_bounds__(NT) void pf_fit_reg_kernel(FitArgs A) {
     for (int t = tid; t < KPAD * KPAD; t += NT) { sT[t] = 0.0; sV[t] = 0.0; sR[t] = 0.0; }
     __syncthreads();
 
-    // ---- Householder QR, one block reduction per column
-    for (int c = 0; c < k; ++c) {
-        // row c belongs to thread c (slot 0): publish it
-        if (tid == c) {
+    // ---- Householder QR, one block reduction per column.  Thread aa < KPAD keeps row aa of the compact-WY T in
+    //      registers (dlarft: T[0:c, c] = -tau T[0:c,0:c] (Vh' v_c)), so the column loop has no serial section.
+    double trow[KPAD];
 #pragma unroll
-            for (int cc = 0; cc < KPAD; ++cc) sRow[cc] = a[0][cc];
+    for (int cc = 0; cc < KPAD; ++cc) trow[cc] = 0.0;
+    for (int c = 0; c < k; ++c) {
+        double *srow = sRow[c & 1];
+        if (tid == c) {                       // row c belongs to thread c (slot 0): publish it
+#pragma unroll
+            for (int cc = 0; cc < KPAD; ++cc) srow[cc] = a[0][cc];
         }
 #pragma unroll
         for (int cc = 0; cc < KPAD; ++cc) acc[cc] = 0.0;
@@ -576,11 +602,11 @@ __global__ __launch_bounds__(NT) void pf_fit_reg_kernel(FitArgs A) {
                 for (int cc = 0; cc < KPAD; ++cc) acc[cc] += xc * a[i][cc];
             }
         }
-        pf_block_sum<KPAD>(acc, red);       // its barriers also publish sRow
+        pf_block_sum<KPAD>(acc, red);       // its barriers also publish srow (double buffered: no trailing barrier)
         double xn2 = 0.0;
 #pragma unroll
         for (int cc = 0; cc < KPAD; ++cc) if (cc == c) xn2 = acc[cc];
-        const double alpha_c = sRow[c];
+        const double alpha_c = srow[c];
         const double xnorm = sqrt(xn2);
         double tau, scal, beta;
         if (xnorm == 0.0) { tau = 0.0; scal = 0.0; beta = alpha_c; }
@@ -592,20 +618,16 @@ __global__ __launch_bounds__(NT) void pf_fit_reg_kernel(FitArgs A) {
         double wv[KPAD];                     // cc > c: tau * (v_c . column cc); cc < c: v_c . v_cc
 #pragma unroll
         for (int cc = 0; cc < KPAD; ++cc) {
-            const double vdot = sRow[cc] + scal * acc[cc];
+            const double vdot = srow[cc] + scal * acc[cc];
             wv[cc] = (cc > c) ? tau * vdot : vdot;
         }
-        if (tid == 0) {                      // T[0:c, c] = -tau T[0:c,0:c] (Vh' v_c)   (dlarft)
-            double g[KPAD];
+        if (tid <= c && tid < KPAD) {        // T column c, one row per thread
+            double v = 0.0;
 #pragma unroll
-            for (int cc = 0; cc < KPAD; ++cc) g[cc] = wv[cc];
-            sT[c * KPAD + c] = tau;
-            for (int aa = 0; aa < c; ++aa) {
-                double v = 0.0;
+            for (int b = 0; b < KPAD; ++b) if (b >= tid && b < c) v += trow[b] * wv[b];
+            const double tnew = (tid == c) ? tau : -tau * v;
 #pragma unroll
-                for (int b = 0; b < KPAD; ++b) if (b >= aa && b < c) v += sT[aa * KPAD + b] * g[b];
-                sT[aa * KPAD + c] = -tau * v;
-            }
+            for (int b = 0; b < KPAD; ++b) if (b == c) trow[b] = tnew;
         }
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
@@ -627,7 +649,10 @@ __global__ __launch_bounds__(NT) void pf_fit_reg_kernel(FitArgs A) {
                 }
             }
         }
-        __syncthreads();                     // sRow is rewritten by the next column's owner
+    }
+    if (tid < KPAD) {
+#pragma unroll
+        for (int cc = 0; cc < KPAD; ++cc) sT[tid * KPAD + cc] = trow[cc];
     }
     // ---- split: R (k x m) -> sR; Householder vectors get an explicit unit diagonal
     if (tid < k) {
@@ -657,25 +682,30 @@ __global__ __launch_bounds__(NT) void pf_fit_reg_kernel(FitArgs A) {
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        int st = PFMI_FIT_OK;
-        double ldv = 0.0;
-        for (int c = 0; c < k && st == PFMI_FIT_OK; ++c) {
-            double diag = sV[c * KPAD + c];
-            for (int t = 0; t < c; ++t) diag -= sV[t * KPAD + c] * sV[t * KPAD + c];
-            if (!(diag > 0.0) || !isfinite(diag)) { st = PFMI_FIT_C_NOT_PD; break; }
-            diag = sqrt(diag);
-            sV[c * KPAD + c] = diag;
-            ldv += log(diag);
-            for (int b = c + 1; b < k; ++b) {
-                double v = sV[c * KPAD + b];
-                for (int t = 0; t < c; ++t) v -= sV[t * KPAD + c] * sV[t * KPAD + b];
-                sV[c * KPAD + b] = v / diag;
+    if (tid < 64) {                          // wave 0: left-looking Cholesky, lane b owns column b.  LDS operations of one
+        const int b = tid;                   // wave execute in program order; volatile keeps the compiler from caching
+        volatile double *Vv = sV;            // or hoisting values that another lane of the wave writes.
+        volatile int *vst = &sStatus;
+        volatile double *vld = &sLogdetV;
+        if (b == 0) { *vst = PFMI_FIT_OK; *vld = 0.0; }
+        for (int c = 0; c < k; ++c) {
+            if (*vst != PFMI_FIT_OK) break;
+            if (b == c) {
+                double diag = Vv[c * KPAD + c];
+                for (int t = 0; t < c; ++t) { const double x = Vv[t * KPAD + c]; diag -= x * x; }
+                if (!(diag > 0.0) || !isfinite(diag)) *vst = PFMI_FIT_C_NOT_PD;    // src/woodbury.jl:205
+                else { diag = sqrt(diag); Vv[c * KPAD + c] = diag; *vld = *vld + log(diag); }
             }
+            __builtin_amdgcn_wave_barrier();
+            if (*vst != PFMI_FIT_OK) break;
+            if (b > c && b < k) {
+                double v = Vv[c * KPAD + b];
+                for (int t = 0; t < c; ++t) v -= Vv[t * KPAD + c] * Vv[t * KPAD + b];
+                Vv[c * KPAD + b] = v / Vv[c * KPAD + c];
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        for (int aa = k; aa < KPAD; ++aa) sV[aa * KPAD + aa] = 1.0;
-        sStatus = st;
-        sLogdetV = ldv;
+        if (b >= k && b < KPAD) Vv[b * KPAD + b] = 1.0;                             // identity padding
     }
     __syncthreads();
     for (int t = tid; t < KPAD * KPAD; t += NT) {
@@ -723,17 +753,18 @@ __global__ __launch_bounds__(NT) void pf_fit_reg_kernel(FitArgs A) {
     }
     if (tid < k) sHead[tid] = bv[0];
     __syncthreads();
-    if (tid == 0) {
-        for (int aa = 0; aa < k; ++aa) {
-            double v = 0.0;
-            for (int b = aa; b < k; ++b) v += sV[aa * KPAD + b] * sHead[b];
-            sHead[aa] = v;
-        }
-        for (int aa = k - 1; aa >= 0; --aa) {
-            double v = 0.0;
-            for (int b = 0; b <= aa; ++b) v += sV[b * KPAD + aa] * sHead[b];
-            sHead[aa] = v;
-        }
+    if (tid < 64) {                          // head <- V'(V head), lane a owns entry a (two ordered LDS phases of wave 0)
+        const int aa = tid;
+        volatile double *tmp = sRow[0];
+        volatile double *hd = sHead;
+        double v = 0.0;
+        if (aa < k) for (int b = aa; b < k; ++b) v += sV[aa * KPAD + b] * hd[b];
+        if (aa < k) tmp[aa] = v;
+        __builtin_amdgcn_wave_barrier();
+        double v2 = 0.0;
+        if (aa < k) for (int b = 0; b <= aa; ++b) v2 += sV[b * KPAD + aa] * tmp[b];
+        __builtin_amdgcn_wave_barrier();
+        if (aa < k) hd[aa] = v2;
     }
     __syncthreads();
     if (tid < k) bv[0] = sHead[tid];

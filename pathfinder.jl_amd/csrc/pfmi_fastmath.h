@@ -382,78 +382,6 @@ __device__ __forceinline__ void pf_randn4_fast(uint64_t seed, uint32_t g, uint32
     pf_boxmuller4_fast(x, tab, z);
 }
 
-// ---- the same Box-Muller pair, cut into three phases of ~20 fp64 VALU instructions each so that a kernel can
-//      interleave them with MFMA issue (elbo_mfma_kernel.hip).  pf_bm_a/b/c(x_radius, x_angle) == one pair of
-//      pf_boxmuller4_fast, bit for bit.
-struct PfBM {
-    double v;        // -2 ln u_radius
-    double rad;      // sqrt(v)
-    double f, f2;    // half-turn fraction of the angle and its square
-    double ps;       // partial sine polynomial
-    int iq;          // quadrant
-};
-__device__ __forceinline__ void pf_bm_a(uint32_t xr, uint32_t xa, const double2 *tab, PfBM &st) {
-    const double S = 2.3283064365386962890625e-10;  // 2^-32
-    const double ur = ((double)xr + 0.5) * S, ua = ((double)xa + 0.5) * S;
-    st.v = pf_neg2log_fast(ur, tab);
-    const double t4 = 4.0 * ua;
-    const double q = rint(t4);
-    st.f = 0.5 * (t4 - q);
-    st.iq = (int)q;
-}
-__device__ __forceinline__ void pf_bm_b(PfBM &st) {
-    st.rad = pf_sqrt_fast(st.v);
-    const double f2 = st.f * st.f;
-    st.f2 = f2;
-    double ps = -2.1915353447830217e-05;
-    ps = fma(ps, f2, 0.00046630280576761255);
-    ps = fma(ps, f2, -0.0073704309457143504);
-    ps = fma(ps, f2, 0.08214588661112823);
-    st.ps = ps;
-}
-__device__ __forceinline__ void pf_bm_c(const PfBM &st, double &z0, double &z1) {
-    const double f2 = st.f2;
-    double ps = st.ps;
-    ps = fma(ps, f2, -0.5992645293207921);
-    ps = fma(ps, f2, 2.5501640398773455);
-    ps = fma(ps, f2, -5.16771278004997);
-    ps = fma(ps, f2, 3.141592653589793);
-    ps *= st.f;
-    double pc = 4.303069587032947e-06;
-    pc = fma(pc, f2, -0.0001046381049248457);
-    pc = fma(pc, f2, 0.0019295743094039231);
-    pc = fma(pc, f2, -0.02580689139001406);
-    pc = fma(pc, f2, 0.2353306303588932);
-    pc = fma(pc, f2, -1.3352627688545895);
-    pc = fma(pc, f2, 4.0587121264167685);
-    pc = fma(pc, f2, -4.934802200544679);
-    pc = fma(pc, f2, 1.0);
-    const bool swap = (st.iq & 1) != 0;
-    const double ss = swap ? pc : ps;
-    const double cc = swap ? ps : pc;
-    const long long sflip = ((long long)(st.iq & 2)) << 62;
-    const long long cflip = ((long long)((st.iq + 1) & 2)) << 62;
-    const double s = __longlong_as_double(__double_as_longlong(ss) ^ sflip);
-    const double c = __longlong_as_double(__double_as_longlong(cc) ^ cflip);
-    z0 = st.rad * c;
-    z1 = st.rad * s;
-}
-// two Philox4x32 rounds (the generator is split 5 x 2 rounds by the pipelined kernel)
-__device__ __forceinline__ void pf_philox_2rounds(uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3,
-                                                  uint32_t &k0, uint32_t &k1) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-        const uint32_t n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-}
-
 // ---- Box-Muller pair in seven pieces for kernels that interleave several independent chains (two pairs + the next
 //      Philox call) inside one scheduling region.  Radius: -2 ln u via the log table; angle: theta = theta_i + delta with
 //      {cos, sin}(theta_i) from a 256-entry LDS table and degree-5/6 Taylor polynomials in |delta| <= pi/256

@@ -131,12 +131,11 @@ __global__ __launch_bounds__(PSIS_THREADS) void pf_psis_kernel(long long S, cons
     __shared__ SelectState st;
     __shared__ double red[PSIS_THREADS / 64];
     __shared__ double s_theta[128], s_ll[128];
-    __shared__ double s_k, s_sigma, s_mu, s_lmax;
-    __shared__ int s_ok;
+    __shared__ double s_sigma, s_mu;
 
     for (long long i = tid; i < S; i += nt) lw[i] = lr[i];
     double pareto_k = NAN;
-    if (tid == 0) { s_ok = 0; s_k = NAN; s_sigma = NAN; }
+    if (tid == 0) s_sigma = NAN;
     __syncthreads();
     if (M >= 5 && M + 1 <= TAILCAP && (long long)(M + 1) <= S) {
         pf_select_top_sorted(lr, S, M + 1, tkeys, tidx, &st);

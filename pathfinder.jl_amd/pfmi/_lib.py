@@ -59,8 +59,7 @@ def lib():
         except Exception:  # pragma: no cover
             pass
     if not os.path.exists(_SO):
-        raise PfmiError(f"{_SO} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                        "(there is no CPU fallback)")
+        build()   # in-tree hipcc build; raises if hipcc is unavailable (there is no CPU fallback)
     L = C.CDLL(_SO, mode=C.RTLD_GLOBAL)
     L.pfmi_last_error.restype = C.c_char_p
     for s in SYMBOLS:
