@@ -21,44 +21,69 @@
 #define FIT_THREADS 256
 
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(HIST_THREADS) void pf_history_kernel(
+// 1024 threads per path; each thread keeps its EPT coordinates of alpha, theta_l, grad_l in registers and prefetches
+// point l+1 while the four dot products of step l are block-reduced, so one trace iteration costs one reduction
+// instead of a round trip through HBM.
+#define HIST_NT 1024
+template <int EPT>
+__global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
     int d, int J, double eps, const int64_t *__restrict__ off, const double *__restrict__ theta,
-    const double *__restrict__ grad, double *alpha_all, int *__restrict__ hist_len,
+    const double *__restrict__ grad, double *__restrict__ alpha_all, int *__restrict__ hist_len,
     int *__restrict__ hist_src, int *__restrict__ n_rej) {
-    const int k = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int k = blockIdx.x, tid = threadIdx.x;
     const int64_t p0 = off[k];
     const int L = (int)(off[k + 1] - p0 - 1);
-    __shared__ double red[4 * (HIST_THREADS / 64)];
+    __shared__ double red[4 * (HIST_NT / 64)];
     __shared__ int s_slot[64];
     __shared__ int s_ind, s_eff, s_rej;
 
-    for (int i = tid; i < d; i += nt) alpha_all[(size_t)p0 * d + i] = 1.0;   // H0 = I  (:38-39)
+    double al[EPT], t0[EPT], g0[EPT], t1[EPT], g1[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid + HIST_NT * e;
+        al[e] = 1.0;                                                           // H0 = I  (:38-39)
+        t0[e] = g0[e] = t1[e] = g1[e] = 0.0;
+        if (i < d) {
+            alpha_all[(size_t)p0 * d + i] = 1.0;
+            t0[e] = theta[(size_t)p0 * d + i];
+            g0[e] = grad[(size_t)p0 * d + i];
+            if (L >= 1) { t1[e] = theta[(size_t)(p0 + 1) * d + i]; g1[e] = grad[(size_t)(p0 + 1) * d + i]; }
+        }
+    }
     if (tid == 0) { hist_len[p0] = 0; s_ind = 0; s_eff = 0; s_rej = 0; }
-    __syncthreads();
     for (int l = 1; l <= L; ++l) {                                              // :43
-        const double *th0 = theta + (size_t)(p0 + l - 1) * d, *th1 = theta + (size_t)(p0 + l) * d;
-        const double *g0 = grad + (size_t)(p0 + l - 1) * d, *g1 = grad + (size_t)(p0 + l) * d;
-        const double *a0 = alpha_all + (size_t)(p0 + l - 1) * d;
-        double *a1 = alpha_all + (size_t)(p0 + l) * d;
+        double tn[EPT], gn[EPT];                                                // prefetch point l + 1
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = tid + HIST_NT * e;
+            tn[e] = gn[e] = 0.0;
+            if (i < d && l < L) { tn[e] = theta[(size_t)(p0 + l + 1) * d + i]; gn[e] = grad[(size_t)(p0 + l + 1) * d + i]; }
+        }
         double v[4] = {0.0, 0.0, 0.0, 0.0};   // y.s, y.y, y'diag(a)y, s'diag(1/a)s
-        for (int i = tid; i < d; i += nt) {
-            double s = th1[i] - th0[i], y = g0[i] - g1[i], al = a0[i];       // :45-46
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const double s = t1[e] - t0[e], y = g0[e] - g1[e];                  // :45-46 (zero beyond d)
             v[0] += y * s;
             v[1] += y * y;
-            v[2] += y * al * y;
-            v[3] += s * (1.0 / al) * s;
+            v[2] += y * al[e] * y;
+            v[3] += s * (1.0 / al[e]) * s;
         }
         pf_block_sum<4>(v, red);
         const bool accept = v[0] > eps * v[1];                                  // :47
         if (accept) {                                                           // gilbert_init :5-10
             const double a = v[2], b = v[0], c = v[3];
-            for (int i = tid; i < d; i += nt) {
-                double s = th1[i] - th0[i], y = g0[i] - g1[i], al = a0[i];
-                double sa = s / al;
-                a1[i] = b / (a / al + y * y - (a / c) * sa * sa);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const double s = t1[e] - t0[e], y = g0[e] - g1[e];
+                const double sa = s / al[e];
+                al[e] = b / (a / al[e] + y * y - (a / c) * sa * sa);
             }
-        } else {
-            for (int i = tid; i < d; i += nt) a1[i] = a0[i];
+        }
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = tid + HIST_NT * e;
+            if (i < d) alpha_all[(size_t)(p0 + l) * d + i] = al[e];
+            t0[e] = t1[e]; g0[e] = g1[e]; t1[e] = tn[e]; g1[e] = gn[e];
         }
         if (tid == 0) {
             if (accept) {
@@ -73,7 +98,6 @@ __global__ __launch_bounds__(HIST_THREADS) void pf_history_kernel(
             for (int t = s_ind + 1; t <= s_eff; ++t) hist_src[(size_t)(p0 + l) * J + c++] = s_slot[t - 1];
             for (int t = 1; t <= s_ind; ++t) hist_src[(size_t)(p0 + l) * J + c++] = s_slot[t - 1];
         }
-        __syncthreads();
     }
     if (tid == 0) n_rej[k] = s_rej;
 }
@@ -805,11 +829,16 @@ __global__ __launch_bounds__(NT) void pf_fit_reg_kernel(FitArgs A) {
 // ---------------------------------------------------------------------------------------------------
 int32_t pf_launch_history(pfmi_ctx *c, double eps) {
     PF_CHECK(c->J <= 64, PFMI_ERR_UNSUPPORTED, "history_length %d > 64 unsupported", c->J);
+    PF_CHECK(c->d <= 16 * HIST_NT, PFMI_ERR_UNSUPPORTED, "dimension %d > %d unsupported", c->d, 16 * HIST_NT);
     pf_kernel_begin(c);
-    hipLaunchKernelGGL(pf_history_kernel, dim3(c->K), dim3(HIST_THREADS), 0, c->stream, c->d, c->J, eps,
-                       c->d_off.as<int64_t>(), c->theta.as<double>(), c->grad.as<double>(),
-                       c->alpha_all.as<double>(), c->hist_len.as<int>(), c->hist_src.as<int>(),
-                       c->n_rej.as<int>());
+    const int ept = (c->d + HIST_NT - 1) / HIST_NT;
+#define PF_HIST(E)                                                                                               \
+    hipLaunchKernelGGL(pf_history_kernel<E>, dim3(c->K), dim3(HIST_NT), 0, c->stream, c->d, c->J, eps,           \
+                       c->d_off.as<int64_t>(), c->theta.as<double>(), c->grad.as<double>(),                      \
+                       c->alpha_all.as<double>(), c->hist_len.as<int>(), c->hist_src.as<int>(), c->n_rej.as<int>())
+    if (ept <= 1) PF_HIST(1); else if (ept <= 2) PF_HIST(2); else if (ept <= 4) PF_HIST(4);
+    else if (ept <= 8) PF_HIST(8); else PF_HIST(16);
+#undef PF_HIST
     pf_kernel_end(c, "history");
     PF_HIP(hipGetLastError());
     return PFMI_OK;
