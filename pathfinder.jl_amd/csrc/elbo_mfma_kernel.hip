@@ -47,6 +47,7 @@ __device__ __forceinline__ double pf_mfma4(double a, double b, double c) {
 template <int KC, int NBW, int TGT, int RPAD, bool WX>
 __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, int groups_per_block, int ngroups) {
     extern __shared__ double lds[];
+    constexpr bool FOLD = (TGT == 1) && !WX;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, q = lane >> 4, c = lane & 15;
     const int d = A.d;
     const int nblk = (d + 15) >> 4;            // 16-row blocks that contain real rows
@@ -88,10 +89,18 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
         const double *Vh = A.vh + (size_t)p * d * KC;
         for (int i = tid; i < rows * KC; i += MF_THREADS) vh_s[i] = (i < d * KC) ? Vh[i] : 0.0;
         const double *mu = A.mu + (size_t)p * d, *sqa = A.sqrt_alpha + (size_t)p * d;
+        // ELBO scan of a Gaussian-family target (no draws written): only e = x - m is needed, so the three per-row LDS
+        // vectors hold (mu - m, sqrt(alpha), a); otherwise (mu, sqrt(alpha), m) and the diagonal precision comes from L2
         for (int i = tid; i < rows; i += MF_THREADS) {
-            mu_s[i] = (i < d) ? mu[i] : 0.0;
+            const double mi = (i < d) ? mu[i] : 0.0;
             sqa_s[i] = (i < d) ? sqa[i] : 0.0;
-            if (TGT == 1) tm_s[i] = (i < d) ? A.t_mean[i] : 0.0;
+            if (FOLD) {
+                mu_s[i] = (i < d) ? mi - A.t_mean[i] : 0.0;
+                tm_s[i] = (i < d) ? A.t_a[i] : 0.0;
+            } else {
+                mu_s[i] = mi;
+                if (TGT == 1) tm_s[i] = (i < d) ? A.t_mean[i] : 0.0;
+            }
         }
         const double *T = A.tmat + (size_t)p * KC * KC;
         for (int i = tid; i < KC * KC; i += MF_THREADS) t_s[i] = T[i];
@@ -252,8 +261,10 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
 #pragma unroll
                         for (int I = 0; I < TR; ++I) a3[r][I] = w16[r * 16 + 4 * I];
                 }
+                if (!FOLD) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ta4[r] = A.t_a[(rowbase + r < d) ? rowbase + r : d - 1];
+                    for (int r = 0; r < 4; ++r) ta4[r] = A.t_a[(rowbase + r < d) ? rowbase + r : d - 1];
+                }
             }
             const double *a2p = vh_s + (blk * 16 + rho) * KC + q;                       // A[i'][k = q] = Vh[16 blk + rho(i')][4s + q]
             double a2v[KC / 4];
@@ -296,8 +307,8 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
             pf_philox_round(c0, c1, c2, c3, k0, k1); p1.s4(); p2.s4();
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                xi4[r] = mu4[r] + sq4[r] * xa[r];
-                e4[r] = xi4[r] - tm4[r];
+                xi4[r] = mu4[r] + sq4[r] * xa[r];                                       // FOLD: this is already e = x - m
+                e4[r] = FOLD ? xi4[r] : xi4[r] - tm4[r];
             }
             PF_PIN_RNG(); PF_PIN(p1.rad); PF_PIN(p1.sd); PF_PIN(p2.rad); PF_PIN(p2.sd);
 #pragma unroll
@@ -309,7 +320,7 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = rowbase + r;
-                if (TGT == 1) qd += ta4[r] * e4[r] * e4[r];                             // padded rows: e = 0
+                if (TGT == 1) qd += (FOLD ? tm4[r] : ta4[r]) * e4[r] * e4[r];           // padded rows: e = 0
                 else if (TGT == 2) { if (row == 0) tau = xi4[r]; else qd += xi4[r] * xi4[r]; }   // padded rows: xi = 0
                 if (WX) { if (X && row < d) X[row] = xi4[r]; }
             }
