@@ -139,6 +139,21 @@ int32_t pfmi_draws(pfmi_ctx *ctx, int64_t point, uint64_t seed, int64_t n0, int6
  * (src/resample.jl:85-89 -> src/woodbury.jl:378-382,158-165) */
 int32_t pfmi_logpdf(pfmi_ctx *ctx, int64_t point, int64_t N, const double *X, double *out);
 
+/* ---- remaining WoodburyPDMat / PDMats operator surface of a fitted covariance -------------- */
+/* What the HMC integrations call on a fitted metric (ext/PathfinderAdvancedHMCExt.jl:17-23,
+ * ext/PathfinderDynamicHMCExt.jl:7-15).  X is d x N column-major; out is d x N, or N values for the quadratic forms. */
+#define PFMI_OP_UNWHITEN 0     /* unwhiten!(r, W, x) = L x            src/woodbury.jl:401-406, 136-143 */
+#define PFMI_OP_WHITEN 1       /* whiten!(r, W, x)   = L \ x          src/woodbury.jl:410-415, 158-165 */
+#define PFMI_OP_RMUL 2         /* R x  (lmul!(R, x))                  src/woodbury.jl:129-135          */
+#define PFMI_OP_INVUNWHITEN 3  /* invunwhiten!(r, W, x) = R \ x       src/woodbury.jl:417-422, 151-157 */
+#define PFMI_OP_MUL 4          /* mul!(y, W, x) = L (R x)             src/woodbury.jl:340-349, 64-68   */
+#define PFMI_OP_SOLVE 5        /* W \ x = R \ (L \ x)                src/woodbury.jl:344, 70-74       */
+#define PFMI_OP_QUAD 6         /* quad(W, x)    = |R x|^2 per column  src/woodbury.jl:384-397          */
+#define PFMI_OP_INVQUAD 7      /* invquad(W, x) = |L \ x|^2           src/woodbury.jl:369-382          */
+int32_t pfmi_woodbury_apply(pfmi_ctx *ctx, int64_t point, int32_t op, int64_t N, const double *X, double *out);
+/* diag(W) = diag(A) + rowwise b' D b   (src/woodbury.jl:326-329); diag[d] */
+int32_t pfmi_woodbury_diag(pfmi_ctx *ctx, int64_t point, double *diag);
+
 /* ---- pooling, _compute_psis_result, _resample ---------------------------------------------------- */
 /* draws_per_component = stack(draws) (src/multipath.jl:217): for path k take N_r draws of fit
  * `points[k]` with seed seeds[k] into the device-resident pool (d, N_r, K) and

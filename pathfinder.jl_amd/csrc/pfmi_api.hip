@@ -451,6 +451,53 @@ int32_t pfmi_logpdf(pfmi_ctx *c, int64_t p, int64_t N, const double *X, double *
     return PFMI_OK;
 }
 
+// ---- remaining Woodbury operator surface ------------------------------------------------------------------
+int32_t pfmi_woodbury_apply(pfmi_ctx *c, int64_t p, int32_t op, int64_t N, const double *X, double *out) {
+    PF_CTX(c);
+    PF_CHECK(c->fitted, PFMI_ERR_STATE, "woodbury_apply: call pfmi_fit_batch first");
+    PF_CHECK(p >= 0 && p < c->P && N >= 1 && X && out, PFMI_ERR_ARG, "woodbury_apply: bad arguments");
+    PF_CHECK(op >= PFMI_OP_UNWHITEN && op <= PFMI_OP_INVQUAD, PFMI_ERR_ARG, "woodbury_apply: unknown op %d", op);
+    const size_t bytes = sizeof(double) * (size_t)c->d * N;
+    PF_TRY(c->xbuf.ensure(bytes));
+    PF_TRY(c->gbuf.ensure(bytes));
+    PF_TRY(c->scratch.ensure(bytes));
+    PF_TRY(h2d(c, c->xbuf.p, X, bytes));
+    double *in = c->xbuf.as<double>(), *o1 = c->gbuf.as<double>(), *o2 = c->scratch.as<double>();
+    const double *res = o1;
+    switch (op) {
+        case PFMI_OP_UNWHITEN: PF_TRY(pf_launch_woodbury_prim(c, 0, p, N, in, o1)); break;
+        case PFMI_OP_WHITEN: PF_TRY(pf_launch_woodbury_prim(c, 1, p, N, in, o1)); break;
+        case PFMI_OP_RMUL: PF_TRY(pf_launch_woodbury_prim(c, 2, p, N, in, o1)); break;
+        case PFMI_OP_INVUNWHITEN: PF_TRY(pf_launch_woodbury_prim(c, 3, p, N, in, o1)); break;
+        case PFMI_OP_MUL:                                            // lmul!(F.L, lmul!(F.R, x))
+            PF_TRY(pf_launch_woodbury_prim(c, 2, p, N, in, o1));
+            PF_TRY(pf_launch_woodbury_prim(c, 0, p, N, o1, o2));
+            res = o2; break;
+        case PFMI_OP_SOLVE:                                          // ldiv!(F.R, ldiv!(F.L, x))
+            PF_TRY(pf_launch_woodbury_prim(c, 1, p, N, in, o1));
+            PF_TRY(pf_launch_woodbury_prim(c, 3, p, N, o1, o2));
+            res = o2; break;
+        case PFMI_OP_QUAD:
+            PF_TRY(pf_launch_woodbury_prim(c, 2, p, N, in, o1));
+            PF_TRY(pf_launch_colsumsq(c, N, o1, o2));
+            return d2h(c, out, o2, sizeof(double) * N);
+        case PFMI_OP_INVQUAD:
+            PF_TRY(pf_launch_woodbury_prim(c, 1, p, N, in, o1));
+            PF_TRY(pf_launch_colsumsq(c, N, o1, o2));
+            return d2h(c, out, o2, sizeof(double) * N);
+    }
+    return d2h(c, out, res, bytes);
+}
+
+int32_t pfmi_woodbury_diag(pfmi_ctx *c, int64_t p, double *diag) {
+    PF_CTX(c);
+    PF_CHECK(c->fitted, PFMI_ERR_STATE, "woodbury_diag: call pfmi_fit_batch first");
+    PF_CHECK(p >= 0 && p < c->P && diag, PFMI_ERR_ARG, "woodbury_diag: bad arguments");
+    PF_TRY(c->gbuf.ensure(sizeof(double) * c->d));
+    PF_TRY(pf_launch_woodbury_diag(c, p, c->gbuf.as<double>()));
+    return d2h(c, diag, c->gbuf.p, sizeof(double) * c->d);
+}
+
 // ---- pool / PSIS / resample ---------------------------------------------------------------------------
 int32_t pfmi_pool_build(pfmi_ctx *c, int64_t N_r, const int64_t *points, const uint64_t *seeds) {
     PF_CTX(c);

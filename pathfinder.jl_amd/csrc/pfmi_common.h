@@ -137,6 +137,9 @@ int32_t pf_launch_resample(pfmi_ctx *c, int64_t S, int64_t ndraws, int importanc
                            uint64_t seed, const double *d_uniforms);
 int32_t pf_launch_gather(pfmi_ctx *c, int64_t ndraws, const int64_t *d_idx, int64_t col_offset, double *d_out);
 int32_t pf_launch_logratio(pfmi_ctx *c, int64_t n);
+int32_t pf_launch_woodbury_prim(pfmi_ctx *c, int mode, int64_t p, int64_t N, const double *d_in, double *d_out);
+int32_t pf_launch_colsumsq(pfmi_ctx *c, int64_t N, const double *d_x, double *d_out);
+int32_t pf_launch_woodbury_diag(pfmi_ctx *c, int64_t p, double *d_out);
 
 void pf_kernel_begin(pfmi_ctx *c);
 void pf_kernel_end(pfmi_ctx *c, const char *name);

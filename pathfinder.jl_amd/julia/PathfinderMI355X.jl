@@ -157,4 +157,35 @@ function pool_psis_resample!(ctx::Context, N_r::Integer, points::Vector{Int64}, 
     return X, ids, (importance ? w : nothing), k̂[]
 end
 
+# ---- the PDMats surface of a fitted covariance (src/woodbury.jl:326-423), as the HMC extensions use it -------
+# (ext/PathfinderAdvancedHMCExt.jl:17-23 builds a metric from Σ; its sampling calls unwhiten!/mul!/quad on it)
+struct DeviceWoodbury
+    ctx::Context
+    point::Int64      # 0-based global trace-point index of the fit
+    dim::Int
+end
+const OP = (unwhiten=Int32(0), whiten=Int32(1), rmul=Int32(2), invunwhiten=Int32(3), mul=Int32(4), solve=Int32(5),
+            quad=Int32(6), invquad=Int32(7))
+
+function _apply(W::DeviceWoodbury, op::Int32, x::AbstractVecOrMat{Float64})
+    X = Matrix{Float64}(reshape(x, W.dim, :))
+    N = size(X, 2)
+    out = op >= OP.quad ? Vector{Float64}(undef, N) : similar(X)
+    check(ccall((:pfmi_woodbury_apply, libpfmi), Int32, (Ptr{Cvoid}, Int64, Int32, Int64, Ptr{Float64}, Ptr{Float64}),
+                W.ctx.ptr, W.point, op, N, X, out))
+    return (x isa AbstractVector && op < OP.quad) ? vec(out) : out
+end
+unwhiten(W::DeviceWoodbury, x) = _apply(W, OP.unwhiten, x)          # PDMats.unwhiten!   src/woodbury.jl:401-406
+whiten(W::DeviceWoodbury, x) = _apply(W, OP.whiten, x)              # PDMats.whiten!     src/woodbury.jl:410-415
+invunwhiten(W::DeviceWoodbury, x) = _apply(W, OP.invunwhiten, x)    # PDMats.invunwhiten! src/woodbury.jl:417-422
+Base.:*(W::DeviceWoodbury, x::AbstractVecOrMat{Float64}) = _apply(W, OP.mul, x)    # src/woodbury.jl:340-349
+Base.:\(W::DeviceWoodbury, x::AbstractVecOrMat{Float64}) = _apply(W, OP.solve, x)
+quad(W::DeviceWoodbury, x) = _apply(W, OP.quad, x)                  # src/woodbury.jl:384-397
+invquad(W::DeviceWoodbury, x) = _apply(W, OP.invquad, x)            # src/woodbury.jl:369-382
+function diag(W::DeviceWoodbury)                                    # src/woodbury.jl:326-329
+    out = Vector{Float64}(undef, W.dim)
+    check(ccall((:pfmi_woodbury_diag, libpfmi), Int32, (Ptr{Cvoid}, Int64, Ptr{Float64}), W.ctx.ptr, W.point, out))
+    return out
+end
+
 end # module

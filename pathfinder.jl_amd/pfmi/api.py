@@ -48,8 +48,21 @@ class WoodburyPDMat:                # src/woodbury.jl:246-257
     F: WoodburyPDFactorization
     logdet: float
 
+    engine: Any = field(repr=False, default=None)
+    point: int = -1
+
     def dense(self):
         return np.diag(self.A) + self.B @ self.D @ self.B.T
+
+    # PDMats surface on the device (reference src/woodbury.jl:326-423)
+    def unwhiten(self, x): return self.engine.woodbury_apply(self.point, "unwhiten", x)
+    def whiten(self, x): return self.engine.woodbury_apply(self.point, "whiten", x)
+    def invunwhiten(self, x): return self.engine.woodbury_apply(self.point, "invunwhiten", x)
+    def mul(self, x): return self.engine.woodbury_apply(self.point, "mul", x)
+    def solve(self, x): return self.engine.woodbury_apply(self.point, "solve", x)
+    def quad(self, x): return self.engine.woodbury_apply(self.point, "quad", x)
+    def invquad(self, x): return self.engine.woodbury_apply(self.point, "invquad", x)
+    def diag(self): return self.engine.woodbury_diag(self.point)
 
 
 @dataclass
@@ -159,7 +172,7 @@ def _make_dists(eng, p0, npts, status, jeff, materialise=True):
             continue
         f = eng.get_fit(p, int(jeff[p]))
         F = WoodburyPDFactorization(np.sqrt(f["alpha"]), f["qr_factors"], f["T"], f["V"])
-        W = WoodburyPDMat(f["alpha"], f["B"], f["D"], F, f["logdet"])
+        W = WoodburyPDMat(f["alpha"], f["B"], f["D"], F, f["logdet"], eng, p)
         dists.append(MvNormal(f["mu"], W, eng, p))
     return dists
 

@@ -138,6 +138,27 @@ class Engine:
         check(self.L.pfmi_logpdf(self.ctx, C.c_int64(p), C.c_int64(N), _d(X), _d(out)))
         return out
 
+    # ---- remaining WoodburyPDMat operator surface -------------------------------------------------------
+    OPS = dict(unwhiten=0, whiten=1, rmul=2, invunwhiten=3, mul=4, solve=5, quad=6, invquad=7)
+
+    def woodbury_apply(self, p, op, X):
+        """op in Engine.OPS applied to the columns of X (d, N); quad/invquad return N values."""
+        X = np.asfortranarray(X, dtype=np.float64)
+        vec = X.ndim == 1
+        X2 = X.reshape(self.d, -1, order="F")
+        N = X2.shape[1]
+        code = self.OPS[op]
+        out = np.empty(N) if code >= 6 else np.empty((self.d, N), order="F")
+        check(self.L.pfmi_woodbury_apply(self.ctx, C.c_int64(p), C.c_int32(code), C.c_int64(N), _d(X2), _d(out)))
+        if code >= 6:
+            return out[0] if vec else out
+        return out[:, 0].copy() if vec else out
+
+    def woodbury_diag(self, p):
+        out = np.empty(self.d)
+        check(self.L.pfmi_woodbury_diag(self.ctx, C.c_int64(p), _d(out)))
+        return out
+
     # ---- pool / PSIS / resample -------------------------------------------------------------------------
     def pool_build(self, N_r, points, seeds):
         points = np.ascontiguousarray(points, dtype=np.int64)

@@ -597,3 +597,39 @@ print(json.dumps(dict(elbo=np.nan_to_num(elbo).tolist(), best=best.tolist(), x=X
     for key in ("elbo", "x", "lp", "lq"):
         x, y = np.array(a[key]), np.array(b[key])
         assert np.max(np.abs(x - y) / (1 + np.abs(y))) <= 1e-10, key
+
+
+@pytest.mark.parametrize("name,K,J", [("iso10", 1, 6), ("lr50", 2, 6), ("diag30", 1, 10)])
+def test_woodbury_operator_surface(pfmi_mod, eng, name, K, J):
+    """remaining PDMats surface on the device vs the oracle and dense algebra (reference test/woodbury.jl:239-402):
+    unwhiten / whiten / invunwhiten / R*x / W*x / W\\x / quad / invquad / diag, matrices and vectors, incl. n < m."""
+    tg, traces = _setup(pfmi_mod, eng, name, K, J)
+    status, jeff, logdet, _ = eng.fit_status()
+    rng = np.random.default_rng(5)
+    tr = traces[0]
+    alpha_all, hl, hs, _ = po.lbfgs_history(tr.points, tr.gradients, J)
+    for l in sorted({0, 1, min(4, len(tr) - 1), len(tr) - 1}):
+        if status[l] != 0:
+            continue
+        F = _oracle_factor(tr, alpha_all, hl, hs, l, tg.d)
+        W = F.dense()
+        X = rng.normal(size=(tg.d, 9))
+        tol = dict(rtol=1e-8, atol=1e-9 * max(1.0, np.abs(W).max()))
+        np.testing.assert_allclose(eng.woodbury_apply(l, "mul", X), W @ X, **tol)
+        np.testing.assert_allclose(eng.woodbury_apply(l, "solve", X), np.linalg.solve(W, X), rtol=1e-6, atol=1e-7 * np.abs(np.linalg.solve(W, X)).max())
+        np.testing.assert_allclose(eng.woodbury_apply(l, "quad", X), np.einsum("ij,ij->j", X, W @ X), rtol=1e-8)
+        np.testing.assert_allclose(eng.woodbury_apply(l, "invquad", X), np.einsum("ij,ij->j", X, np.linalg.solve(W, X)), rtol=1e-6)
+        np.testing.assert_allclose(eng.woodbury_diag(l), np.diag(W), rtol=1e-9, atol=1e-12)
+        x = X[:, 0].copy()
+        np.testing.assert_allclose(eng.woodbury_apply(l, "mul", x), W @ x, **tol)
+        # L and R themselves agree with the oracle's factor when the QR is well conditioned, and always satisfy
+        # L (L \ x) = x, R \ (R x) = x, unwhiten(whiten(x)) = x
+        if _well_conditioned(F):
+            np.testing.assert_allclose(eng.woodbury_apply(l, "unwhiten", X), F.lmul_L(X), rtol=1e-7, atol=1e-8 * np.abs(X).max() * np.sqrt(np.abs(W).max()))
+            np.testing.assert_allclose(eng.woodbury_apply(l, "rmul", X), F.lmul_R(X), rtol=1e-7, atol=1e-8 * np.abs(X).max() * np.sqrt(np.abs(W).max()))
+            np.testing.assert_allclose(eng.woodbury_apply(l, "whiten", X), F.ldiv_L(X), rtol=1e-6, atol=1e-7 * np.abs(F.ldiv_L(X)).max())
+            np.testing.assert_allclose(eng.woodbury_apply(l, "invunwhiten", X), F.ldiv_R(X), rtol=1e-6, atol=1e-7 * np.abs(F.ldiv_R(X)).max())
+        back = eng.woodbury_apply(l, "unwhiten", eng.woodbury_apply(l, "whiten", X))
+        np.testing.assert_allclose(back, X, rtol=1e-6, atol=1e-7 * np.abs(X).max())
+        back = eng.woodbury_apply(l, "invunwhiten", eng.woodbury_apply(l, "rmul", X))
+        np.testing.assert_allclose(back, X, rtol=1e-6, atol=1e-7 * np.abs(X).max())
