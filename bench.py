@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--history", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--host-traces", action="store_true", help="make the input traces with the host numpy driver")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -71,17 +72,20 @@ def main():
     # ---- synthetic inputs: target T_lr(d, r=8, seed=2), one L-BFGS trace per path ----------
     tg = pfmi.t_lowrank(d, r=8, seed=2)
     run_seeds = rand_u64(master, np.arange(K, dtype=np.uint64), 9)
-    traces = []
-    for k in range(k0, k0 + Kl):
-        rng = pfmi.HostRNG(int(run_seeds[k]))
-        x0 = rng.rand(d) * 4.0 - 2.0                                # U[-2, 2]  (src/singlepath.jl:158-159)
-        traces.append(pfmi.optimize_with_trace(tg, x0, history_length=J))
+    x0s = np.stack([pfmi.HostRNG(int(run_seeds[k])).rand(d) * 4.0 - 2.0          # U[-2, 2]  (src/singlepath.jl:158-159)
+                    for k in range(k0, k0 + Kl)])
     eng = pfmi.Engine(local_rank)
     eng.set_target(tg)
-    eng.set_traces([t.points for t in traces], [t.gradients for t in traces])     # H2D: outside the timed region
+    traces = None
+    if args.host_traces:
+        traces = [pfmi.optimize_with_trace(tg, x0, history_length=J) for x0 in x0s]
+        eng.set_traces([t.points for t in traces], [t.gradients for t in traces])  # H2D: outside the timed region
+        npts = np.array([len(t) for t in traces])
+    else:                                                           # device L-BFGS: traces are born in HBM
+        npts = eng.optimize_batch(x0s, J)
     P = eng.P
-    seeds = np.concatenate([rand_u64(int(run_seeds[k0 + i]), np.arange(len(t), dtype=np.uint64), 10)
-                            for i, t in enumerate(traces)])
+    seeds = np.concatenate([rand_u64(int(run_seeds[k0 + i]), np.arange(n, dtype=np.uint64), 10)
+                            for i, n in enumerate(npts)])
     nfits_local = P - Kl
     draws_local = nfits_local * N_e
 
@@ -143,15 +147,28 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = total_draws / (ms_per_step * 1e-3)
 
+    # ---- metric (ii): end-to-end wall-clock incl. trajectory generation (x0 on the host -> resampled draws on the host)
+    wall_e2e = None
+    if not args.host_traces:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.optimize_batch(x0s, J)
+            step()
+        barrier()
+        wall_e2e = (time.perf_counter() - t0) / args.steps * 1e3
+
     # ---- roofline of the dominant kernel (pf_elbo_draws_kernel), hipEvents on the engine's stream ---------
     roofline = None
     stages = {}
     if rank == 0:
         eng.profile(True)
+    if not args.host_traces:
+        eng.optimize_batch(x0s, J)
     step()                      # every rank takes part (collectives); only rank 0 records kernel events
     barrier()
     if rank == 0:
-        for name in ("history", "fit", "elbo_draws", "elbo_draws_x", "elbo_reduce", "psis", "resample"):
+        for name in ("optimize", "trace_pack", "history", "fit", "elbo_draws", "elbo_draws_x", "elbo_reduce", "psis", "resample"):
             ms, n = eng.kernel_time(name)
             stages[name] = {"ms": round(ms, 4), "launches": int(n)}
         eng.profile(False)
@@ -186,6 +203,12 @@ def main():
             from oracle import pf_oracle as po
             cores = os.cpu_count() or 1
             otg = oracle_target(tg)
+            if traces is None:                                         # device-made traces: download a sample for the CPU leg
+                from types import SimpleNamespace
+                traces = []
+                for kk in range(min(Kl, cores)):
+                    th_k, _, gr_k = eng.get_trace(kk, logp=False)
+                    traces.append(SimpleNamespace(points=th_k, gradients=gr_k))
             # bounded sample: `cores` paths (this rank's traces re-used cyclically), first `nf` fits of each; `nf` is
             # calibrated with a 2-fit probe so that the timed sample costs about args.cpu_seconds of wall-clock
             sel = [traces[i % len(traces)] for i in range(cores)]
@@ -200,7 +223,7 @@ def main():
                 return r, time.perf_counter() - t1
 
             _, t_probe = run(2)
-            nf = int(max(2, min(args.cpu_seconds / max(t_probe / 2, 1e-3), min(len(t) for t in traces) - 1)))
+            nf = int(max(2, min(args.cpu_seconds / max(t_probe / 2, 1e-3), min(len(t.points) for t in traces) - 1)))
             r, t_cpu = run(nf)
             cpu = {"value": round(r["total_draws"] / t_cpu, 1), "unit": "ELBO draws/s", "cores": cores,
                    "kind": "port",
@@ -221,6 +244,8 @@ def main():
                        "npaths": K, "paths_per_gpu": Kl, "fits_total": int(total_draws // N_e),
                        "elbo_draws_per_step": int(total_draws), "parallelism": f"paths sharded x{G}"},
             "multipathfinder_hot_path_ms": round(ms_per_step, 3),
+            "multipathfinder_wall_ms_incl_device_lbfgs": None if wall_e2e is None else round(wall_e2e, 3),
+            "traces": "host numpy L-BFGS driver" if args.host_traces else "device L-BFGS (pfmi_optimize_batch)",
             "pareto_k": state.get("pareto_k"),
             "stages_ms": stages,
             "roofline": roofline,

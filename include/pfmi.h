@@ -97,6 +97,19 @@ int32_t pfmi_set_target(pfmi_ctx *ctx, const pfmi_target *target);
 int32_t pfmi_set_traces(pfmi_ctx *ctx, int32_t K, const int64_t *npoints, int32_t d,
                         const double *theta, const double *grad);
 
+/* ---- trajectory generation on the device ---------------------------------- */
+/* Plays optimize_with_trace (src/optimize.jl:35-121) for the BUILT-IN targets: runs K independent L-BFGS
+ * optimisations of -logp from x0[k] (K x d, point-major), one persistent workgroup per path, and leaves the
+ * traces resident in HBM exactly as pfmi_set_traces would (so pfmi_fit_batch follows without a host round trip).
+ * This repo's own driver (two-loop recursion, strong-Wolfe line search, maxiters as src/optimize.jl:40, stop at
+ * |grad|_inf <= g_tol); Optim.LBFGS + HagerZhang of the reference is third party: trajectory parity unpinned.
+ * npoints[k] = L_k + 1 out.  Callback targets -> PFMI_ERR_UNSUPPORTED (optimise on the host, pfmi_set_traces). */
+int32_t pfmi_optimize_batch(pfmi_ctx *ctx, int32_t K, const double *x0, int32_t history_length, int32_t maxiters,
+                            double g_tol, int64_t *npoints);
+/* OptimizationTrace of path k (src/optimize.jl:94-100): theta/grad (L_k+1) x d point-major, logp L_k+1; any may be
+ * NULL.  logp is only available for traces made by pfmi_optimize_batch. */
+int32_t pfmi_get_trace(pfmi_ctx *ctx, int32_t k, double *theta, double *logp, double *grad);
+
 /* ---- fit_mvnormals / lbfgs_inverse_hessians / pdfactorize --------------------------------------- */
 /* replaces fit_mvnormals (src/mvnormal.jl:14-21) = lbfgs_inverse_hessians (src/inverse_hessian.jl:25-66)
  * + lbfgs_inverse_hessian (:98-133) + WoodburyPDMat/pdfactorize (src/woodbury.jl:259-263, 201-207)

@@ -833,3 +833,199 @@ long pfo_multipath_fit_elbo(int K, const long *off, int d, const double *theta, 
     (void)nthreads;
     return total;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* L-BFGS trajectory generation: produces the hot path's INPUT.           */
+/* The reference delegates to Optim.LBFGS + LineSearches.HagerZhang (src/optimize.jl:35-59,     */
+/* src/Pathfinder.jl:29-35) -- third party, absent from /root/reference, no trajectory values   */
+/* pinned by the reference's tests (test/optimize.jl:96-136 checks convergence + trace shape    */
+/* only): PARITY UNPINNED against Optim.  What is restated here is this repo's own driver       */
+/* (two-loop recursion with gamma = s'y / y'y, strong-Wolfe bracketing + bisection zoom,         */
+/* maxiters 1000 as src/optimize.jl:40, stop when |g|_inf <= g_tol), the same algorithm the      */
+/* device kernel pf_lbfgs_kernel runs; the trace (theta_l, logp_l, grad logp_l) has the layout   */
+/* of OptimizationTrace (src/optimize.jl:94-100).                                                */
+/* ------------------------------------------------------------------------------------------ */
+/* f = -logp and its gradient at x */
+static double neg_logp_grad(const pfo_target *t, const double *x, double *gout) {
+    int d = t->d;
+    if (t->kind == 1) {                          /* funnel, docs/src/examples/quickstart.md:229-234 */
+        double tau = x[0], ss = 0.0, e = exp(-tau);
+        for (int i = 1; i < d; ++i) ss += x[i] * x[i];
+        gout[0] = 0.5 * (2.0 * tau / 9.0 + (double)(d - 1) - e * ss);
+        for (int i = 1; i < d; ++i) gout[i] = e * x[i];
+        return 0.5 * ((tau / 3.0) * (tau / 3.0) + (double)(d - 1) * tau + e * ss);
+    }
+    int r = t->r;
+    double tt[64], gg[64], hh[64], q = 0.0, corr = 0.0;
+    for (int j = 0; j < r; ++j) tt[j] = 0.0;
+    for (int i = 0; i < d; ++i) {
+        double e = x[i] - t->mean[i];
+        q += t->a[i] * e * e;
+        for (int j = 0; j < r; ++j) tt[j] += t->Wd[i + (long)d * j] * e;
+    }
+    for (int j = 0; j < r; ++j) {
+        gg[j] = 0.0;
+        for (int l = 0; l <= j; ++l) gg[j] += t->G[j + r * l] * tt[l];
+        corr += gg[j] * gg[j];
+    }
+    for (int l = 0; l < r; ++l) {                /* hh = G' gg */
+        hh[l] = 0.0;
+        for (int j = l; j < r; ++j) hh[l] += t->G[j + r * l] * gg[j];
+    }
+    for (int i = 0; i < d; ++i) {
+        double v = t->a[i] * (x[i] - t->mean[i]);
+        for (int j = 0; j < r; ++j) v -= t->Wd[i + (long)d * j] * hh[j];
+        gout[i] = v;
+    }
+    return 0.5 * (q - corr) - t->offset;
+}
+
+/* logp and its gradient at one point (checker for the trace the device optimiser records) */
+double pfo_logp_grad(int kind, int d, int r, const double *mean, const double *a, const double *Wd, const double *G,
+                     double offset, const double *x, double *grad) {
+    pfo_target tg = {kind, d, r, mean, a, Wd, G, offset};
+    double f = neg_logp_grad(&tg, x, grad);
+    for (int i = 0; i < d; ++i) grad[i] = -grad[i];
+    return -f;
+}
+
+typedef struct {
+    const pfo_target *t;
+    int d;
+    const double *x, *p;
+    double *xn, *gn;     /* last evaluated point and gradient (the "pack") */
+    double fn;
+    int evaluated;
+} ls_ctx;
+
+static double dotd(int d, const double *a, const double *b) {
+    double s = 0.0;
+    for (int i = 0; i < d; ++i) s += a[i] * b[i];
+    return s;
+}
+static void ls_phi(ls_ctx *c, double a, double *f, double *g) {
+    for (int i = 0; i < c->d; ++i) c->xn[i] = c->x[i] + a * c->p[i];
+    c->fn = neg_logp_grad(c->t, c->xn, c->gn);
+    c->evaluated = 1;
+    *f = c->fn;
+    *g = dotd(c->d, c->gn, c->p);
+}
+static double ls_zoom(ls_ctx *c, double lo, double hi, double f_lo, double f_hi, double f0, double g0,
+                      double c1, double c2) {
+    double a = 0.5 * (lo + hi);
+    (void)f_hi;
+    for (int it = 0; it < 30; ++it) {
+        double f, g;
+        a = 0.5 * (lo + hi);
+        ls_phi(c, a, &f, &g);
+        if ((f > f0 + c1 * a * g0) || (f >= f_lo)) {
+            hi = a;
+        } else {
+            if (fabs(g) <= -c2 * g0) return a;
+            if (g * (hi - lo) >= 0) hi = lo;
+            lo = a; f_lo = f;
+        }
+    }
+    return a;
+}
+static double ls_search(ls_ctx *c, double f0, double g0, double a_init) {
+    const double c1 = 1e-4, c2 = 0.9, amax = 1e10;
+    double a_prev = 0.0, f_prev = f0, a = a_init;
+    for (int it = 0; it < 25; ++it) {
+        double f, g;
+        ls_phi(c, a, &f, &g);
+        if (!isfinite(f)) { a = 0.5 * (a_prev + a); continue; }
+        if ((f > f0 + c1 * a * g0) || (it > 0 && f >= f_prev)) return ls_zoom(c, a_prev, a, f_prev, f, f0, g0, c1, c2);
+        if (fabs(g) <= -c2 * g0) return a;
+        if (g >= 0) return ls_zoom(c, a, a_prev, f, f_prev, f0, g0, c1, c2);
+        a_prev = a; f_prev = f;
+        a = 2 * a < amax ? 2 * a : amax;
+    }
+    return a;
+}
+
+/* Minimise f = -logp from x0.  pts/grads: (maxiters+1) x d point-major; lps: maxiters+1.
+ * grads hold the gradient of the LOG DENSITY.  Returns the number of trace points (>= 1). */
+int pfo_optimize_trace(int kind, int d, int r, const double *mean, const double *a, const double *Wd,
+                       const double *G, double offset, const double *x0, int J, int maxiters, double g_tol,
+                       double *pts, double *lps, double *grads) {
+    pfo_target tg = {kind, d, r, mean, a, Wd, G, offset};
+    double *x = (double *)malloc(sizeof(double) * d), *g = (double *)malloc(sizeof(double) * d);
+    double *q = (double *)malloc(sizeof(double) * d), *p = (double *)malloc(sizeof(double) * d);
+    double *xn = (double *)malloc(sizeof(double) * d), *gn = (double *)malloc(sizeof(double) * d);
+    double *S = (double *)malloc(sizeof(double) * (size_t)d * J), *Y = (double *)malloc(sizeof(double) * (size_t)d * J);
+    double al[64];
+    int h = 0, n = 0;                                   /* history length (oldest first in slots 0..h-1) */
+    memcpy(x, x0, sizeof(double) * d);
+    double f = neg_logp_grad(&tg, x, g);
+    memcpy(pts, x, sizeof(double) * d); lps[0] = -f;
+    for (int i = 0; i < d; ++i) grads[i] = -g[i];
+    n = 1;
+    for (int it = 0; it < maxiters; ++it) {
+        int fin = isfinite(f);
+        double gmax = 0.0;
+        for (int i = 0; i < d; ++i) { if (!isfinite(g[i])) fin = 0; if (fabs(g[i]) > gmax) gmax = fabs(g[i]); }
+        if (!fin) break;
+        if (gmax <= g_tol) break;
+        memcpy(q, g, sizeof(double) * d);
+        for (int c = h - 1; c >= 0; --c) {
+            const double *s = S + (size_t)c * d, *y = Y + (size_t)c * d;
+            double rho = 1.0 / dotd(d, y, s);
+            al[c] = rho * dotd(d, s, q);
+            for (int i = 0; i < d; ++i) q[i] -= al[c] * y[i];
+        }
+        if (h) {
+            const double *s = S + (size_t)(h - 1) * d, *y = Y + (size_t)(h - 1) * d;
+            double gam = dotd(d, s, y) / dotd(d, y, y);
+            for (int i = 0; i < d; ++i) q[i] *= gam;
+        }
+        for (int c = 0; c < h; ++c) {
+            const double *s = S + (size_t)c * d, *y = Y + (size_t)c * d;
+            double rho = 1.0 / dotd(d, y, s);
+            double b = rho * dotd(d, y, q);
+            for (int i = 0; i < d; ++i) q[i] += (al[c] - b) * s[i];
+        }
+        for (int i = 0; i < d; ++i) p[i] = -q[i];
+        double g0 = dotd(d, g, p);
+        if (g0 >= 0) {
+            h = 0;
+            for (int i = 0; i < d; ++i) p[i] = -g[i];
+            g0 = dotd(d, g, p);
+        }
+        double a0 = 1.0;
+        if (!h) {
+            double nrm = sqrt(dotd(d, g, g));
+            if (nrm < 1e-300) nrm = 1e-300;
+            a0 = 1.0 / nrm < 1.0 ? 1.0 / nrm : 1.0;
+        }
+        ls_ctx lc = {&tg, d, x, p, xn, gn, 0.0, 0};
+        ls_search(&lc, f, g0, a0);
+        if (!lc.evaluated) break;
+        int ok = isfinite(lc.fn);
+        for (int i = 0; i < d; ++i) if (!isfinite(gn[i])) ok = 0;
+        if (!ok) break;
+        double ys = 0.0, yy = 0.0;
+        int moved = 0;
+        for (int i = 0; i < d; ++i) {
+            double si = xn[i] - x[i], yi = gn[i] - g[i];
+            ys += yi * si; yy += yi * yi;
+            if (xn[i] != x[i]) moved = 1;
+        }
+        if (ys > 1e-10 * yy) {
+            if (h == J) {
+                memmove(S, S + d, sizeof(double) * (size_t)d * (J - 1));
+                memmove(Y, Y + d, sizeof(double) * (size_t)d * (J - 1));
+                h = J - 1;
+            }
+            for (int i = 0; i < d; ++i) { S[(size_t)h * d + i] = xn[i] - x[i]; Y[(size_t)h * d + i] = gn[i] - g[i]; }
+            ++h;
+        }
+        memcpy(x, xn, sizeof(double) * d); memcpy(g, gn, sizeof(double) * d); f = lc.fn;
+        memcpy(pts + (size_t)n * d, x, sizeof(double) * d); lps[n] = -f;
+        for (int i = 0; i < d; ++i) grads[(size_t)n * d + i] = -g[i];
+        ++n;
+        if (!moved) break;
+    }
+    free(x); free(g); free(q); free(p); free(xn); free(gn); free(S); free(Y);
+    return n;
+}

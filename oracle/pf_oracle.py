@@ -36,6 +36,7 @@ def lib():
     if _LIB is None:
         _LIB = C.CDLL(build())
         _LIB.pfo_logdet.restype = C.c_double
+        _LIB.pfo_logp_grad.restype = C.c_double
         _LIB.pfo_findmax_skipnan.restype = C.c_long
         _LIB.pfo_psis.restype = C.c_long
         _LIB.pfo_psis_tail_length.restype = C.c_long
@@ -212,6 +213,25 @@ class FunnelTarget:
         out = np.empty(X2.shape[1])
         lib().pfo_logp_funnel(self.d, C.c_long(X2.shape[1]), _p(X2), _p(out))
         return out
+
+
+def logp_grad(tg, x):
+    """(logp, grad logp) of a built-in target at one point."""
+    x = _f(x)
+    g = np.empty(len(x))
+    lp = lib().pfo_logp_grad(tg.kind, len(x), tg.r, _p(tg.mean), _p(tg.a), _p(tg.Wd), _p(tg.G), C.c_double(tg.offset), _p(x), _p(g))
+    return lp, g
+
+
+def optimize_trace(tg, x0, history_length=6, maxiters=1000, g_tol=1e-8):
+    """C restatement of this repo's L-BFGS trace driver (see pfo_optimize_trace).  Returns
+    (points (L+1,d), log_densities (L+1,), gradients of logp (L+1,d))."""
+    x0 = _f(x0)
+    d = len(x0)
+    pts = np.empty((maxiters + 1, d)); grads = np.empty((maxiters + 1, d)); lps = np.empty(maxiters + 1)
+    n = lib().pfo_optimize_trace(tg.kind, d, tg.r, _p(tg.mean), _p(tg.a), _p(tg.Wd), _p(tg.G), C.c_double(tg.offset),
+                                 _p(x0), history_length, maxiters, C.c_double(g_tol), _p(pts), _p(lps), _p(grads))
+    return pts[:n].copy(), lps[:n].copy(), grads[:n].copy()
 
 
 # ---- RNG -----------------------------------------------------------------------------------------------

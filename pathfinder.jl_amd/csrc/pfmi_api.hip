@@ -93,7 +93,8 @@ int32_t pfmi_destroy(pfmi_ctx *c) {
                       &c->rq, &c->dmat, &c->sqrt_alpha, &c->mu, &c->logdet, &c->status, &c->seeds, &c->logp, &c->logq,
                       &c->elbo, &c->se, &c->best_iter, &c->fit_list, &c->ubuf, &c->xbuf, &c->scratch, &c->pool,
                       &c->pool_lr, &c->pool_lp, &c->pool_lq, &c->pool_points, &c->pool_seeds, &c->lw, &c->w,
-                      &c->psis_out, &c->tailbuf, &c->cdf, &c->idx, &c->gbuf};
+                      &c->psis_out, &c->tailbuf, &c->cdf, &c->idx, &c->gbuf, &c->trace_lp, &c->st_theta, &c->st_grad,
+                      &c->st_lp, &c->st_npts, &c->lb_hs, &c->lb_hy, &c->lb_x0};
     for (DevBuf *b : bufs) b->release();
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     (void)hipEventDestroy(c->kev0); (void)hipEventDestroy(c->kev1);
@@ -198,7 +199,7 @@ int32_t pfmi_set_traces(pfmi_ctx *c, int32_t K, const int64_t *npoints, int32_t 
     for (int k = 0; k < K; ++k)
         for (int64_t p = c->off[k]; p < c->off[k + 1]; ++p) c->path_of[(size_t)p] = k;
     c->K = K; c->d = d; c->P = P;
-    c->fitted = false; c->elbo_done = false; c->pooled = false;
+    c->fitted = false; c->elbo_done = false; c->pooled = false; c->have_trace_lp = false;
     const size_t bytes = sizeof(double) * (size_t)P * d;
     PF_TRY(c->theta.ensure(bytes));
     PF_TRY(c->grad.ensure(bytes));
@@ -208,6 +209,71 @@ int32_t pfmi_set_traces(pfmi_ctx *c, int32_t K, const int64_t *npoints, int32_t 
     PF_TRY(h2d(c, c->grad.p, grad, bytes));
     PF_TRY(h2d(c, c->d_off.p, c->off.data(), sizeof(int64_t) * (K + 1)));
     PF_TRY(h2d(c, c->d_path_of.p, c->path_of.data(), sizeof(int32_t) * P));
+    return PFMI_OK;
+}
+
+// ---- device trajectory generation ------------------------------------------------------------------------
+int32_t pfmi_optimize_batch(pfmi_ctx *c, int32_t K, const double *x0, int32_t J, int32_t maxiters, double g_tol,
+                            int64_t *npoints) {
+    PF_CTX(c);
+    const TargetDev &T = c->target;
+    PF_CHECK(T.kind == PFMI_TARGET_GAUSS || T.kind == PFMI_TARGET_FUNNEL, PFMI_ERR_UNSUPPORTED,
+             "optimize_batch: needs a built-in target (optimise callback targets on the host, then pfmi_set_traces)");
+    PF_CHECK(K > 0 && x0 && npoints && maxiters >= 0, PFMI_ERR_ARG, "optimize_batch: bad arguments");
+    PF_CHECK(J >= 1 && J <= 16, PFMI_ERR_UNSUPPORTED, "optimize_batch: history_length %d outside 1..16", J);
+    const int d = T.d;
+    const size_t cap = (size_t)maxiters + 1;
+    PF_TRY(c->st_theta.ensure(sizeof(double) * K * cap * d));
+    PF_TRY(c->st_grad.ensure(sizeof(double) * K * cap * d));
+    PF_TRY(c->st_lp.ensure(sizeof(double) * K * cap));
+    PF_TRY(c->st_npts.ensure(sizeof(int32_t) * K));
+    PF_TRY(c->lb_x0.ensure(sizeof(double) * (size_t)K * d));
+    PF_TRY(h2d(c, c->lb_x0.p, x0, sizeof(double) * (size_t)K * d));
+    pf_kernel_begin(c);
+    PF_TRY(pf_launch_lbfgs(c, K, J, maxiters, g_tol, c->lb_x0.as<double>()));
+    pf_kernel_end(c, "optimize");
+    std::vector<int32_t> np32((size_t)K);
+    PF_TRY(d2h(c, np32.data(), c->st_npts.p, sizeof(int32_t) * K));
+    c->off.assign((size_t)K + 1, 0);
+    for (int k = 0; k < K; ++k) {
+        PF_CHECK(np32[(size_t)k] >= 1 && (size_t)np32[(size_t)k] <= cap, PFMI_ERR_NUMERIC, "optimize_batch: path %d produced %d points", k,
+                 np32[(size_t)k]);
+        npoints[k] = np32[(size_t)k];
+        c->off[k + 1] = c->off[k] + np32[(size_t)k];
+    }
+    const int64_t P = c->off[K];
+    PF_CHECK(P < (1ll << 31), PFMI_ERR_UNSUPPORTED, "too many trace points");
+    c->path_of.resize((size_t)P);
+    for (int k = 0; k < K; ++k)
+        for (int64_t p = c->off[k]; p < c->off[k + 1]; ++p) c->path_of[(size_t)p] = k;
+    c->K = K; c->d = d; c->P = P;
+    c->fitted = false; c->elbo_done = false; c->pooled = false;
+    const size_t bytes = sizeof(double) * (size_t)P * d;
+    PF_TRY(c->theta.ensure(bytes));
+    PF_TRY(c->grad.ensure(bytes));
+    PF_TRY(c->trace_lp.ensure(sizeof(double) * P));
+    PF_TRY(c->d_off.ensure(sizeof(int64_t) * (K + 1)));
+    PF_TRY(c->d_path_of.ensure(sizeof(int32_t) * P));
+    PF_TRY(h2d(c, c->d_off.p, c->off.data(), sizeof(int64_t) * (K + 1)));
+    PF_TRY(h2d(c, c->d_path_of.p, c->path_of.data(), sizeof(int32_t) * P));
+    pf_kernel_begin(c);
+    PF_TRY(pf_launch_trace_pack(c, (int64_t)cap));
+    pf_kernel_end(c, "trace_pack");
+    c->have_trace_lp = true;
+    return PFMI_OK;
+}
+
+int32_t pfmi_get_trace(pfmi_ctx *c, int32_t k, double *theta, double *logp, double *grad) {
+    PF_CTX(c);
+    PF_CHECK(c->P > 0 && k >= 0 && k < c->K, PFMI_ERR_ARG, "get_trace: bad path index");
+    const int64_t p0 = c->off[(size_t)k], n = c->off[(size_t)k + 1] - p0;
+    const size_t bytes = sizeof(double) * (size_t)n * c->d;
+    if (theta) PF_TRY(d2h(c, theta, c->theta.as<double>() + (size_t)p0 * c->d, bytes));
+    if (grad) PF_TRY(d2h(c, grad, c->grad.as<double>() + (size_t)p0 * c->d, bytes));
+    if (logp) {
+        PF_CHECK(c->have_trace_lp, PFMI_ERR_STATE, "get_trace: log densities exist only for pfmi_optimize_batch traces");
+        PF_TRY(d2h(c, logp, c->trace_lp.as<double>() + p0, sizeof(double) * n));
+    }
     return PFMI_OK;
 }
 

@@ -75,6 +75,11 @@ struct pfmi_ctx {
     std::vector<int32_t> path_of;  // P
     DevBuf theta, grad, d_off /* int64 K+1 */, d_path_of /* int32 P */;
     TargetDev target;
+    // device trajectory generation
+    bool have_trace_lp = false;
+    DevBuf trace_lp;                          // [P]
+    DevBuf st_theta, st_grad, st_lp, st_npts; // staging [K][maxiters+1][d]
+    DevBuf lb_hs, lb_hy, lb_x0;               // (s, y) ring scratch [K][J][d], x0 [K][d]
 
     // fit state
     bool fitted = false;
@@ -137,6 +142,8 @@ int32_t pf_launch_resample(pfmi_ctx *c, int64_t S, int64_t ndraws, int importanc
                            uint64_t seed, const double *d_uniforms);
 int32_t pf_launch_gather(pfmi_ctx *c, int64_t ndraws, const int64_t *d_idx, int64_t col_offset, double *d_out);
 int32_t pf_launch_logratio(pfmi_ctx *c, int64_t n);
+int32_t pf_launch_lbfgs(pfmi_ctx *c, int K, int J, int maxiters, double g_tol, const double *d_x0);
+int32_t pf_launch_trace_pack(pfmi_ctx *c, int64_t cap);
 int32_t pf_launch_woodbury_prim(pfmi_ctx *c, int mode, int64_t p, int64_t N, const double *d_in, double *d_out);
 int32_t pf_launch_colsumsq(pfmi_ctx *c, int64_t N, const double *d_x, double *d_out);
 int32_t pf_launch_woodbury_diag(pfmi_ctx *c, int64_t p, double *d_out);

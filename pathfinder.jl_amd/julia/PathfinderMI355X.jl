@@ -157,6 +157,20 @@ function pool_psis_resample!(ctx::Context, N_r::Integer, points::Vector{Int64}, 
     return X, ids, (importance ? w : nothing), k̂[]
 end
 
+# ---- optional: device L-BFGS for the built-in targets (plays optimize_with_trace, src/optimize.jl:35-59) ------
+function optimize_batch!(ctx::Context, x0::Matrix{Float64}; history_length::Int=6, maxiters::Int=1000, g_tol::Float64=1e-8)
+    K = size(x0, 2)                              # x0 is d x K column-major == K x d point-major for the C side
+    npts = Vector{Int64}(undef, K)
+    check(ccall((:pfmi_optimize_batch, libpfmi), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Int32, Int32, Float64, Ptr{Int64}),
+                ctx.ptr, K, x0, history_length, maxiters, g_tol, npts))
+    return npts
+end
+function get_trace(ctx::Context, k::Integer, npoints::Integer, d::Integer)   # OptimizationTrace, src/optimize.jl:94-100
+    θ = Matrix{Float64}(undef, d, npoints); g = similar(θ); lp = Vector{Float64}(undef, npoints)
+    check(ccall((:pfmi_get_trace, libpfmi), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), ctx.ptr, k, θ, lp, g))
+    return (points=collect(eachcol(θ)), log_densities=lp, gradients=collect(eachcol(g)))
+end
+
 # ---- the PDMats surface of a fitted covariance (src/woodbury.jl:326-423), as the HMC extensions use it -------
 # (ext/PathfinderAdvancedHMCExt.jl:17-23 builds a metric from Σ; its sampling calls unwhiten!/mul!/quad on it)
 struct DeviceWoodbury

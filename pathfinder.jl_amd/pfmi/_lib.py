@@ -28,7 +28,7 @@ LOGP_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int32, C.c_int64, C.POINT
 SYMBOLS = [
     "pfmi_last_error", "pfmi_version", "pfmi_device_count", "pfmi_create", "pfmi_destroy", "pfmi_sync",
     "pfmi_timer_start", "pfmi_timer_stop", "pfmi_profile", "pfmi_kernel_time", "pfmi_set_target",
-    "pfmi_set_traces", "pfmi_fit_batch", "pfmi_get_fit_status", "pfmi_get_fit", "pfmi_elbo_batch",
+    "pfmi_set_traces", "pfmi_optimize_batch", "pfmi_get_trace", "pfmi_fit_batch", "pfmi_get_fit_status", "pfmi_get_fit", "pfmi_elbo_batch",
     "pfmi_get_elbo_logs", "pfmi_draws", "pfmi_logpdf", "pfmi_woodbury_apply", "pfmi_woodbury_diag", "pfmi_pool_build", "pfmi_pool_get",
     "pfmi_pool_log_ratios_dev", "pfmi_psis_dev", "pfmi_psis", "pfmi_resample_indices", "pfmi_pool_gather",
     "pfmi_pool_gather_dev", "pfmi_malloc_dev", "pfmi_free_dev", "pfmi_memcpy_h2d", "pfmi_memcpy_d2h",

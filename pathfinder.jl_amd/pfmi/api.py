@@ -232,27 +232,70 @@ class UniformSampler:               # src/singlepath.jl:332-344
         return point
 
 
+class DeviceOptimizationTrace:
+    """OptimizationTrace (src/optimize.jl:94-100) of a path optimised on the device; the arrays are downloaded on
+    first access (valid while the engine still holds this batch of traces)."""
+
+    def __init__(self, engine, k, n):
+        self._eng, self._k, self._n, self._cache = engine, k, n, None
+
+    def __len__(self):
+        return self._n
+
+    def materialise(self):
+        if self._cache is None:
+            self._cache = self._eng.get_trace(self._k)
+        return self
+
+    @property
+    def points(self): return self.materialise()._cache[0]
+    @property
+    def log_densities(self): return self.materialise()._cache[1]
+    @property
+    def gradients(self): return self.materialise()._cache[2]
+
+
+def _use_device_optimizer(target, optimizer):
+    builtin = getattr(target, "kind", 2) in (0, 1)
+    if optimizer == "device" and not builtin:
+        raise ValueError("optimizer='device' needs a built-in target (analytic gradient on the GPU)")
+    return builtin if optimizer == "auto" else optimizer == "device"
+
+
 # ---- batched driver shared by pathfinder / multipathfinder ------------------------------------------------
 def _run_paths(eng, target, inits, run_rngs, *, dim, history_length, ndraws_elbo, ntries, init_sampler,
-               optimizer_kwargs, materialise):
-    """Runs every path to success (or ntries), batching the GPU work.  Returns per-path dicts."""
+               optimizer_kwargs, materialise, optimizer="auto"):
+    """Runs every path to success (or ntries), batching the GPU work.  Returns per-path dicts.
+    The K optimisations run on the device for built-in targets (pfmi_optimize_batch, all paths in one launch) and
+    through the host driver for callback targets (the reference's general case, src/optimize.jl:35-59)."""
     K = len(inits)
     state = [dict(itry=0, done=False) for _ in range(K)]
     pending = list(range(K))
+    on_device = _use_device_optimizer(target, optimizer)
+    okw = {k: v for k, v in optimizer_kwargs.items() if k in ("maxiters", "g_tol")}
     while pending:
         for k in pending:
             st = state[k]
             st["itry"] += 1
             rng = run_rngs[k]
             if st["itry"] == 1 and inits[k] is not None:
-                x0 = np.array(inits[k], dtype=np.float64)
+                st["x0"] = np.array(inits[k], dtype=np.float64)
             else:
-                x0 = init_sampler(rng, np.empty(dim))          # src/singlepath.jl:167-168, 277
-            st["trace"] = optimize_with_trace(target, x0, history_length=history_length, **optimizer_kwargs)
-            L = len(st["trace"]) - 1
-            st["seeds"] = np.concatenate([[np.uint64(0)], rng.rand_u64(L)]).astype(np.uint64)  # src/elbo.jl:2
+                st["x0"] = init_sampler(rng, np.empty(dim))    # src/singlepath.jl:167-168, 277
+            if not on_device:
+                st["trace"] = optimize_with_trace(target, st["x0"], history_length=history_length, **optimizer_kwargs)
+        if on_device:     # every path in one launch; finished paths are recomputed identically from their x0
+            npts = eng.optimize_batch(np.stack([s["x0"] for s in state]), history_length, **okw)
+            for k in range(K):
+                state[k]["trace"] = DeviceOptimizationTrace(eng, k, int(npts[k]))
+                if materialise:
+                    state[k]["trace"].materialise()
+        else:
+            eng.set_traces([s["trace"].points for s in state], [s["trace"].gradients for s in state])
+        for k in pending:
+            L = len(state[k]["trace"]) - 1
+            state[k]["seeds"] = np.concatenate([[np.uint64(0)], run_rngs[k].rand_u64(L)]).astype(np.uint64)  # src/elbo.jl:2
         # one batched fit + ELBO over every path (finished paths are recomputed identically from their seeds)
-        eng.set_traces([s["trace"].points for s in state], [s["trace"].gradients for s in state])
         eng.fit_batch(history_length)
         status, jeff, logdet, nrej = eng.fit_status()
         seeds = np.concatenate([s["seeds"] for s in state])
@@ -302,8 +345,9 @@ def _assemble_path(eng, target, st, rng, ndraws, ndraws_elbo, input_, status, je
 
 def pathfinder(target, *, rng=None, init=None, dim=-1, init_scale=2, init_sampler=None, input=None,
                history_length=DEFAULT_HISTORY_LENGTH, ndraws_elbo=DEFAULT_NDRAWS_ELBO, ndraws=None, ntries=1000,
-               ntasks=1, engine=None, materialise=True, **optimizer_kwargs):
-    """Single-path Pathfinder (reference src/singlepath.jl:142-257)."""
+               ntasks=1, engine=None, materialise=True, optimizer="auto", **optimizer_kwargs):
+    """Single-path Pathfinder (reference src/singlepath.jl:142-257).  optimizer: "auto" (device L-BFGS for built-in
+    targets, host driver for callbacks), "device" or "host"."""
     rng = rng if rng is not None else HostRNG(0)
     ndraws = ndraws_elbo if ndraws is None else ndraws
     init_sampler = init_sampler or UniformSampler(init_scale)
@@ -318,7 +362,7 @@ def pathfinder(target, *, rng=None, init=None, dim=-1, init_scale=2, init_sample
     eng.set_target(target)
     state, status, jeff = _run_paths(eng, target, [init], [rng], dim=dim, history_length=history_length,
                                      ndraws_elbo=ndraws_elbo, ntries=ntries, init_sampler=init_sampler,
-                                     optimizer_kwargs=optimizer_kwargs, materialise=materialise)
+                                     optimizer_kwargs=optimizer_kwargs, materialise=materialise, optimizer=optimizer)
     st = state[0]
     a = _assemble_path(eng, target, st, rng, ndraws, ndraws_elbo, input, status, jeff, materialise)
     X = eng.draws(a["fit_point"], a["draw_seed"], ndraws)[0]     # src/singlepath.jl:226-233
@@ -330,8 +374,8 @@ def pathfinder(target, *, rng=None, init=None, dim=-1, init_scale=2, init_sample
 def multipathfinder(target, ndraws, *, init=None, nruns=-1, ndraws_elbo=DEFAULT_NDRAWS_ELBO, ndraws_per_run=None,
                     rng=None, history_length=DEFAULT_HISTORY_LENGTH, importance=True, dim=-1, init_scale=2,
                     init_sampler=None, ntries=1000, ntasks=1, ntasks_per_run=1, input=None, engine=None,
-                    materialise=False, **optimizer_kwargs):
-    """Multi-path Pathfinder (reference src/multipath.jl:118-245)."""
+                    materialise=False, optimizer="auto", **optimizer_kwargs):
+    """Multi-path Pathfinder (reference src/multipath.jl:118-245).  optimizer: see pathfinder()."""
     if init is None:
         if nruns <= 0:
             raise ValueError("A positive `nruns` must be set or `init` must be provided.")     # :148-150
@@ -353,7 +397,7 @@ def multipathfinder(target, ndraws, *, init=None, nruns=-1, ndraws_elbo=DEFAULT_
     eng.set_target(target)
     state, status, jeff = _run_paths(eng, target, inits, run_rngs, dim=dim, history_length=history_length,
                                      ndraws_elbo=ndraws_elbo, ntries=ntries, init_sampler=init_sampler,
-                                     optimizer_kwargs=optimizer_kwargs, materialise=materialise)
+                                     optimizer_kwargs=optimizer_kwargs, materialise=materialise, optimizer=optimizer)
     parts = [_assemble_path(eng, target, st, r, ndraws_per_run, ndraws_elbo, input, status, jeff, materialise)
              for st, r in zip(state, run_rngs)]
     # draws_per_component = stack(draws)   (:217) -- device resident

@@ -76,6 +76,26 @@ class Engine:
         check(self.L.pfmi_set_traces(self.ctx, C.c_int32(self.K), npts.ctypes.data_as(_i64p), C.c_int32(self.d),
                                      _d(theta), _d(grad)))
 
+    def optimize_batch(self, x0, history_length=6, maxiters=1000, g_tol=1e-8):
+        """K L-BFGS optimisations on the device from x0 (K, d); the traces stay resident (as after set_traces).
+        Returns npoints (K,)."""
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        K, d = x0.shape
+        assert self.target is not None and d == self.target.d
+        npts = np.empty(K, dtype=np.int64)
+        check(self.L.pfmi_optimize_batch(self.ctx, C.c_int32(K), _d(x0), C.c_int32(history_length), C.c_int32(maxiters),
+                                         C.c_double(g_tol), npts.ctypes.data_as(_i64p)))
+        self.K, self.P, self.d = K, int(npts.sum()), d
+        self.offsets = np.concatenate([[0], np.cumsum(npts)]).astype(np.int64)
+        return npts
+
+    def get_trace(self, k, logp=True):
+        n = int(self.offsets[k + 1] - self.offsets[k])
+        theta, grad = np.empty((n, self.d)), np.empty((n, self.d))
+        lp = np.empty(n) if logp else None
+        check(self.L.pfmi_get_trace(self.ctx, C.c_int32(k), _d(theta), _d(lp) if logp else None, _d(grad)))
+        return theta, lp, grad
+
     # ---- fit -------------------------------------------------------------------------------------------
     def fit_batch(self, history_length=6, eps=1e-12):
         self.J = history_length

@@ -633,3 +633,82 @@ def test_woodbury_operator_surface(pfmi_mod, eng, name, K, J):
         np.testing.assert_allclose(back, X, rtol=1e-6, atol=1e-7 * np.abs(X).max())
         back = eng.woodbury_apply(l, "invunwhiten", eng.woodbury_apply(l, "rmul", X))
         np.testing.assert_allclose(back, X, rtol=1e-6, atol=1e-7 * np.abs(X).max())
+
+
+# ---- device trajectory generation -----------------------------------------------------
+@pytest.mark.parametrize("name,d,scale,maxit", [("iso", 10, 2, 1000), ("diag", 30, 2, 1000), ("lr", 50, 2, 1000), ("funnel", 12, 10, 60),
+                                               ("lr", 1000, 2, 1000), ("diag", 3000, 2, 200)])
+def test_device_lbfgs_traces_match_oracle_driver(pfmi_mod, eng, name, d, scale, maxit):
+    """pfmi_optimize_batch vs oracle pfo_optimize_trace (same algorithm, scalar C): early iterates agree to roundoff
+    (later ones drift apart through line-search branches, as between any two L-BFGS implementations), every recorded
+    (logp, grad) belongs to its recorded point, the objective never increases, Gaussian targets converge to g_tol.
+    d = 1000 exercises the LDS ring, d = 3000 the global ring and the 1024-thread variant."""
+    tg = {"iso": pfmi_mod.t_iso, "diag": lambda d: pfmi_mod.t_diag(d, 1), "lr": lambda d: pfmi_mod.t_lowrank(d, 8, 2),
+          "funnel": pfmi_mod.t_funnel}[name](d)
+    ot = oracle_target(tg)
+    K = 3
+    x0 = pfmi_mod.HostRNG(3).rand(K * d).reshape(K, d) * 2 * scale - scale
+    eng.set_target(tg)
+    npts = eng.optimize_batch(x0, 6, maxit)
+    assert np.all(npts >= 2) and np.all(npts <= maxit + 1)
+    for k in range(K):
+        th, lp, gr = eng.get_trace(k)
+        assert th.shape == (npts[k], d) and np.array_equal(th[0], x0[k])
+        P, L, G = po.optimize_trace(ot, x0[k], 6, maxit)
+        n = min(len(P), len(th), 8)
+        np.testing.assert_allclose(th[:n], P[:n], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(gr[:n], G[:n], rtol=1e-8, atol=1e-9 * max(1.0, np.abs(G[:n]).max()))
+        for l in sorted({0, 1, len(th) // 2, len(th) - 1}):
+            lpo, go = po.logp_grad(ot, th[l])
+            assert abs(lpo - lp[l]) <= 1e-11 * max(1.0, abs(lpo))
+            np.testing.assert_allclose(gr[l], go, rtol=1e-10, atol=1e-11 * max(1.0, np.abs(go).max()))
+        assert np.all(np.diff(lp) >= -1e-9 * np.maximum(1.0, np.abs(lp[1:])))
+        if name != "funnel" and npts[k] <= maxit:
+            assert np.abs(gr[-1]).max() <= 1e-8
+            np.testing.assert_allclose(th[-1], P[-1], atol=1e-5)
+
+
+def test_device_traces_feed_fit_batch_like_uploaded_ones(pfmi_mod, eng):
+    """the traces pfmi_optimize_batch leaves in HBM are the same input pfmi_set_traces would upload: refitting from
+    the downloaded copy gives bit-identical ELBOs."""
+    tg = pfmi_mod.t_lowrank(64, 8, 2)
+    eng.set_target(tg)
+    x0 = pfmi_mod.HostRNG(7).rand(5 * 64).reshape(5, 64) * 4 - 2
+    npts = eng.optimize_batch(x0, 6)
+    seeds = fit_seeds(int(npts.sum()), 4)
+    eng.fit_batch(6)
+    e1, s1, b1 = eng.elbo_batch(200, seeds)
+    traces = [eng.get_trace(k) for k in range(5)]
+    eng.set_traces([t[0] for t in traces], [t[2] for t in traces])
+    eng.fit_batch(6)
+    e2, s2, b2 = eng.elbo_batch(200, seeds)
+    np.testing.assert_array_equal(e1, e2)
+    np.testing.assert_array_equal(b1, b2)
+    with pytest.raises(pfmi_mod.PfmiError):
+        eng.get_trace(0)                                   # log densities only exist for device-made traces
+    eng.set_target(pfmi_mod.CallbackTarget(64, lambda x: 0.0))
+    with pytest.raises(pfmi_mod.PfmiError):
+        eng.optimize_batch(x0, 6)
+
+
+def test_multipathfinder_device_and_host_optimizers_agree(pfmi_mod):
+    """same target, same rng: the device-optimised run and the host-optimised run find the same optimum / ELBO level
+    and both recover the target moments (reference test/multipath.jl:12-85 tolerances)."""
+    tg = pfmi_mod.t_diag(10, 1)
+    out = {}
+    for opt in ("device", "host"):
+        res = pfmi_mod.multipathfinder(tg, 4000, nruns=8, ndraws_elbo=100, ndraws_per_run=1000, rng=pfmi_mod.HostRNG(9), optimizer=opt)
+        best = [max(e.value for e in r.elbo_estimates) for r in res.pathfinder_results]
+        out[opt] = (res, np.array(best))
+        assert all(r.success for r in res.pathfinder_results)
+        tr = res.pathfinder_results[0].optim_trace
+        assert len(tr) == len(res.pathfinder_results[0].fit_distributions) and tr.points.shape == (len(tr), 10)
+        assert res.psis_result.pareto_shape < 0.7
+    np.testing.assert_allclose(out["device"][1], out["host"][1], atol=0.5)
+    sd = np.sqrt(1 / tg.a)
+    for res, _ in out.values():
+        assert np.all(np.abs(res.draws.mean(1) - tg.mean) < 0.15 * sd)
+        assert np.all(np.abs(res.draws.std(1) / sd - 1) < 0.15)
+    r1 = pfmi_mod.multipathfinder(tg, 500, nruns=4, ndraws_elbo=50, rng=pfmi_mod.HostRNG(2))
+    r2 = pfmi_mod.multipathfinder(tg, 500, nruns=4, ndraws_elbo=50, rng=pfmi_mod.HostRNG(2))
+    np.testing.assert_array_equal(r1.draws, r2.draws)       # device optimiser is deterministic

@@ -199,3 +199,31 @@ def test_fit_mean_is_theta_plus_sigma_grad():
     F = po.Factor(alpha, B, D)
     th, g = rng.normal(size=n), rng.normal(size=n)
     np.testing.assert_allclose(F.fit_mean(th, g), th + F.dense() @ g, rtol=1e-11, atol=1e-12)
+
+
+def test_oracle_lbfgs_driver_matches_host_driver_and_converges():
+    """pfo_optimize_trace (the checker of the device optimiser) against the independent numpy driver
+    pfmi/optimize.py and against scipy's finite-difference gradient check; Optim's own trajectory is third party
+    (parity unpinned)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "pathfinder.jl_amd"))
+    os.environ.setdefault("PFMI_NO_TORCH", "1")
+    from pfmi import targets, optimize, hostrng
+    from helpers import oracle_target
+    from scipy.optimize import check_grad
+    for tg, scale in [(targets.t_iso(10), 2), (targets.t_diag(30, 1), 2), (targets.t_lowrank(50, 8, 2), 2), (targets.t_funnel(12), 3)]:
+        ot = oracle_target(tg)
+        x0 = hostrng.HostRNG(3).rand(tg.d) * 2 * scale - scale
+        err = check_grad(lambda x: po.logp_grad(ot, x)[0], lambda x: po.logp_grad(ot, x)[1], x0)
+        assert err < 1e-4 * max(1.0, np.abs(po.logp_grad(ot, x0)[1]).max())
+        if tg.kind == 1:
+            continue                                      # funnel: unbounded, trajectories are chaotic
+        P, L, G = po.optimize_trace(ot, x0, 6)
+        tr = optimize.optimize_with_trace(tg, x0, history_length=6)
+        n = min(len(P), len(tr), 10)
+        np.testing.assert_allclose(P[:n], tr.points[:n], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(G[:n], tr.gradients[:n], rtol=1e-8, atol=1e-10)
+        assert np.abs(G[-1]).max() <= 1e-8 and np.all(np.diff(L) >= -1e-12)
+        for l in (0, len(P) // 2, len(P) - 1):            # the recorded (logp, grad) belong to the recorded point
+            lp, g = po.logp_grad(ot, P[l])
+            assert abs(lp - L[l]) <= 1e-12 * max(1, abs(lp)) and np.allclose(g, G[l], rtol=1e-12, atol=1e-14)
