@@ -24,3 +24,5 @@ struct ElboArgs {
 
 // implemented in elbo_mfma_kernel.hip; returns PFMI_ERR_UNSUPPORTED when the shape is outside its range
 int32_t pf_launch_elbo_mfma(struct pfmi_ctx *c, const ElboArgs &a, int64_t nfits, int tgt, int rpad, bool *handled);
+// implemented in elbo_qf_kernel.hip: single-pass quadratic-form scan (in-kernel RNG, no draws written), any d
+int32_t pf_launch_elbo_qf(struct pfmi_ctx *c, const ElboArgs &a, int64_t nfits, int tgt, int rpad, bool *handled);

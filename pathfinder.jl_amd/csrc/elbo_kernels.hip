@@ -355,7 +355,12 @@ int32_t pf_launch_elbo_draws(pfmi_ctx *c, const int32_t *d_points, const uint64_
     if (!mem && !(force && force[0] == 'l')) {
         bool handled = false;
         pf_kernel_begin(c);
-        int32_t rc = pf_launch_elbo_mfma(c, a, nfits, tgt, rpad, &handled);
+        int32_t rc = PFMI_OK;
+        // single-pass quadratic-form scan: every shape the two-pass MFMA kernel does not cover (d > 1024, J > 8), or on request
+        const bool mf_shape = a.d <= 1024 && c->kpad <= 16;
+        const bool want_qf = (force && force[0] == 'q') || (!(force && force[0] == 'm') && !mf_shape && N >= 16);
+        if (want_qf && !d_x) rc = pf_launch_elbo_qf(c, a, nfits, tgt, rpad, &handled);
+        if (!handled) rc = pf_launch_elbo_mfma(c, a, nfits, tgt, rpad, &handled);
         if (handled) {
             pf_kernel_end(c, d_x ? "elbo_draws_x" : "elbo_draws");
             PF_TRY(rc);

@@ -712,3 +712,44 @@ def test_multipathfinder_device_and_host_optimizers_agree(pfmi_mod):
     r1 = pfmi_mod.multipathfinder(tg, 500, nruns=4, ndraws_elbo=50, rng=pfmi_mod.HostRNG(2))
     r2 = pfmi_mod.multipathfinder(tg, 500, nruns=4, ndraws_elbo=50, rng=pfmi_mod.HostRNG(2))
     np.testing.assert_array_equal(r1.draws, r2.draws)       # device optimiser is deterministic
+
+
+@pytest.mark.parametrize("tname,d,K,J,N,scale,maxit", [
+    ("iso", 10, 2, 6, 100, 2, 1000), ("diag", 30, 2, 6, 200, 2, 1000), ("lr", 50, 2, 6, 200, 2, 1000), ("lr", 300, 2, 6, 500, 2, 1000),
+    ("funnel", 12, 2, 6, 100, 10, 40), ("diag", 30, 2, 10, 200, 2, 1000), ("lr", 50, 2, 16, 200, 2, 1000),
+    ("diag", 3000, 2, 6, 200, 2, 30), ("funnel", 2500, 2, 10, 300, 10, 30), ("lr", 1100, 2, 8, 130, 2, 40)])
+def test_single_pass_scan_matches_lane_kernel(pfmi_mod, eng, tname, d, K, J, N, scale, maxit):
+    """the single-pass quadratic-form scan (elbo_qf_kernel.hip: logp from per-draw contractions, x never formed; Vh resident or
+    streamed through LDS; KC up to 32) against the lane-per-draw kernel that evaluates logp(x) on the materialised draw, same
+    seeds: per-draw logp / logq and the per-fit ELBO agree to fp64 roundoff.  Covers the head transform spilling into
+    block 1 (J = 10, 16), chunked streaming (d = 2500, 3000), ragged last block / last group and the low-rank target."""
+    tg = {"iso": pfmi_mod.t_iso, "diag": lambda d: pfmi_mod.t_diag(d, 1), "lr": lambda d: pfmi_mod.t_lowrank(d, 8, 2),
+          "funnel": pfmi_mod.t_funnel}[tname](d)
+    eng.set_target(tg)
+    x0 = pfmi_mod.HostRNG(3).rand(K * d).reshape(K, d) * 2 * scale - scale
+    eng.optimize_batch(x0, J, maxit)
+    eng.fit_batch(J)
+    seeds = fit_seeds(eng.P, 1)
+    out = {}
+    old = os.environ.get("PFMI_ELBO_KERNEL")
+    try:
+        for mode in ("lane", "qf"):
+            os.environ["PFMI_ELBO_KERNEL"] = mode
+            elbo, se, best = eng.elbo_batch(N, seeds)
+            pts = sorted({1, min(3, eng.P - 1), eng.P // 2, eng.P - 1})
+            out[mode] = (elbo, se, best, [eng.elbo_logs(p, N) for p in pts])
+    finally:
+        if old is None:
+            os.environ.pop("PFMI_ELBO_KERNEL", None)
+        else:
+            os.environ["PFMI_ELBO_KERNEL"] = old
+    a, b = out["qf"], out["lane"]
+    assert np.array_equal(np.isnan(a[0]), np.isnan(b[0]))
+    ok = np.isfinite(b[0])
+    assert np.max(np.abs(a[0][ok] - b[0][ok]) / (1 + np.abs(b[0][ok]))) <= 1e-10
+    oks = ok & np.isfinite(b[1])
+    assert np.array_equal(np.isfinite(a[1][ok]), np.isfinite(b[1][ok]))
+    assert np.max(np.abs(a[1][oks] - b[1][oks]) / (1 + np.abs(b[1][oks]))) <= 1e-8
+    for (lpa, lqa), (lpb, lqb) in zip(a[3], b[3]):
+        assert np.max(np.abs(lpa - lpb) / (1 + np.abs(lpb))) <= 1e-10
+        assert np.max(np.abs(lqa - lqb) / (1 + np.abs(lqb))) <= 1e-12
