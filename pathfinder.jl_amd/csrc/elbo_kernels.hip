@@ -356,9 +356,11 @@ int32_t pf_launch_elbo_draws(pfmi_ctx *c, const int32_t *d_points, const uint64_
         bool handled = false;
         pf_kernel_begin(c);
         int32_t rc = PFMI_OK;
-        // single-pass quadratic-form scan: every shape the two-pass MFMA kernel does not cover (d > 1024, J > 8), or on request
+        // ELBO scans (no draws written) take the single-pass quadratic-form kernel: one wave per 16-draw group, so it wants
+        // N >= 64; tiny scans (ndraws_elbo = 5 default) and draw-writing launches take the two-pass MFMA kernel, which
+        // splits the rows of ONE 16-draw group over the waves (d <= 1024, J <= 8); PFMI_ELBO_KERNEL = qf | mfma | lane forces one
         const bool mf_shape = a.d <= 1024 && c->kpad <= 16;
-        const bool want_qf = (force && force[0] == 'q') || (!(force && force[0] == 'm') && !mf_shape && N >= 16);
+        const bool want_qf = (force && force[0] == 'q') || (!(force && force[0] == 'm') && (N >= 64 || (!mf_shape && N >= 16)));
         if (want_qf && !d_x) rc = pf_launch_elbo_qf(c, a, nfits, tgt, rpad, &handled);
         if (!handled) rc = pf_launch_elbo_mfma(c, a, nfits, tgt, rpad, &handled);
         if (handled) {

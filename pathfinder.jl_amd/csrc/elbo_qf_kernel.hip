@@ -25,8 +25,13 @@
 #include "pfmi_fastmath.h"
 #include "elbo_args.h"
 
-#define QF_THREADS 512
-#define QF_WAVES 8
+#ifndef QF_WAVES
+#define QF_WAVES 8                     // waves per workgroup = 16-draw groups in flight per fit
+#endif
+#define QF_THREADS (QF_WAVES * 64)
+#ifndef QF_PF2
+#define QF_PF2 0                       // 1: operands fetched one block ahead into a second register set
+#endif
 #define QF_CHB 16                      // blocks (of 16 rows) per streamed chunk
 
 typedef double qf_d4 __attribute__((ext_vector_type(4)));
@@ -142,13 +147,11 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, cons
         }
         return;
     }
-    // ---- LDS carve-up
+    // ---- LDS carve-up (offsets in doubles from `lds`; plain offsets keep every access a ds_ instruction)
     const int vh_sz = ch_blocks * 16 * KC, rs_sz = ch_blocks * 48;
-    double *vh_b[2], *rs_b[2];
-    vh_b[0] = lds; rs_b[0] = vh_b[0] + vh_sz;
-    vh_b[1] = (nchunks > 1) ? rs_b[0] + rs_sz : vh_b[0];
-    rs_b[1] = (nchunks > 1) ? vh_b[1] + vh_sz : rs_b[0];
-    double *t_s = rs_b[1] + rs_sz;                 // [KC][KC]
+    const int buf_stride = (nchunks > 1) ? vh_sz + rs_sz : 0;       // second staging buffer only when streaming
+    const int fix_off = (nchunks > 1 ? 2 : 1) * (vh_sz + rs_sz);
+    double *t_s = lds + fix_off;                   // [KC][KC]
     double *cn_s = t_s + KC * KC;                  // [NC]
     double *g_s = cn_s + NC;                       // [RPAD][RPAD]
     double2 *logtab = reinterpret_cast<double2 *>(g_s + RPAD * RPAD + ((KC * KC + NC + RPAD * RPAD) & 1));
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, cons
     const double *Vh = A.vh + (size_t)p * d * KC, *mu = A.mu + (size_t)p * d, *sqa = A.sqrt_alpha + (size_t)p * d;
     auto stage_direct = [&](int ck, int buf) {
         const int row0 = ck * ch_blocks * 16;
-        double *vs = vh_b[buf], *rs = rs_b[buf];
+        double *vs = lds + buf * buf_stride, *rs = vs + vh_sz;
         for (int idx = tid; idx < ch_blocks * 16 * KC; idx += QF_THREADS) {
             const int lrow = idx / KC, col = idx - lrow * KC, row = row0 + lrow;
             vs[qf_vh_pos<KC>(lrow, col)] = (row < d) ? Vh[(size_t)row * KC + col] : 0.0;
@@ -237,11 +240,31 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, cons
                 }
             }
             if (active) {
-                const double *vs = vh_b[cur], *rs = rs_b[cur];
+                const double *vs = lds + cur * buf_stride, *rs = vs + vh_sz;
                 const int blk0 = ck * ch_blocks;
                 const int nb = (nblk - blk0 < ch_blocks) ? nblk - blk0 : ch_blocks;
-                for (int bl = 0; bl < nb; ++bl) {
-                    const int blk = blk0 + bl;
+                // operands of one block: A tiles of Vh (LDS), A tiles of Wd (L2), row scalars (LDS).  They are fetched one block
+                // AHEAD into a second register set (the loop is unrolled by two so that the sets swap roles without moves):
+                // the fetch latency hides behind the RNG + MFMA work of the current block.
+                struct Ops { double av[4][NT]; double wd[4][TR > 0 ? TR : 1]; double rs[12]; };
+                auto load_ops = [&](const int bl, Ops &o) {
+                    const double *rp = rs + bl * 48 + 4 * q;
+                    const double *ap = vs + ((bl * 4) * NT << 4) + q * 4 + l3;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                        for (int T = 0; T < NT; ++T) o.av[r][T] = ap[(r * NT + T) << 4];
+                        o.rs[r] = rp[r]; o.rs[4 + r] = rp[16 + r]; o.rs[8 + r] = rp[32 + r];
+                    }
+                    if (TGT == 1 && RPAD > 0) {
+                        const double *wp = A.t_wd16 + ((size_t)(blk0 + bl) * 16 + 4 * q) * 16 + l3;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int T = 0; T < TR; ++T) o.wd[r][T] = wp[r * 16 + 4 * T];
+                    }
+                };
+                auto compute = [&](const int blk, const Ops &o) {
                     // ---- normals of rows 16 blk + 4q + {0..3} of draw n
                     uint32_t x[4];
                     pf_philox4x32_10(n, (uint32_t)(blk * 4 + q), 0u, 0u, k0, k1, x);
@@ -273,35 +296,49 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, cons
 #pragma unroll
                         for (int r = 0; r < 4; ++r) z[r] = h[r];
                     }
-                    // ---- operands
-                    const double *rp = rs + bl * 48 + 4 * q;
-                    const double *ap = vs + ((bl * 4) * NT << 4) + q * 4 + l3;
-                    const double *wp = (TGT == 1 && RPAD > 0) ? A.t_wd16 + ((size_t)blk * 16 + 4 * q) * 16 + l3 : nullptr;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const double zr = z[r];
                         double bp = 0.0;
                         if (TGT != 0) {
-                            bp = rp[r] * zr;
-                            q12 = fma(bp + rp[16 + r], zr, q12);
+                            bp = o.rs[r] * zr;
+                            q12 = fma(bp + o.rs[4 + r], zr, q12);
                         }
 #pragma unroll
                         for (int T = 0; T < NT; ++T) {
-                            const double av = ap[(r * NT + T) << 4];
-                            accw[T] = qf_mfma4(av, zr, accw[T]);
-                            if (TGT != 0) acc3[T] = qf_mfma4(av, bp, acc3[T]);
+                            accw[T] = qf_mfma4(o.av[r][T], zr, accw[T]);
+                            if (TGT != 0) acc3[T] = qf_mfma4(o.av[r][T], bp, acc3[T]);
                         }
                         if (TGT == 1 && RPAD > 0) {
-                            const double bs = rp[32 + r] * zr;
+                            const double bs = o.rs[8 + r] * zr;
 #pragma unroll
-                            for (int T = 0; T < TR; ++T) acc4[T] = qf_mfma4(wp[r * 16 + 4 * T], bs, acc4[T]);
+                            for (int T = 0; T < TR; ++T) acc4[T] = qf_mfma4(o.wd[r][T], bs, acc4[T]);
                         }
                     }
+                };
+#if QF_PF2
+                Ops oa, ob;
+                load_ops(0, oa);
+                for (int bl = 0; bl < nb; bl += 2) {
+                    if (bl + 1 < nb) load_ops(bl + 1, ob);
+                    compute(blk0 + bl, oa);
+                    if (bl + 1 < nb) {
+                        if (bl + 2 < nb) load_ops(bl + 2, oa);
+                        compute(blk0 + bl + 1, ob);
+                    }
                 }
+#else
+                for (int bl = 0; bl < nb; ++bl) {
+                    Ops oa;
+                    load_ops(bl, oa);                          // issued first; the RNG below hides the LDS / L2 latency
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute(blk0 + bl, oa);
+                }
+#endif
             }
             if (nchunks > 1) {
                 if (do_pre) {
-                    double *vs = vh_b[cur ^ 1], *rs = rs_b[cur ^ 1];
+                    double *vs = lds + (cur ^ 1) * buf_stride, *rs = vs + vh_sz;
 #pragma unroll
                     for (int e = 0; e < PRE; ++e) {
                         const int idx = tid + e * QF_THREADS;

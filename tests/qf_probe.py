@@ -30,7 +30,11 @@ def run(tg, K, J, N, scale=2, maxit=1000, modes=("lane", "qf")):
         nfit = eng.P - K
         print(f"d={tg.d} J={J} N={N} P={eng.P}: {m} vs {modes[0]}: elbo {e_err:.2e} lp {lp_err:.2e} lq {lq_err:.2e} best_equal {np.array_equal(o[2], ref[2])} nan_equal {np.array_equal(np.isnan(o[0]), np.isnan(ref[0]))}"
               f" | {modes[0]} {ref[4]*1e3:.2f} ms, {m} {o[4]*1e3:.2f} ms ({nfit*N/o[4]:.3e} draws/s)")
-if len(sys.argv) > 1 and sys.argv[1] == "big":
+if len(sys.argv) > 1 and sys.argv[1] == "c3":
+    run(pfmi.t_lowrank(1000, 8, 2), 64, 6, 1000, modes=("mfma", "qf"))
+elif len(sys.argv) > 1 and sys.argv[1] == "c5":
+    run(pfmi.t_funnel(10000), 4, 10, 2000, scale=10, maxit=60, modes=("qf", "qf"))
+elif len(sys.argv) > 1 and sys.argv[1] == "big":
     run(pfmi.t_lowrank(1000, 8, 2), 64, 6, 1000, modes=("mfma", "qf"))
     run(pfmi.t_funnel(10000), 4, 10, 2000, scale=10, maxit=60, modes=("lane", "qf"))
 else:
