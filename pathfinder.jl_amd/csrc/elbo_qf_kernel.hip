@@ -50,68 +50,107 @@ __device__ __forceinline__ void qf_row_ac(const ElboArgs &A, const double *mu, i
 }
 
 // ---------------------------------------------------------------------------------------------------
-// per-fit constants.  One 256-thread workgroup per fit; rows are staged through LDS 64 at a time and every thread owns
-// a strided set of output entries.
+// per-fit constants.  One 256-thread workgroup per fit.  Every output strip of 4 adjacent entries is the same "job"
+//   acc[j] += scal_i * row_i[el] * row_i[vec + j]   over the rows i,   row_i = [ Vh_i (KC) | Wd_i (RPAD) | 1 0 0 0 ]
+// (M strips (a, 4Tb..4Tb+3), 4Tb+3 >= a: scal = a s^2, el = a;  Nn strips: scal = s, el = KC + jr;  v strips: scal = a c s,
+// el = the 1;  t0 strips: scal = c, el = the 1, vec in the Wd part;  C0: scal = a c^2, el = vec = the 1) so all lanes run
+// one divergence-free loop.  Lane l of every wave owns jobs l, l + 64, ...; the 4 waves split the rows and their partial
+// strips are summed through LDS at the end.
 template <int KC, int TGT, int RPAD>
 __global__ __launch_bounds__(256) void pf_qf_prep_kernel(ElboArgs A, double *__restrict__ qfc) {
-    constexpr int NE = KC * KC + KC + RPAD * KC + RPAD + 1;       // M, v, Nn, t0, C0
-    constexpr int EPT = (NE + 255) / 256;
+    constexpr int NT = KC / 4, TR = RPAD / 4;
+    constexpr int NMS = 4 * (NT * (NT + 1) / 2);                   // M strips with 4 Tb + 3 >= a
+    constexpr int NJ = NMS + RPAD * NT + NT + TR + 1;
+    constexpr int JPL = (NJ + 63) / 64;
     constexpr int NC = qf_nconst(KC, RPAD);
-    __shared__ double vh_s[64 * KC], as2_s[64], acs_s[64], ac2_s[64], s_s[64], c_s[64];
-    __shared__ double wd_s[64 * (RPAD > 0 ? RPAD : 1)];
-    const int slot = blockIdx.x, tid = threadIdx.x, d = A.d;
+    constexpr int CR = 128, RS = KC + RPAD + 4, ONE = KC + RPAD;
+    __shared__ double row_s[CR * RS], sc_s[5 * CR];                 // sc: a s^2 | a c s | a c^2 | s | c
+    __shared__ double red_s[4 * 64 * JPL * 4];
+    const int slot = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, d = A.d;
     const int p = A.points[slot];
     double *out = qfc + (size_t)p * NC;
     if (A.status[p] != PFMI_FIT_OK) return;
     const double *Vh = A.vh + (size_t)p * d * KC, *mu = A.mu + (size_t)p * d, *sqa = A.sqrt_alpha + (size_t)p * d;
-    double acc[EPT];
+    int j_sc[JPL], j_el[JPL], j_vec[JPL], j_kind[JPL], j_a[JPL], j_t[JPL];   // kind 0 M, 1 Nn, 2 v, 3 t0, 4 C0, -1 none
+    double acc[JPL][4];
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) acc[e] = 0.0;
-    for (int r0 = 0; r0 < d; r0 += 64) {
-        const int nr = (d - r0 < 64) ? d - r0 : 64;
+    for (int e = 0; e < JPL; ++e) {
+        int idx = lane + e * 64;
+        j_kind[e] = -1; j_sc[e] = 0; j_el[e] = ONE + 1; j_vec[e] = 0; j_a[e] = 0; j_t[e] = 0;     // el = a zero -> no-op job
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[e][j] = 0.0;
+        if (idx < NMS) {
+            int g = 0;                                             // a in group g = a / 4 has NT - g strips
+            while (idx >= 4 * (NT - g)) { idx -= 4 * (NT - g); ++g; }
+            const int a = 4 * g + idx / (NT - g), tb = g + idx % (NT - g);
+            j_kind[e] = 0; j_sc[e] = 0; j_el[e] = a; j_vec[e] = 4 * tb; j_a[e] = a; j_t[e] = tb;
+        } else if (idx < NMS + RPAD * NT) {
+            const int k = idx - NMS;
+            j_kind[e] = 1; j_sc[e] = 3 * CR; j_el[e] = KC + k / NT; j_vec[e] = 4 * (k % NT); j_a[e] = k / NT; j_t[e] = k % NT;
+        } else if (idx < NMS + RPAD * NT + NT) {
+            const int k = idx - NMS - RPAD * NT;
+            j_kind[e] = 2; j_sc[e] = CR; j_el[e] = ONE; j_vec[e] = 4 * k; j_t[e] = k;
+        } else if (idx < NMS + RPAD * NT + NT + TR) {
+            const int k = idx - NMS - RPAD * NT - NT;
+            j_kind[e] = 3; j_sc[e] = 4 * CR; j_el[e] = ONE; j_vec[e] = KC + 4 * k; j_t[e] = k;
+        } else if (idx < NJ) { j_kind[e] = 4; j_sc[e] = 2 * CR; j_el[e] = ONE; j_vec[e] = ONE; }
+    }
+    for (int r0 = 0; r0 < d; r0 += CR) {
+        const int nr = (d - r0 < CR) ? d - r0 : CR;
         __syncthreads();
-        for (int i = tid; i < 64 * KC; i += 256) vh_s[i] = (i < nr * KC) ? Vh[(size_t)r0 * KC + i] : 0.0;
-        if (tid < 64) {
+        for (int i = tid; i < CR * KC; i += 256) { const int r = i / KC, cc = i - r * KC; row_s[r * RS + cc] = (r < nr) ? Vh[(size_t)r0 * KC + i] : 0.0; }
+        if (RPAD > 0)
+            for (int i = tid; i < CR * RPAD; i += 256) { const int r = i / RPAD, cc = i - r * RPAD; row_s[r * RS + KC + cc] = (r < nr) ? A.t_wd[(size_t)r0 * RPAD + i] : 0.0; }
+        if (tid < CR) {
             double a = 0.0, c = 0.0, s = 0.0;
             if (tid < nr) { qf_row_ac<TGT>(A, mu, r0 + tid, a, c); s = sqa[r0 + tid]; }
-            as2_s[tid] = a * s * s; acs_s[tid] = a * c * s; ac2_s[tid] = a * c * c; s_s[tid] = s; c_s[tid] = c;
+            sc_s[tid] = a * s * s; sc_s[CR + tid] = a * c * s; sc_s[2 * CR + tid] = a * c * c; sc_s[3 * CR + tid] = s; sc_s[4 * CR + tid] = c;
+            row_s[tid * RS + ONE] = 1.0; row_s[tid * RS + ONE + 1] = 0.0; row_s[tid * RS + ONE + 2] = 0.0; row_s[tid * RS + ONE + 3] = 0.0;
         }
-        if (RPAD > 0) for (int i = tid; i < 64 * RPAD; i += 256) wd_s[i] = (i < nr * RPAD) ? A.t_wd[(size_t)r0 * RPAD + i] : 0.0;
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            const int idx = tid + e * 256;
-            if (idx >= NE) break;
-            double s = acc[e];
-            if (idx < KC * KC) {                                   // M[a][b]
-                const int a = idx / KC, b = idx % KC;
-                for (int i = 0; i < 64; ++i) s += as2_s[i] * vh_s[i * KC + a] * vh_s[i * KC + b];
-            } else if (idx < KC * KC + KC) {                       // v[a]
-                const int a = idx - KC * KC;
-                for (int i = 0; i < 64; ++i) s += acs_s[i] * vh_s[i * KC + a];
-            } else if (idx < KC * KC + KC + RPAD * KC) {           // Nn[j][b]
-                const int j = (idx - KC * KC - KC) / KC, b = (idx - KC * KC - KC) % KC;
-                for (int i = 0; i < 64; ++i) s += wd_s[i * (RPAD > 0 ? RPAD : 1) + j] * s_s[i] * vh_s[i * KC + b];
-            } else if (idx < KC * KC + KC + RPAD * KC + RPAD) {    // t0[j]
-                const int j = idx - KC * KC - KC - RPAD * KC;
-                for (int i = 0; i < 64; ++i) s += wd_s[i * (RPAD > 0 ? RPAD : 1) + j] * c_s[i];
-            } else {                                               // C0
-                for (int i = 0; i < 64; ++i) s += ac2_s[i];
+        for (int e = 0; e < JPL; ++e) {
+            const double *scp = sc_s + j_sc[e], *elp = row_s + j_el[e], *vcp = row_s + j_vec[e];
+#pragma unroll 8
+            for (int i = wv; i < CR; i += 4) {
+                const double coef = scp[i] * elp[i * RS];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[e][j] = fma(coef, vcp[i * RS + j], acc[e][j]);
             }
-            acc[e] = s;
         }
     }
+    // sum the 4 row-partitions and scatter to the constant block
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int idx = tid + e * 256;
-        if (idx >= NE) break;
-        int pos;
-        if (idx < KC * KC) pos = 4 + KC + idx;
-        else if (idx < KC * KC + KC) pos = 4 + (idx - KC * KC);
-        else if (idx < KC * KC + KC + RPAD * KC) pos = 4 + KC + KC * KC + RPAD + (idx - KC * KC - KC);
-        else if (idx < KC * KC + KC + RPAD * KC + RPAD) pos = 4 + KC + KC * KC + (idx - KC * KC - KC - RPAD * KC);
-        else pos = 0;
-        out[pos] = acc[e];
+    for (int e = 0; e < JPL; ++e)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red_s[((wv * JPL + e) * 64 + lane) * 4 + j] = acc[e][j];
+    __syncthreads();
+    if (wv == 0) {
+        double *vv = out + 4, *Mm = vv + KC, *t0 = Mm + KC * KC, *Nn = t0 + RPAD;
+#pragma unroll
+        for (int e = 0; e < JPL; ++e) {
+            double r[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                r[j] = 0.0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) r[j] += red_s[((w * JPL + e) * 64 + lane) * 4 + j];
+            }
+            const int kind = j_kind[e], a = j_a[e], t = j_t[e];
+            if (kind == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const int b = 4 * t + j; if (b >= a) { Mm[a * KC + b] = r[j]; Mm[b * KC + a] = r[j]; } }
+            } else if (kind == 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Nn[a * KC + 4 * t + j] = r[j];
+            } else if (kind == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) vv[4 * t + j] = r[j];
+            } else if (kind == 3) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t0[4 * t + j] = r[j];
+            } else if (kind == 4) out[0] = r[0];
+        }
     }
     if (tid < KC) out[4 + KC + KC * KC + RPAD + RPAD * KC + tid] = Vh[tid];     // row 0 of Vh
     if (tid == 0) { out[1] = mu[0]; out[2] = sqa[0]; out[3] = 0.0; }
