@@ -14,17 +14,40 @@ src/multipath.jl:190-193), then ONE fit_batch / elbo_batch / pool_build covers e
 is Python and the Julia `ccall` wrapper lives, untested, in pathfinder.jl_amd/julia/ -- INTEGRATION.md.)
 """
 import warnings
+from collections.abc import Sequence
 from dataclasses import dataclass, field
 from typing import Any, List, Optional
 
 import numpy as np
 
 from .core import Engine
-from .hostrng import HostRNG
+from .hostrng import HostRNG, rand_u64_multi
 from .optimize import OptimizationTrace, optimize_with_trace
 
 DEFAULT_HISTORY_LENGTH = 6     # src/Pathfinder.jl:24
 DEFAULT_NDRAWS_ELBO = 5        # src/Pathfinder.jl:27
+
+
+class _LazySeq(Sequence):
+    """list-like whose items are built on first access (the reference materialises L fits / ELBO estimates per path;
+    at 10^4 fits that is pure host overhead when only a few are ever looked at)"""
+
+    def __init__(self, n, make):
+        self._n, self._make, self._items = n, make, {}
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(self._n))]
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        if i not in self._items:
+            self._items[i] = self._make(i)
+        return self._items[i]
 
 
 class PosDefException(ArithmeticError):
@@ -123,15 +146,21 @@ class PathfinderResult:             # src/singlepath.jl:53-70
     rng: Any
     logp: Any
     fit_distribution: MvNormal
-    draws: np.ndarray
-    fit_iteration: int
-    num_tries: int
-    optim_trace: OptimizationTrace
-    fit_distributions: List[MvNormal]
-    elbo_estimates: List[ELBOEstimate]
-    num_bfgs_updates_rejected: int
+    draws_: Any = field(repr=False)     # (d, ndraws) array, or a thunk that downloads / regenerates it on first access
+    fit_iteration: int = 0
+    num_tries: int = 0
+    optim_trace: Any = None
+    fit_distributions: Any = None       # sequence of MvNormal
+    elbo_estimates: Any = None          # sequence of ELBOEstimate
+    num_bfgs_updates_rejected: int = 0
     success: bool = True
     draw_seed: int = 0
+
+    @property
+    def draws(self):
+        if callable(self.draws_):
+            self.draws_ = self.draws_()
+        return self.draws_
 
     @property
     def fit_distribution_transformed(self): return self.fit_distribution
@@ -163,18 +192,19 @@ _STATUS_MSG = {1: "A = diag(alpha) is not positive definite", 2: "C = I + R D R'
                3: "non-finite factor"}
 
 
+def _make_dist(eng, p, jeff, materialise=True):
+    if not materialise:
+        return MvNormal(None, None, eng, p)
+    f = eng.get_fit(p, int(jeff[p]))
+    F = WoodburyPDFactorization(np.sqrt(f["alpha"]), f["qr_factors"], f["T"], f["V"])
+    W = WoodburyPDMat(f["alpha"], f["B"], f["D"], F, f["logdet"], eng, p)
+    return MvNormal(f["mu"], W, eng, p)
+
+
 def _make_dists(eng, p0, npts, status, jeff, materialise=True):
-    dists = []
-    for l in range(npts):
-        p = p0 + l
-        if not materialise:
-            dists.append(MvNormal(None, None, eng, p))
-            continue
-        f = eng.get_fit(p, int(jeff[p]))
-        F = WoodburyPDFactorization(np.sqrt(f["alpha"]), f["qr_factors"], f["T"], f["V"])
-        W = WoodburyPDMat(f["alpha"], f["B"], f["D"], F, f["logdet"], eng, p)
-        dists.append(MvNormal(f["mu"], W, eng, p))
-    return dists
+    if not materialise:                       # handles only: built on first access
+        return _LazySeq(npts, lambda l: _make_dist(eng, p0 + l, jeff, False))
+    return [_make_dist(eng, p0 + l, jeff, True) for l in range(npts)]
 
 
 def fit_mvnormals(points, gradients, history_length=5, engine=None, eps=1e-12):
@@ -292,9 +322,9 @@ def _run_paths(eng, target, inits, run_rngs, *, dim, history_length, ndraws_elbo
                     state[k]["trace"].materialise()
         else:
             eng.set_traces([s["trace"].points for s in state], [s["trace"].gradients for s in state])
-        for k in pending:
-            L = len(state[k]["trace"]) - 1
-            state[k]["seeds"] = np.concatenate([[np.uint64(0)], run_rngs[k].rand_u64(L)]).astype(np.uint64)  # src/elbo.jl:2
+        fresh = rand_u64_multi([run_rngs[k] for k in pending], [len(state[k]["trace"]) - 1 for k in pending])
+        for k, sd in zip(pending, fresh):                           # seeds = rand!(rng_k, UInt64[L_k])  (src/elbo.jl:2)
+            state[k]["seeds"] = np.concatenate([[np.uint64(0)], sd]).astype(np.uint64)
         # one batched fit + ELBO over every path (finished paths are recomputed identically from their seeds)
         eng.fit_batch(history_length)
         status, jeff, logdet, nrej = eng.fit_status()
@@ -332,8 +362,11 @@ def _assemble_path(eng, target, st, rng, ndraws, ndraws_elbo, input_, status, je
         warnings.warn(f"{st['nrej']} ({perc}%) updates to the inverse Hessian estimate were rejected to keep it "
                       "positive definite.")
     dists = _make_dists(eng, p0, L + 1, status, jeff, materialise)
-    ests = [ELBOEstimate(float(st["elbo"][l]), float(st["se"][l]), eng, p0 + l, int(st["seeds"][l]), ndraws_elbo)
-            for l in range(1, L + 1)]
+    def _est(i, st=st):
+        l = i + 1
+        return ELBOEstimate(float(st["elbo"][l]), float(st["se"][l]), eng, p0 + l, int(st["seeds"][l]), ndraws_elbo)
+
+    ests = _LazySeq(L, _est) if not materialise else [_est(i) for i in range(L)]
     fit_it = st["fit_iteration"]
     fit_point = p0 + fit_it                                       # fit_distributions[fit_iteration + 1]
     if st["success"]:
@@ -402,13 +435,16 @@ def multipathfinder(target, ndraws, *, init=None, nruns=-1, ndraws_elbo=DEFAULT_
              for st, r in zip(state, run_rngs)]
     # draws_per_component = stack(draws)   (:217) -- device resident
     eng.pool_build(ndraws_per_run, [a["fit_point"] for a in parts], [a["draw_seed"] for a in parts])
-    pool, log_ratios = eng.pool_get(draws=True)
+    # the per-run draws (d, N_r, K) stay on the device; a run's block is downloaded from the pool when it is looked at
     results = []
     for k, (st, a) in enumerate(zip(state, parts)):
+        thunk = (lambda k=k: eng.pool_gather(np.arange(k * ndraws_per_run, (k + 1) * ndraws_per_run, dtype=np.int64)))
         results.append(PathfinderResult(input if input is not None else target, run_rngs[k], target.logp,
-                                        a["dists"][st["fit_iteration"]], pool[:, :, k], st["fit_iteration"],
+                                        a["dists"][st["fit_iteration"]], thunk, st["fit_iteration"],
                                         st["itry"], st["trace"], a["dists"], a["ests"], st["nrej"], st["success"],
                                         a["draw_seed"]))
+        if materialise:
+            results[-1].draws
     S = nruns * ndraws_per_run
     psis_result = None
     if importance:                                                                               # :220-224
