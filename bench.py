@@ -199,7 +199,7 @@ def main():
             pass
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                    "kernel": "pf_elbo_qf_kernel<12, 1, 8> (single-pass ELBO scan) + pf_qf_prep_kernel",
+                    "kernel": "pf_elbo_qf_kernel<12, 1, 8> (single-pass ELBO scan)",
                     "launches": int(n), "avg_launch_ms": round(ms / max(n, 1), 4),
                     "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_draw": bytes_per_draw,
                     "note": "achieved = algorithmic bytes (16*d + factor bytes per draw, SURVEY 8d) / measured launch time. The "

@@ -7,7 +7,7 @@
 //   sum_i a_i e_i^2 = C0 + sum a s^2 z^2 + 2 sum a c s z  +  tv'M tv - 2 tv'(v + A3),      A3 = Vh'(a s^2 . z)
 //   Wd'e            = t0 + A4 - Nn tv,                                                        A4 = Wd'(s . z)
 // with per-fit constants C0 = sum a c^2, M = Vh' diag(a s^2) Vh, v = Vh'(a c s), t0 = Wd'c, Nn = Wd' diag(s) Vh
-// (pf_qf_prep_kernel).  One pass over the rows therefore accumulates, per draw, |u|^2, two scalars and the three skinny
+// (computed by the scan itself from "pseudo draws", see the kernel).  One pass over the rows therefore accumulates, per draw, |u|^2, two scalars and the three skinny
 // contractions w = Vh'z, A3, A4 -- all with the SAME A operand tiles -- and the draw is finished with O(KC^2) flops.
 // (Verified against the direct evaluation in extended precision: same 1e-14 relative error, no cancellation, because
 // every term is a sum of squares or a projection of one.)
@@ -38,7 +38,7 @@ typedef double qf_d4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ qf_d4 qf_mfma16(double a, double b, qf_d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ double qf_mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
 
-// per-fit constant block (doubles): [0] C0  [1] mu_0  [2] s_0  [3] -   then v[KC], M[KC][KC], t0[RPAD], Nn[RPAD][KC], vh0[KC]
+// per-fit constant block in LDS (doubles): [0] C0  [1] mu_0  [2] s_0  [3] -   then v[KC], M[KC][KC], t0[RPAD], Nn[RPAD][KC], vh0[KC]
 __host__ __device__ constexpr int qf_nconst(int KC, int RPAD) { return 4 + KC + KC * KC + RPAD + RPAD * KC + KC; }
 
 // a_i (target diagonal weight), c_i = mu_i - m_i for row i
@@ -47,113 +47,6 @@ __device__ __forceinline__ void qf_row_ac(const ElboArgs &A, const double *mu, i
     if (TGT == 1) { a = A.t_a[i]; c = mu[i] - A.t_mean[i]; }
     else if (TGT == 2) { a = (i >= 1) ? 1.0 : 0.0; c = mu[i]; }
     else { a = 0.0; c = 0.0; }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// per-fit constants.  One 256-thread workgroup per fit.  Every output strip of 4 adjacent entries is the same "job"
-//   acc[j] += scal_i * row_i[el] * row_i[vec + j]   over the rows i,   row_i = [ Vh_i (KC) | Wd_i (RPAD) | 1 0 0 0 ]
-// (M strips (a, 4Tb..4Tb+3), 4Tb+3 >= a: scal = a s^2, el = a;  Nn strips: scal = s, el = KC + jr;  v strips: scal = a c s,
-// el = the 1;  t0 strips: scal = c, el = the 1, vec in the Wd part;  C0: scal = a c^2, el = vec = the 1) so all lanes run
-// one divergence-free loop.  Lane l of every wave owns jobs l, l + 64, ...; the 4 waves split the rows and their partial
-// strips are summed through LDS at the end.
-template <int KC, int TGT, int RPAD>
-__global__ __launch_bounds__(256) void pf_qf_prep_kernel(ElboArgs A, double *__restrict__ qfc) {
-    constexpr int NT = KC / 4, TR = RPAD / 4;
-    constexpr int NMS = 4 * (NT * (NT + 1) / 2);                   // M strips with 4 Tb + 3 >= a
-    constexpr int NJ = NMS + RPAD * NT + NT + TR + 1;
-    constexpr int JPL = (NJ + 63) / 64;
-    constexpr int NC = qf_nconst(KC, RPAD);
-    constexpr int CR = 128, RS = KC + RPAD + 4, ONE = KC + RPAD;
-    __shared__ double row_s[CR * RS], sc_s[5 * CR];                 // sc: a s^2 | a c s | a c^2 | s | c
-    __shared__ double red_s[4 * 64 * JPL * 4];
-    const int slot = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, d = A.d;
-    const int p = A.points[slot];
-    double *out = qfc + (size_t)p * NC;
-    if (A.status[p] != PFMI_FIT_OK) return;
-    const double *Vh = A.vh + (size_t)p * d * KC, *mu = A.mu + (size_t)p * d, *sqa = A.sqrt_alpha + (size_t)p * d;
-    int j_sc[JPL], j_el[JPL], j_vec[JPL], j_kind[JPL], j_a[JPL], j_t[JPL];   // kind 0 M, 1 Nn, 2 v, 3 t0, 4 C0, -1 none
-    double acc[JPL][4];
-#pragma unroll
-    for (int e = 0; e < JPL; ++e) {
-        int idx = lane + e * 64;
-        j_kind[e] = -1; j_sc[e] = 0; j_el[e] = ONE + 1; j_vec[e] = 0; j_a[e] = 0; j_t[e] = 0;     // el = a zero -> no-op job
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[e][j] = 0.0;
-        if (idx < NMS) {
-            int g = 0;                                             // a in group g = a / 4 has NT - g strips
-            while (idx >= 4 * (NT - g)) { idx -= 4 * (NT - g); ++g; }
-            const int a = 4 * g + idx / (NT - g), tb = g + idx % (NT - g);
-            j_kind[e] = 0; j_sc[e] = 0; j_el[e] = a; j_vec[e] = 4 * tb; j_a[e] = a; j_t[e] = tb;
-        } else if (idx < NMS + RPAD * NT) {
-            const int k = idx - NMS;
-            j_kind[e] = 1; j_sc[e] = 3 * CR; j_el[e] = KC + k / NT; j_vec[e] = 4 * (k % NT); j_a[e] = k / NT; j_t[e] = k % NT;
-        } else if (idx < NMS + RPAD * NT + NT) {
-            const int k = idx - NMS - RPAD * NT;
-            j_kind[e] = 2; j_sc[e] = CR; j_el[e] = ONE; j_vec[e] = 4 * k; j_t[e] = k;
-        } else if (idx < NMS + RPAD * NT + NT + TR) {
-            const int k = idx - NMS - RPAD * NT - NT;
-            j_kind[e] = 3; j_sc[e] = 4 * CR; j_el[e] = ONE; j_vec[e] = KC + 4 * k; j_t[e] = k;
-        } else if (idx < NJ) { j_kind[e] = 4; j_sc[e] = 2 * CR; j_el[e] = ONE; j_vec[e] = ONE; }
-    }
-    for (int r0 = 0; r0 < d; r0 += CR) {
-        const int nr = (d - r0 < CR) ? d - r0 : CR;
-        __syncthreads();
-        for (int i = tid; i < CR * KC; i += 256) { const int r = i / KC, cc = i - r * KC; row_s[r * RS + cc] = (r < nr) ? Vh[(size_t)r0 * KC + i] : 0.0; }
-        if (RPAD > 0)
-            for (int i = tid; i < CR * RPAD; i += 256) { const int r = i / RPAD, cc = i - r * RPAD; row_s[r * RS + KC + cc] = (r < nr) ? A.t_wd[(size_t)r0 * RPAD + i] : 0.0; }
-        if (tid < CR) {
-            double a = 0.0, c = 0.0, s = 0.0;
-            if (tid < nr) { qf_row_ac<TGT>(A, mu, r0 + tid, a, c); s = sqa[r0 + tid]; }
-            sc_s[tid] = a * s * s; sc_s[CR + tid] = a * c * s; sc_s[2 * CR + tid] = a * c * c; sc_s[3 * CR + tid] = s; sc_s[4 * CR + tid] = c;
-            row_s[tid * RS + ONE] = 1.0; row_s[tid * RS + ONE + 1] = 0.0; row_s[tid * RS + ONE + 2] = 0.0; row_s[tid * RS + ONE + 3] = 0.0;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < JPL; ++e) {
-            const double *scp = sc_s + j_sc[e], *elp = row_s + j_el[e], *vcp = row_s + j_vec[e];
-#pragma unroll 8
-            for (int i = wv; i < CR; i += 4) {
-                const double coef = scp[i] * elp[i * RS];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[e][j] = fma(coef, vcp[i * RS + j], acc[e][j]);
-            }
-        }
-    }
-    // sum the 4 row-partitions and scatter to the constant block
-#pragma unroll
-    for (int e = 0; e < JPL; ++e)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) red_s[((wv * JPL + e) * 64 + lane) * 4 + j] = acc[e][j];
-    __syncthreads();
-    if (wv == 0) {
-        double *vv = out + 4, *Mm = vv + KC, *t0 = Mm + KC * KC, *Nn = t0 + RPAD;
-#pragma unroll
-        for (int e = 0; e < JPL; ++e) {
-            double r[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                r[j] = 0.0;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) r[j] += red_s[((w * JPL + e) * 64 + lane) * 4 + j];
-            }
-            const int kind = j_kind[e], a = j_a[e], t = j_t[e];
-            if (kind == 0) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { const int b = 4 * t + j; if (b >= a) { Mm[a * KC + b] = r[j]; Mm[b * KC + a] = r[j]; } }
-            } else if (kind == 1) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) Nn[a * KC + 4 * t + j] = r[j];
-            } else if (kind == 2) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) vv[4 * t + j] = r[j];
-            } else if (kind == 3) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) t0[4 * t + j] = r[j];
-            } else if (kind == 4) out[0] = r[0];
-        }
-    }
-    if (tid < KC) out[4 + KC + KC * KC + RPAD + RPAD * KC + tid] = Vh[tid];     // row 0 of Vh
-    if (tid == 0) { out[1] = mu[0]; out[2] = sqa[0]; out[3] = 0.0; }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -167,8 +60,7 @@ __device__ __forceinline__ int qf_vh_pos(int lrow, int col) {
 }
 
 template <int KC, int TGT, int RPAD>
-__global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, const double *__restrict__ qfc, int ch_blocks, int nchunks,
-                                                                int batches_per_wg, int nbatches, int ngroups) {
+__global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int ch_blocks, int nchunks, int groups_per_wg, int ngroups) {
     extern __shared__ double lds[];
     constexpr int NT = KC / 4, TR = RPAD / 4, NC = qf_nconst(KC, RPAD);
     constexpr int PRE = (QF_CHB * 16 * KC + QF_THREADS - 1) / QF_THREADS;      // prefetch registers per thread (streaming)
@@ -178,10 +70,16 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, cons
     const int p = A.points[slot];
     const size_t blkidx = A.by_point ? (size_t)p : (size_t)slot;
     double *out_lp = A.logp + blkidx * A.log_stride, *out_lq = A.logq + blkidx * A.log_stride;
-    const int b_begin = blockIdx.x * batches_per_wg;
-    const int b_end = (b_begin + batches_per_wg < nbatches) ? b_begin + batches_per_wg : nbatches;
+    // this workgroup's 16-draw groups [g_begin, g_end), preceded by NPG "pseudo groups" whose columns are the KC columns of
+    // Vh and c/s: pushing them through the SAME contraction code yields the per-fit constants
+    //   A3(Vh[:, j]) = M[:, j], A4(Vh[:, j]) = Nn[:, j], A3(c/s) = v, A4(c/s) = t0, q12(c/s) = 3 C0
+    // in the first batch, for one wave-slot (the 63 real groups of N = 1000 leave exactly one of 64 slots free)
+    constexpr int NPG = (TGT != 0) ? (KC + 1 + 15) / 16 : 0;
+    const int g_begin = blockIdx.x * groups_per_wg;
+    const int g_end = (g_begin + groups_per_wg < ngroups) ? g_begin + groups_per_wg : ngroups;
+    const int nlb = (NPG + (g_end - g_begin) + QF_WAVES - 1) / QF_WAVES;      // batches of this workgroup
     if (A.status[p] != PFMI_FIT_OK) {
-        for (int64_t n = (int64_t)b_begin * QF_WAVES * 16 + tid; n < (int64_t)b_end * QF_WAVES * 16 && n < A.N; n += QF_THREADS) {
+        for (int64_t n = (int64_t)g_begin * 16 + tid; n < (int64_t)g_end * 16 && n < A.N; n += QF_THREADS) {
             out_lp[n] = NAN; out_lq[n] = NAN;
         }
         return;
@@ -215,7 +113,7 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, cons
     {
         const double *T = A.tmat + (size_t)p * KC * KC;
         for (int i = tid; i < KC * KC; i += QF_THREADS) t_s[i] = T[i];
-        for (int i = tid; i < NC; i += QF_THREADS) cn_s[i] = qfc[(size_t)p * NC + i];
+        for (int i = tid; i < NC; i += QF_THREADS) cn_s[i] = 0.0;
         if (RPAD > 0) for (int i = tid; i < RPAD * RPAD; i += QF_THREADS) g_s[i] = A.t_g[i];
         pf_logtab_load(logtab);
         pf_sctab_load(sctab);
@@ -246,11 +144,17 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, cons
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     const double logdet = A.logdet[p];
     __syncthreads();
+    if (TGT == 2) {                                                 // funnel: tau = x_1 needs row 0 of the factor
+        if (tid == 0) { cn_s[1] = mu[0]; cn_s[2] = sqa[0]; }
+        if (tid < KC) cn_s[4 + KC + KC * KC + RPAD + RPAD * KC + tid] = Vh[tid];
+    }
 
     int cur = 0;
-    for (int batch = b_begin; batch < b_end; ++batch) {
-        const int grp = batch * QF_WAVES + wv;
-        const bool active = grp < ngroups;                          // wave-uniform
+    for (int lb = 0; lb < nlb; ++lb) {
+        const int sl = lb * QF_WAVES + wv;                          // wave-uniform slot
+        const bool pseudo = sl < NPG;
+        const int grp = g_begin + sl - NPG;
+        const bool active = pseudo || grp < g_end;
         const int64_t nl = (int64_t)grp * 16 + c;
         const uint32_t n = (uint32_t)(A.n0 + nl);
         double accw[NT], acc3[NT], acc4[TR > 0 ? TR : 1];
@@ -264,7 +168,7 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, cons
             // ---- streaming: fetch the next chunk (or chunk 0 for the next batch) into registers while this one is consumed
             double pre[PRE], pr_s = 0.0, pr_a = 0.0, pr_c = 0.0;
             const int nck = (ck + 1 < nchunks) ? ck + 1 : 0;
-            const bool do_pre = (nchunks > 1) && (ck + 1 < nchunks || batch + 1 < b_end);
+            const bool do_pre = (nchunks > 1) && (ck + 1 < nchunks || lb + 1 < nlb);
             if (do_pre) {
                 const int row0 = nck * QF_CHB * 16;
 #pragma unroll
@@ -355,6 +259,42 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, cons
                         }
                     }
                 };
+                // pseudo group: column j of this lane is Vh[:, j] (j < KC) or c/s (j == KC); no RNG, no head transform
+                auto compute_pseudo = [&](const int blk, const int bl, const Ops &o) {
+                    const int j = 16 * sl + c;
+                    double z[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = blk * 16 + 4 * q + r;
+                        double v = 0.0;
+                        if (j < KC) v = vs[qf_vh_pos<KC>(bl * 16 + 4 * q + r, j)];
+                        else if (j == KC && row < d) {
+                            double aa, cc;
+                            qf_row_ac<TGT>(A, mu, row, aa, cc);
+                            v = cc / sqa[row];
+                        }
+                        z[r] = v;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double zr = z[r], bp = o.rs[r] * zr;
+                        q12 = fma(bp + o.rs[4 + r], zr, q12);
+#pragma unroll
+                        for (int T = 0; T < NT; ++T) acc3[T] = qf_mfma4(o.av[r][T], bp, acc3[T]);
+                        if (TGT == 1 && RPAD > 0) {
+                            const double bs = o.rs[8 + r] * zr;
+#pragma unroll
+                            for (int T = 0; T < TR; ++T) acc4[T] = qf_mfma4(o.wd[r][T], bs, acc4[T]);
+                        }
+                    }
+                };
+                if (pseudo) {
+                    for (int bl = 0; bl < nb; ++bl) {
+                        Ops oa;
+                        load_ops(bl, oa);
+                        compute_pseudo(blk0 + bl, bl, oa);
+                    }
+                } else {
 #if QF_PF2
                 Ops oa, ob;
                 load_ops(0, oa);
@@ -374,6 +314,7 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, cons
                     compute(blk0 + bl, oa);
                 }
 #endif
+                }
             }
             if (nchunks > 1) {
                 if (do_pre) {
@@ -392,7 +333,29 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, cons
                 cur ^= 1;
             }
         }
-        if (!active) continue;
+        if (NPG > 0 && lb == 0) {                                  // publish the per-fit constants before any draw is finished
+            if (pseudo) {
+                const int j = 16 * sl + c;
+                double *vv = cn_s + 4, *Mm = cn_s + 4 + KC, *t0 = Mm + KC * KC, *Nn = t0 + RPAD;
+                const double q3 = q12 + __shfl_xor(q12, 16, 64);
+                const double q4 = q3 + __shfl_xor(q3, 32, 64);
+#pragma unroll
+                for (int T = 0; T < NT; ++T) {
+                    const int a = 4 * T + q;
+                    if (j < KC) Mm[a * KC + j] = acc3[T];
+                    else if (j == KC) vv[a] = acc3[T];
+                }
+#pragma unroll
+                for (int T = 0; T < TR; ++T) {
+                    const int jr = 4 * T + q;
+                    if (j < KC) Nn[jr * KC + j] = acc4[T];
+                    else if (j == KC) t0[jr] = acc4[T];
+                }
+                if (j == KC && q == 0) cn_s[0] = q4 / 3.0;          // q12(c/s) = sum a c^2 + 2 sum a c^2
+            }
+            __syncthreads();
+        }
+        if (!active || pseudo) continue;
         // ---- finish the 16 draws of this wave in registers: lane (q, c) holds entries 4T + q of w, A3, A4 of draw c
         usq += __shfl_xor(usq, 16, 64); usq += __shfl_xor(usq, 32, 64);
         double lp = NAN;
@@ -474,7 +437,6 @@ static int32_t launch_qf(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
     if (qf_lds_bytes(nblk, 1, KC, RPAD) > 156 * 1024) { ch_blocks = QF_CHB; nchunks = (nblk + QF_CHB - 1) / QF_CHB; }
     const size_t lds_bytes = qf_lds_bytes(ch_blocks, nchunks, KC, RPAD);
     PF_CHECK(lds_bytes <= 160 * 1024, PFMI_ERR_UNSUPPORTED, "qf kernel LDS %zu too large", lds_bytes);
-    PF_TRY(c->qfc.ensure(sizeof(double) * (size_t)c->P * qf_nconst(KC, RPAD)));
     auto kern = pf_elbo_qf_kernel<KC, TGT, RPAD>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -482,20 +444,22 @@ static int32_t launch_qf(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
         attr_set = true;
     }
     const int ngroups = (int)((a.N + 15) / 16);
-    const int nbatches = (ngroups + QF_WAVES - 1) / QF_WAVES;
-    int split = 1;                              // split a fit's batches over several workgroups only when there are few fits
-    while ((int64_t)split * nfits < 1024 && split * 2 <= nbatches) split *= 2;
-    const int bpw = (nbatches + split - 1) / split;
-    const int gx = (nbatches + bpw - 1) / bpw;
+    constexpr int NPG = (TGT != 0) ? (KC + 1 + 15) / 16 : 0;
+    // one workgroup per fit; a fit's groups are split over several workgroups only when there are few fits (every
+    // workgroup recomputes the per-fit constants, so the pieces are kept to whole batches)
+    int split = 1;
+    while ((int64_t)split * nfits < 1024 && (ngroups + NPG) / (split * 2) >= QF_WAVES) split *= 2;
+    int gpw = (ngroups + split - 1) / split;
+    if (split > 1) gpw = ((gpw + NPG + QF_WAVES - 1) / QF_WAVES) * QF_WAVES - NPG;   // fill the last batch
+    if (gpw < 1) gpw = 1;
+    const int gx = (ngroups + gpw - 1) / gpw;
     for (int64_t s0 = 0; s0 < nfits; s0 += 32768) {
         const int64_t ns = (nfits - s0 < 32768) ? (nfits - s0) : 32768;
         ElboArgs b = a;
         b.points = a.points + s0; b.seeds = a.seeds + s0;
         if (!a.by_point) { b.logp += s0 * a.log_stride; b.logq += s0 * a.log_stride; }
-        if (TGT != 0)
-            hipLaunchKernelGGL((pf_qf_prep_kernel<KC, TGT, RPAD>), dim3((unsigned)ns), dim3(256), 0, c->stream, b, c->qfc.as<double>());
-        hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)ns), dim3(QF_THREADS), lds_bytes, c->stream, b,
-                           (const double *)c->qfc.as<double>(), ch_blocks, nchunks, bpw, nbatches, ngroups);
+        hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)ns), dim3(QF_THREADS), lds_bytes, c->stream, b, ch_blocks, nchunks, gpw,
+                           ngroups);
     }
     return PFMI_OK;
 }

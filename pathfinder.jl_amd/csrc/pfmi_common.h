@@ -109,7 +109,6 @@ struct pfmi_ctx {
     DevBuf ubuf;        // parity-mode normals
     DevBuf xbuf;        // scratch draws (callback path / pfmi_draws)
     DevBuf scratch;     // misc
-    DevBuf qfc;         // [P][qf_nconst] per-fit constants of the single-pass scan
 
     // pool / PSIS / resample state
     bool pooled = false;

@@ -19,7 +19,7 @@ def per_launch(db, counter, pattern):
 pat = "%pf_elbo_qf_kernel%"
 f = per_launch(sys.argv[1], "FETCH_SIZE", pat)
 w = per_launch(sys.argv[2], "WRITE_SIZE", pat)
-out = {"command": sys.argv[3] if len(sys.argv) > 3 else "", "kernel": "pf_elbo_qf_kernel (single-pass ELBO scan, largest grid) + pf_qf_prep_kernel",
+out = {"command": sys.argv[3] if len(sys.argv) > 3 else "", "kernel": "pf_elbo_qf_kernel (single-pass ELBO scan, largest grid)",
        "fetch_correction": 2.0}
 g, v, n, dur = f[0]
 out["fetch_bytes_per_launch"] = 2.0 * v / n * 1024
@@ -27,10 +27,5 @@ out["launches_profiled"] = n
 out["avg_duration_ms_under_pmc"] = dur / 1e6
 g, v, n, dur = w[0]
 out["write_bytes_per_launch"] = v / n * 1024
-pf = per_launch(sys.argv[1], "FETCH_SIZE", "%pf_qf_prep_kernel%")
-pw = per_launch(sys.argv[2], "WRITE_SIZE", "%pf_qf_prep_kernel%")
-out["prep_fetch_bytes_per_launch"] = 2.0 * pf[0][1] / pf[0][2] * 1024 if pf else 0.0
-out["prep_write_bytes_per_launch"] = pw[0][1] / pw[0][2] * 1024 if pw else 0.0
-out["traffic_bytes_per_launch"] = (out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"] +
-                                   out["prep_fetch_bytes_per_launch"] + out["prep_write_bytes_per_launch"])
+out["traffic_bytes_per_launch"] = out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
 print(json.dumps(out, indent=1))
