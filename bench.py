@@ -47,17 +47,29 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--host-traces", action="store_true", help="make the input traces with the host numpy driver")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the multi-GPU code path (RCCL all-gather / all-reduce) even in a single-rank world")
+    ap.add_argument("--target", default="lowrank", choices=["lowrank", "diag", "iso", "funnel"],
+                    help="synthetic target of SURVEY 8(d); the headline config uses lowrank (r = 8)")
+    ap.add_argument("--maxiters", type=int, default=1000)
+    ap.add_argument("--init-scale", type=float, default=2.0)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     import pfmi
     from pfmi.hostrng import rand_u64
 
@@ -70,26 +82,27 @@ def main():
     master = 20260928
 
     # ---- synthetic inputs: target T_lr(d, r=8, seed=2), one L-BFGS trace per path ----------
-    tg = pfmi.t_lowrank(d, r=8, seed=2)
+    tg = {"lowrank": lambda: pfmi.t_lowrank(d, r=8, seed=2), "diag": lambda: pfmi.t_diag(d, seed=1), "iso": lambda: pfmi.t_iso(d),
+          "funnel": lambda: pfmi.t_funnel(d)}[args.target]()
     run_seeds = rand_u64(master, np.arange(K, dtype=np.uint64), 9)
-    x0s = np.stack([pfmi.HostRNG(int(run_seeds[k])).rand(d) * 4.0 - 2.0          # U[-2, 2]  (src/singlepath.jl:158-159)
-                    for k in range(k0, k0 + Kl)])
+    sc = args.init_scale                                             # U[-2, 2] by default (src/singlepath.jl:158-159)
+    x0s = np.stack([pfmi.HostRNG(int(run_seeds[k])).rand(d) * 2 * sc - sc for k in range(k0, k0 + Kl)])
     eng = pfmi.Engine(local_rank)
     eng.set_target(tg)
     traces = None
     if args.host_traces:
-        traces = [pfmi.optimize_with_trace(tg, x0, history_length=J) for x0 in x0s]
+        traces = [pfmi.optimize_with_trace(tg, x0, history_length=J, maxiters=args.maxiters) for x0 in x0s]
         eng.set_traces([t.points for t in traces], [t.gradients for t in traces])  # H2D: outside the timed region
         npts = np.array([len(t) for t in traces])
     else:                                                           # device L-BFGS: traces are born in HBM
-        npts = eng.optimize_batch(x0s, J)
+        npts = eng.optimize_batch(x0s, J, args.maxiters)
     P = eng.P
     seeds = np.concatenate([rand_u64(int(run_seeds[k0 + i]), np.arange(n, dtype=np.uint64), 10)
                             for i, n in enumerate(npts)])
     nfits_local = P - Kl
     draws_local = nfits_local * N_e
 
-    if G > 1:
+    if use_dist:
         import torch
         lr_all = torch.empty(K * N_r, dtype=torch.float64, device=f"cuda:{local_rank}")
         out_dev = torch.zeros(ndraws * d, dtype=torch.float64, device=f"cuda:{local_rank}")
@@ -102,7 +115,7 @@ def main():
         pts = [int(eng.offsets[k]) + int(best[k]) for k in range(Kl)]
         eng.pool_build(N_r, pts, seeds[pts])
         ptr, cnt = eng.pool_log_ratios_dev()                        # syncs the engine stream
-        if G > 1:
+        if use_dist:
             import torch
             from pfmi.distributed import pooled_psis_resample
             shard = torch.as_tensor(_DevArray(ptr, cnt), device=f"cuda:{local_rank}")
@@ -111,7 +124,7 @@ def main():
                 psis_fn=lambda t: eng.psis_dev(t.data_ptr(), t.numel(), want_weights=False),
                 sample_fn=lambda S: eng.resample_indices(S, ndraws, seed=master),
                 gather_fn=lambda ix, o: eng.pool_gather_dev(ix, k0 * N_r, o.data_ptr()),
-                sync_fn=torch.cuda.synchronize)
+                sync_fn=torch.cuda.synchronize, min_world=1)
             state["draws"] = out_dev
         else:
             res = eng.psis_dev(ptr, cnt, want_weights=False)
@@ -121,7 +134,7 @@ def main():
 
     def barrier():
         eng.sync()
-        if G > 1:
+        if use_dist:
             import torch
             torch.cuda.synchronize()
             dist.barrier()
@@ -134,7 +147,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if G > 1:
+    if use_dist:
         import torch
         tt = torch.tensor([dt, float(draws_local)], dtype=torch.float64, device=f"cuda:{local_rank}")
         tmax = tt.clone()
@@ -153,7 +166,7 @@ def main():
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            eng.optimize_batch(x0s, J)
+            eng.optimize_batch(x0s, J, args.maxiters)
             step()
         barrier()
         wall_e2e = (time.perf_counter() - t0) / args.steps * 1e3
@@ -161,14 +174,15 @@ def main():
     # ---- the same job through the public host API (pfmi.multipathfinder: x0 sampling, device L-BFGS, fit, ELBO, pool, PSIS,
     #      resample, result objects), single GPU only
     api_wall = None
-    if G == 1 and not args.host_traces:
+    if G == 1 and not use_dist and not args.host_traces:
         ts = []
         for rep in range(4):
             t0 = time.perf_counter()
-            pfmi.multipathfinder(tg, ndraws, nruns=K, ndraws_elbo=N_e, history_length=J, rng=pfmi.HostRNG(master), engine=eng)
+            pfmi.multipathfinder(tg, ndraws, nruns=K, ndraws_elbo=N_e, history_length=J, rng=pfmi.HostRNG(master), engine=eng,
+                                 init_scale=sc, maxiters=args.maxiters)
             ts.append((time.perf_counter() - t0) * 1e3)
         api_wall = sorted(ts[1:])[1]
-        npts = eng.optimize_batch(x0s, J)                              # restore the benchmark's own traces for the profile step
+        npts = eng.optimize_batch(x0s, J, args.maxiters)               # restore the benchmark's own traces for the profile step
 
     # ---- roofline of the dominant kernel (pf_elbo_draws_kernel), hipEvents on the engine's stream ---------
     roofline = None
@@ -176,7 +190,7 @@ def main():
     if rank == 0:
         eng.profile(True)
     if not args.host_traces:
-        eng.optimize_batch(x0s, J)
+        eng.optimize_batch(x0s, J, args.maxiters)
     step()                      # every rank takes part (collectives); only rank 0 records kernel events
     barrier()
     if rank == 0:
@@ -199,7 +213,7 @@ def main():
             pass
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                    "kernel": "pf_elbo_qf_kernel<12, 1, 8> (single-pass ELBO scan)",
+                    "kernel": "pf_elbo_qf_kernel (single-pass ELBO scan)",
                     "launches": int(n), "avg_launch_ms": round(ms / max(n, 1), 4),
                     "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_draw": bytes_per_draw,
                     "note": "achieved = algorithmic bytes (16*d + factor bytes per draw, SURVEY 8d) / measured launch time. The "
@@ -251,7 +265,8 @@ def main():
             "value": round(value, 1), "unit": "ELBO draws/s", "n_gpus": G, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"multipathfinder npaths={K} d={d} correlated Gaussian (low-rank r=8 + diag), "
+            "config": {"workload": f"multipathfinder npaths={K} d={d} " + {"lowrank": "correlated Gaussian (low-rank r=8 + diag)",
+                                   "diag": "diagonal Gaussian", "iso": "isotropic Gaussian", "funnel": "funnel"}[args.target] + ", "
                                    f"history_length={J}, ndraws_elbo={N_e}, ndraws={ndraws}",
                        "npaths": K, "paths_per_gpu": Kl, "fits_total": int(total_draws // N_e),
                        "elbo_draws_per_step": int(total_draws), "parallelism": f"paths sharded x{G}"},
@@ -264,11 +279,20 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(line), flush=True)
-    if G > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+    if rank == 0:
+        # RCCL writes a version banner through C stdio that would otherwise be flushed at exit, AFTER this line:
+        # drain it first so that the JSON result is the last line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -24,7 +24,7 @@ def shard_paths(K, world, rank):
     return rank * per, (rank + 1) * per
 
 
-def pooled_psis_resample(dist, lr_local, lr_all, out, *, psis_fn, sample_fn, gather_fn, sync_fn=None):
+def pooled_psis_resample(dist, lr_local, lr_all, out, *, psis_fn, sample_fn, gather_fn, sync_fn=None, min_world=2):
     """Run the pooled stage collectively.
 
     dist       torch.distributed (initialised) or None for a single process
@@ -35,9 +35,12 @@ def pooled_psis_resample(dist, lr_local, lr_all, out, *, psis_fn, sample_fn, gat
     sample_fn  (S) -> index array (identical on every rank)
     gather_fn  (idx, out tensor) -> fills `out` with this rank's owned columns, zeros elsewhere
     sync_fn    optional device synchronisation between engine work and collectives
+    min_world  collectives are issued when the world has at least this many ranks (1: also in a single-rank world,
+               used to exercise the RCCL path on a 1-GPU box)
     returns    (psis result, idx)
     """
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    collective = dist is not None and dist.is_initialized() and dist.get_world_size() >= min_world
+    if collective:
         dist.all_gather_into_tensor(lr_all, lr_local)      # the single exchange step of the data path
         if sync_fn:
             sync_fn()
@@ -47,7 +50,7 @@ def pooled_psis_resample(dist, lr_local, lr_all, out, *, psis_fn, sample_fn, gat
     res = psis_fn(pooled)
     idx = sample_fn(int(pooled.numel()))
     gather_fn(idx, out)
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if collective:
         if sync_fn:
             sync_fn()
         dist.all_reduce(out)                               # every column is owned by exactly one rank

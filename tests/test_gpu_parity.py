@@ -753,3 +753,51 @@ def test_single_pass_scan_matches_lane_kernel(pfmi_mod, eng, tname, d, K, J, N, 
     for (lpa, lqa), (lpb, lqb) in zip(a[3], b[3]):
         assert np.max(np.abs(lpa - lpb) / (1 + np.abs(lpb))) <= 1e-10
         assert np.max(np.abs(lqa - lqb) / (1 + np.abs(lqb))) <= 1e-12
+
+
+def test_rccl_collectives_on_engine_memory_world1(pfmi_mod, eng):
+    """bench.py's N > 1 data path (one RCCL all-gather of the log-ratio shard + one all-reduce of the result) with the
+    `nccl` backend at world_size 1 -- the only RCCL configuration a 1-GPU box allows: the collectives run directly on
+    device memory owned by libpfmi (zero-copy view) and on torch tensors the engine writes through raw pointers, and the
+    stream hand-over (engine stream -> torch stream -> engine stream) leaves the data intact.  world_size 2 is covered on
+    CPU by tests/test_distributed_cpu.py (gloo)."""
+    import torch
+    import torch.distributed as dist
+    from pfmi.distributed import pooled_psis_resample
+
+    class DevArray:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    try:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    except Exception as e:  # pragma: no cover
+        pytest.skip(f"RCCL process group could not be created on this box: {e!r}")
+    try:
+        tg, traces = _setup(pfmi_mod, eng, "lr50", 4, 6)
+        seeds = fit_seeds(eng.P, 4)
+        elbo, se, best = eng.elbo_batch(64, seeds)
+        pts = [int(eng.offsets[k]) + int(best[k]) for k in range(4)]
+        eng.pool_build(64, pts, seeds[pts])
+        pool, lr = eng.pool_get()
+        ptr, cnt = eng.pool_log_ratios_dev()
+        shard = torch.as_tensor(DevArray(ptr, cnt), device="cuda:0")
+        lr_all = torch.empty(cnt, dtype=torch.float64, device="cuda:0")
+        dist.all_gather_into_tensor(lr_all, shard)                    # RCCL reads libpfmi's buffer
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(lr_all.cpu().numpy(), lr)
+        res = eng.psis_dev(lr_all.data_ptr(), lr_all.numel())
+        idx = eng.resample_indices(cnt, 32, seed=9)
+        out = torch.zeros(tg.d * 32, dtype=torch.float64, device="cuda:0")
+        eng.pool_gather_dev(idx, 0, out.data_ptr())                 # engine stream writes a torch tensor ...
+        eng.sync()
+        dist.all_reduce(out)                                          # ... RCCL reduces it in place
+        torch.cuda.synchronize()
+        ref = eng.psis(lr)
+        np.testing.assert_array_equal(res["weights"], ref["weights"])
+        np.testing.assert_array_equal(out.cpu().numpy().reshape(32, tg.d).T, pool.reshape(tg.d, -1, order="F")[:, idx])
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
