@@ -103,15 +103,7 @@ __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------
-struct FitArgs {
-    int d, J;
-    const int64_t *off;
-    const int32_t *path_of;
-    const double *theta, *grad, *alpha_all;
-    const int32_t *hist_len, *hist_src;
-    double *vh, *tmat, *vchol, *rq, *dmat, *sqrt_alpha, *mu, *logdet;
-    int32_t *status;
-};
+#include "fit_args.h"
 
 // acc[cc] = sum_{i >= i0} M[i][c] * M[i][cc]  for all cc (block-wide, every thread gets the result)
 template <int KPAD>
@@ -139,6 +131,18 @@ __device__ __forceinline__ void pf_vec_dot(const double *M, int d, F f, double (
         for (int cc = 0; cc < KPAD; ++cc) acc[cc] += x * row[cc];
     }
     pf_block_sum<KPAD>(acc, red);
+}
+
+// block sum of 2 KPAD values through a `red` buffer sized for KPAD values per wave (two rounds)
+template <int KPAD>
+__device__ __forceinline__ void pf_block_sum2(double (&v)[2 * KPAD], double *red) {
+    double lo[KPAD], hi[KPAD];
+#pragma unroll
+    for (int cc = 0; cc < KPAD; ++cc) { lo[cc] = v[cc]; hi[cc] = v[KPAD + cc]; }
+    pf_block_sum<KPAD>(lo, red);
+    pf_block_sum<KPAD>(hi, red);
+#pragma unroll
+    for (int cc = 0; cc < KPAD; ++cc) { v[cc] = lo[cc]; v[KPAD + cc] = hi[cc]; }
 }
 
 template <int KPAD>
@@ -209,11 +213,23 @@ __global__ __launch_bounds__(FIT_THREADS) void pf_fit_kernel(FitArgs A) {
 
     double acc[KPAD];
     // ---- Gram matrix G = B~'B~ : G[c][b] (c < j, b < j) = Y'alpha Y ; G[j+a][b] = S'Y
-    for (int c = 0; c < m; ++c) {
-        pf_multi_dot<KPAD>(Vh, d, 0, c, acc, red);
+    // two Gram rows per sweep over the block (the kernel is bound by these sweeps at large d)
+    for (int c = 0; c < m; c += 2) {
+        double acc2[2 * KPAD];
+#pragma unroll
+        for (int cc = 0; cc < 2 * KPAD; ++cc) acc2[cc] = 0.0;
+        for (int i = tid; i < d; i += nt) {
+            const double *row = Vh + (size_t)i * KPAD;
+            double r[KPAD], x0 = 0.0, x1 = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < KPAD; ++cc) { r[cc] = row[cc]; if (cc == c) x0 = r[cc]; if (cc == c + 1) x1 = r[cc]; }
+#pragma unroll
+            for (int cc = 0; cc < KPAD; ++cc) { acc2[cc] += x0 * r[cc]; acc2[KPAD + cc] += x1 * r[cc]; }
+        }
+        pf_block_sum2<KPAD>(acc2, red);
         if (tid == 0) {
 #pragma unroll
-            for (int cc = 0; cc < KPAD; ++cc) sG[c * KPAD + cc] = acc[cc];
+            for (int cc = 0; cc < KPAD; ++cc) { sG[c * KPAD + cc] = acc2[cc]; if (c + 1 < m) sG[(c + 1) * KPAD + cc] = acc2[KPAD + cc]; }
         }
     }
     __syncthreads();
@@ -257,8 +273,10 @@ __global__ __launch_bounds__(FIT_THREADS) void pf_fit_kernel(FitArgs A) {
     __syncthreads();
 
     // ---- Householder QR of B~ (d x m), dgeqr2/dlarfg convention, + compact-WY T (dlarft)
+    // The sweep that applies reflector c to the trailing block also accumulates the dot products reflector c + 1 needs
+    // (column c + 1 against every column, rows > c + 1): one read + write of the block per column instead of 2 reads + 1 write.
     for (int c = 0; c < k; ++c) {
-        pf_multi_dot<KPAD>(Vh, d, c + 1, c, acc, red);
+        if (c == 0) pf_multi_dot<KPAD>(Vh, d, c + 1, c, acc, red);
         if (tid == 0) {
             const double *rowc = Vh + (size_t)c * KPAD;
             double xn2 = 0.0;
@@ -289,18 +307,39 @@ __global__ __launch_bounds__(FIT_THREADS) void pf_fit_kernel(FitArgs A) {
         __syncthreads();
         {
             const double scal = sScal;
+            double acc2[KPAD];
+#pragma unroll
+            for (int cc = 0; cc < KPAD; ++cc) acc2[cc] = 0.0;
             for (int i = c + 1 + tid; i < d; i += nt) {
                 double *row = Vh + (size_t)i * KPAD;
-                const double v = row[c] * scal;
-                row[c] = v;
+                double r[KPAD];
 #pragma unroll
-                for (int cc = 0; cc < KPAD; ++cc) if (cc > c) row[cc] -= sP[cc] * v;
+                for (int cc = 0; cc < KPAD; ++cc) r[cc] = row[cc];
+                double v = 0.0;
+#pragma unroll
+                for (int cc = 0; cc < KPAD; ++cc) if (cc == c) v = r[cc] * scal;
+                double xn = 0.0;
+#pragma unroll
+                for (int cc = 0; cc < KPAD; ++cc) {
+                    if (cc == c) { r[cc] = v; row[cc] = v; }
+                    else if (cc > c) { r[cc] -= sP[cc] * v; row[cc] = r[cc]; }
+                    if (cc == c + 1) xn = r[cc];
+                }
+                if (i > c + 1) {
+#pragma unroll
+                    for (int cc = 0; cc < KPAD; ++cc) acc2[cc] += xn * r[cc];
+                }
             }
             if (tid == 0) {
                 double *rowc = Vh + (size_t)c * KPAD;
                 rowc[c] = sBeta;
 #pragma unroll
                 for (int cc = 0; cc < KPAD; ++cc) if (cc > c) rowc[cc] -= sP[cc];
+            }
+            if (c + 1 < k) {
+                pf_block_sum<KPAD>(acc2, red);
+#pragma unroll
+                for (int cc = 0; cc < KPAD; ++cc) acc[cc] = acc2[cc];
             }
         }
         __threadfence_block();
@@ -868,8 +907,11 @@ int32_t pf_launch_fit(pfmi_ctx *c) {
     a.vh = c->vh.as<double>(); a.tmat = c->tmat.as<double>(); a.vchol = c->vchol.as<double>();
     a.rq = c->rq.as<double>(); a.dmat = c->dmat.as<double>(); a.sqrt_alpha = c->sqrt_alpha.as<double>();
     a.mu = c->mu.as<double>(); a.logdet = c->logdet.as<double>(); a.status = c->status.as<int32_t>();
+    a.P = c->P; a.cl_counter = nullptr; a.cl_buf = nullptr; a.cl_nwg = 1; a.cl_nclusters = 0;
     pf_kernel_begin(c);
-    switch (c->kpad) {
+    bool handled = false;                                     // large d: one cluster of workgroups per fit
+    PF_TRY(pf_launch_fit_cluster(c, a, &handled));
+    if (!handled) switch (c->kpad) {
         case 4: launch_fit_t<4>(c, a); break;
         case 8: launch_fit_t<8>(c, a); break;
         case 12: launch_fit_t<12>(c, a); break;
