@@ -251,8 +251,19 @@ def main():
             _, t_probe = run(2)
             nf = int(max(2, min(args.cpu_seconds / max(t_probe / 2, 1e-3), min(len(t.points) for t in traces) - 1)))
             r, t_cpu = run(nf)
+            # single-thread figure (SURVEY 8d asks for 1 thread and all cores): one path, a few fits
+            one = None
+            try:
+                nf1 = max(2, min(int(2.0 / max(t_probe / 2 / 1.0, 1e-3) * cores / max(cores, 1)), 12))
+                th1, gr1 = sel[0].points[:nf1 + 1], sel[0].gradients[:nf1 + 1]
+                t1 = time.perf_counter()
+                r1 = po.multipath_fit_elbo(np.array([0, nf1 + 1], dtype=np.int64), th1, gr1, J, otg, N_e,
+                                           np.arange(nf1 + 1, dtype=np.uint64) + np.uint64(1), nthreads=1)
+                one = round(r1["total_draws"] / (time.perf_counter() - t1), 1)
+            except Exception:
+                pass
             cpu = {"value": round(r["total_draws"] / t_cpu, 1), "unit": "ELBO draws/s", "cores": cores,
-                   "kind": "port",
+                   "kind": "port", "value_1_thread": one,
                    "sample": f"{cores} paths x first {nf} fits x {N_e} draws (d={d}, J={J}) = "
                              f"{r['total_draws']} draws in {t_cpu:.1f} s, OpenMP over paths"}
         except Exception as e:  # pragma: no cover

@@ -24,8 +24,7 @@
 // 1024 threads per path; each thread keeps its EPT coordinates of alpha, theta_l, grad_l in registers and prefetches
 // point l+1 while the four dot products of step l are block-reduced, so one trace iteration costs one reduction
 // instead of a round trip through HBM.
-#define HIST_NT 1024
-template <int EPT>
+template <int EPT, int HIST_NT>
 __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
     int d, int J, double eps, const int64_t *__restrict__ off, const double *__restrict__ theta,
     const double *__restrict__ grad, double *__restrict__ alpha_all, int *__restrict__ hist_len,
@@ -868,15 +867,16 @@ __global__ __launch_bounds__(NT) void pf_fit_reg_kernel(FitArgs A) {
 // ---------------------------------------------------------------------------------------------------
 int32_t pf_launch_history(pfmi_ctx *c, double eps) {
     PF_CHECK(c->J <= 64, PFMI_ERR_UNSUPPORTED, "history_length %d > 64 unsupported", c->J);
-    PF_CHECK(c->d <= 16 * HIST_NT, PFMI_ERR_UNSUPPORTED, "dimension %d > %d unsupported", c->d, 16 * HIST_NT);
+    PF_CHECK(c->d <= 16 * 1024, PFMI_ERR_UNSUPPORTED, "dimension %d > %d unsupported", c->d, 16 * 1024);
     pf_kernel_begin(c);
-    const int ept = (c->d + HIST_NT - 1) / HIST_NT;
-#define PF_HIST(E)                                                                                               \
-    hipLaunchKernelGGL(pf_history_kernel<E>, dim3(c->K), dim3(HIST_NT), 0, c->stream, c->d, c->J, eps,           \
+#define PF_HIST(E, NT)                                                                                           \
+    hipLaunchKernelGGL((pf_history_kernel<E, NT>), dim3(c->K), dim3(NT), 0, c->stream, c->d, c->J, eps,           \
                        c->d_off.as<int64_t>(), c->theta.as<double>(), c->grad.as<double>(),                      \
                        c->alpha_all.as<double>(), c->hist_len.as<int>(), c->hist_src.as<int>(), c->n_rej.as<int>())
-    if (ept <= 1) PF_HIST(1); else if (ept <= 2) PF_HIST(2); else if (ept <= 4) PF_HIST(4);
-    else if (ept <= 8) PF_HIST(8); else PF_HIST(16);
+    // the walk is sequential in l: one block reduction per iteration, cheaper across 4 waves than across 16
+    if (c->d <= 256) PF_HIST(1, 256); else if (c->d <= 512) PF_HIST(2, 256); else if (c->d <= 1024) PF_HIST(4, 256);
+    else { const int ept = (c->d + 1023) / 1024;
+           if (ept <= 2) PF_HIST(2, 1024); else if (ept <= 4) PF_HIST(4, 1024); else if (ept <= 8) PF_HIST(8, 1024); else PF_HIST(16, 1024); }
 #undef PF_HIST
     pf_kernel_end(c, "history");
     PF_HIP(hipGetLastError());
