@@ -844,3 +844,18 @@ def test_fit_kernel_variants_agree_at_large_d(pfmi_mod, eng, tname, d, J):
             assert abs(F.logdet - fa["logdet"]) <= 1e-9 * (1 + abs(F.logdet))
             mu_o = F.fit_mean(th[p], gr[p])
             np.testing.assert_allclose(fa["mu"], mu_o, rtol=1e-7, atol=1e-8 * (1 + np.abs(mu_o).max()))
+
+
+@pytest.mark.parametrize("name,K,J", [("iso10", 2, 6), ("lr50", 2, 6), ("diag30", 2, 10), ("funnel12", 2, 6)])
+def test_memory_resident_fit_kernel_matches_oracle(pfmi_mod, eng, name, K, J):
+    """the general fit kernel (the default only for d > 1024 or J > 8) forced onto the small oracle cases:
+    same dense W / logdet / mu / reflector-level checks as test_fit_batch_matches_oracle."""
+    old = os.environ.get("PFMI_FIT_KERNEL")
+    os.environ["PFMI_FIT_KERNEL"] = "mem"
+    try:
+        test_fit_batch_matches_oracle(pfmi_mod, eng, name, K, J)
+    finally:
+        if old is None:
+            os.environ.pop("PFMI_FIT_KERNEL", None)
+        else:
+            os.environ["PFMI_FIT_KERNEL"] = old
