@@ -212,23 +212,37 @@ __global__ __launch_bounds__(FIT_THREADS) void pf_fit_kernel(FitArgs A) {
 
     double acc[KPAD];
     // ---- Gram matrix G = B~'B~ : G[c][b] (c < j, b < j) = Y'alpha Y ; G[j+a][b] = S'Y
-    // two Gram rows per sweep over the block (the kernel is bound by these sweeps at large d)
-    for (int c = 0; c < m; c += 2) {
-        double acc2[2 * KPAD];
+    // four Gram rows per sweep over the block (the kernel is bound by these sweeps at large d)
+    constexpr int GR = 4;
+    for (int c = 0; c < m; c += GR) {
+        double accg[GR][KPAD];
 #pragma unroll
-        for (int cc = 0; cc < 2 * KPAD; ++cc) acc2[cc] = 0.0;
+        for (int g = 0; g < GR; ++g)
+#pragma unroll
+            for (int cc = 0; cc < KPAD; ++cc) accg[g][cc] = 0.0;
         for (int i = tid; i < d; i += nt) {
             const double *row = Vh + (size_t)i * KPAD;
-            double r[KPAD], x0 = 0.0, x1 = 0.0;
+            double r[KPAD], x[GR];
 #pragma unroll
-            for (int cc = 0; cc < KPAD; ++cc) { r[cc] = row[cc]; if (cc == c) x0 = r[cc]; if (cc == c + 1) x1 = r[cc]; }
+            for (int g = 0; g < GR; ++g) x[g] = 0.0;
 #pragma unroll
-            for (int cc = 0; cc < KPAD; ++cc) { acc2[cc] += x0 * r[cc]; acc2[KPAD + cc] += x1 * r[cc]; }
+            for (int cc = 0; cc < KPAD; ++cc) {
+                r[cc] = row[cc];
+#pragma unroll
+                for (int g = 0; g < GR; ++g) if (cc == c + g) x[g] = r[cc];
+            }
+#pragma unroll
+            for (int g = 0; g < GR; ++g)
+#pragma unroll
+                for (int cc = 0; cc < KPAD; ++cc) accg[g][cc] += x[g] * r[cc];
         }
-        pf_block_sum2<KPAD>(acc2, red);
-        if (tid == 0) {
 #pragma unroll
-            for (int cc = 0; cc < KPAD; ++cc) { sG[c * KPAD + cc] = acc2[cc]; if (c + 1 < m) sG[(c + 1) * KPAD + cc] = acc2[KPAD + cc]; }
+        for (int g = 0; g < GR; ++g) {
+            pf_block_sum<KPAD>(accg[g], red);
+            if (tid == 0 && c + g < m) {
+#pragma unroll
+                for (int cc = 0; cc < KPAD; ++cc) sG[(c + g) * KPAD + cc] = accg[g][cc];
+            }
         }
     }
     __syncthreads();
