@@ -859,3 +859,26 @@ def test_memory_resident_fit_kernel_matches_oracle(pfmi_mod, eng, name, K, J):
             os.environ.pop("PFMI_FIT_KERNEL", None)
         else:
             os.environ["PFMI_FIT_KERNEL"] = old
+
+
+@pytest.mark.parametrize("optimizer", ["device", "host"])
+def test_reference_literal_5x5_covariance_recovered(pfmi_mod, optimizer):
+    """reference test/singlepath.jl:67-100 (same matrix as docs/src/examples/quickstart.md:26-33): single-path Pathfinder on
+    N(0, Sigma) with the literal 5 x 5 Sigma, history 6, ndraws_elbo = 500: fit_distribution.Sigma ~ Sigma (rtol 0.1 in the
+    Frobenius norm, the reference's `isapprox`), reseeding reproduces fit, draws and ELBO values."""
+    Sigma = np.array([[2.71, 0.5, 0.19, 0.07, 1.04], [0.5, 1.11, -0.08, -0.17, -0.08], [0.19, -0.08, 0.26, 0.07, -0.7],
+                      [0.07, -0.17, 0.07, 0.11, -0.21], [1.04, -0.08, -0.7, -0.21, 8.65]])
+    lam, V = np.linalg.eigh(Sigma)
+    s2 = 0.5 * lam.min()                                              # Sigma = s2 I + W W'  (built-in Gaussian family, r = 5)
+    W = V * np.sqrt(lam - s2)
+    tg = pfmi_mod.GaussTarget(np.zeros(5), np.full(5, s2), W)
+    np.testing.assert_allclose(np.diag(np.full(5, s2)) + W @ W.T, Sigma, atol=1e-12)
+    x0 = pfmi_mod.HostRNG(38).randn(5)
+    res = pfmi_mod.pathfinder(tg, init=x0, ndraws_elbo=500, history_length=6, rng=pfmi_mod.HostRNG(38), optimizer=optimizer)
+    assert res.success
+    S = res.fit_distribution.Sigma.dense()
+    assert np.linalg.norm(S - Sigma) <= 0.1 * max(np.linalg.norm(S), np.linalg.norm(Sigma))
+    res2 = pfmi_mod.pathfinder(tg, init=x0, ndraws_elbo=500, history_length=6, rng=pfmi_mod.HostRNG(38), optimizer=optimizer)
+    np.testing.assert_array_equal(res2.draws, res.draws)
+    assert [e.value for e in res2.elbo_estimates] == [e.value for e in res.elbo_estimates]
+    np.testing.assert_array_equal(res2.fit_distribution.Sigma.dense(), S)

@@ -293,3 +293,35 @@ def test_log_ratio_ordering_identity():
         np.testing.assert_allclose(tgt.logp(X) - logq, exp, rtol=1e-10, atol=1e-10)
         ratios.append(got)
     assert np.concatenate(ratios).shape == (N * K,)
+
+
+def test_oracle_single_path_recovers_the_reference_literal_covariance():
+    """pins the whole oracle chain (driver -> history -> compact form -> factor -> ELBO argmax) on the reference's own
+    known answer: test/singlepath.jl:67-95 -- N(0, Sigma) with the literal 5 x 5 Sigma, history 6, ndraws_elbo = 500,
+    fit_distribution.Sigma ~ Sigma with rtol 0.1 (Frobenius, Julia's isapprox)."""
+    Sigma = np.array([[2.71, 0.5, 0.19, 0.07, 1.04], [0.5, 1.11, -0.08, -0.17, -0.08], [0.19, -0.08, 0.26, 0.07, -0.7],
+                      [0.07, -0.17, 0.07, 0.11, -0.21], [1.04, -0.08, -0.7, -0.21, 8.65]])
+    lam, V = np.linalg.eigh(Sigma)
+    s2 = 0.5 * lam.min()
+    W = V * np.sqrt(lam - s2)                                          # Sigma = s2 I + W W'
+    a = np.full(5, 1.0 / s2)
+    Wd = W * a[:, None]
+    G = np.linalg.inv(np.linalg.cholesky(np.eye(5) + W.T @ Wd))
+    tg = po.GaussTarget(np.zeros(5), a, Wd, G)
+    P = np.linalg.inv(Sigma)
+    x = np.random.default_rng(1).normal(size=(5, 3))
+    np.testing.assert_allclose(tg.logp(x), -0.5 * np.einsum("in,ij,jn->n", x, P, x), rtol=1e-11)
+    for seed in (38, 5):
+        x0 = np.random.default_rng(seed).normal(size=5)
+        pts, lps, grads = po.optimize_trace(tg, x0, 6)
+        seeds = np.arange(len(pts), dtype=np.uint64) + np.uint64(1000 * seed)
+        ref = po.path_fit_elbo(pts, grads, 6, tg, 500, seeds)
+        l = ref["best_iter"]
+        assert l >= 1
+        alpha_all, hl, hs, _ = po.lbfgs_history(pts, grads, 6)
+        j = int(hl[l])
+        S = np.stack([pts[s + 1] - pts[s] for s in hs[l, :j]], axis=1)
+        Y = np.stack([grads[s] - grads[s + 1] for s in hs[l, :j]], axis=1)
+        B, D = po.lbfgs_inverse_hessian(alpha_all[l], S, Y)
+        Sfit = np.diag(alpha_all[l]) + B @ D @ B.T
+        assert np.linalg.norm(Sfit - Sigma) <= 0.1 * max(np.linalg.norm(Sfit), np.linalg.norm(Sigma))
