@@ -882,3 +882,27 @@ def test_reference_literal_5x5_covariance_recovered(pfmi_mod, optimizer):
     np.testing.assert_array_equal(res2.draws, res.draws)
     assert [e.value for e in res2.elbo_estimates] == [e.value for e in res.elbo_estimates]
     np.testing.assert_array_equal(res2.fit_distribution.Sigma.dense(), S)
+
+
+def test_consistency_of_rand_300k_draws(pfmi_mod, eng):
+    """reference test/mvnormal.jl:66-109 ("consistency of rand"): 300 000 draws of a fitted MvNormal{WoodburyPDMat} -- sample
+    means, variances and (variance-stabilised) correlations against mu / Sigma with the reference's Bonferroni-corrected
+    normal tolerances.  Pins the device generator + transform statistically (d = 50, history 4)."""
+    from scipy.stats import norm
+    tg, traces = _setup(pfmi_mod, eng, "lr50", 1, 4)
+    status, jeff, _, _ = eng.fit_status()
+    p = int(np.flatnonzero((status == 0) & (jeff == 4))[3])
+    f = eng.get_fit(p, 4)
+    d = tg.d
+    Sig = np.diag(f["alpha"]) + f["B"] @ f["D"] @ f["B"].T
+    nd = 300_000
+    X = eng.draws(p, 123456789, nd)[0]
+    v = np.diag(Sig)
+    R = Sig / np.sqrt(v) / np.sqrt(v)[:, None]
+    mu_est, v_est, R_est = X.mean(1), X.var(1), np.corrcoef(X)
+    nchecks = 2 * d + d * (d - 1) // 2
+    tol = norm.ppf(1 - (0.01 / nchecks) / 2) / np.sqrt(nd)
+    assert np.all(np.abs(mu_est - f["mu"]) <= tol * np.sqrt(v))
+    assert np.all(np.abs(v_est - v) <= tol * np.sqrt(2) * v)
+    iu = np.triu_indices(d, 1)
+    assert np.all(np.abs(np.arctanh(R_est[iu]) - np.arctanh(R[iu])) <= tol)
