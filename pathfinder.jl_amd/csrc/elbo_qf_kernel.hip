@@ -29,8 +29,8 @@
 #define QF_WAVES 8                     // waves per workgroup = 16-draw groups in flight per fit
 #endif
 #define QF_THREADS (QF_WAVES * 64)
-#ifndef QF_PF2
-#define QF_PF2 0                       // 1: operands fetched one block ahead into a second register set
+#ifndef QF_NG
+#define QF_NG 2                        // 16-draw groups per wave (share the operand fetches of a block)
 #endif
 #define QF_CHB 16                      // blocks (of 16 rows) per streamed chunk
 
@@ -59,7 +59,7 @@ __device__ __forceinline__ int qf_vh_pos(int lrow, int col) {
     return (((bl * 4 + r) * (KC / 4) + T) << 4) + q * 4 + i;
 }
 
-template <int KC, int TGT, int RPAD>
+template <int KC, int TGT, int RPAD, int NG>
 __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int ch_blocks, int nchunks, int groups_per_wg, int ngroups) {
     extern __shared__ double lds[];
     constexpr int NT = KC / 4, TR = RPAD / 4, NC = qf_nconst(KC, RPAD);
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
     constexpr int NPG = (TGT != 0) ? (KC + 1 + 15) / 16 : 0;
     const int g_begin = blockIdx.x * groups_per_wg;
     const int g_end = (g_begin + groups_per_wg < ngroups) ? g_begin + groups_per_wg : ngroups;
-    const int nlb = (NPG + (g_end - g_begin) + QF_WAVES - 1) / QF_WAVES;      // batches of this workgroup
+    const int nlb = (NPG + (g_end - g_begin) + QF_WAVES * NG - 1) / (QF_WAVES * NG);   // batches of this workgroup
     if (A.status[p] != PFMI_FIT_OK) {
         for (int64_t n = (int64_t)g_begin * 16 + tid; n < (int64_t)g_end * 16 && n < A.N; n += QF_THREADS) {
             out_lp[n] = NAN; out_lq[n] = NAN;
@@ -149,21 +149,34 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
         if (tid < KC) cn_s[4 + KC + KC * KC + RPAD + RPAD * KC + tid] = Vh[tid];
     }
 
+    // A wave owns NG 16-draw groups at a time ("slots" NG*wv + g of the batch): they share every operand fetch of a block
+    // and give the scheduler NG independent RNG / MFMA streams to interleave.
     int cur = 0;
     for (int lb = 0; lb < nlb; ++lb) {
-        const int sl = lb * QF_WAVES + wv;                          // wave-uniform slot
-        const bool pseudo = sl < NPG;
-        const int grp = g_begin + sl - NPG;
-        const bool active = pseudo || grp < g_end;
-        const int64_t nl = (int64_t)grp * 16 + c;
-        const uint32_t n = (uint32_t)(A.n0 + nl);
-        double accw[NT], acc3[NT], acc4[TR > 0 ? TR : 1];
+        bool pseudo[NG], active[NG];
+        int sl[NG];
+        int64_t nl[NG];
+        uint32_t n[NG];
+        double accw[NG][NT], acc3[NG][NT], acc4[NG][TR > 0 ? TR : 1];
+        double usq[NG], q12[NG], z00[NG], u0[NG][4];
+        bool any_active = false, any_pseudo = false, any_real = false;
 #pragma unroll
-        for (int T = 0; T < NT; ++T) { accw[T] = 0.0; acc3[T] = 0.0; }
+        for (int g = 0; g < NG; ++g) {
+            sl[g] = (lb * QF_WAVES + wv) * NG + g;                  // wave-uniform slot
+            pseudo[g] = sl[g] < NPG;
+            const int grp = g_begin + sl[g] - NPG;
+            active[g] = pseudo[g] || grp < g_end;
+            nl[g] = (int64_t)grp * 16 + c;
+            n[g] = (uint32_t)(A.n0 + nl[g]);
+            any_active |= active[g]; any_pseudo |= pseudo[g]; any_real |= active[g] && !pseudo[g];
 #pragma unroll
-        for (int T = 0; T < (TR > 0 ? TR : 1); ++T) acc4[T] = 0.0;
-        double usq = 0.0, q12 = 0.0, z00 = 0.0;
-        double u0[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int T = 0; T < NT; ++T) { accw[g][T] = 0.0; acc3[g][T] = 0.0; }
+#pragma unroll
+            for (int T = 0; T < (TR > 0 ? TR : 1); ++T) acc4[g][T] = 0.0;
+            usq[g] = 0.0; q12[g] = 0.0; z00[g] = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u0[g][r] = 0.0;
+        }
         for (int ck = 0; ck < nchunks; ++ck) {
             // ---- streaming: fetch the next chunk (or chunk 0 for the next batch) into registers while this one is consumed
             double pre[PRE], pr_s = 0.0, pr_a = 0.0, pr_c = 0.0;
@@ -182,13 +195,11 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
                     if (row < d) { qf_row_ac<TGT>(A, mu, row, pr_a, pr_c); pr_s = sqa[row]; }
                 }
             }
-            if (active) {
+            if (any_active) {
                 const double *vs = lds + cur * buf_stride, *rs = vs + vh_sz;
                 const int blk0 = ck * ch_blocks;
                 const int nb = (nblk - blk0 < ch_blocks) ? nblk - blk0 : ch_blocks;
-                // operands of one block: A tiles of Vh (LDS), A tiles of Wd (L2), row scalars (LDS).  They are fetched one block
-                // AHEAD into a second register set (the loop is unrolled by two so that the sets swap roles without moves):
-                // the fetch latency hides behind the RNG + MFMA work of the current block.
+                // operands of one block: A tiles of Vh (LDS), A tiles of Wd (L2), row scalars (LDS), fetched before the RNG
                 struct Ops { double av[4][NT]; double wd[4][TR > 0 ? TR : 1]; double rs[12]; };
                 auto load_ops = [&](const int bl, Ops &o) {
                     const double *rp = rs + bl * 48 + 4 * q;
@@ -207,62 +218,63 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
                             for (int T = 0; T < TR; ++T) o.wd[r][T] = wp[r * 16 + 4 * T];
                     }
                 };
-                auto compute = [&](const int blk, const Ops &o) {
-                    // ---- normals of rows 16 blk + 4q + {0..3} of draw n
-                    uint32_t x[4];
-                    pf_philox4x32_10(n, (uint32_t)(blk * 4 + q), 0u, 0u, k0, k1, x);
-                    PfPair p1, p2;
-                    p1.s0(x[0], x[1]); p2.s0(x[2], x[3]);
-                    p1.s1(logtab, sctab); p2.s1(logtab, sctab);
-                    p1.s2(); p2.s2(); p1.s3(); p2.s3(); p1.s4(); p2.s4(); p1.s5(); p2.s5();
-                    double z[4];
-                    p1.s6(z[0], z[1]); p2.s6(z[2], z[3]);
-                    if (blk == nblk - 1) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) z[r] = (blk * 16 + 4 * q + r < d) ? z[r] : 0.0;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) usq = fma(z[r], z[r], usq);            // |u|^2 before the transform (src/mvnormal.jl:31)
-                    if (blk == 0) {                                                    // z[1:k] = V'u[1:k] (src/woodbury.jl:139)
-                        qf_d4 h = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { u0[r] = z[r]; h = qf_mfma16(a_h00[r], z[r], h); }
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) z[r] = h[r];
-                        z00 = z[0];
-                    } else if (KC > 16 && blk == 1) {
-                        qf_d4 h = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) h = qf_mfma16(a_h10[r], u0[r], h);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) h = qf_mfma16(a_h11[r], z[r], h);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) z[r] = h[r];
-                    }
+                // the contractions of one group: w = Vh'z, A3 = Vh'(a s^2 z), A4 = Wd'(s z), and the two scalars
+                auto contract = [&](const int g, const double (&z)[4], const Ops &o, const bool with_w) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const double zr = z[r];
                         double bp = 0.0;
                         if (TGT != 0) {
                             bp = o.rs[r] * zr;
-                            q12 = fma(bp + o.rs[4 + r], zr, q12);
+                            q12[g] = fma(bp + o.rs[4 + r], zr, q12[g]);
                         }
 #pragma unroll
                         for (int T = 0; T < NT; ++T) {
-                            accw[T] = qf_mfma4(o.av[r][T], zr, accw[T]);
-                            if (TGT != 0) acc3[T] = qf_mfma4(o.av[r][T], bp, acc3[T]);
+                            if (with_w) accw[g][T] = qf_mfma4(o.av[r][T], zr, accw[g][T]);
+                            if (TGT != 0) acc3[g][T] = qf_mfma4(o.av[r][T], bp, acc3[g][T]);
                         }
                         if (TGT == 1 && RPAD > 0) {
                             const double bs = o.rs[8 + r] * zr;
 #pragma unroll
-                            for (int T = 0; T < TR; ++T) acc4[T] = qf_mfma4(o.wd[r][T], bs, acc4[T]);
+                            for (int T = 0; T < TR; ++T) acc4[g][T] = qf_mfma4(o.wd[r][T], bs, acc4[g][T]);
                         }
                     }
                 };
+                // normals of rows 16 blk + 4q + {0..3} of draw n[g], head transform included
+                auto normals = [&](const int g, const int blk, double (&z)[4]) {
+                    uint32_t x[4];
+                    pf_philox4x32_10(n[g], (uint32_t)(blk * 4 + q), 0u, 0u, k0, k1, x);
+                    PfPair p1, p2;
+                    p1.s0(x[0], x[1]); p2.s0(x[2], x[3]);
+                    p1.s1(logtab, sctab); p2.s1(logtab, sctab);
+                    p1.s2(); p2.s2(); p1.s3(); p2.s3(); p1.s4(); p2.s4(); p1.s5(); p2.s5();
+                    p1.s6(z[0], z[1]); p2.s6(z[2], z[3]);
+                    if (blk == nblk - 1) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) z[r] = (blk * 16 + 4 * q + r < d) ? z[r] : 0.0;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) usq[g] = fma(z[r], z[r], usq[g]);      // |u|^2 before the transform (src/mvnormal.jl:31)
+                    if (blk == 0) {                                                    // z[1:k] = V'u[1:k] (src/woodbury.jl:139)
+                        qf_d4 h = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { u0[g][r] = z[r]; h = qf_mfma16(a_h00[r], z[r], h); }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) z[r] = h[r];
+                        z00[g] = z[0];
+                    } else if (KC > 16 && blk == 1) {
+                        qf_d4 h = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) h = qf_mfma16(a_h10[r], u0[g][r], h);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) h = qf_mfma16(a_h11[r], z[r], h);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) z[r] = h[r];
+                    }
+                };
                 // pseudo group: column j of this lane is Vh[:, j] (j < KC) or c/s (j == KC); no RNG, no head transform
-                auto compute_pseudo = [&](const int blk, const int bl, const Ops &o) {
-                    const int j = 16 * sl + c;
-                    double z[4];
+                auto pseudo_cols = [&](const int g, const int blk, const int bl, double (&z)[4]) {
+                    const int j = 16 * sl[g] + c;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = blk * 16 + 4 * q + r;
@@ -275,45 +287,30 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
                         }
                         z[r] = v;
                     }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const double zr = z[r], bp = o.rs[r] * zr;
-                        q12 = fma(bp + o.rs[4 + r], zr, q12);
-#pragma unroll
-                        for (int T = 0; T < NT; ++T) acc3[T] = qf_mfma4(o.av[r][T], bp, acc3[T]);
-                        if (TGT == 1 && RPAD > 0) {
-                            const double bs = o.rs[8 + r] * zr;
-#pragma unroll
-                            for (int T = 0; T < TR; ++T) acc4[T] = qf_mfma4(o.wd[r][T], bs, acc4[T]);
-                        }
-                    }
                 };
-                if (pseudo) {
+                if (any_pseudo) {                            // first batch only: mixed pseudo / real wave, no need to be fast
                     for (int bl = 0; bl < nb; ++bl) {
                         Ops oa;
                         load_ops(bl, oa);
-                        compute_pseudo(blk0 + bl, bl, oa);
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) {
+                            if (!active[g]) continue;
+                            double z[4];
+                            if (pseudo[g]) { pseudo_cols(g, blk0 + bl, bl, z); contract(g, z, oa, false); }
+                            else { normals(g, blk0 + bl, z); contract(g, z, oa, true); }
+                        }
                     }
                 } else {
-#if QF_PF2
-                Ops oa, ob;
-                load_ops(0, oa);
-                for (int bl = 0; bl < nb; bl += 2) {
-                    if (bl + 1 < nb) load_ops(bl + 1, ob);
-                    compute(blk0 + bl, oa);
-                    if (bl + 1 < nb) {
-                        if (bl + 2 < nb) load_ops(bl + 2, oa);
-                        compute(blk0 + bl + 1, ob);
+                    for (int bl = 0; bl < nb; ++bl) {
+                        Ops oa;
+                        load_ops(bl, oa);                    // issued first; the RNG below hides the LDS / L2 latency
+                        __builtin_amdgcn_sched_barrier(0);
+                        double z[NG][4];
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) normals(g, blk0 + bl, z[g]);   // a trailing inactive group only wastes its own lanes
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) contract(g, z[g], oa, true);
                     }
-                }
-#else
-                for (int bl = 0; bl < nb; ++bl) {
-                    Ops oa;
-                    load_ops(bl, oa);                          // issued first; the RNG below hides the LDS / L2 latency
-                    __builtin_amdgcn_sched_barrier(0);
-                    compute(blk0 + bl, oa);
-                }
-#endif
                 }
             }
             if (nchunks > 1) {
@@ -334,92 +331,100 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
             }
         }
         if (NPG > 0 && lb == 0) {                                  // publish the per-fit constants before any draw is finished
-            if (pseudo) {
-                const int j = 16 * sl + c;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (!pseudo[g]) continue;
+                const int j = 16 * sl[g] + c;
                 double *vv = cn_s + 4, *Mm = cn_s + 4 + KC, *t0 = Mm + KC * KC, *Nn = t0 + RPAD;
-                const double q3 = q12 + __shfl_xor(q12, 16, 64);
+                const double q3 = q12[g] + __shfl_xor(q12[g], 16, 64);
                 const double q4 = q3 + __shfl_xor(q3, 32, 64);
 #pragma unroll
                 for (int T = 0; T < NT; ++T) {
                     const int a = 4 * T + q;
-                    if (j < KC) Mm[a * KC + j] = acc3[T];
-                    else if (j == KC) vv[a] = acc3[T];
+                    if (j < KC) Mm[a * KC + j] = acc3[g][T];
+                    else if (j == KC) vv[a] = acc3[g][T];
                 }
 #pragma unroll
                 for (int T = 0; T < TR; ++T) {
                     const int jr = 4 * T + q;
-                    if (j < KC) Nn[jr * KC + j] = acc4[T];
-                    else if (j == KC) t0[jr] = acc4[T];
+                    if (j < KC) Nn[jr * KC + j] = acc4[g][T];
+                    else if (j == KC) t0[jr] = acc4[g][T];
                 }
                 if (j == KC && q == 0) cn_s[0] = q4 / 3.0;          // q12(c/s) = sum a c^2 + 2 sum a c^2
             }
             __syncthreads();
         }
-        if (!active || pseudo) continue;
-        // ---- finish the 16 draws of this wave in registers: lane (q, c) holds entries 4T + q of w, A3, A4 of draw c
-        usq += __shfl_xor(usq, 16, 64); usq += __shfl_xor(usq, 32, 64);
-        double lp = NAN;
-        if (TGT != 0) {
-            q12 += __shfl_xor(q12, 16, 64); q12 += __shfl_xor(q12, 32, 64);
-            double tv[KC];
+        if (!any_real) continue;
+        // ---- finish the 16 draws of each group in registers: lane (q, c) holds entries 4T + q of w, A3, A4 of draw c
 #pragma unroll
-            for (int a = 0; a < KC; ++a) {
-                double s = 0.0;
+        for (int g = 0; g < NG; ++g) {
+            if (!active[g] || pseudo[g]) continue;
+            double us = usq[g];
+            us += __shfl_xor(us, 16, 64); us += __shfl_xor(us, 32, 64);
+            double lp = NAN;
+            if (TGT != 0) {
+                double qs = q12[g];
+                qs += __shfl_xor(qs, 16, 64); qs += __shfl_xor(qs, 32, 64);
+                double tv[KC];
 #pragma unroll
-                for (int T = 0; T < NT; ++T) s = fma(t_s[a * KC + 4 * T + q], accw[T], s);
-                s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-                tv[a] = s;
-            }
-            const double *vv = cn_s + 4, *Mm = cn_s + 4 + KC, *t0 = Mm + KC * KC, *Nn = t0 + RPAD, *vh0 = Nn + RPAD * KC;
-            double qa = 0.0;
+                for (int a = 0; a < KC; ++a) {
+                    double s = 0.0;
 #pragma unroll
-            for (int T = 0; T < NT; ++T) {
-                const int a = 4 * T + q;
-                double mt = 0.0, tva = 0.0;
-#pragma unroll
-                for (int b = 0; b < KC; ++b) mt = fma(Mm[a * KC + b], tv[b], mt);
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) tva = (q == qq) ? tv[4 * T + qq] : tva;
-                qa = fma(tva, mt - 2.0 * (vv[a] + acc3[T]), qa);
-            }
-            qa += __shfl_xor(qa, 16, 64); qa += __shfl_xor(qa, 32, 64);
-            const double q1 = cn_s[0] + q12 + qa;
-            if (TGT == 1) {
-                double corr = 0.0;
-                if (RPAD > 0) {
-                    double tt[TR > 0 ? TR : 1];
-#pragma unroll
-                    for (int T = 0; T < TR; ++T) {
-                        const int j = 4 * T + q;
-                        double s = t0[j] + acc4[T];
-#pragma unroll
-                        for (int b = 0; b < KC; ++b) s = fma(-Nn[j * KC + b], tv[b], s);
-                        tt[T] = s;
-                    }
-                    double tall[RPAD > 0 ? RPAD : 1];
-#pragma unroll
-                    for (int j = 0; j < RPAD; ++j) tall[j] = __shfl(tt[j >> 2], (j & 3) * 16 + c, 64);
-#pragma unroll
-                    for (int j = 0; j < RPAD; ++j) {
-                        double g = 0.0;
-#pragma unroll
-                        for (int l = 0; l <= j; ++l) g = fma(g_s[j * RPAD + l], tall[l], g);
-                        corr = fma(g, g, corr);
-                    }
+                    for (int T = 0; T < NT; ++T) s = fma(t_s[a * KC + 4 * T + q], accw[g][T], s);
+                    s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+                    tv[a] = s;
                 }
-                lp = A.t_offset - 0.5 * (q1 - corr);
-            } else {                                                   // funnel: tau = x_1, ss = sum_{i>=2} x_i^2
-                const double zh = __shfl(z00, c, 64);
-                double pr = 0.0;
+                const double *vv = cn_s + 4, *Mm = cn_s + 4 + KC, *t0 = Mm + KC * KC, *Nn = t0 + RPAD, *vh0 = Nn + RPAD * KC;
+                double qa = 0.0;
 #pragma unroll
-                for (int b = 0; b < KC; ++b) pr = fma(vh0[b], tv[b], pr);
-                const double ta = cn_s[1] + cn_s[2] * (zh - pr), t3 = ta / 3.0;
-                lp = (t3 * t3 + (double)(d - 1) * ta + q1 * exp(-ta)) / -2.0;
+                for (int T = 0; T < NT; ++T) {
+                    const int a = 4 * T + q;
+                    double mt = 0.0, tva = 0.0;
+#pragma unroll
+                    for (int b = 0; b < KC; ++b) mt = fma(Mm[a * KC + b], tv[b], mt);
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) tva = (q == qq) ? tv[4 * T + qq] : tva;
+                    qa = fma(tva, mt - 2.0 * (vv[a] + acc3[g][T]), qa);
+                }
+                qa += __shfl_xor(qa, 16, 64); qa += __shfl_xor(qa, 32, 64);
+                const double q1 = cn_s[0] + qs + qa;
+                if (TGT == 1) {
+                    double corr = 0.0;
+                    if (RPAD > 0) {
+                        double tt[TR > 0 ? TR : 1];
+#pragma unroll
+                        for (int T = 0; T < TR; ++T) {
+                            const int j = 4 * T + q;
+                            double s = t0[j] + acc4[g][T];
+#pragma unroll
+                            for (int b = 0; b < KC; ++b) s = fma(-Nn[j * KC + b], tv[b], s);
+                            tt[T] = s;
+                        }
+                        double tall[RPAD > 0 ? RPAD : 1];
+#pragma unroll
+                        for (int j = 0; j < RPAD; ++j) tall[j] = __shfl(tt[j >> 2], (j & 3) * 16 + c, 64);
+#pragma unroll
+                        for (int j = 0; j < RPAD; ++j) {
+                            double gg = 0.0;
+#pragma unroll
+                            for (int l = 0; l <= j; ++l) gg = fma(g_s[j * RPAD + l], tall[l], gg);
+                            corr = fma(gg, gg, corr);
+                        }
+                    }
+                    lp = A.t_offset - 0.5 * (q1 - corr);
+                } else {                                                   // funnel: tau = x_1, ss = sum_{i>=2} x_i^2
+                    const double zh = __shfl(z00[g], c, 64);
+                    double pr = 0.0;
+#pragma unroll
+                    for (int b = 0; b < KC; ++b) pr = fma(vh0[b], tv[b], pr);
+                    const double ta = cn_s[1] + cn_s[2] * (zh - pr), t3 = ta / 3.0;
+                    lp = (t3 * t3 + (double)(d - 1) * ta + q1 * exp(-ta)) / -2.0;
+                }
             }
-        }
-        if (q == 0 && nl < A.N) {
-            out_lq[nl] = ((double)d * PF_LOG2PI + logdet + usq) / -2.0;        // src/mvnormal.jl:36
-            out_lp[nl] = lp;
+            if (q == 0 && nl[g] < A.N) {
+                out_lq[nl[g]] = ((double)d * PF_LOG2PI + logdet + us) / -2.0;        // src/mvnormal.jl:36
+                out_lp[nl[g]] = lp;
+            }
         }
     }
 }
@@ -430,14 +435,14 @@ static size_t qf_lds_bytes(int ch_blocks, int nchunks, int kc, int rpad) {
     return sizeof(double) * (per * (nchunks > 1 ? 2 : 1) + (size_t)kc * kc + qf_nconst(kc, rpad) + (size_t)rpad * rpad + 1 + 256 + 512);
 }
 
-template <int KC, int TGT, int RPAD>
-static int32_t launch_qf(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
+template <int KC, int TGT, int RPAD, int NG>
+static int32_t launch_qf_ng(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
     const int nblk = (a.d + 15) / 16;
     int ch_blocks = nblk, nchunks = 1;
     if (qf_lds_bytes(nblk, 1, KC, RPAD) > 156 * 1024) { ch_blocks = QF_CHB; nchunks = (nblk + QF_CHB - 1) / QF_CHB; }
     const size_t lds_bytes = qf_lds_bytes(ch_blocks, nchunks, KC, RPAD);
     PF_CHECK(lds_bytes <= 160 * 1024, PFMI_ERR_UNSUPPORTED, "qf kernel LDS %zu too large", lds_bytes);
-    auto kern = pf_elbo_qf_kernel<KC, TGT, RPAD>;
+    auto kern = pf_elbo_qf_kernel<KC, TGT, RPAD, NG>;
     static bool attr_set = false;
     if (!attr_set) {
         PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -448,9 +453,9 @@ static int32_t launch_qf(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
     // one workgroup per fit; a fit's groups are split over several workgroups only when there are few fits (every
     // workgroup recomputes the per-fit constants, so the pieces are kept to whole batches)
     int split = 1;
-    while ((int64_t)split * nfits < 1024 && (ngroups + NPG) / (split * 2) >= QF_WAVES) split *= 2;
+    while ((int64_t)split * nfits < 1024 && (ngroups + NPG) / (split * 2) >= QF_WAVES * NG) split *= 2;
     int gpw = (ngroups + split - 1) / split;
-    if (split > 1) gpw = ((gpw + NPG + QF_WAVES - 1) / QF_WAVES) * QF_WAVES - NPG;   // fill the last batch
+    if (split > 1) gpw = ((gpw + NPG + QF_WAVES * NG - 1) / (QF_WAVES * NG)) * (QF_WAVES * NG) - NPG;   // fill the last batch
     if (gpw < 1) gpw = 1;
     const int gx = (ngroups + gpw - 1) / gpw;
     for (int64_t s0 = 0; s0 < nfits; s0 += 32768) {
@@ -462,6 +467,16 @@ static int32_t launch_qf(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
                            ngroups);
     }
     return PFMI_OK;
+}
+
+// two 16-draw groups per wave when the scan is long enough to fill whole batches of 2 x 8 slots (measured +1 % at N = 1000;
+// short scans keep one group per wave so that more waves are busy); KC >= 16 would spill with two groups
+template <int KC, int TGT, int RPAD>
+static int32_t launch_qf(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
+    if constexpr (KC <= 12 && QF_NG == 2) {
+        if (a.N >= 768) return launch_qf_ng<KC, TGT, RPAD, 2>(c, a, nfits);
+    }
+    return launch_qf_ng<KC, TGT, RPAD, 1>(c, a, nfits);
 }
 
 template <int KC>
