@@ -306,8 +306,35 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
                         load_ops(bl, oa);                    // issued first; the RNG below hides the LDS / L2 latency
                         __builtin_amdgcn_sched_barrier(0);
                         double z[NG][4];
+                        if (NG == 2 && blk0 + bl > 1 && blk0 + bl < nblk - 1) {
+                            // interior block: the 2 x 2 Box-Muller pairs advance stage by stage (4 independent dependency chains)
+                            const int blk = blk0 + bl;
+                            uint32_t x[NG][4];
 #pragma unroll
-                        for (int g = 0; g < NG; ++g) normals(g, blk0 + bl, z[g]);   // a trailing inactive group only wastes its own lanes
+                            for (int g = 0; g < NG; ++g) pf_philox4x32_10(n[g], (uint32_t)(blk * 4 + q), 0u, 0u, k0, k1, x[g]);
+                            PfPair pp[NG][2];
+#pragma unroll
+                            for (int g = 0; g < NG; ++g) { pp[g][0].s0(x[g][0], x[g][1]); pp[g][1].s0(x[g][2], x[g][3]); }
+#pragma unroll
+                            for (int g = 0; g < NG; ++g) { pp[g][0].s1(logtab, sctab); pp[g][1].s1(logtab, sctab); }
+#pragma unroll
+                            for (int g = 0; g < NG; ++g) { pp[g][0].s2(); pp[g][1].s2(); }
+#pragma unroll
+                            for (int g = 0; g < NG; ++g) { pp[g][0].s3(); pp[g][1].s3(); }
+#pragma unroll
+                            for (int g = 0; g < NG; ++g) { pp[g][0].s4(); pp[g][1].s4(); }
+#pragma unroll
+                            for (int g = 0; g < NG; ++g) { pp[g][0].s5(); pp[g][1].s5(); }
+#pragma unroll
+                            for (int g = 0; g < NG; ++g) {
+                                pp[g][0].s6(z[g][0], z[g][1]); pp[g][1].s6(z[g][2], z[g][3]);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) usq[g] = fma(z[g][r], z[g][r], usq[g]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int g = 0; g < NG; ++g) normals(g, blk0 + bl, z[g]);   // a trailing inactive group only wastes its own lanes
+                        }
 #pragma unroll
                         for (int g = 0; g < NG; ++g) contract(g, z[g], oa, true);
                     }
