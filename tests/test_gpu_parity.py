@@ -906,3 +906,20 @@ def test_consistency_of_rand_300k_draws(pfmi_mod, eng):
     assert np.all(np.abs(v_est - v) <= tol * np.sqrt(2) * v)
     iu = np.triu_indices(d, 1)
     assert np.all(np.abs(np.arctanh(R_est[iu]) - np.arctanh(R[iu])) <= tol)
+
+
+def test_c_abi_demo_program(tmp_path):
+    """examples/c_abi_demo.c: the whole hot path driven from plain C through include/pfmi.h (what a Julia ccall / cgo / JNI
+    binding does) -- compiled here with gcc against the in-tree libpfmi.so, no Python or torch in the process."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc on this box")
+    exe = str(tmp_path / "c_abi_demo")
+    libdir = os.path.join(root, "pathfinder.jl_amd", "lib")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "c_abi_demo.c"), "-o", exe,
+                           "-L", libdir, "-lpfmi", f"-Wl,-rpath,{libdir}", "-lm"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.strip().splitlines()[-1].startswith("OK ")
