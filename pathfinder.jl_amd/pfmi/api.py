@@ -162,6 +162,14 @@ class PathfinderResult:             # src/singlepath.jl:53-70
             self.draws_ = self.draws_()
         return self.draws_
 
+    def __str__(self):                  # Base.show, src/singlepath.jl:72-83
+        lines = ["Single-path Pathfinder result", f"  tries: {self.num_tries}", f"  draws: {self.draws.shape[1]}",
+                 f"  fit iteration: {self.fit_iteration} (total: {len(self.optim_trace) - 1})"]
+        if self.fit_iteration >= 1:
+            lines.append(f"  fit ELBO: {str(self.elbo_estimates[self.fit_iteration - 1]).replace('ELBO estimate: ', '')}")
+        lines.append(f"  fit distribution: MvNormal(dim = {self.draws.shape[0]}, Sigma = WoodburyPDMat)")
+        return "\n".join(lines)
+
     @property
     def fit_distribution_transformed(self): return self.fit_distribution
     @property
@@ -185,6 +193,14 @@ class MultiPathfinderResult:        # src/multipath.jl:31-44
     def fit_distribution_transformed(self): return self.fit_distribution
     @property
     def draws_transformed(self): return self.draws
+
+    def __str__(self):                  # Base.show, src/multipath.jl:46-65
+        lines = ["Multi-path Pathfinder result", f"  runs: {len(self.pathfinder_results)}", f"  draws: {self.draws.shape[1]}"]
+        if self.psis_result is not None:
+            k = self.psis_result.pareto_shape
+            assessment = "very bad" if k > 1 else "bad" if k > 0.7 else "ok" if k > 0.5 else "good"
+            lines.append(f"  Pareto shape diagnostic: {round(k, 2)} ({assessment})")
+        return "\n".join(lines)
 
 
 # ---- helpers --------------------------------------------------------------------------------------------

@@ -473,6 +473,7 @@ def test_multipathfinder_end_to_end(pfmi_mod):
     assert r3.draws.shape == (d, 500)
     r4 = pfmi_mod.resample(res, 300, ndraws_per_run=100, rng=pfmi_mod.HostRNG(1))
     assert r4.draws.shape == (d, 300) and len(r4.psis_result.weights) == 100 * nruns
+    assert "Multi-path Pathfinder result" in str(res) and f"runs: {nruns}" in str(res) and "Pareto shape diagnostic" in str(res)
     r5 = pfmi_mod.resample(res, 50, importance=False, replace=False)
     assert r5.psis_result is None and len({tuple(c) for c in r5.draws.T}) == 50
 
@@ -493,6 +494,8 @@ def test_pathfinder_single_path_plumbing(pfmi_mod):
     np.testing.assert_array_equal(res.draws, res2.draws)
     assert [e.value for e in res2.elbo_estimates] == vals
     assert pfmi_mod.pathfinder(tg, init=init, ndraws=2).draws.shape == (10, 2)
+    txt = str(res)                                                       # Base.show (src/singlepath.jl:72-83)
+    assert txt.startswith("Single-path Pathfinder result") and f"fit iteration: {res.fit_iteration} (total: {len(res.optim_trace) - 1})" in txt
     with pytest.raises(ValueError):
         pfmi_mod.pathfinder(pfmi_mod.CallbackTarget(0, lambda x: 0.0))
 
