@@ -1,6 +1,6 @@
 """exploration script (not a test): wall-clock of the public multipathfinder() at config 3"""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "pathfinder.jl_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "pathfinder.jl_amd"))
 import numpy as np, pfmi, cProfile, pstats
 tg = pfmi.t_lowrank(1000, 8, 2)
 eng = pfmi.Engine(0)

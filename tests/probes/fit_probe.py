@@ -1,6 +1,6 @@
 """exploration script (not a test): fit kernel time vs history length / dimension"""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "pathfinder.jl_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "pathfinder.jl_amd"))
 import numpy as np, pfmi
 eng = pfmi.Engine(0)
 for d in (250, 1000):

@@ -1,6 +1,6 @@
 """exploration script (not a test): cluster fit kernel vs memory-resident kernel (PFMI_FIT_KERNEL=mem)"""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "pathfinder.jl_amd")); sys.path.insert(0, os.path.dirname(__file__)); sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "pathfinder.jl_amd")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np, pfmi
 eng = pfmi.Engine(0)
 def run(tg, K, J, scale, maxit):

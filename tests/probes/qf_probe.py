@@ -1,6 +1,6 @@
 """exploration script (not a test): qf kernel vs lane kernel agreement + timing"""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "pathfinder.jl_amd")); sys.path.insert(0, os.path.dirname(__file__)); sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "pathfinder.jl_amd")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np, pfmi
 from helpers import fit_seeds
 eng = pfmi.Engine(0)
