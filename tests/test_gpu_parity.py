@@ -926,3 +926,36 @@ def test_c_abi_demo_program(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.strip().splitlines()[-1].startswith("OK ")
+
+
+def test_c_abi_error_behaviour(pfmi_mod):
+    """the boundary never aborts: wrong call order / bad arguments come back as negative return codes with a message
+    (SURVEY.md 8b "Errors"), and the context stays usable afterwards."""
+    import ctypes as C
+    from pfmi import _lib
+    L = _lib.lib()
+    e = pfmi_mod.Engine(0)
+    assert L.pfmi_fit_batch(e.ctx, C.c_int32(6), C.c_double(1e-12)) == -3                      # PFMI_ERR_STATE: no traces yet
+    assert b"no traces" in L.pfmi_last_error()
+    tg = pfmi_mod.t_iso(8)
+    e.set_target(tg)
+    x0 = np.ones((2, 8))
+    e.optimize_batch(x0, 6)
+    elbo = np.empty(e.P); se = np.empty(e.P); best = np.empty(2, dtype=np.int64)
+    seeds = fit_seeds(e.P, 1)
+    rc = L.pfmi_elbo_batch(e.ctx, C.c_int64(10), seeds.ctypes.data_as(C.POINTER(C.c_uint64)), None,
+                           elbo.ctypes.data_as(C.POINTER(C.c_double)), se.ctypes.data_as(C.POINTER(C.c_double)),
+                           best.ctypes.data_as(C.POINTER(C.c_int64)))
+    assert rc == -3                                                                          # fit_batch not called yet
+    assert L.pfmi_fit_batch(e.ctx, C.c_int32(0), C.c_double(1e-12)) == -1                      # PFMI_ERR_ARG
+    assert L.pfmi_fit_batch(e.ctx, C.c_int32(40), C.c_double(1e-12)) == -4                     # PFMI_ERR_UNSUPPORTED (J > 16)
+    e.fit_batch(6)
+    X = np.zeros((8, 3), order="F"); out = np.zeros((8, 3), order="F")
+    dp = C.POINTER(C.c_double)
+    assert L.pfmi_woodbury_apply(e.ctx, C.c_int64(0), C.c_int32(99), C.c_int64(3), X.ctypes.data_as(dp), out.ctypes.data_as(dp)) == -1
+    assert L.pfmi_woodbury_apply(e.ctx, C.c_int64(10**6), C.c_int32(0), C.c_int64(3), X.ctypes.data_as(dp), out.ctypes.data_as(dp)) == -1
+    assert L.pfmi_create(C.c_int32(99), C.byref(C.c_void_p())) == -1                           # no such device
+    assert L.pfmi_fit_batch(None, C.c_int32(6), C.c_double(1e-12)) == -1                       # null context
+    el, _, b = e.elbo_batch(32, seeds)                                                       # still usable
+    assert np.isfinite(el[1]) and b[0] >= 1
+    e.close()
