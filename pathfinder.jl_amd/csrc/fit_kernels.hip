@@ -132,18 +132,6 @@ __device__ __forceinline__ void pf_vec_dot(const double *M, int d, F f, double (
     pf_block_sum<KPAD>(acc, red);
 }
 
-// block sum of 2 KPAD values through a `red` buffer sized for KPAD values per wave (two rounds)
-template <int KPAD>
-__device__ __forceinline__ void pf_block_sum2(double (&v)[2 * KPAD], double *red) {
-    double lo[KPAD], hi[KPAD];
-#pragma unroll
-    for (int cc = 0; cc < KPAD; ++cc) { lo[cc] = v[cc]; hi[cc] = v[KPAD + cc]; }
-    pf_block_sum<KPAD>(lo, red);
-    pf_block_sum<KPAD>(hi, red);
-#pragma unroll
-    for (int cc = 0; cc < KPAD; ++cc) { v[cc] = lo[cc]; v[KPAD + cc] = hi[cc]; }
-}
-
 template <int KPAD>
 __global__ __launch_bounds__(FIT_THREADS) void pf_fit_kernel(FitArgs A) {
     const int p = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
