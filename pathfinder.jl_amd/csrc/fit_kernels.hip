@@ -876,7 +876,9 @@ int32_t pf_launch_history(pfmi_ctx *c, double eps) {
                        c->d_off.as<int64_t>(), c->theta.as<double>(), c->grad.as<double>(),                      \
                        c->alpha_all.as<double>(), c->hist_len.as<int>(), c->hist_src.as<int>(), c->n_rej.as<int>())
     // the walk is sequential in l: one block reduction per iteration, cheaper across 4 waves than across 16
-    if (c->d <= 256) PF_HIST(1, 256); else if (c->d <= 512) PF_HIST(2, 256); else if (c->d <= 1024) PF_HIST(4, 256);
+    // (a single wave for d <= 256: no cross-wave exchange at all)
+    if (c->d <= 64) PF_HIST(1, 64); else if (c->d <= 128) PF_HIST(2, 64); else if (c->d <= 256) PF_HIST(4, 64);
+    else if (c->d <= 512) PF_HIST(2, 256); else if (c->d <= 1024) PF_HIST(4, 256);
     else { const int ept = (c->d + 1023) / 1024;
            if (ept <= 2) PF_HIST(2, 1024); else if (ept <= 4) PF_HIST(4, 1024); else if (ept <= 8) PF_HIST(8, 1024); else PF_HIST(16, 1024); }
 #undef PF_HIST

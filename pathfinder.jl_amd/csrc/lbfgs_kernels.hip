@@ -325,6 +325,7 @@ int32_t pf_launch_lbfgs(pfmi_ctx *c, int K, int J, int maxiters, double g_tol, c
 #define PF_LB(EPT, NT)                                                                    \
     (rp == 0 ? launch_lb<EPT, NT, 0>(c, A, K, dyn)                                        \
              : rp == 8 ? launch_lb<EPT, NT, 8>(c, A, K, dyn) : launch_lb<EPT, NT, 16>(c, A, K, dyn))
+    if (d <= 256) return PF_LB(4, 64);                       // a single wave: block reductions need no cross-wave exchange
     if (d <= 1024) return PF_LB(4, 256);
     if (d <= 10240) return PF_LB(10, 1024);
     PF_CHECK(d <= 16384, PFMI_ERR_UNSUPPORTED, "optimize_batch: d = %d > 16384 unsupported", d);
