@@ -101,14 +101,21 @@ class CallbackTarget:
     ``logp(x) -> float``; ``grad(x)`` optional (finite differences otherwise)."""
     kind = KIND_CALLBACK
 
-    def __init__(self, d, logp, grad=None):
+    def __init__(self, d, logp, grad=None, logp_batch=None):
+        """logp(x) -> float for one point (the reference's contract, src/elbo.jl:15); optional
+        logp_batch(X) -> (n,) for X of shape (d, n) evaluates a whole block of draws at once (the C ABI hands the
+        callback all draws of a block, so a vectorised target avoids n Python calls)."""
         self.d = d
         self._logp = logp
         self._grad = grad
+        self._logp_batch = logp_batch
 
         def _cb(Xp, d_, n, outp, _user):
             X = np.ctypeslib.as_array(Xp, shape=(n, d_))
             out = np.ctypeslib.as_array(outp, shape=(n,))
+            if self._logp_batch is not None:
+                out[:] = np.asarray(self._logp_batch(X.T), dtype=np.float64)
+                return
             for i in range(n):
                 out[i] = self._logp(X[i])
 
@@ -118,6 +125,8 @@ class CallbackTarget:
         x = np.asarray(x, dtype=np.float64)
         if x.ndim == 1:
             return float(self._logp(x))
+        if self._logp_batch is not None:
+            return np.asarray(self._logp_batch(x), dtype=np.float64)
         return np.array([self._logp(x[:, i]) for i in range(x.shape[1])])
 
     def grad(self, x):

@@ -288,7 +288,8 @@ def test_callback_target_equals_builtin(pfmi_mod, eng):
     traces = make_traces(tg, 2, 5)
     seeds = None
     out = []
-    for target in (tg, pfmi_mod.CallbackTarget(20, lambda x: float(tg.logp(x)))):
+    for target in (tg, pfmi_mod.CallbackTarget(20, lambda x: float(tg.logp(x))),
+                   pfmi_mod.CallbackTarget(20, lambda x: float(tg.logp(x)), logp_batch=lambda X: tg.logp(X))):   # vectorised closure
         eng.set_target(target)
         eng.set_traces([t.points for t in traces], [t.gradients for t in traces])
         eng.fit_batch(6)
@@ -296,8 +297,9 @@ def test_callback_target_equals_builtin(pfmi_mod, eng):
         out.append(eng.elbo_batch(64, seeds))
         eng.pool_build(70, [int(eng.offsets[k]) + int(out[-1][2][k]) for k in range(2)], [1, 2])
         out[-1] = out[-1] + eng.pool_get()
-    for a, b in zip(out[0], out[1]):
-        np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-12, equal_nan=True)
+    for o in out[1:]:
+        for a, b in zip(out[0], o):
+            np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-12, equal_nan=True)
 
 
 # ---- PSIS / resampling ----------------------------------------------------------------------------------
