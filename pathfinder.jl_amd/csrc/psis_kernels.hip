@@ -29,18 +29,69 @@ struct SelectState {
     unsigned hist[256];
     unsigned long long prefix;
     long long remaining;
-    unsigned count;
+    unsigned count, eq_count;
+    unsigned long long wmin[16], wmax[16];
+    unsigned wtot[4];
 };
+
+// From the 256-bin histogram pick the bin (scanning from the top) in which the `remaining`-th largest element falls;
+// updates st->prefix / st->remaining (and eq_count = population of the picked bin).  Parallel suffix scan by the first 256
+// threads (thread t owns bin 255 - t) instead of a 256-step serial walk by one thread.  All threads must call it.
+__device__ __forceinline__ void pf_hist_pick(SelectState *st, unsigned long long prefix, int pass) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const long long rem = st->remaining;
+    unsigned h = 0u, incl = 0u;
+    if (tid < 256) {
+        h = st->hist[255 - tid];
+        incl = h;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) st->wtot[tid >> 6] = incl;
+    }
+    __syncthreads();
+    if (tid < 256) {
+        unsigned base = 0u;
+        for (int w = 0; w < (tid >> 6); ++w) base += st->wtot[w];
+        incl += base;
+        const unsigned excl = incl - h;
+        if ((long long)excl < rem && (long long)incl >= rem) {          // exactly one bin qualifies
+            st->remaining = rem - (long long)excl;
+            st->prefix = prefix | ((unsigned long long)(255 - tid) << (8 * pass));
+            st->eq_count = h;
+        }
+    }
+    __syncthreads();
+}
 
 // Select the R largest elements of vals[0..S) in (value, index) order.  On return (all threads):
 // tkeys/tidx [0..R) hold them sorted ASCENDING (LDS).  Requires R <= TAILCAP, blockDim = PSIS_THREADS.
 __device__ void pf_select_top_sorted(const double *__restrict__ vals, long long S, int R, uint64_t *tkeys,
                                      uint32_t *tidx, SelectState *st) {
     const int tid = threadIdx.x, nt = blockDim.x;
-    // ---- radix select of the R-th largest key
-    if (tid == 0) { st->prefix = 0ull; st->remaining = R; }
+    // ---- radix select of the R-th largest key.  Bytes shared by ALL keys are skipped: log ratios of one pool have the same
+    //      sign / exponent, so the top 1-2 passes would serialise every LDS atomic on a single histogram bin.
+    int top_pass = 7;
+    {
+        uint64_t kmin = ~0ull, kmax = 0ull;
+        for (long long i = tid; i < S; i += nt) { const uint64_t k = pf_key_of(vals[i]); kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax; }
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint64_t a = __shfl_xor(kmin, off, 64), b = __shfl_xor(kmax, off, 64);
+            kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax;
+        }
+        if ((tid & 63) == 0) { st->wmin[tid >> 6] = kmin; st->wmax[tid >> 6] = kmax; }
+        __syncthreads();
+        kmin = st->wmin[0]; kmax = st->wmax[0];
+        for (int w = 1; w < (nt >> 6); ++w) { kmin = st->wmin[w] < kmin ? st->wmin[w] : kmin; kmax = st->wmax[w] > kmax ? st->wmax[w] : kmax; }
+        const uint64_t diff = kmin ^ kmax;
+        top_pass = diff ? (63 - __clzll((long long)diff)) / 8 : 0;
+        __syncthreads();
+        if (tid == 0) { st->prefix = (top_pass == 7) ? 0ull : (kmax & (~0ull << (8 * (top_pass + 1)))); st->remaining = R; st->eq_count = 0u; }
+    }
     __syncthreads();
-    for (int pass = 7; pass >= 0; --pass) {
+    for (int pass = top_pass; pass >= 0; --pass) {
         for (int b = tid; b < 256; b += nt) st->hist[b] = 0u;
         __syncthreads();
         const unsigned long long prefix = st->prefix;
@@ -50,25 +101,16 @@ __device__ void pf_select_top_sorted(const double *__restrict__ vals, long long 
             if ((k & himask) == prefix) atomicAdd(&st->hist[(unsigned)((k >> (8 * pass)) & 0xFF)], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            long long rem = st->remaining;
-            int b = 255;
-            for (; b > 0; --b) {
-                if ((long long)st->hist[b] >= rem) break;
-                rem -= st->hist[b];
-            }
-            st->remaining = rem;
-            st->prefix = prefix | ((unsigned long long)b << (8 * pass));
-        }
-        __syncthreads();
+        pf_hist_pick(st, prefix, pass);
     }
     const uint64_t tk = st->prefix;          // threshold key; st->remaining of the equal-key elements are needed
     const long long need_eq = st->remaining;
+    const bool all_eq = (long long)st->eq_count == need_eq;     // no tie to break: every equal-key element is selected
     __syncthreads();
-    // ---- among key == tk take the `need_eq` LARGEST indices: radix select on the index
+    // ---- among key == tk take the `need_eq` LARGEST indices: radix select on the index (only when there is a tie)
     if (tid == 0) { st->prefix = 0ull; st->remaining = need_eq; }
     __syncthreads();
-    for (int pass = 3; pass >= 0; --pass) {
+    for (int pass = all_eq ? -1 : 3; pass >= 0; --pass) {
         for (int b = tid; b < 256; b += nt) st->hist[b] = 0u;
         __syncthreads();
         const unsigned long long prefix = st->prefix;
@@ -78,17 +120,7 @@ __device__ void pf_select_top_sorted(const double *__restrict__ vals, long long 
                 atomicAdd(&st->hist[(unsigned)((i >> (8 * pass)) & 0xFF)], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            long long rem = st->remaining;
-            int b = 255;
-            for (; b > 0; --b) {
-                if ((long long)st->hist[b] >= rem) break;
-                rem -= st->hist[b];
-            }
-            st->remaining = rem;
-            st->prefix = prefix | ((unsigned long long)b << (8 * pass));
-        }
-        __syncthreads();
+        pf_hist_pick(st, prefix, pass);
     }
     const unsigned long long ti = st->prefix;   // index threshold
     // ---- compact the selected elements into LDS, pad with sentinels, bitonic sort ascending
