@@ -90,10 +90,26 @@ class WoodburyPDMat:                # src/woodbury.jl:246-257
 
 @dataclass
 class MvNormal:
-    mu: np.ndarray
-    Sigma: WoodburyPDMat
+    """MvNormal{WoodburyPDMat} (src/mvnormal.jl:18).  mu / Sigma may be left to be downloaded from the engine on first access
+    (multipathfinder keeps ~10^4 of these as handles)."""
+    mu_: Any
+    Sigma_: Any
     engine: Any = field(repr=False, default=None)
     point: int = -1
+    j: int = -1                      # effective history length of this fit (needed to size B, D when materialising)
+
+    def _materialise(self):
+        if self.Sigma_ is None and self.engine is not None and self.j >= 0:
+            f = self.engine.get_fit(self.point, self.j)
+            F = WoodburyPDFactorization(np.sqrt(f["alpha"]), f["qr_factors"], f["T"], f["V"])
+            self.Sigma_ = WoodburyPDMat(f["alpha"], f["B"], f["D"], F, f["logdet"], self.engine, self.point)
+            self.mu_ = f["mu"]
+        return self
+
+    @property
+    def mu(self): return self._materialise().mu_
+    @property
+    def Sigma(self): return self._materialise().Sigma_
 
     def logpdf(self, X):
         return self.engine.logpdf(self.point, X)
@@ -209,12 +225,8 @@ _STATUS_MSG = {1: "A = diag(alpha) is not positive definite", 2: "C = I + R D R'
 
 
 def _make_dist(eng, p, jeff, materialise=True):
-    if not materialise:
-        return MvNormal(None, None, eng, p)
-    f = eng.get_fit(p, int(jeff[p]))
-    F = WoodburyPDFactorization(np.sqrt(f["alpha"]), f["qr_factors"], f["T"], f["V"])
-    W = WoodburyPDMat(f["alpha"], f["B"], f["D"], F, f["logdet"], eng, p)
-    return MvNormal(f["mu"], W, eng, p)
+    dist = MvNormal(None, None, eng, p, int(jeff[p]))
+    return dist._materialise() if materialise else dist
 
 
 def _make_dists(eng, p0, npts, status, jeff, materialise=True):
