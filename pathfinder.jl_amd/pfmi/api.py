@@ -332,16 +332,24 @@ def _run_paths(eng, target, inits, run_rngs, *, dim, history_length, ndraws_elbo
     on_device = _use_device_optimizer(target, optimizer)
     okw = {k: v for k, v in optimizer_kwargs.items() if k in ("maxiters", "g_tol")}
     while pending:
+        need = []
         for k in pending:
             st = state[k]
             st["itry"] += 1
-            rng = run_rngs[k]
             if st["itry"] == 1 and inits[k] is not None:
                 st["x0"] = np.array(inits[k], dtype=np.float64)
             else:
-                st["x0"] = init_sampler(rng, np.empty(dim))    # src/singlepath.jl:167-168, 277
-            if not on_device:
-                st["trace"] = optimize_with_trace(target, st["x0"], history_length=history_length, **optimizer_kwargs)
+                need.append(k)
+        if need and type(init_sampler) is UniformSampler:          # src/singlepath.jl:167-168, 277 -- all runs in one Philox batch
+            for k, u in zip(need, rand_u64_multi([run_rngs[k] for k in need], [dim] * len(need))):
+                state[k]["x0"] = ((u >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)) * 2 * init_sampler.scale \
+                    - init_sampler.scale
+        else:
+            for k in need:
+                state[k]["x0"] = init_sampler(run_rngs[k], np.empty(dim))
+        if not on_device:
+            for k in pending:
+                state[k]["trace"] = optimize_with_trace(target, state[k]["x0"], history_length=history_length, **optimizer_kwargs)
         if on_device:     # every path in one launch; finished paths are recomputed identically from their x0
             npts = eng.optimize_batch(np.stack([s["x0"] for s in state]), history_length, **okw)
             for k in range(K):
