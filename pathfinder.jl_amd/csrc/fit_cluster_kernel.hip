@@ -48,6 +48,9 @@ __device__ __forceinline__ void cl_sum(double (&v)[NV], double *red, double *xch
     // release/acquire pair would flush and invalidate the whole L2 on this multi-XCD part (measured: ~30 us per exchange).
     // What remains is ordering: the partials must have been performed before the arrival counter moves (workgroup-scope
     // release = wait for the outstanding stores), and nothing below may be hoisted above the spin loop.
+    // (a workgroup-scope release emits no wait for global stores -- within a workgroup they share the L1 --, so the wait for
+    //  the store acknowledgements is spelled out: without it the arrival counter overtook the partials about once in 10 runs)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (tid == 0) {
