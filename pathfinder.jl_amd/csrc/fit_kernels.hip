@@ -471,7 +471,7 @@ __global__ __launch_bounds__(FIT_THREADS) void pf_fit_kernel(FitArgs A) {
 // LAPACK reflector convention as pf_fit_kernel; only the summation order inside the block reductions differs
 // (fp64 roundoff), which the parity tests cover.
 template <int KPAD, int RPT, int NT>
-__global__ __launch_bounds__(NT) void pf_fit_reg_kernel(FitArgs A) {
+__global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_fit_reg_kernel(FitArgs A) {   // measured best occupancy per KPAD (J = 6: 3 waves per SIMD, 168 VGPRs + 19 spilled dwords beat 2 waves with 221)
     const int p = blockIdx.x, tid = threadIdx.x;
     const int d = A.d, J = A.J;
     const int path = A.path_of[p];
@@ -493,20 +493,16 @@ __global__ __launch_bounds__(NT) void pf_fit_reg_kernel(FitArgs A) {
     __shared__ int sStatus;
 
     double a[RPT][KPAD];       // this thread's rows of B~ (later: Householder vectors)
-    double sq[RPT], ag[RPT];   // sqrt(alpha_i), sqrt(alpha_i) * grad_i
     double bad = 0.0, ldu = 0.0;
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
         const int row = tid + NT * i;
-        sq[i] = 1.0; ag[i] = 0.0;
         if (row < d) {
             const double al = alpha[row];
             if (!(al > 0.0) || !isfinite(al)) bad = 1.0;
             const double s = sqrt(al);
-            sq[i] = s;
             sqa[row] = s;
             ldu += log(s);
-            ag[i] = s * grad_p[row];
         }
     }
     {
@@ -536,7 +532,7 @@ __global__ __launch_bounds__(NT) void pf_fit_reg_kernel(FitArgs A) {
 #pragma unroll
         for (int c = 0; c < KPAD; ++c) a[i][c] = 0.0;
         if (row < d) {
-            const double al = alpha[row], isa = 1.0 / sq[i];         // one reciprocal per row instead of 2 j divisions
+            const double al = alpha[row], isa = 1.0 / sqrt(al);       // one reciprocal per row instead of 2 j divisions
 #pragma unroll
             for (int c = 0; c < KPAD / 2; ++c) {
                 if (c < j) {
@@ -644,9 +640,7 @@ __global__ __launch_bounds__(NT) void pf_fit_reg_kernel(FitArgs A) {
 
     // ---- Householder QR, one block reduction per column.  Thread aa < KPAD keeps row aa of the compact-WY T in
     //      registers (dlarft: T[0:c, c] = -tau T[0:c,0:c] (Vh' v_c)), so the column loop has no serial section.
-    double trow[KPAD];
-#pragma unroll
-    for (int cc = 0; cc < KPAD; ++cc) trow[cc] = 0.0;
+    // (row aa of T lives in LDS and is only ever touched by thread aa: no barrier needed, and 2 KPAD fewer VGPRs)
     for (int c = 0; c < k; ++c) {
         double *srow = sRow[c & 1];
         if (tid == c) {                       // row c belongs to thread c (slot 0): publish it
@@ -679,7 +673,7 @@ __global__ __launch_bounds__(NT) void pf_fit_reg_kernel(FitArgs A) {
             tau = (beta - alpha_c) / beta;
             scal = 1.0 / (alpha_c - beta);
         }
-        double wv[KPAD];                     // cc > c: tau * (v_c . column cc); cc < c: v_c . v_cc
+        double (&wv)[KPAD] = acc;            // in place -- cc > c: tau * (v_c . column cc); cc < c: v_c . v_cc
 #pragma unroll
         for (int cc = 0; cc < KPAD; ++cc) {
             const double vdot = srow[cc] + scal * acc[cc];
@@ -688,10 +682,9 @@ __global__ __launch_bounds__(NT) void pf_fit_reg_kernel(FitArgs A) {
         if (tid <= c && tid < KPAD) {        // T column c, one row per thread
             double v = 0.0;
 #pragma unroll
-            for (int b = 0; b < KPAD; ++b) if (b >= tid && b < c) v += trow[b] * wv[b];
+            for (int b = 0; b < KPAD; ++b) if (b >= tid && b < c) v += sT[tid * KPAD + b] * wv[b];
             const double tnew = (tid == c) ? tau : -tau * v;
-#pragma unroll
-            for (int b = 0; b < KPAD; ++b) if (b == c) trow[b] = tnew;
+            sT[tid * KPAD + c] = tnew;
         }
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
@@ -713,10 +706,6 @@ __global__ __launch_bounds__(NT) void pf_fit_reg_kernel(FitArgs A) {
                 }
             }
         }
-    }
-    if (tid < KPAD) {
-#pragma unroll
-        for (int cc = 0; cc < KPAD; ++cc) sT[tid * KPAD + cc] = trow[cc];
     }
     // ---- split: R (k x m) -> sR; Householder vectors get an explicit unit diagonal
     if (tid < k) {
@@ -791,13 +780,19 @@ __global__ __launch_bounds__(NT) void pf_fit_reg_kernel(FitArgs A) {
         if (tid == 0) { A.status[p] = sStatus; A.logdet[p] = NAN; }
         return;
     }
-    // ---- mu = theta + U' Q [V'V 0;0 I] Q' U g
+    // ---- mu = theta + U' Q [V'V 0;0 I] Q' U g     (sqrt(alpha) and sqrt(alpha) * grad are re-read rather than kept in VGPRs)
+    double agv[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int row = tid + NT * i;
+        agv[i] = (row < d) ? sqa[row] * grad_p[row] : 0.0;
+    }
 #pragma unroll
     for (int cc = 0; cc < KPAD; ++cc) acc[cc] = 0.0;
 #pragma unroll
     for (int i = 0; i < RPT; ++i)
 #pragma unroll
-        for (int cc = 0; cc < KPAD; ++cc) acc[cc] += ag[i] * a[i][cc];
+        for (int cc = 0; cc < KPAD; ++cc) acc[cc] += agv[i] * a[i][cc];
     pf_block_sum<KPAD>(acc, red);
     double t1[KPAD];                          // t1 = T' w1 (every thread, from LDS T)
 #pragma unroll
@@ -810,7 +805,7 @@ __global__ __launch_bounds__(NT) void pf_fit_reg_kernel(FitArgs A) {
     double bv[RPT];
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
-        double v = ag[i];
+        double v = agv[i];
 #pragma unroll
         for (int cc = 0; cc < KPAD; ++cc) v -= a[i][cc] * t1[cc];
         bv[i] = v;
@@ -857,7 +852,7 @@ __global__ __launch_bounds__(NT) void pf_fit_reg_kernel(FitArgs A) {
             double v = bv[i];
 #pragma unroll
             for (int cc = 0; cc < KPAD; ++cc) v -= a[i][cc] * t1[cc];
-            mu[row] = theta_p[row] + sq[i] * v;
+            mu[row] = theta_p[row] + sqa[row] * v;
         }
     }
     if (tid == 0) {
