@@ -51,12 +51,17 @@ __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
     }
     if (tid == 0) { hist_len[p0] = 0; s_ind = 0; s_eff = 0; s_rej = 0; }
     for (int l = 1; l <= L; ++l) {                                              // :43
-        double tn[EPT], gn[EPT];                                                // prefetch point l + 1
+        // prefetch point l + 1 while step l is reduced -- only when the third row set fits the register budget
+        // (1024 threads: 128 VGPRs; at EPT >= 8 it spilled 80..616 B per lane and the walk ran 10x slower)
+        constexpr bool PREF = EPT <= 6;
+        double tn[PREF ? EPT : 1], gn[PREF ? EPT : 1];
+        if (PREF) {
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            const int i = tid + HIST_NT * e;
-            tn[e] = gn[e] = 0.0;
-            if (i < d && l < L) { tn[e] = theta[(size_t)(p0 + l + 1) * d + i]; gn[e] = grad[(size_t)(p0 + l + 1) * d + i]; }
+            for (int e = 0; e < EPT; ++e) {
+                const int i = tid + HIST_NT * e;
+                tn[e] = gn[e] = 0.0;
+                if (i < d && l < L) { tn[e] = theta[(size_t)(p0 + l + 1) * d + i]; gn[e] = grad[(size_t)(p0 + l + 1) * d + i]; }
+            }
         }
         double v[4] = {0.0, 0.0, 0.0, 0.0};   // y.s, y.y, y'diag(a)y, s'diag(1/a)s
 #pragma unroll
@@ -82,7 +87,12 @@ __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
         for (int e = 0; e < EPT; ++e) {
             const int i = tid + HIST_NT * e;
             if (i < d) alpha_all[(size_t)(p0 + l) * d + i] = al[e];
-            t0[e] = t1[e]; g0[e] = g1[e]; t1[e] = tn[e]; g1[e] = gn[e];
+            t0[e] = t1[e]; g0[e] = g1[e];
+            if (PREF) { t1[e] = tn[e]; g1[e] = gn[e]; }
+            else {
+                t1[e] = g1[e] = 0.0;
+                if (i < d && l < L) { t1[e] = theta[(size_t)(p0 + l + 1) * d + i]; g1[e] = grad[(size_t)(p0 + l + 1) * d + i]; }
+            }
         }
         if (tid == 0) {
             if (accept) {
@@ -875,7 +885,8 @@ int32_t pf_launch_history(pfmi_ctx *c, double eps) {
     if (c->d <= 64) PF_HIST(1, 64); else if (c->d <= 128) PF_HIST(2, 64); else if (c->d <= 256) PF_HIST(4, 64);
     else if (c->d <= 512) PF_HIST(2, 256); else if (c->d <= 1024) PF_HIST(4, 256);
     else { const int ept = (c->d + 1023) / 1024;
-           if (ept <= 2) PF_HIST(2, 1024); else if (ept <= 4) PF_HIST(4, 1024); else if (ept <= 8) PF_HIST(8, 1024); else PF_HIST(16, 1024); }
+           if (ept <= 2) PF_HIST(2, 1024); else if (ept <= 4) PF_HIST(4, 1024); else if (ept <= 6) PF_HIST(6, 1024); else if (ept <= 8) PF_HIST(8, 1024);
+           else if (ept <= 10) PF_HIST(10, 1024); else if (ept <= 12) PF_HIST(12, 1024); else PF_HIST(16, 1024); }
 #undef PF_HIST
     pf_kernel_end(c, "history");
     PF_HIP(hipGetLastError());
