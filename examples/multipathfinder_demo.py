@@ -1,4 +1,5 @@
-import sys; sys.path.insert(0, "pathfinder.jl_amd")
+"""README usage example: multi-path Pathfinder on a built-in target, then single-path on a Python closure (needs an MI355X)."""
+import sys; import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pathfinder.jl_amd"))
 import numpy as np, pfmi
 target = pfmi.t_lowrank(200, r=8, seed=2)
 res = pfmi.multipathfinder(target, 1000, nruns=8, ndraws_elbo=200, rng=pfmi.HostRNG(1))
