@@ -400,10 +400,14 @@ def test_not_pd_fit_reports_status_and_nan_elbo(pfmi_mod, eng):
     ref = po.path_fit_elbo(theta, grad, 6, oracle_target(tg), 0, np.zeros(3, dtype=np.uint64))
     np.testing.assert_array_equal(status[:3], ref["status"])
     assert nrej[0] == ref["n_rejected"]
-    elbo, se, best = eng.elbo_batch(32, fit_seeds(eng.P, 2))
-    assert np.all(np.isfinite(elbo[4:]))
+    for N in (32, 200):                                    # two-pass kernel (N < 64) and single-pass scan (N >= 64)
+        elbo, se, best = eng.elbo_batch(N, fit_seeds(eng.P, 2))
+        assert np.all(np.isfinite(elbo[4:]))
+        if np.any(status[:3] != 0):
+            assert np.all(np.isnan(elbo[:3][status[:3] != 0]))
+            lp, lq = eng.elbo_logs(int(np.flatnonzero(status[:3] != 0)[0]), N)
+            assert np.all(np.isnan(lp)) and np.all(np.isnan(lq))
     if np.any(status[:3] != 0):
-        assert np.all(np.isnan(elbo[:3][status[:3] != 0]))
         with pytest.raises(pfmi_mod.PosDefException):
             pfmi_mod.fit_mvnormals(theta, grad, history_length=6, engine=eng)
 
