@@ -539,13 +539,15 @@ def test_torch_interop_for_the_collective_path(pfmi_mod, eng):
     np.testing.assert_array_equal(out.cpu().numpy().reshape(32, tg.d).T, pool.reshape(tg.d, -1, order="F")[:, idx])
 
 
-def test_large_d_general_paths(pfmi_mod, eng):
-    """d beyond the MFMA / register kernels (config-5 style: funnel, history_length = 10 -> KC = 20, d = 2500):
-    exercises the lane-per-draw ELBO kernel and the memory-resident fit kernel against the oracle."""
-    d, J = 2500, 10
+@pytest.mark.parametrize("d,maxit", [(2500, 14), (10000, 8)])
+def test_large_d_general_paths(pfmi_mod, eng, d, maxit):
+    """d beyond the resident-LDS / register kernels (config-5 style: funnel, history_length = 10 -> KC = 20, d = 2500 and the
+    full d = 10^4): the streamed single-pass ELBO scan (V_h through LDS in 256-row chunks, head transform across two blocks)
+    and the memory-resident fit kernel against the oracle; draw-writing launches take the lane-per-draw kernel."""
+    J = 10
     tg = pfmi_mod.t_funnel(d)
     rng = pfmi_mod.HostRNG(5)
-    traces = [pfmi_mod.optimize_with_trace(tg, rng.rand(d) * 2 - 1, history_length=J, maxiters=14) for _ in range(2)]
+    traces = [pfmi_mod.optimize_with_trace(tg, rng.rand(d) * 2 - 1, history_length=J, maxiters=maxit) for _ in range(2)]
     eng.set_target(tg)
     eng.set_traces([t.points for t in traces], [t.gradients for t in traces])
     eng.fit_batch(J)
