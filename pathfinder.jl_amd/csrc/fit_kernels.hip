@@ -64,23 +64,25 @@ __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
             }
         }
         double v[4] = {0.0, 0.0, 0.0, 0.0};   // y.s, y.y, y'diag(a)y, s'diag(1/a)s
+        double ial[EPT];                                                        // 1 / alpha: one division serves the c sum and the update
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             const double s = t1[e] - t0[e], y = g0[e] - g1[e];                  // :45-46 (zero beyond d)
+            ial[e] = 1.0 / al[e];
             v[0] += y * s;
             v[1] += y * y;
             v[2] += y * al[e] * y;
-            v[3] += s * (1.0 / al[e]) * s;
+            v[3] += s * ial[e] * s;
         }
         pf_block_sum<4>(v, red);
         const bool accept = v[0] > eps * v[1];                                  // :47
         if (accept) {                                                           // gilbert_init :5-10
-            const double a = v[2], b = v[0], c = v[3];
+            const double a = v[2], b = v[0], c = v[3], aoc = a / c;
 #pragma unroll
             for (int e = 0; e < EPT; ++e) {
                 const double s = t1[e] - t0[e], y = g0[e] - g1[e];
-                const double sa = s / al[e];
-                al[e] = b / (a / al[e] + y * y - (a / c) * sa * sa);
+                const double sa = s * ial[e];
+                al[e] = b / (a * ial[e] + y * y - aoc * sa * sa);
             }
         }
 #pragma unroll
