@@ -12,11 +12,16 @@ resample indices -> gather of the selected columns [-> xGMI all-reduce].
 value = ELBO draws per second of the whole job = (sum over fits of ndraws_elbo) / step time (the step time
 includes fit, PSIS and resampling, i.e. it is also the hot-path part of the multipathfinder wall-clock).
 
-Run:  python bench.py [--gpus N --steps K --warmup W]      (N > 1: launched by torch.distributed.run)
+Run:  python bench.py [--gpus N --steps K --warmup W]
+N > 1: one rank per GPU.  Either the caller launches the ranks (python -m torch.distributed.run ... bench.py --gpus N:
+WORLD_SIZE is then set and must equal N), or bench.py launches them itself: `python bench.py --gpus N` without
+WORLD_SIZE in the environment re-executes itself under torch.distributed.run on 127.0.0.1.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,6 +37,34 @@ class _DevArray:
     """zero-copy view of a libpfmi device buffer for torch (CUDA array interface)"""
     def __init__(self, ptr, n):
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def _self_launch(ngpus):
+    """`python bench.py --gpus N` outside a torch.distributed.run world: launch the N ranks (one per GPU) ourselves and
+    relay their output; returns the launcher's exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def _launch_only(world, rank):
+    """PFMI_BENCH_LAUNCH_ONLY=1 (CPU test of the launcher, tests/test_bench_launch.py): every rank joins a `gloo` world,
+    one all-reduce counts the ranks, rank 0 prints the JSON skeleton.  No engine, no GPU."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    t = torch.ones(1, dtype=torch.float64)
+    dist.all_reduce(t)
+    n = dist.get_world_size()
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"launch_only": True, "n_gpus": world, "ranks_in_collective": int(t[0]), "world_size": n}), flush=True)
 
 
 def main():
@@ -55,7 +88,16 @@ def main():
     ap.add_argument("--init-scale", type=float, default=2.0)
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the torch.distributed.run world must have one rank "
+                 "per requested GPU")
+    if os.environ.get("PFMI_BENCH_LAUNCH_ONLY") == "1":
+        return _launch_only(world, int(os.environ.get("RANK", "0")))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
@@ -149,14 +191,17 @@ def main():
     dt = time.perf_counter() - t0
     if use_dist:
         import torch
-        tt = torch.tensor([dt, float(draws_local)], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tt = torch.tensor([dt, float(draws_local), 1.0], dtype=torch.float64, device=f"cuda:{local_rank}")
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         dt = float(tmax[0])
         total_draws = float(tt[1])
+        ranks_seen = int(round(float(tt[2])))                           # ranks that took part in the RCCL all-reduce
+        assert ranks_seen == dist.get_world_size() == world, (ranks_seen, dist.get_world_size(), world)
     else:
         total_draws = float(draws_local)
+        ranks_seen = 1
     ms_per_step = dt / args.steps * 1e3
     value = total_draws / (ms_per_step * 1e-3)
 
@@ -280,7 +325,9 @@ def main():
                                    "diag": "diagonal Gaussian", "iso": "isotropic Gaussian", "funnel": "funnel"}[args.target] + ", "
                                    f"history_length={J}, ndraws_elbo={N_e}, ndraws={ndraws}",
                        "npaths": K, "paths_per_gpu": Kl, "fits_total": int(total_draws // N_e),
-                       "elbo_draws_per_step": int(total_draws), "parallelism": f"paths sharded x{G}"},
+                       "elbo_draws_per_step": int(total_draws), "parallelism": f"paths sharded x{G}",
+                       "ranks_in_collective": ranks_seen,
+                       "collective_backend": "nccl (RCCL)" if use_dist else None},
             "multipathfinder_hot_path_ms": round(ms_per_step, 3),
             "multipathfinder_wall_ms_incl_device_lbfgs": None if wall_e2e is None else round(wall_e2e, 3),
             "multipathfinder_api_wall_ms": None if api_wall is None else round(api_wall, 3),
