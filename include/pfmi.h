@@ -189,12 +189,13 @@ int32_t pfmi_psis(pfmi_ctx *ctx, const double *log_ratios, int64_t S, double *we
 int32_t pfmi_resample_indices(pfmi_ctx *ctx, int64_t S, int64_t ndraws, int32_t importance,
                               int32_t replace, uint64_t seed, const double *uniforms, int64_t *idx);
 
-/* draws = draws_all[:, inds] for the columns of idx owned by this ctx's pool: global pool column
- * g = k_global*N_r + n is owned iff col_offset <= g < col_offset + K_local*N_r; columns not owned are
- * written as zeros (multi-GPU: sum the per-rank results).  draws[d*ndraws]. */
+/* draws = draws_all[:, inds] (src/resample.jl:68).  Global pool column g = k_global*N_r + n is owned by this ctx iff
+ * col_offset <= g < col_offset + K_local*N_r.  Host variant: every index must be owned (PFMI_ERR_ARG otherwise -- a
+ * stale or out-of-range index is an error, never a silent zero column).  draws[d*ndraws]. */
 int32_t pfmi_pool_gather(pfmi_ctx *ctx, int64_t ndraws, const int64_t *idx, int64_t col_offset,
                          double *draws);
-/* same, into a device buffer (for the xGMI all-reduce) */
+/* multi-GPU variant into a device buffer: columns not owned are written as zeros, so that a sum all-reduce over the
+ * ranks (xGMI) assembles the result */
 int32_t pfmi_pool_gather_dev(pfmi_ctx *ctx, int64_t ndraws, const int64_t *idx, int64_t col_offset,
                              void *draws_dev);
 

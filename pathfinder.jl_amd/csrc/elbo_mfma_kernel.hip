@@ -469,12 +469,7 @@ static int32_t launch_mf(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
     const size_t lds_bytes = mf_lds_bytes(a.d, KC, RPAD);
     PF_CHECK(lds_bytes <= 160 * 1024, PFMI_ERR_UNSUPPORTED, "mfma kernel LDS %zu too large", lds_bytes);
     auto kern = pf_elbo_mfma_kernel<KC, NBW, TGT, RPAD, WX>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   160 * 1024));
-        attr_set = true;
-    }
+    PF_TRY(pf_raise_lds_limit(c, reinterpret_cast<const void *>(kern), 160 * 1024));
     const int ngroups = (int)((a.N + 15) / 16);
     // one fit per workgroup; split a fit's draw groups over several workgroups only when there are few fits
     int split = 1;

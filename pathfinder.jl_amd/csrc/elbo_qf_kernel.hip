@@ -470,11 +470,7 @@ static int32_t launch_qf_ng(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
     const size_t lds_bytes = qf_lds_bytes(ch_blocks, nchunks, KC, RPAD);
     PF_CHECK(lds_bytes <= 160 * 1024, PFMI_ERR_UNSUPPORTED, "qf kernel LDS %zu too large", lds_bytes);
     auto kern = pf_elbo_qf_kernel<KC, TGT, RPAD, NG>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    PF_TRY(pf_raise_lds_limit(c, reinterpret_cast<const void *>(kern), 160 * 1024));
     const int ngroups = (int)((a.N + 15) / 16);
     constexpr int NPG = (TGT != 0) ? (KC + 1 + 15) / 16 : 0;
     // one workgroup per fit; a fit's groups are split over several workgroups only when there are few fits (every

@@ -669,6 +669,13 @@ int32_t pfmi_pool_gather_dev(pfmi_ctx *c, int64_t ndraws, const int64_t *idx, in
 int32_t pfmi_pool_gather(pfmi_ctx *c, int64_t ndraws, const int64_t *idx, int64_t col_offset, double *draws) {
     PF_CTX(c);
     PF_CHECK(draws != nullptr, PFMI_ERR_ARG, "pool_gather: null output");
+    PF_CHECK(c->pooled, PFMI_ERR_STATE, "pool_gather: call pfmi_pool_build first");
+    PF_CHECK(ndraws >= 0 && (idx != nullptr || ndraws == 0), PFMI_ERR_ARG, "pool_gather: bad arguments");
+    const int64_t owned = (int64_t)c->K * c->N_r;
+    for (int64_t t = 0; t < ndraws; ++t)   // the host variant hands back real columns only: no silent zero fill
+        PF_CHECK(idx[t] >= col_offset && idx[t] < col_offset + owned, PFMI_ERR_ARG,
+                 "pool_gather: index %lld (position %lld) is outside this pool's columns [%lld, %lld)", (long long)idx[t],
+                 (long long)t, (long long)col_offset, (long long)(col_offset + owned));
     PF_TRY(c->gbuf.ensure(sizeof(double) * (size_t)(ndraws > 0 ? ndraws : 1) * c->d));
     PF_TRY(pfmi_pool_gather_dev(c, ndraws, idx, col_offset, c->gbuf.p));
     PF_TRY(d2h(c, draws, c->gbuf.p, sizeof(double) * (size_t)ndraws * c->d));

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <string>
 #include <map>
+#include <set>
 #include <vector>
 
 #include "../../include/pfmi.h"
@@ -67,6 +68,7 @@ struct pfmi_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, kev0 = nullptr, kev1 = nullptr;
     bool profile = false;
     std::map<std::string, KernelStat> kstats;
+    std::set<const void *> lds_attr_done;   // kernels whose dynamic-LDS limit was raised on THIS ctx's device (see pf_raise_lds_limit)
 
     // traces
     int32_t K = 0, d = 0;
@@ -148,6 +150,15 @@ int32_t pf_launch_trace_pack(pfmi_ctx *c, int64_t cap);
 int32_t pf_launch_woodbury_prim(pfmi_ctx *c, int mode, int64_t p, int64_t N, const double *d_in, double *d_out);
 int32_t pf_launch_colsumsq(pfmi_ctx *c, int64_t N, const double *d_x, double *d_out);
 int32_t pf_launch_woodbury_diag(pfmi_ctx *c, int64_t p, double *d_out);
+
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the (device, kernel) pair: remembered per ctx (one ctx = one device, one
+// host thread), never in a process-wide static -- a second ctx on another GPU must raise the limit again.
+inline int32_t pf_raise_lds_limit(pfmi_ctx *c, const void *kern, int bytes) {
+    if (c->lds_attr_done.count(kern)) return PFMI_OK;
+    PF_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    c->lds_attr_done.insert(kern);
+    return PFMI_OK;
+}
 
 void pf_kernel_begin(pfmi_ctx *c);
 void pf_kernel_end(pfmi_ctx *c, const char *name);

@@ -20,7 +20,7 @@ from typing import Any, List, Optional
 
 import numpy as np
 
-from .core import Engine
+from .core import Engine, StaleHandleError  # noqa: F401
 from .hostrng import HostRNG, rand_u64_multi
 from .optimize import OptimizationTrace, optimize_with_trace
 
@@ -73,19 +73,27 @@ class WoodburyPDMat:                # src/woodbury.jl:246-257
 
     engine: Any = field(repr=False, default=None)
     point: int = -1
+    token: Any = field(repr=False, default=None)      # engine.fit_token() this handle was made under
 
     def dense(self):
         return np.diag(self.A) + self.B @ self.D @ self.B.T
 
+    def _op(self, op, x):
+        self.engine.check_token(self.token, "WoodburyPDMat")
+        return self.engine.woodbury_apply(self.point, op, x)
+
     # PDMats surface on the device (reference src/woodbury.jl:326-423)
-    def unwhiten(self, x): return self.engine.woodbury_apply(self.point, "unwhiten", x)
-    def whiten(self, x): return self.engine.woodbury_apply(self.point, "whiten", x)
-    def invunwhiten(self, x): return self.engine.woodbury_apply(self.point, "invunwhiten", x)
-    def mul(self, x): return self.engine.woodbury_apply(self.point, "mul", x)
-    def solve(self, x): return self.engine.woodbury_apply(self.point, "solve", x)
-    def quad(self, x): return self.engine.woodbury_apply(self.point, "quad", x)
-    def invquad(self, x): return self.engine.woodbury_apply(self.point, "invquad", x)
-    def diag(self): return self.engine.woodbury_diag(self.point)
+    def unwhiten(self, x): return self._op("unwhiten", x)
+    def whiten(self, x): return self._op("whiten", x)
+    def invunwhiten(self, x): return self._op("invunwhiten", x)
+    def mul(self, x): return self._op("mul", x)
+    def solve(self, x): return self._op("solve", x)
+    def quad(self, x): return self._op("quad", x)
+    def invquad(self, x): return self._op("invquad", x)
+
+    def diag(self):
+        self.engine.check_token(self.token, "WoodburyPDMat")
+        return self.engine.woodbury_diag(self.point)
 
 
 @dataclass
@@ -97,12 +105,17 @@ class MvNormal:
     engine: Any = field(repr=False, default=None)
     point: int = -1
     j: int = -1                      # effective history length of this fit (needed to size B, D when materialising)
+    token: Any = field(repr=False, default=None)      # engine.fit_token() this handle was made under
+
+    def _live(self):
+        self.engine.check_token(self.token, "MvNormal")
 
     def _materialise(self):
         if self.Sigma_ is None and self.engine is not None and self.j >= 0:
+            self._live()
             f = self.engine.get_fit(self.point, self.j)
             F = WoodburyPDFactorization(np.sqrt(f["alpha"]), f["qr_factors"], f["T"], f["V"])
-            self.Sigma_ = WoodburyPDMat(f["alpha"], f["B"], f["D"], F, f["logdet"], self.engine, self.point)
+            self.Sigma_ = WoodburyPDMat(f["alpha"], f["B"], f["D"], F, f["logdet"], self.engine, self.point, self.token)
             self.mu_ = f["mu"]
         return self
 
@@ -112,9 +125,11 @@ class MvNormal:
     def Sigma(self): return self._materialise().Sigma_
 
     def logpdf(self, X):
+        self._live()
         return self.engine.logpdf(self.point, X)
 
     def rand(self, seed, n, n0=0):
+        self._live()
         return self.engine.draws(self.point, seed, n, n0)[0]
 
 
@@ -127,9 +142,11 @@ class ELBOEstimate:                 # src/elbo.jl:22-29
     seed: int = 0
     ndraws: int = 0
     _cache: Any = field(repr=False, default=None)
+    token: Any = field(repr=False, default=None)
 
     def _materialise(self):         # draws are regenerated on demand from the seed
         if self._cache is None:
+            self.engine.check_token(self.token, "ELBOEstimate")
             self._cache = self.engine.draws(self.point, self.seed, self.ndraws)
         return self._cache
 
@@ -171,6 +188,7 @@ class PathfinderResult:             # src/singlepath.jl:53-70
     num_bfgs_updates_rejected: int = 0
     success: bool = True
     draw_seed: int = 0
+    ndraws_per_run: int = 0             # number of columns of `draws` (the stored candidates resample() reuses)
 
     @property
     def draws(self):
@@ -225,7 +243,7 @@ _STATUS_MSG = {1: "A = diag(alpha) is not positive definite", 2: "C = I + R D R'
 
 
 def _make_dist(eng, p, jeff, materialise=True):
-    dist = MvNormal(None, None, eng, p, int(jeff[p]))
+    dist = MvNormal(None, None, eng, p, int(jeff[p]), eng.fit_token())
     return dist._materialise() if materialise else dist
 
 
@@ -260,8 +278,8 @@ def maximize_elbo(rng, target, dists, ndraws, ntasks=1):
         seeds[dist.point] = s
     eng.set_target(target)
     elbo, se, _ = eng.elbo_batch(ndraws, seeds)
-    ests = [ELBOEstimate(float(elbo[d.point]), float(se[d.point]), eng, d.point, int(seeds[d.point]), ndraws)
-            for d in dists]
+    ests = [ELBOEstimate(float(elbo[d.point]), float(se[d.point]), eng, d.point, int(seeds[d.point]), ndraws,
+                         token=eng.fit_token()) for d in dists]
     return _findmax_skipnan([e.value for e in ests])[1], ests
 
 
@@ -296,12 +314,14 @@ class DeviceOptimizationTrace:
 
     def __init__(self, engine, k, n):
         self._eng, self._k, self._n, self._cache = engine, k, n, None
+        self._token = engine.trace_token()
 
     def __len__(self):
         return self._n
 
     def materialise(self):
         if self._cache is None:
+            self._eng.check_token(self._token, "DeviceOptimizationTrace")
             self._cache = self._eng.get_trace(self._k)
         return self
 
@@ -398,9 +418,12 @@ def _assemble_path(eng, target, st, rng, ndraws, ndraws_elbo, input_, status, je
         warnings.warn(f"{st['nrej']} ({perc}%) updates to the inverse Hessian estimate were rejected to keep it "
                       "positive definite.")
     dists = _make_dists(eng, p0, L + 1, status, jeff, materialise)
+    tok = eng.fit_token()
+
     def _est(i, st=st):
         l = i + 1
-        return ELBOEstimate(float(st["elbo"][l]), float(st["se"][l]), eng, p0 + l, int(st["seeds"][l]), ndraws_elbo)
+        return ELBOEstimate(float(st["elbo"][l]), float(st["se"][l]), eng, p0 + l, int(st["seeds"][l]), ndraws_elbo,
+                            token=tok)
 
     ests = _LazySeq(L, _est) if not materialise else [_est(i) for i in range(L)]
     fit_it = st["fit_iteration"]
@@ -437,7 +460,7 @@ def pathfinder(target, *, rng=None, init=None, dim=-1, init_scale=2, init_sample
     X = eng.draws(a["fit_point"], a["draw_seed"], ndraws)[0]     # src/singlepath.jl:226-233
     return PathfinderResult(input if input is not None else target, rng, target.logp,
                             a["dists"][st["fit_iteration"]], X, st["fit_iteration"], st["itry"], st["trace"],
-                            a["dists"], a["ests"], st["nrej"], st["success"], a["draw_seed"])
+                            a["dists"], a["ests"], st["nrej"], st["success"], a["draw_seed"], ndraws)
 
 
 def multipathfinder(target, ndraws, *, init=None, nruns=-1, ndraws_elbo=DEFAULT_NDRAWS_ELBO, ndraws_per_run=None,
@@ -471,14 +494,22 @@ def multipathfinder(target, ndraws, *, init=None, nruns=-1, ndraws_elbo=DEFAULT_
              for st, r in zip(state, run_rngs)]
     # draws_per_component = stack(draws)   (:217) -- device resident
     eng.pool_build(ndraws_per_run, [a["fit_point"] for a in parts], [a["draw_seed"] for a in parts])
-    # the per-run draws (d, N_r, K) stay on the device; a run's block is downloaded from the pool when it is looked at
+    # the per-run draws (d, N_r, K) stay on the device.  A run's block is a pure function of (fit, draw_seed, N_r): when it is
+    # looked at it is REGENERATED from the seed (bit-identical to the pool block, tests: pool == eng.draws), so the handle
+    # does not depend on what a later resample() put into the pool; it does depend on the fits, hence the token.
     results = []
+    tok = eng.fit_token()
+
+    def _run_draws(fit_point, seed):
+        eng.check_token(tok, "PathfinderResult.draws")
+        return eng.draws(fit_point, seed, ndraws_per_run)[0]
+
     for k, (st, a) in enumerate(zip(state, parts)):
-        thunk = (lambda k=k: eng.pool_gather(np.arange(k * ndraws_per_run, (k + 1) * ndraws_per_run, dtype=np.int64)))
+        thunk = (lambda a=a: _run_draws(a["fit_point"], a["draw_seed"]))
         results.append(PathfinderResult(input if input is not None else target, run_rngs[k], target.logp,
                                         a["dists"][st["fit_iteration"]], thunk, st["fit_iteration"],
                                         st["itry"], st["trace"], a["dists"], a["ests"], st["nrej"], st["success"],
-                                        a["draw_seed"]))
+                                        a["draw_seed"], ndraws_per_run))
         if materialise:
             results[-1].draws
     S = nruns * ndraws_per_run
@@ -506,23 +537,19 @@ def resample(result, ndraws, *, rng=None, replace=True, importance=True, ndraws_
     rng = rng if rng is not None else result.rng
     eng = result.engine
     K = len(result.pathfinder_results)
-    psis_result = result.psis_result
+    for r in result.pathfinder_results:
+        r.fit_distribution._live()                                  # the fits must still be the engine's current ones
     if ndraws_per_run is not None:                                  # fresh candidates (:102-109)
         seeds = rng.rand_u64(K)
         eng.pool_build(ndraws_per_run, [r.fit_distribution.point for r in result.pathfinder_results], seeds)
-        psis_result = None
         npr = ndraws_per_run
-    else:                                                           # reuse stored draws (:97-101)
-        npr = result.ndraws_per_run
-        eng.pool_build(npr, [r.fit_distribution.point for r in result.pathfinder_results],
+    else:                                                           # reuse stored draws (:97-101): the candidates are
+        npr = result.pathfinder_results[0].ndraws_per_run           # pathfinder_results[k].draws, whatever an earlier
+        eng.pool_build(npr, [r.fit_distribution.point for r in result.pathfinder_results],   # resample() drew fresh
                        [r.draw_seed for r in result.pathfinder_results])
     S = K * npr
-    if importance:
-        if psis_result is None or ndraws_per_run is not None:
-            ptr, cnt = eng.pool_log_ratios_dev()
-            psis_result = PSISResult(**eng.psis_dev(ptr, cnt))
-        else:                                                       # stored PSIS weights back onto the device
-            psis_result = PSISResult(**eng.psis_dev(*eng.pool_log_ratios_dev()))
+    if importance:                                                  # PSIS of the (re)built pool: for stored draws this
+        psis_result = PSISResult(**eng.psis_dev(*eng.pool_log_ratios_dev()))   # reproduces result.psis_result bit for bit
     else:
         psis_result = None
     draws, ids = _resample(rng, eng, S, npr, psis_result, ndraws, replace=replace)

@@ -17,8 +17,14 @@ def _d(a):
     return a.ctypes.data_as(_dp) if a is not None else None
 
 
+class StaleHandleError(RuntimeError):
+    """A lazy result handle (MvNormal, ELBOEstimate, trace, per-run draws) was used after the engine it points into was
+    given new traces / refitted: the reference's results own their data, these handles only index device buffers."""
+
+
 class Engine:
     def __init__(self, device=0):
+        self.gen_traces = self.gen_fit = self.gen_pool = 0   # bumped by set_traces/optimize_batch, fit_batch, pool_build
         self.L = _lib.lib()
         self.ctx = C.c_void_p()
         check(self.L.pfmi_create(C.c_int32(device), C.byref(self.ctx)))
@@ -38,6 +44,19 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    # ---- generations of the device state lazy handles point into ------------------------------------
+    def trace_token(self):
+        return (self.gen_traces,)
+
+    def fit_token(self):
+        return (self.gen_traces, self.gen_fit)
+
+    def check_token(self, token, what):
+        cur = self.fit_token() if len(token) == 2 else self.trace_token()
+        if self.ctx is None or token != cur:
+            raise StaleHandleError(f"{what}: the engine holds a newer batch of traces / fits than this handle was made for "
+                                   "(materialise results before reusing the engine, or use a separate Engine)")
 
     # ---- instrumentation -------------------------------------------------------------------------
     def sync(self):
@@ -73,6 +92,7 @@ class Engine:
         assert theta.shape == grad.shape and theta.ndim == 2
         self.K, self.P, self.d = len(npts), int(npts.sum()), theta.shape[1]
         self.offsets = np.concatenate([[0], np.cumsum(npts)]).astype(np.int64)
+        self.gen_traces += 1
         check(self.L.pfmi_set_traces(self.ctx, C.c_int32(self.K), npts.ctypes.data_as(_i64p), C.c_int32(self.d),
                                      _d(theta), _d(grad)))
 
@@ -83,6 +103,7 @@ class Engine:
         K, d = x0.shape
         assert self.target is not None and d == self.target.d
         npts = np.empty(K, dtype=np.int64)
+        self.gen_traces += 1
         check(self.L.pfmi_optimize_batch(self.ctx, C.c_int32(K), _d(x0), C.c_int32(history_length), C.c_int32(maxiters),
                                          C.c_double(g_tol), npts.ctypes.data_as(_i64p)))
         self.K, self.P, self.d = K, int(npts.sum()), d
@@ -99,6 +120,7 @@ class Engine:
     # ---- fit -------------------------------------------------------------------------------------------
     def fit_batch(self, history_length=6, eps=1e-12):
         self.J = history_length
+        self.gen_fit += 1
         check(self.L.pfmi_fit_batch(self.ctx, C.c_int32(history_length), C.c_double(eps)))
 
     def fit_status(self):
@@ -184,6 +206,7 @@ class Engine:
         points = np.ascontiguousarray(points, dtype=np.int64)
         seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
         self.N_r = N_r
+        self.gen_pool += 1
         check(self.L.pfmi_pool_build(self.ctx, C.c_int64(N_r), points.ctypes.data_as(_i64p),
                                      seeds.ctypes.data_as(_u64p)))
 
@@ -231,6 +254,23 @@ class Engine:
         check(self.L.pfmi_pool_gather(self.ctx, C.c_int64(len(idx)), idx.ctypes.data_as(_i64p),
                                       C.c_int64(col_offset), _d(out)))
         return out
+
+    # ---- raw device buffers (hosts that keep results on the GPU) ----------------------------------------------
+    def malloc_dev(self, nbytes):
+        p = C.c_void_p()
+        check(self.L.pfmi_malloc_dev(self.ctx, C.c_int64(nbytes), C.byref(p)))
+        return p.value
+
+    def free_dev(self, ptr):
+        check(self.L.pfmi_free_dev(self.ctx, C.c_void_p(ptr)))
+
+    def memcpy_d2h(self, host_array, dev_ptr):
+        check(self.L.pfmi_memcpy_d2h(self.ctx, host_array.ctypes.data_as(C.c_void_p), C.c_void_p(dev_ptr), C.c_int64(host_array.nbytes)))
+        return host_array
+
+    def memcpy_h2d(self, dev_ptr, host_array):
+        host_array = np.ascontiguousarray(host_array)
+        check(self.L.pfmi_memcpy_h2d(self.ctx, C.c_void_p(dev_ptr), host_array.ctypes.data_as(C.c_void_p), C.c_int64(host_array.nbytes)))
 
     def pool_gather_dev(self, idx, col_offset, dev_ptr):
         idx = np.ascontiguousarray(idx, dtype=np.int64)

@@ -29,7 +29,9 @@ def eng(pfmi_mod):
 
 def _targets(pfmi):
     return {
-        "iso10": pfmi.t_iso(10),                 # d < 2J = 12: k = min(d, m) path (reference test/woodbury.jl:21-31)
+        "iso10": pfmi.t_iso(10),                 # converges in <= 2 iterations (m <= 4 < d): the TINY-history corner, not n < m
+        "lr10": pfmi.t_lowrank(10, r=3, seed=3), # d = 10 < 2J = 12 / 16 with >= 20 iterations: the real k = min(d, m) = d path
+                                                 # (n < m, reference test/woodbury.jl:21-31), well-conditioned QR
         "diag30": pfmi.t_diag(30, seed=1),
         "lr50": pfmi.t_lowrank(50, r=8, seed=2),
         "lr64r3": pfmi.t_lowrank(64, r=3, seed=5),
@@ -38,7 +40,13 @@ def _targets(pfmi):
 
 
 CASES = [("iso10", 3, 6), ("diag30", 4, 6), ("lr50", 3, 6), ("lr64r3", 2, 2), ("funnel12", 3, 6), ("diag30", 2, 10),
-         ("lr50", 2, 4), ("lr50", 2, 16)]
+         ("lr10", 3, 8), ("lr10", 2, 6), ("lr50", 2, 4), ("lr50", 2, 16)]
+
+# minimum number of STRICT (well-conditioned QR => same u -> same x) comparisons a case must reach, so that a gated loop can
+# never go vacuous.  iso: y == s makes U'\B rank deficient for every fit and funnel12's scaled block is
+# numerically rank deficient too (measured on the oracle: 0 / 6 and 3 / 75 fits pass the gate) -- those two cases are pinned
+# through the dense W / logdet / mu and the statistical ELBO branch, and say so here instead of silently skipping.
+MIN_STRICT = {"iso10": 0, "funnel12": 0}
 
 
 def _qr_ratio(F):
@@ -84,6 +92,7 @@ def test_fit_batch_matches_oracle(pfmi_mod, eng, name, K, J):
     tg, traces = _setup(pfmi_mod, eng, name, K, J)
     status, jeff, logdet, nrej = eng.fit_status()
     otg = oracle_target(tg)
+    n_strict = n_wide = 0
     for k, tr in enumerate(traces):
         p0 = int(eng.offsets[k])
         P = len(tr)
@@ -94,10 +103,11 @@ def test_fit_batch_matches_oracle(pfmi_mod, eng, name, K, J):
         ok = ref["status"] == 0
         np.testing.assert_allclose(logdet[p0:p0 + P][ok], ref["logdet"][ok], rtol=0, atol=1e-10 * (1 + np.abs(ref["logdet"][ok]).max()))
         alpha_all, hl, hs, _ = po.lbfgs_history(tr.points, tr.gradients, J)
-        for l in list(range(min(P, 9))) + [P - 1]:
+        for l in sorted(set(list(range(min(P, 9))) + [P // 2, min(P - 1, 2 * J + 3), P - 1])):
             if not ok[l]:
                 continue
             f = eng.get_fit(p0 + l, int(jeff[p0 + l]))
+            n_wide += int(2 * int(jeff[p0 + l]) > tg.d)
             mu_ref = ref["mu"][l]
             assert np.max(np.abs(f["mu"] - mu_ref)) <= 1e-10 * (1 + np.abs(mu_ref).max())
             np.testing.assert_allclose(f["alpha"], alpha_all[l], rtol=1e-12)
@@ -124,6 +134,7 @@ def test_fit_batch_matches_oracle(pfmi_mod, eng, name, K, J):
                 # (b) reflector-level parity with the oracle (LAPACK convention) whenever the QR is well
                 #     conditioned; for rank-deficient B~ (e.g. iso: y == s) later reflectors are roundoff-defined
                 if _well_conditioned(F):
+                    n_strict += 1
                     amp = 1e-13 / _qr_ratio(F)            # roundoff amplification of the reflectors
                     np.testing.assert_allclose(f["V"], F.V[:kk, :kk], rtol=1e-8, atol=max(1e-9, amp) * np.abs(F.V).max())
                     np.testing.assert_allclose(f["qr_factors"], F.QR[:, :2 * j], rtol=1e-8,
@@ -131,9 +142,12 @@ def test_fit_batch_matches_oracle(pfmi_mod, eng, name, K, J):
                     z = np.eye(tg.d, order="F").copy(order="F")
                     po.lib().pfo_apply_q(tg.d, kk, po._p(F.QR), po._p(F.tau), 0, po._p(z), tg.d)
                     np.testing.assert_allclose(Q, z, atol=max(1e-10, amp))
+    assert n_strict >= MIN_STRICT.get(name, 3 * K), (name, n_strict)
+    if name == "lr10":
+        assert n_wide >= 3 * K, n_wide                     # fits with 2j > d really ran (k = d, R is d x 2j upper trapezoidal)
 
 
-@pytest.mark.parametrize("name,K,J", CASES[:6])
+@pytest.mark.parametrize("name,K,J", CASES[:8])
 def test_draws_and_logq_match_oracle_same_u_and_rng(pfmi_mod, eng, name, K, J):
     """rand_and_logpdf (src/mvnormal.jl:24-39) + target: identical host-supplied u (parity mode) and
     the in-kernel Philox normals (production mode) against the oracle."""
@@ -142,10 +156,11 @@ def test_draws_and_logq_match_oracle_same_u_and_rng(pfmi_mod, eng, name, K, J):
     status, jeff, logdet, _ = eng.fit_status()
     N = 130
     rng = np.random.default_rng(0)
+    n_strict = n_wide = 0
     for k, tr in enumerate(traces):
         p0 = int(eng.offsets[k])
         alpha_all, hl, hs, _ = po.lbfgs_history(tr.points, tr.gradients, J)
-        for l in sorted({1, min(3, len(tr) - 1), len(tr) - 1}):
+        for l in sorted({1, min(3, len(tr) - 1), len(tr) // 2, min(len(tr) - 1, 2 * J + 3), len(tr) - 1}):
             if status[p0 + l] != 0:
                 continue
             j = int(hl[l])
@@ -155,6 +170,8 @@ def test_draws_and_logq_match_oracle_same_u_and_rng(pfmi_mod, eng, name, K, J):
             F = po.Factor(alpha_all[l], B, D)
             if not _well_conditioned(F):
                 continue                      # draw-level parity is only defined for a well-conditioned QR
+            n_strict += 1
+            n_wide += int(2 * j > tg.d)
             mu = F.fit_mean(tr.points[l], tr.gradients[l])
             seed = 1000 + 17 * l + k
             for mode in ("mem", "rng"):
@@ -173,6 +190,9 @@ def test_draws_and_logq_match_oracle_same_u_and_rng(pfmi_mod, eng, name, K, J):
             lpdf = eng.logpdf(p0 + l, X)
             assert np.max(np.abs(lpdf - lq) / (1 + np.abs(lq))) <= 1e-9
             np.testing.assert_allclose(lpdf, F.logpdf(mu, X), rtol=1e-9, atol=1e-9)
+    assert n_strict >= MIN_STRICT.get(name, 2 * K), (name, n_strict)
+    if name == "lr10":
+        assert n_wide >= K, n_wide                         # same-u draw parity on fits with 2j > d
 
 
 @pytest.mark.parametrize("name,K,J", CASES)
@@ -186,6 +206,7 @@ def test_elbo_batch_matches_oracle(pfmi_mod, eng, name, K, J):
     # parity mode with uploaded normals gives the same answers as the in-kernel generator
     U = np.concatenate([po.randn_fill(int(seeds[p]), tg.d, N).T.ravel() for p in range(eng.P)])
     elbo_m, se_m, best_m = eng.elbo_batch(N, seeds, u=U)
+    n_strict = 0
     for k, tr in enumerate(traces):
         p0, p1 = int(eng.offsets[k]), int(eng.offsets[k + 1])
         ref = po.path_fit_elbo(tr.points, tr.gradients, J, otg, N, seeds[p0:p1])
@@ -198,6 +219,7 @@ def test_elbo_batch_matches_oracle(pfmi_mod, eng, name, K, J):
             fin = np.isfinite(y)
             np.testing.assert_array_equal(np.isfinite(x), fin)
             strict = fin & wc
+            n_strict += int(strict.sum())
             assert np.all(np.abs(x[strict] - y[strict]) <= 1e-9 * (1 + np.abs(y[strict])))
             assert np.all(np.abs(sa[p0 + 1:p1][strict] - sb[1:][strict]) <= 1e-9 * (1 + np.abs(sb[1:][strict])))
             loose = fin & ~wc     # rank-deficient QR: same distribution, roundoff-defined draws -> statistical agreement
@@ -210,6 +232,12 @@ def test_elbo_batch_matches_oracle(pfmi_mod, eng, name, K, J):
         lp, lq = eng.elbo_logs(p0 + int(best[k]), N)
         v, s, _ = po.elbo_stats(lp, lq)
         assert abs(v - elbo[p0 + int(best[k])]) <= 1e-10 * (1 + abs(v))
+        # per-draw log densities of the production launch against the oracle's own draws of the same fit
+        if wc[int(best[k]) - 1] and best[k] == ref["best_iter"]:
+            refd = po.path_fit_elbo(tr.points, tr.gradients, J, otg, N, seeds[p0:p1], want_draws=True)
+            assert np.max(np.abs(lp - refd["logp"]) / (1 + np.abs(refd["logp"]))) <= 1e-9
+            assert np.max(np.abs(lq - refd["logq"]) / (1 + np.abs(refd["logq"]))) <= 1e-9
+    assert n_strict >= MIN_STRICT.get(name, 8 * K), (name, n_strict)
 
 
 def test_reference_fixture_S0Y0_through_gpu(pfmi_mod, eng, golden_dir):
@@ -379,10 +407,17 @@ def test_pool_log_ratio_ordering_and_gather(pfmi_mod, eng):
     idx = np.array([0, 79, 80, 239, 100, 100])
     g = eng.pool_gather(idx)
     np.testing.assert_array_equal(g, pool.reshape(tg.d, -1, order="F")[:, idx])
-    # ownership window (multi-GPU): columns outside [col_offset, col_offset + K*N_r) come back as zeros
     g2 = eng.pool_gather(idx + 1000, col_offset=1000)
     np.testing.assert_array_equal(g2, g)
-    g3 = eng.pool_gather(idx, col_offset=100)
+    # the host variant never zero-fills: an index outside this ctx's window is an error
+    for bad, off in ((np.array([0, 240]), 0), (np.array([-1]), 0), (idx, 100)):
+        with pytest.raises(pfmi_mod.PfmiError, match="outside this pool"):
+            eng.pool_gather(bad, col_offset=off)
+    # ownership window (multi-GPU, device variant): columns outside [col_offset, col_offset + K*N_r) come back as zeros
+    buf = eng.malloc_dev(8 * tg.d * len(idx))
+    eng.pool_gather_dev(idx, 100, buf)
+    g3 = eng.memcpy_d2h(np.empty((tg.d, len(idx)), order="F"), buf)
+    eng.free_dev(buf)
     assert np.all(g3[:, :3] == 0) and np.array_equal(g3[:, 3], pool.reshape(tg.d, -1, order="F")[:, 139])
 
 
@@ -610,19 +645,22 @@ print(json.dumps(dict(elbo=np.nan_to_num(elbo).tolist(), best=best.tolist(), x=X
         assert np.max(np.abs(x - y) / (1 + np.abs(y))) <= 1e-10, key
 
 
-@pytest.mark.parametrize("name,K,J", [("iso10", 1, 6), ("lr50", 2, 6), ("diag30", 1, 10)])
+@pytest.mark.parametrize("name,K,J", [("iso10", 1, 6), ("lr50", 2, 6), ("diag30", 1, 10), ("lr10", 1, 8), ("lr10", 1, 6)])
 def test_woodbury_operator_surface(pfmi_mod, eng, name, K, J):
     """remaining PDMats surface on the device vs the oracle and dense algebra (reference test/woodbury.jl:239-402):
-    unwhiten / whiten / invunwhiten / R*x / W*x / W\\x / quad / invquad / diag, matrices and vectors, incl. n < m."""
+    unwhiten / whiten / invunwhiten / R*x / W*x / W\\x / quad / invquad / diag, matrices and vectors; the lr10 cases are the
+    n < m ones (d = 10, 2j = 16 / 12: test/woodbury.jl:21-31 has n = 5, m = 8)."""
     tg, traces = _setup(pfmi_mod, eng, name, K, J)
     status, jeff, logdet, _ = eng.fit_status()
     rng = np.random.default_rng(5)
     tr = traces[0]
     alpha_all, hl, hs, _ = po.lbfgs_history(tr.points, tr.gradients, J)
-    for l in sorted({0, 1, min(4, len(tr) - 1), len(tr) - 1}):
+    n_strict = n_wide = 0
+    for l in sorted({0, 1, min(4, len(tr) - 1), min(len(tr) - 1, J + 2), min(len(tr) - 1, 2 * J + 1), len(tr) - 1}):
         if status[l] != 0:
             continue
         F = _oracle_factor(tr, alpha_all, hl, hs, l, tg.d)
+        n_wide += int(2 * int(hl[l]) > tg.d)
         W = F.dense()
         X = rng.normal(size=(tg.d, 9))
         tol = dict(rtol=1e-8, atol=1e-9 * max(1.0, np.abs(W).max()))
@@ -636,6 +674,7 @@ def test_woodbury_operator_surface(pfmi_mod, eng, name, K, J):
         # L and R themselves agree with the oracle's factor when the QR is well conditioned, and always satisfy
         # L (L \ x) = x, R \ (R x) = x, unwhiten(whiten(x)) = x
         if _well_conditioned(F):
+            n_strict += 1
             np.testing.assert_allclose(eng.woodbury_apply(l, "unwhiten", X), F.lmul_L(X), rtol=1e-7, atol=1e-8 * np.abs(X).max() * np.sqrt(np.abs(W).max()))
             np.testing.assert_allclose(eng.woodbury_apply(l, "rmul", X), F.lmul_R(X), rtol=1e-7, atol=1e-8 * np.abs(X).max() * np.sqrt(np.abs(W).max()))
             np.testing.assert_allclose(eng.woodbury_apply(l, "whiten", X), F.ldiv_L(X), rtol=1e-6, atol=1e-7 * np.abs(F.ldiv_L(X)).max())
@@ -644,6 +683,9 @@ def test_woodbury_operator_surface(pfmi_mod, eng, name, K, J):
         np.testing.assert_allclose(back, X, rtol=1e-6, atol=1e-7 * np.abs(X).max())
         back = eng.woodbury_apply(l, "invunwhiten", eng.woodbury_apply(l, "rmul", X))
         np.testing.assert_allclose(back, X, rtol=1e-6, atol=1e-7 * np.abs(X).max())
+    assert n_strict >= MIN_STRICT.get(name, 2), (name, n_strict)
+    if name == "lr10":
+        assert n_wide >= 2, n_wide
 
 
 # ---- device trajectory generation -----------------------------------------------------

@@ -1,0 +1,435 @@
+"""GPU parity tests added in round 2 (VERDICT r1 "next round" #2, #3 and weak #1-#6):
+
+* failure handling END TO END on the GPU: non-PD fits (both PosDefException sites of src/woodbury.jl:202,205), NaN ELBOs,
+  the NaN-skipping argmax with NaNs first / middle / everywhere (src/utils.jl:55-72, test/utils.jl:8-12), PosDefException
+  from fit_mvnormals, the retry loop of src/singlepath.jl:259-283;
+* every BASELINE config at its stated size on one GPU against the oracle: C2 exactly, C3 with K = 64 device-made traces
+  (first 20 fits of every path + PSIS + resample indices on the pooled log ratios), the single-GPU share of C5 at
+  d = 10^4, J = 10, N_e = 2000 (multi-batch streaming of V_h);
+* value-level tests of resample() (stored draws, fresh candidates, without replacement beyond 4096) and of the lazy result
+  handles' staleness guard.
+All calls go through the C ABI of libpfmi.so.
+"""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from helpers import fit_seeds, make_traces, oracle_target
+from oracle import pf_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pfmi_mod():
+    import pfmi
+    return pfmi
+
+
+@pytest.fixture(scope="module")
+def eng(pfmi_mod):
+    e = pfmi_mod.Engine(0)
+    yield e
+    e.close()
+
+
+def _wc(F, tol=1e-4):
+    k = F.k
+    if k == 0:
+        return True
+    dg = np.abs(np.diag(F.QR[:k, :k]))
+    return dg.max() > 0 and dg.min() / dg.max() > tol
+
+
+def _factor(th, gr, alpha_all, hl, hs, l, d):
+    j = int(hl[l])
+    S = np.stack([th[s + 1] - th[s] for s in hs[l, :j]], axis=1) if j else np.zeros((d, 0))
+    Y = np.stack([gr[s] - gr[s + 1] for s in hs[l, :j]], axis=1) if j else np.zeros((d, 0))
+    B, D = po.lbfgs_inverse_hessian(alpha_all[l], S, Y)
+    return po.Factor(alpha_all[l], B, D)
+
+
+# ---- failure handling on the GPU ---------------------------------------------------------------------------
+def test_failed_fits_nan_elbos_and_skipnan_argmax_on_gpu(pfmi_mod, eng):
+    """The chain non-PD fit -> per-fit status -> NaN ELBO -> NaN-skipping argmax, executed on the GPU and compared with the
+    oracle.  A BFGS-accepted trace is PD in exact arithmetic, so the failures are injected:
+      path 0  random (theta, grad) walk with the curvature threshold eps = -1e300 (the reference's `ϵ` keyword,
+              src/inverse_hessian.jl:25): negative-curvature pairs are accepted -> alpha < 0 (A not PD, :202) and
+              indefinite C = I + R D R' (:205);
+      path 1  NaN gradient at the FIRST fitted point  -> NaN mean -> NaN ELBO first      (test/utils.jl:10)
+      path 2  NaN gradient in the MIDDLE of the trace -> NaN ELBO in the middle           (test/utils.jl:9)
+      path 3  NaN gradient everywhere                 -> all NaN -> (NaN, 1)              (test/utils.jl:11)
+      path 4  clean trace."""
+    d, J, eps = 8, 6, -1e300
+    tg = pfmi_mod.t_diag(d, seed=3)
+    otg = oracle_target(tg)
+    rng = np.random.default_rng(0)
+    bad_th = np.cumsum(rng.normal(size=(9, d)), 0)
+    bad_gr = rng.normal(size=(9, d))
+    good = make_traces(tg, 4, 3)
+    ths = [bad_th] + [t.points.copy() for t in good]
+    grs = [bad_gr] + [t.gradients.copy() for t in good]
+    grs[1][1, 2] = np.nan
+    grs[2][len(grs[2]) // 2, 0] = np.nan
+    grs[3][:, 1] = np.nan
+    eng.set_target(tg)
+    eng.set_traces(ths, grs)
+    eng.fit_batch(J, eps)
+    status, jeff, logdet, nrej = eng.fit_status()
+    refs = []
+    for k in range(5):
+        p0, p1 = int(eng.offsets[k]), int(eng.offsets[k + 1])
+        ref = po.path_fit_elbo(ths[k], grs[k], J, otg, 0, np.zeros(p1 - p0, dtype=np.uint64), eps=eps)
+        np.testing.assert_array_equal(status[p0:p1], ref["status"])
+        np.testing.assert_array_equal(jeff[p0:p1], ref["j_eff"])
+        assert nrej[k] == ref["n_rejected"]
+        assert np.all(np.isnan(logdet[p0:p1][ref["status"] != 0]))
+    p0 = int(eng.offsets[0])
+    st0 = status[p0:int(eng.offsets[1])]
+    assert set(st0.tolist()) >= {0, 1, 2}, st0                  # both PosDefException sites really fired on the GPU
+    assert np.all(status[int(eng.offsets[1]):] == 0)            # a NaN gradient is rejected by the curvature test: the factor stays PD
+    seeds = fit_seeds(eng.P, 2)
+    for N, kern in ((32, None), (200, None), (200, "lane"), (200, "mfma")):      # two-pass (N < 64), single-pass scan, the others
+        old = os.environ.get("PFMI_ELBO_KERNEL")
+        if kern:
+            os.environ["PFMI_ELBO_KERNEL"] = kern
+        try:
+            elbo, se, best = eng.elbo_batch(N, seeds)
+        finally:
+            if kern:
+                os.environ.pop("PFMI_ELBO_KERNEL", None)
+                if old is not None:
+                    os.environ["PFMI_ELBO_KERNEL"] = old
+        for k in range(5):
+            p0, p1 = int(eng.offsets[k]), int(eng.offsets[k + 1])
+            ref = po.path_fit_elbo(ths[k], grs[k], J, otg, N, seeds[p0:p1], eps=eps)
+            np.testing.assert_array_equal(np.isnan(elbo[p0:p1]), np.isnan(ref["elbo"]))
+            fin = np.isfinite(ref["elbo"])
+            if k != 0:                                          # path 0 is indefinite garbage: only the NaN pattern / argmax logic
+                assert np.all(np.abs(elbo[p0:p1][fin] - ref["elbo"][fin]) <= 1e-9 * (1 + np.abs(ref["elbo"][fin])))
+                assert best[k] == ref["best_iter"], (N, kern, k)
+            else:                                               # argmax of the GPU's own values with the reference's rule
+                assert best[k] == po.findmax_skipnan(elbo[p0 + 1:p1])[1]
+            failed = np.flatnonzero(status[p0:p1] != 0)
+            assert np.all(np.isnan(elbo[p0:p1][failed])) and np.all(np.isnan(se[p0:p1][failed]))
+            for l in failed[:2]:
+                lp, lq = eng.elbo_logs(p0 + int(l), N)
+                assert np.all(np.isnan(lp)) and np.all(np.isnan(lq))
+        # the three NaN placements of test/utils.jl:8-12
+        p1_ = int(eng.offsets[1])
+        assert np.isnan(elbo[p1_ + 1]) and best[1] > 1                       # NaN first: a later finite value wins
+        mid = len(grs[2]) // 2
+        p2_ = int(eng.offsets[2])
+        assert np.isnan(elbo[p2_ + mid]) and best[2] != mid and np.isfinite(elbo[p2_ + best[2]])
+        p3_ = int(eng.offsets[3])
+        assert np.all(np.isnan(elbo[p3_:int(eng.offsets[4])])) and best[3] == 1   # all NaN -> (NaN, 1)
+    # WoodburyPDMat's constructor throws (src/woodbury.jl:202,205): fit_mvnormals mirrors it
+    with pytest.raises(pfmi_mod.PosDefException):
+        pfmi_mod.fit_mvnormals(bad_th, bad_gr, history_length=J, engine=eng, eps=eps)
+    dists, nrej1 = pfmi_mod.fit_mvnormals(good[0].points, good[0].gradients, history_length=J, engine=eng)
+    assert len(dists) == len(good[0]) and nrej1 == 0
+
+
+def test_retry_loop_resamples_the_initial_point(pfmi_mod):
+    """src/singlepath.jl:259-283: a failed run is retried from a freshly sampled point, up to ntries; num_tries is reported.
+    The target is NaN exactly at the supplied init, so try 1 has no iterations (L = 0 -> failure, :299) and try 2 starts
+    from init_sampler(rng)."""
+    d = 6
+    base = pfmi_mod.t_diag(d, seed=5)
+    init = np.full(d, 0.25)
+
+    def logp(x):
+        return float("nan") if np.array_equal(x, init) else float(base.logp(x))
+
+    tgt = pfmi_mod.CallbackTarget(d, logp, grad=lambda x: base.grad(x))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = pfmi_mod.pathfinder(tgt, init=init, ndraws=20, ndraws_elbo=50, rng=pfmi_mod.HostRNG(4), ntries=5)
+        assert res.success and res.num_tries == 2 and len(res.optim_trace) > 2
+        assert not np.array_equal(res.optim_trace.points[0], init)
+        with pytest.warns(UserWarning, match="Pathfinder failed after 1 tries"):
+            r1 = pfmi_mod.pathfinder(tgt, init=init, ndraws=20, ndraws_elbo=50, rng=pfmi_mod.HostRNG(4), ntries=1)
+    assert not r1.success and r1.num_tries == 1 and r1.fit_iteration == 0
+    assert r1.draws.shape == (d, 20)                              # src/singlepath.jl:231-233: draws from fit_distributions[1]
+
+
+# ---- BASELINE configs at their stated size -------------------------------------------------------------------
+def _pool_stage_vs_oracle(eng, K, N_r, ndraws, seeds, best):
+    """pool_build -> PSIS -> resample on the GPU; PSIS and the index draw re-run by the oracle on the SAME pooled log ratios."""
+    pts = [int(eng.offsets[k]) + int(best[k]) for k in range(K)]
+    eng.pool_build(N_r, pts, seeds[pts])
+    _, lr = eng.pool_get(draws=False)
+    res = eng.psis(lr)
+    lw, w, khat, M = po.psis(lr)
+    assert res["tail_length"] == M == min(-(-len(lr) // 5), int(np.ceil(3 * np.sqrt(len(lr)))))
+    if np.isfinite(khat):
+        assert abs(res["pareto_shape"] - khat) <= 1e-8 * max(1.0, abs(khat))
+    assert np.max(np.abs(res["log_weights"] - lw)) <= 1e-10 * (1 + np.abs(lw).max())
+    idx = eng.resample_indices(len(lr), ndraws, seed=20260928)
+    np.testing.assert_array_equal(idx, po.sample_weighted(res["weights"], ndraws, seed=20260928))
+    draws = eng.pool_gather(idx)
+    for t in (0, ndraws // 2, ndraws - 1):                       # draws = draws_all[:, inds], ids = cld(inds, N_r)
+        k, n = divmod(int(idx[t]), N_r)
+        X, _, _ = eng.draws(pts[k], seeds[pts[k]], 1, n0=n)
+        np.testing.assert_array_equal(draws[:, t], X[:, 0])
+    return res, idx
+
+
+def test_config2_exact_size_vs_oracle(pfmi_mod, eng):
+    """BASELINE config 2 exactly: multipathfinder npaths = 8, d = 100 diagonal Gaussian, ndraws_elbo = 1000, history 6,
+    device-made traces -- EVERY fit of every path against the oracle, then the pooled stage."""
+    K, d, J, N = 8, 100, 6, 1000
+    tg = pfmi_mod.t_diag(d, seed=1)
+    otg = oracle_target(tg)
+    eng.set_target(tg)
+    run_seeds = pfmi_mod.hostrng.rand_u64(20260928, np.arange(K, dtype=np.uint64), 9)
+    x0 = np.stack([pfmi_mod.HostRNG(int(s)).rand(d) * 4 - 2 for s in run_seeds])
+    npts = eng.optimize_batch(x0, J)
+    eng.fit_batch(J)
+    status, jeff, logdet, nrej = eng.fit_status()
+    seeds = fit_seeds(eng.P, 21)
+    elbo, se, best = eng.elbo_batch(N, seeds)
+    th = np.concatenate([eng.get_trace(k, logp=False)[0] for k in range(K)])
+    gr = np.concatenate([eng.get_trace(k, logp=False)[2] for k in range(K)])
+    ref = po.multipath_fit_elbo(eng.offsets, th, gr, J, otg, N, seeds, nthreads=min(K, os.cpu_count() or 1))
+    np.testing.assert_array_equal(status, ref["status"])
+    np.testing.assert_array_equal(jeff, ref["j_eff"])
+    np.testing.assert_array_equal(nrej, ref["n_rejected"])
+    assert jeff.max() == J and eng.P - K > 200
+    n_strict = 0
+    for k in range(K):
+        p0, p1 = int(eng.offsets[k]), int(eng.offsets[k + 1])
+        alpha_all, hl, hs, _ = po.lbfgs_history(th[p0:p1], gr[p0:p1], J)
+        wc = np.array([_wc(_factor(th[p0:p1], gr[p0:p1], alpha_all, hl, hs, l, d)) for l in range(1, p1 - p0)])
+        x, y = elbo[p0 + 1:p1], ref["elbo"][p0 + 1:p1]
+        assert np.all(np.isfinite(x)) and np.all(np.isfinite(y))
+        assert np.all(np.abs(logdet[p0:p1] - ref["logdet"][p0:p1]) <= 1e-10 * (1 + np.abs(ref["logdet"][p0:p1])))
+        assert np.all(np.abs(x[wc] - y[wc]) <= 1e-9 * (1 + np.abs(y[wc])))
+        assert np.all(np.abs(se[p0 + 1:p1][wc] - ref["se"][p0 + 1:p1][wc]) <= 1e-9 * (1 + ref["se"][p0 + 1:p1][wc]))
+        loose = ~wc
+        assert np.all(np.abs(x[loose] - y[loose]) <= 8 * np.maximum(se[p0 + 1:p1][loose], ref["se"][p0 + 1:p1][loose]) + 1e-9)
+        n_strict += int(wc.sum())
+        if np.all(wc):
+            top = np.sort(y)[-2:]
+            if top[1] - top[0] > 1e-8 * (1 + abs(top[1])):
+                assert best[k] == ref["best_iter"][k]
+    assert n_strict >= (eng.P - K) // 2, (n_strict, eng.P)
+    res, idx = _pool_stage_vs_oracle(eng, K, 1000, 1000, seeds, best)
+    assert res["pareto_shape"] < 0.7                            # a diagonal Gaussian is fitted well: PSIS says "ok"
+
+
+@pytest.mark.timeout(900)
+def test_config3_exact_size_vs_oracle(pfmi_mod, eng):
+    """BASELINE config 3 (the headline): npaths = 64, d = 1000 low-rank + diagonal Gaussian, history 6, ndraws_elbo = 1000,
+    traces made on the device -- the first 20 fits of EVERY path against the oracle (OpenMP over paths on the host cores),
+    then PSIS k-hat, smoothed weights and resample indices re-computed by the oracle on the pooled log ratios."""
+    K, d, J, N, NF = 64, 1000, 6, 1000, 20
+    tg = pfmi_mod.t_lowrank(d, r=8, seed=2)
+    otg = oracle_target(tg)
+    eng.set_target(tg)
+    run_seeds = pfmi_mod.hostrng.rand_u64(20260928, np.arange(K, dtype=np.uint64), 9)
+    x0 = np.stack([pfmi_mod.HostRNG(int(s)).rand(d) * 4 - 2 for s in run_seeds])
+    npts = eng.optimize_batch(x0, J)
+    assert npts.min() > NF + 1
+    eng.fit_batch(J)
+    status, jeff, logdet, nrej = eng.fit_status()
+    assert np.all(status == 0)
+    seeds = np.concatenate([pfmi_mod.hostrng.rand_u64(int(run_seeds[k]), np.arange(n, dtype=np.uint64), 10)
+                            for k, n in enumerate(npts)])
+    elbo, se, best = eng.elbo_batch(N, seeds)
+    # oracle on the truncated traces (history and fits of point l only depend on points <= l)
+    ths, grs, sds = [], [], []
+    for k in range(K):
+        t, _, g = eng.get_trace(k, logp=False)
+        ths.append(t[:NF + 1]); grs.append(g[:NF + 1])
+        sds.append(seeds[int(eng.offsets[k]):int(eng.offsets[k]) + NF + 1])
+    off = np.arange(K + 1, dtype=np.int64) * (NF + 1)
+    ref = po.multipath_fit_elbo(off, np.concatenate(ths), np.concatenate(grs), J, otg, N, np.concatenate(sds),
+                                nthreads=min(K, os.cpu_count() or 1))
+    n_strict = 0
+    for k in range(K):
+        p0 = int(eng.offsets[k])
+        sl = slice(p0, p0 + NF + 1)
+        rs = slice(k * (NF + 1), (k + 1) * (NF + 1))
+        np.testing.assert_array_equal(jeff[sl], ref["j_eff"][rs])
+        np.testing.assert_array_equal(status[sl], ref["status"][rs])
+        assert np.all(np.abs(logdet[sl] - ref["logdet"][rs]) <= 1e-10 * (1 + np.abs(ref["logdet"][rs])))
+        x, y = elbo[sl][1:], ref["elbo"][rs][1:]
+        alpha_all, hl, hs, _ = po.lbfgs_history(ths[k], grs[k], J)
+        wc = np.array([_wc(_factor(ths[k], grs[k], alpha_all, hl, hs, l, d)) for l in range(1, NF + 1)])
+        assert np.all(np.abs(x[wc] - y[wc]) <= 1e-9 * (1 + np.abs(y[wc]))), k
+        assert np.all(np.abs(se[sl][1:][wc] - ref["se"][rs][1:][wc]) <= 1e-9 * (1 + ref["se"][rs][1:][wc]))
+        lo = ~wc
+        assert np.all(np.abs(x[lo] - y[lo]) <= 8 * np.maximum(se[sl][1:][lo], ref["se"][rs][1:][lo]) + 1e-9 * (1 + np.abs(y[lo])))
+        n_strict += int(wc.sum())
+    assert n_strict >= K * NF * 3 // 4, n_strict
+    res, idx = _pool_stage_vs_oracle(eng, K, 1000, 1000, seeds, best)
+    # the headline workload's Pareto k-hat is what the ORACLE's PSIS gives on the same pool
+    assert np.isfinite(res["pareto_shape"])
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("tname,maxit", [("funnel", 12), ("diag", 10)])
+def test_config5_share_exact_shape_vs_oracle(pfmi_mod, eng, tname, maxit):
+    """The single-GPU share of BASELINE config 5 at its stated shape: d = 10^4, history_length = 10 (KC = 20), ndraws_elbo =
+    2000 -- 2 paths.  N_e = 2000 is 16 batches of 128 draws per fit, so V_h (1.6 MB per fit) is re-streamed through LDS for
+    every batch (only d = 2500 covered multi-batch streaming before).  The funnel is BASELINE's
+    target (its scaled block is numerically rank deficient -> statistical branch for most fits); the diagonal Gaussian at the
+    same shape has a well-conditioned QR, so there every fit is compared strictly."""
+    d, J, N, K = 10000, 10, 2000, 2
+    tg = pfmi_mod.t_funnel(d) if tname == "funnel" else pfmi_mod.t_diag(d, seed=1)
+    otg = oracle_target(tg)
+    eng.set_target(tg)
+    sc = 10.0 if tname == "funnel" else 2.0
+    x0 = pfmi_mod.HostRNG(5).rand(K * d).reshape(K, d) * 2 * sc - sc
+    npts = eng.optimize_batch(x0, J, maxit)
+    eng.fit_batch(J)
+    status, jeff, logdet, nrej = eng.fit_status()
+    seeds = fit_seeds(eng.P, 8)
+    elbo, se, best = eng.elbo_batch(N, seeds)
+    th = np.concatenate([eng.get_trace(k, logp=False)[0] for k in range(K)])
+    gr = np.concatenate([eng.get_trace(k, logp=False)[2] for k in range(K)])
+    ref = po.multipath_fit_elbo(eng.offsets, th, gr, J, otg, N, seeds, nthreads=K)
+    np.testing.assert_array_equal(status, ref["status"])
+    np.testing.assert_array_equal(jeff, ref["j_eff"])
+    n_strict = n_fits = 0
+    for k in range(K):
+        p0, p1 = int(eng.offsets[k]), int(eng.offsets[k + 1])
+        alpha_all, hl, hs, _ = po.lbfgs_history(th[p0:p1], gr[p0:p1], J)
+        for l in range(1, p1 - p0):
+            if ref["status"][p0 + l] != 0:
+                assert np.isnan(elbo[p0 + l])
+                continue
+            n_fits += 1
+            a, b = elbo[p0 + l], ref["elbo"][p0 + l]
+            assert abs(logdet[p0 + l] - ref["logdet"][p0 + l]) <= 1e-9 * (1 + abs(ref["logdet"][p0 + l]))
+            if _wc(_factor(th[p0:p1], gr[p0:p1], alpha_all, hl, hs, l, d)):
+                n_strict += 1
+                assert abs(a - b) <= 1e-8 * (1 + abs(b)), (k, l, a, b)
+                assert abs(se[p0 + l] - ref["se"][p0 + l]) <= 1e-7 * (1 + ref["se"][p0 + l])
+            else:
+                assert abs(a - b) <= 8 * max(se[p0 + l], ref["se"][p0 + l]) + 1e-8 * (1 + abs(b)), (k, l, a, b)
+    assert n_fits >= K * (maxit - 2)
+    if tname == "diag":
+        assert n_strict >= n_fits * 3 // 4 and jeff.max() >= 9, (n_strict, n_fits, jeff.max())
+    # winner's per-draw log densities straight from the production scan against the oracle's draws of the same fit
+    k = 0
+    p0, p1 = int(eng.offsets[0]), int(eng.offsets[1])
+    if best[k] == ref["best_iter"][k]:
+        refd = po.path_fit_elbo(th[p0:p1], gr[p0:p1], J, otg, N, seeds[p0:p1], want_draws=True)
+        lp, lq = eng.elbo_logs(p0 + int(best[k]), N)
+        alpha_all, hl, hs, _ = po.lbfgs_history(th[p0:p1], gr[p0:p1], J)
+        if _wc(_factor(th[p0:p1], gr[p0:p1], alpha_all, hl, hs, int(best[k]), d)):
+            assert np.max(np.abs(lp - refd["logp"]) / (1 + np.abs(refd["logp"]))) <= 1e-8
+        assert np.max(np.abs(lq - refd["logq"]) / (1 + np.abs(refd["logq"]))) <= 1e-9
+    # pooled stage at N_r = ndraws = 2000 (config 5's resample size)
+    _pool_stage_vs_oracle(eng, K, 2000, 2000, seeds, best)
+
+
+# ---- resample(): value-level -----------------------------------------------------
+def test_resample_modes_value_level_vs_oracle(pfmi_mod):
+    """src/resample.jl:20-46, 97-109 (test/resample.jl:111-159): (i) stored draws + stored PSIS reproduce the original
+    candidates and weights, (ii) fresh candidates: per-component draws, log ratios, PSIS and the selected columns against the
+    oracle, (iii) uniform / without replacement."""
+    d, K, N_r = 12, 5, 400
+    tg = pfmi_mod.t_lowrank(d, r=3, seed=4)
+    otg = oracle_target(tg)
+    res = pfmi_mod.multipathfinder(tg, 300, nruns=K, ndraws_elbo=60, ndraws_per_run=N_r, rng=pfmi_mod.HostRNG(17), optimizer="host")
+    eng = res.engine
+    cand = np.stack([r.draws for r in res.pathfinder_results], axis=2)              # (d, N_r, K) = stack(draws)
+    # (i) stored draws: same candidates, same PSIS weights, indices = oracle sampler on those weights
+    rng = pfmi_mod.HostRNG(5)
+    r1 = pfmi_mod.resample(res, 250, rng=rng)
+    np.testing.assert_array_equal(r1.psis_result.weights, res.psis_result.weights)
+    sd = int(pfmi_mod.HostRNG(5).rand_u64(1)[0])
+    idx = po.sample_weighted(res.psis_result.weights, 250, seed=sd)
+    np.testing.assert_array_equal(r1.draws, cand.reshape(d, -1, order="F")[:, idx])
+    np.testing.assert_array_equal(r1.draw_component_ids, idx // N_r + 1)
+    # (ii) fresh candidates (ndraws_per_run = M): rand(rng, component_k, M) for every component, then PSIS again
+    M = 150
+    rng = pfmi_mod.HostRNG(6)
+    r2 = pfmi_mod.resample(res, 200, rng=rng, ndraws_per_run=M)
+    chk = pfmi_mod.HostRNG(6)
+    cseeds = chk.rand_u64(K)
+    sd = int(chk.rand_u64(1)[0])
+    lrs, cands = [], []
+    for k, pr in enumerate(res.pathfinder_results):
+        tr = pr.optim_trace
+        alpha_all, hl, hs, _ = po.lbfgs_history(tr.points, tr.gradients, 6)
+        l = pr.fit_iteration
+        F = _factor(tr.points, tr.gradients, alpha_all, hl, hs, l, d)
+        assert _wc(F)
+        mu = F.fit_mean(tr.points[l], tr.gradients[l])
+        X, lq = F.rand_and_logpdf(mu, po.randn_fill(int(cseeds[k]), d, M))
+        cands.append(X); lrs.append(otg.logp(X) - lq)
+    lr = np.concatenate(lrs)
+    lw, w, khat, _ = po.psis(lr)
+    assert len(r2.psis_result.weights) == K * M
+    np.testing.assert_allclose(r2.psis_result.log_weights, lw, rtol=0, atol=1e-8 * (1 + np.abs(lw).max()))
+    assert abs(r2.psis_result.pareto_shape - khat) <= 1e-6
+    idx2 = po.sample_weighted(r2.psis_result.weights, 200, seed=sd)
+    allc = np.concatenate(cands, axis=1)
+    assert np.max(np.abs(r2.draws - allc[:, idx2]) / (1 + np.abs(allc[:, idx2]))) <= 1e-10
+    np.testing.assert_array_equal(r2.draw_component_ids, idx2 // M + 1)
+    # the original per-run draws are still the ORIGINAL ones after the pool was rebuilt (stale handles)
+    for k in (0, K - 1):
+        np.testing.assert_array_equal(res.pathfinder_results[k].draws, cand[:, :, k])
+    # and a second stored-draws resample of the fresh result goes back to the stored candidates (reference :97-101)
+    r3 = pfmi_mod.resample(r2, 100, rng=pfmi_mod.HostRNG(5))
+    np.testing.assert_array_equal(r3.psis_result.weights, res.psis_result.weights)
+    # (iii) importance = false: uniform over the pool, psis_result === nothing; replace = false: unique columns
+    r4 = pfmi_mod.resample(res, 120, rng=pfmi_mod.HostRNG(8), importance=False)
+    sd = int(pfmi_mod.HostRNG(8).rand_u64(1)[0])
+    idx4 = po.sample_uniform(K * N_r, 120, seed=sd)
+    assert r4.psis_result is None
+    np.testing.assert_array_equal(r4.draws, cand.reshape(d, -1, order="F")[:, idx4])
+    r5 = pfmi_mod.resample(res, 300, rng=pfmi_mod.HostRNG(9), replace=False)
+    sd = int(pfmi_mod.HostRNG(9).rand_u64(1)[0])
+    idx5 = po.sample_weighted_norep(res.psis_result.weights, 300, seed=sd)
+    assert len(set(idx5.tolist())) == 300
+    np.testing.assert_array_equal(r5.draws, cand.reshape(d, -1, order="F")[:, idx5])
+    eng.close()
+
+
+def test_stale_result_handles_raise(pfmi_mod):
+    """lazy handles index the engine's CURRENT buffers; after the engine is reused they must fail loudly."""
+    tg = pfmi_mod.t_diag(10, 1)
+    e = pfmi_mod.Engine(0)
+    r1 = pfmi_mod.multipathfinder(tg, 100, nruns=3, ndraws_elbo=40, rng=pfmi_mod.HostRNG(1), engine=e)
+    d0 = r1.pathfinder_results[0].draws.copy()                  # materialised: stays valid
+    mu1 = r1.pathfinder_results[1].fit_distribution.mu.copy()
+    r2 = pfmi_mod.multipathfinder(tg, 100, nruns=3, ndraws_elbo=40, rng=pfmi_mod.HostRNG(2), engine=e)
+    np.testing.assert_array_equal(r1.pathfinder_results[0].draws, d0)
+    np.testing.assert_array_equal(r1.pathfinder_results[1].fit_distribution.mu, mu1)
+    with pytest.raises(pfmi_mod.StaleHandleError):
+        r1.pathfinder_results[2].draws
+    with pytest.raises(pfmi_mod.StaleHandleError):
+        r1.pathfinder_results[2].fit_distribution.mu
+    with pytest.raises(pfmi_mod.StaleHandleError):
+        r1.pathfinder_results[0].elbo_estimates[0].draws
+    with pytest.raises(pfmi_mod.StaleHandleError):
+        r1.pathfinder_results[0].optim_trace.points
+    with pytest.raises(pfmi_mod.StaleHandleError):
+        pfmi_mod.resample(r1, 10)
+    assert r2.pathfinder_results[2].draws.shape == (10, 40)     # the current result's handles work
+    e.close()
+
+
+# ---- bench.py contract on the GPU box ---------------------------------------------------------------------------
+def test_bench_force_dist_counts_its_ranks():
+    """bench.py --gpus 1 --force-dist: the N > 1 code path (RCCL all-gather + all-reduce) in a single-rank world; the JSON line
+    reports the ranks counted through the collective."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "1", "--warmup", "1",
+                        "--npaths", "8", "--dim", "100", "--target", "diag", "--no-cpu-baseline"], capture_output=True, text=True,
+                       env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["ranks_in_collective"] == 1 and line["config"]["collective_backend"].startswith("nccl")
+    assert line["value"] > 0 and line["roofline"]["frac"] > 0
