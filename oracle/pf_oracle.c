@@ -506,33 +506,48 @@ void pfo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
     }
     out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
 }
-/* sin(2 pi u), cos(2 pi u) for u in (0,1) with exact octant reduction */
-static void sincos2pi(double u, double *s, double *c) {
-    double t = 4.0 * u;              /* quarter turns, exact */
-    double q = floor(t + 0.5);       /* nearest quarter */
-    double f = t - q;                /* in [-0.5, 0.5], exact */
-    double a = f * (M_PI / 2.0);
-    double sa = sin(a), ca = cos(a);
-    int iq = ((int)q) & 3;
-    switch (iq) {
-        case 0: *s = sa;  *c = ca;  break;
-        case 1: *s = ca;  *c = -sa; break;
-        case 2: *s = -sa; *c = -ca; break;
-        default:*s = -ca; *c = sa;  break;
-    }
+/* The standard-normal generator (replaces Julia's randn! of src/mvnormal.jl:30, whose Xoshiro/ziggurat stream cannot be
+ * reproduced outside Julia -- SURVEY.md H3).  One 32-bit Philox word -> one normal through the piecewise-cubic inverse normal
+ * CDF tabulated in pathfinder.jl_amd/csrc/pfmi_icdftab.h (generated by pathfinder.jl_amd/tools/gen_icdf_table.py, which
+ * documents the construction; |Q(p) + Phi^-1(p)| <= 7.5e-10).  That header is DATA shared with the device code on purpose: the
+ * table IS the definition of the generator, and because the evaluation uses only exactly rounded IEEE operations
+ * (int -> double, fma, subtraction) the GPU reproduces these normals BIT FOR BIT.  The table itself is pinned against
+ * scipy.special.ndtri and by distribution tests in tests/test_oracle_rng.py. */
+#include "../pathfinder.jl_amd/csrc/pfmi_icdftab.h"
+static const double PFO_ICDF_TAB[PF_ICDF_ENTRIES][4] = { PF_ICDF_TABLE_ROWS };
+
+/* Q(p) ~ -Phi^-1(p) for p in (2^-65, 1/2), p a double */
+double pfo_icdf_q(double p) {
+    uint64_t bits;
+    memcpy(&bits, &p, 8);
+    uint32_t hi = (uint32_t)(bits >> 32);
+    int idx = PF_ICDF_IDX0 - (int)(hi >> (20 - PF_ICDF_B));
+    uint64_t bb = (uint64_t)(hi & ~((1u << (20 - PF_ICDF_B)) - 1u)) << 32;      /* p with the low mantissa bits cleared */
+    double pb;
+    memcpy(&pb, &bb, 8);
+    const double dp = p - pb;
+    const double *c = PFO_ICDF_TAB[idx];
+    return fma(fma(fma(c[3], dp, c[2]), dp, c[1]), dp, c[0]);
+}
+/* one normal from the Philox word x; x2 = the matching word of the refinement call (counter word 3 = 1), only read when
+ * mag < 2^PF_ICDF_TAILBITS (probability 2^-19) */
+double pfo_icdf_normal(uint32_t x, uint32_t x2) {
+    const uint32_t mag = x & 0x7FFFFFFFu;
+    double p;
+    if (mag >= (1u << PF_ICDF_TAILBITS)) p = fma((double)mag, 0x1p-32, 0x1p-33);                 /* (mag + 1/2) 2^-32 */
+    else p = ((double)(((uint64_t)mag << 32) | x2) + 0.5) * 0x1p-64;                              /* exact: < 2^44 */
+    const double q = pfo_icdf_q(p);
+    return (x >> 31) ? -q : q;
 }
 void pfo_randn4(uint64_t seed, uint32_t g, uint32_t n, uint32_t stream, double z[4]) {
     uint32_t ctr[4] = {n, g, stream, 0u};
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-    uint32_t x[4];
+    uint32_t x[4], x2[4] = {0u, 0u, 0u, 0u};
     pfo_philox4x32_10(ctr, key, x);
-    const double S = 2.3283064365386962890625e-10; /* 2^-32 */
-    double u0 = ((double)x[0] + 0.5) * S, u1 = ((double)x[1] + 0.5) * S;
-    double u2 = ((double)x[2] + 0.5) * S, u3 = ((double)x[3] + 0.5) * S;
-    double r0 = sqrt(-2.0 * log(u0)), r1 = sqrt(-2.0 * log(u2));
-    double s, c;
-    sincos2pi(u1, &s, &c); z[0] = r0 * c; z[1] = r0 * s;
-    sincos2pi(u3, &s, &c); z[2] = r1 * c; z[3] = r1 * s;
+    int tail = 0;
+    for (int t = 0; t < 4; ++t) tail |= (x[t] & 0x7FFFFFFFu) < (1u << PF_ICDF_TAILBITS);
+    if (tail) { ctr[3] = 1u; pfo_philox4x32_10(ctr, key, x2); }
+    for (int t = 0; t < 4; ++t) z[t] = pfo_icdf_normal(x[t], x2[t]);
 }
 /* fill U (d x N col-major) with the standard normals of draws n0 .. n0+N-1 of `seed` */
 void pfo_randn_fill(uint64_t seed, int d, long n0, long N, double *U) {

@@ -69,9 +69,9 @@ struct TargetAcc {
 
 template <int KPAD, int TGT, int RPAD, bool MEM>
 __global__ __launch_bounds__(ELBO_THREADS) void pf_elbo_draws_kernel(ElboArgs A) {
-    __shared__ double2 logtab[128];
+    __shared__ double2 icdf_s[MEM ? 2 : 2 * PF_ICDF_LDS_ENTRIES];       // inverse-CDF table of the in-kernel generator
     if (!MEM) {
-        pf_logtab_load(logtab);
+        pf_icdf_load(icdf_s);
         __syncthreads();
     }
     const int slot = blockIdx.y;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(ELBO_THREADS) void pf_elbo_draws_kernel(ElboArgs A)
 #pragma unroll
             for (int t = 0; t < 4; ++t) z[t] = (4 * g + t < d) ? U[4 * g + t] : 0.0;
         } else {
-            pf_randn4_fast(seed, (uint32_t)g, n, 0u, logtab, z);
+            pf_randn4(seed, (uint32_t)g, n, 0u, icdf_s, z);
 #pragma unroll
             for (int t = 0; t < 4; ++t) if (4 * g + t >= d) z[t] = 0.0;
         }

@@ -81,9 +81,8 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
     double *ssum = tsum + 64 * ((RPAD + 3) / 4);              // [2][16] summed |u|^2 and diagonal quadratic form
     double *gs = ssum + 32;                    // [RPAD][RPAD] target capacitance factor
     double *red2 = gs + RPAD * RPAD;           // [8][16][4] per-wave per-draw scalars
-    double2 *logtab = reinterpret_cast<double2 *>(red2 + MF_WAVES * 64);   // [128] log table
-    double2 *sctab = logtab + 128;                                         // [256] {cos, sin} angle table
-    double *zero_s = red2 + MF_WAVES * 64 + 256 + 512;                     // [2] zeros (masked A-operand lanes)
+    double2 *icdf = reinterpret_cast<double2 *>(red2 + MF_WAVES * 64);     // [2 * 608] inverse-CDF table of the generator
+    double *zero_s = red2 + MF_WAVES * 64 + 4 * PF_ICDF_LDS_ENTRIES;       // [2] zeros (masked A-operand lanes)
 
     {
         const double *Vh = A.vh + (size_t)p * d * KC;
@@ -105,8 +104,7 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
         const double *T = A.tmat + (size_t)p * KC * KC;
         for (int i = tid; i < KC * KC; i += MF_THREADS) t_s[i] = T[i];
         if (TGT == 1 && RPAD > 0) for (int i = tid; i < RPAD * RPAD; i += MF_THREADS) gs[i] = A.t_g[i];
-        pf_logtab_load(logtab);
-        pf_sctab_load(sctab);
+        pf_icdf_load(icdf);
         if (tid < 2) zero_s[tid] = 0.0;
     }
     // head transform z_head = V' u_head as 4 MFMAs: A_r[i'][k] = M[rho(i')][4k + r], M = V' (identity padded)
@@ -143,11 +141,7 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
     auto pass1_block = [&](const int blk, const uint32_t n, const bool head, double (&zz)[4]) {
         uint32_t x[4];
         pf_philox4x32_10(n, (uint32_t)(blk * 4 + q), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
-        PfPair p1, p2;                                              // same arithmetic as the pipelined body
-        p1.s0(x[0], x[1]); p2.s0(x[2], x[3]);
-        p1.s1(logtab, sctab); p2.s1(logtab, sctab);
-        p1.s2(); p2.s2(); p1.s3(); p2.s3(); p1.s4(); p2.s4(); p1.s5(); p2.s5();
-        p1.s6(zz[0], zz[1]); p2.s6(zz[2], zz[3]);
+        pf_icdf4(x, n, (uint32_t)(blk * 4 + q), 0u, (uint32_t)seed, (uint32_t)(seed >> 32), icdf, zz);
         const int rowbase = blk * 16 + 4 * q;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -279,44 +273,44 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
             uint32_t c0 = nbv ? n_next : n_next + 16u;
             uint32_t c1 = (uint32_t)((nbv ? blk + 1 : wvs * NBW) * 4 + q), c2 = 0u, c3 = 0u;
             uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-            PfPair p1, p2;
             double zz[4], e4[4], xi4[4];
-            // P0
+            // P0: the normals of (next group, this block) from the Philox words xc = philox(n_next, 4 blk + q)
             xa = pf_mfma(a2v[0], ntv[0], xa);
-            pf_philox_round(c0, c1, c2, c3, k0, k1); p1.s0(xc[0], xc[1]); p2.s0(xc[2], xc[3]);
-            PF_PIN_RNG(); PF_PIN(p1.m); PF_PIN(p1.dlt); PF_PIN(p2.m); PF_PIN(p2.dlt);
+            pf_icdf4(xc, n_next, (uint32_t)(blk * 4 + q), 0u, (uint32_t)seed, (uint32_t)(seed >> 32), icdf, zz);
+            pf_philox_round(c0, c1, c2, c3, k0, k1);
+            PF_PIN_RNG(); PF_PIN(zz[0]); PF_PIN(zz[1]); PF_PIN(zz[2]); PF_PIN(zz[3]);
             PF_PHASE_END();
             // P1
             if (KC >= 8) xa = pf_mfma(a2v[KC >= 8 ? 1 : 0], ntv[KC >= 8 ? 1 : 0], xa);
-            pf_philox_round(c0, c1, c2, c3, k0, k1); p1.s1(logtab, sctab); p2.s1(logtab, sctab);
-            PF_PIN_RNG(); PF_PIN(p1.r); PF_PIN(p1.d2); PF_PIN(p2.r); PF_PIN(p2.d2);
+            pf_philox_round(c0, c1, c2, c3, k0, k1);
+            PF_PIN_RNG();
             PF_PHASE_END();
             // P2
             if (KC >= 12) xa = pf_mfma(a2v[KC >= 12 ? 2 : 0], ntv[KC >= 12 ? 2 : 0], xa);
             if (KC >= 16) xa = pf_mfma(a2v[KC >= 16 ? 3 : 0], ntv[KC >= 16 ? 3 : 0], xa);
-            pf_philox_round(c0, c1, c2, c3, k0, k1); p1.s2(); p2.s2();
-            PF_PIN_RNG(); PF_PIN(p1.p); PF_PIN(p2.p);
+            pf_philox_round(c0, c1, c2, c3, k0, k1);
+            PF_PIN_RNG();
             PF_PHASE_END();
             // P3
             if (b > 0) pass1_mfma_r(blk - 1, 0, z[b > 0 ? b - 1 : 0][0]);
-            pf_philox_round(c0, c1, c2, c3, k0, k1); p1.s3(); p2.s3();
-            PF_PIN_RNG(); PF_PIN(p1.g); PF_PIN(p1.h); PF_PIN(p2.g); PF_PIN(p2.h);
+            pf_philox_round(c0, c1, c2, c3, k0, k1);
+            PF_PIN_RNG();
             PF_PHASE_END();
             // P4: first half of the epilogue of the current group: x = mu + sqrt(alpha) x~
             if (b > 0) pass1_mfma_r(blk - 1, 1, z[b > 0 ? b - 1 : 0][1]);
-            pf_philox_round(c0, c1, c2, c3, k0, k1); p1.s4(); p2.s4();
+            pf_philox_round(c0, c1, c2, c3, k0, k1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 xi4[r] = mu4[r] + sq4[r] * xa[r];                                       // FOLD: this is already e = x - m
                 e4[r] = FOLD ? xi4[r] : xi4[r] - tm4[r];
             }
-            PF_PIN_RNG(); PF_PIN(p1.rad); PF_PIN(p1.sd); PF_PIN(p2.rad); PF_PIN(p2.sd);
+            PF_PIN_RNG();
 #pragma unroll
             for (int r = 0; r < 4; ++r) PF_PIN(e4[r]);
             PF_PHASE_END();
             // P5: second half: target accumulation, optional store
             if (b > 0) pass1_mfma_r(blk - 1, 2, z[b > 0 ? b - 1 : 0][2]);
-            pf_philox_round(c0, c1, c2, c3, k0, k1); p1.s5(); p2.s5();
+            pf_philox_round(c0, c1, c2, c3, k0, k1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = rowbase + r;
@@ -324,15 +318,15 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
                 else if (TGT == 2) { if (row == 0) tau = xi4[r]; else qd += xi4[r] * xi4[r]; }   // padded rows: xi = 0
                 if (WX) { if (X && row < d) X[row] = xi4[r]; }
             }
-            PF_PIN_RNG(); PF_PIN(p1.cs); PF_PIN(p1.sn); PF_PIN(p2.cs); PF_PIN(p2.sn); PF_PIN(qd);
+            PF_PIN_RNG(); PF_PIN(qd);
             PF_PHASE_END();
             // P6
             if (TGT == 1 && RPAD > 0) {
 #pragma unroll
                 for (int I = 0; I < TR; ++I) acc3[I] = pf_mfma4(a3[0][I], e4[0], acc3[I]);
             }
-            pf_philox_round(c0, c1, c2, c3, k0, k1); p1.s6(zz[0], zz[1]); p2.s6(zz[2], zz[3]);
-            PF_PIN_RNG(); PF_PIN(zz[0]); PF_PIN(zz[1]); PF_PIN(zz[2]); PF_PIN(zz[3]);
+            pf_philox_round(c0, c1, c2, c3, k0, k1);
+            PF_PIN_RNG();
             PF_PHASE_END();
             // P7
             if (TGT == 1 && RPAD > 0) {
@@ -461,7 +455,7 @@ static size_t mf_lds_bytes(int d, int kc, int rpad) {
     const size_t rows = (size_t)((d + 15) / 16) * 16;
     return sizeof(double) * (rows * kc + 3 * rows + (size_t)kc * kc + MF_WAVES * 64 * (kc / 4) +
                              MF_WAVES * 64 * ((rpad + 3) / 4) + 256 + 64 * ((rpad + 3) / 4) + 32 + (size_t)rpad * rpad +
-                             MF_WAVES * 64 + 256 + 512 + 2);
+                             MF_WAVES * 64 + 4 * PF_ICDF_LDS_ENTRIES + 2);
 }
 
 template <int KC, int NBW, int TGT, int RPAD, bool WX>

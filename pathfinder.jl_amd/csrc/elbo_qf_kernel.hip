@@ -91,8 +91,7 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
     double *t_s = lds + fix_off;                   // [KC][KC]
     double *cn_s = t_s + KC * KC;                  // [NC]
     double *g_s = cn_s + NC;                       // [RPAD][RPAD]
-    double2 *logtab = reinterpret_cast<double2 *>(g_s + RPAD * RPAD + ((KC * KC + NC + RPAD * RPAD) & 1));
-    double2 *sctab = logtab + 128;
+    double2 *icdf = reinterpret_cast<double2 *>(g_s + RPAD * RPAD + ((KC * KC + NC + RPAD * RPAD) & 1));   // [2 * 608] inverse-CDF table
 
     const double *Vh = A.vh + (size_t)p * d * KC, *mu = A.mu + (size_t)p * d, *sqa = A.sqrt_alpha + (size_t)p * d;
     auto stage_direct = [&](int ck, int buf) {
@@ -115,8 +114,7 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
         for (int i = tid; i < KC * KC; i += QF_THREADS) t_s[i] = T[i];
         for (int i = tid; i < NC; i += QF_THREADS) cn_s[i] = 0.0;
         if (RPAD > 0) for (int i = tid; i < RPAD * RPAD; i += QF_THREADS) g_s[i] = A.t_g[i];
-        pf_logtab_load(logtab);
-        pf_sctab_load(sctab);
+        pf_icdf_load(icdf);
         stage_direct(0, 0);
     }
     // head transform z_head = V'u_head as 16x16x4 MFMAs (same operand trick as the two-pass kernel): lane (q, c) supplies
@@ -244,11 +242,7 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
                 auto normals = [&](const int g, const int blk, double (&z)[4]) {
                     uint32_t x[4];
                     pf_philox4x32_10(n[g], (uint32_t)(blk * 4 + q), 0u, 0u, k0, k1, x);
-                    PfPair p1, p2;
-                    p1.s0(x[0], x[1]); p2.s0(x[2], x[3]);
-                    p1.s1(logtab, sctab); p2.s1(logtab, sctab);
-                    p1.s2(); p2.s2(); p1.s3(); p2.s3(); p1.s4(); p2.s4(); p1.s5(); p2.s5();
-                    p1.s6(z[0], z[1]); p2.s6(z[2], z[3]);
+                    pf_icdf4(x, n[g], (uint32_t)(blk * 4 + q), 0u, k0, k1, icdf, z);
                     if (blk == nblk - 1) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) z[r] = (blk * 16 + 4 * q + r < d) ? z[r] : 0.0;
@@ -307,27 +301,24 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
                         __builtin_amdgcn_sched_barrier(0);
                         double z[NG][4];
                         if (NG == 2 && blk0 + bl > 1 && blk0 + bl < nblk - 1) {
-                            // interior block: the 2 x 2 Box-Muller pairs advance stage by stage (4 independent dependency chains)
+                            // interior block: Philox calls and table look-ups of both groups side by side (independent chains)
                             const int blk = blk0 + bl;
                             uint32_t x[NG][4];
 #pragma unroll
                             for (int g = 0; g < NG; ++g) pf_philox4x32_10(n[g], (uint32_t)(blk * 4 + q), 0u, 0u, k0, k1, x[g]);
-                            PfPair pp[NG][2];
-#pragma unroll
-                            for (int g = 0; g < NG; ++g) { pp[g][0].s0(x[g][0], x[g][1]); pp[g][1].s0(x[g][2], x[g][3]); }
-#pragma unroll
-                            for (int g = 0; g < NG; ++g) { pp[g][0].s1(logtab, sctab); pp[g][1].s1(logtab, sctab); }
-#pragma unroll
-                            for (int g = 0; g < NG; ++g) { pp[g][0].s2(); pp[g][1].s2(); }
-#pragma unroll
-                            for (int g = 0; g < NG; ++g) { pp[g][0].s3(); pp[g][1].s3(); }
-#pragma unroll
-                            for (int g = 0; g < NG; ++g) { pp[g][0].s4(); pp[g][1].s4(); }
-#pragma unroll
-                            for (int g = 0; g < NG; ++g) { pp[g][0].s5(); pp[g][1].s5(); }
+                            bool tail = false;
 #pragma unroll
                             for (int g = 0; g < NG; ++g) {
-                                pp[g][0].s6(z[g][0], z[g][1]); pp[g][1].s6(z[g][2], z[g][3]);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) z[g][r] = pf_icdf_main(x[g][r], icdf);
+                                tail |= pf_icdf_tail4(x[g]);
+                            }
+                            if (__builtin_expect(__any(tail), 0)) {          // probability 2^-19 per normal
+#pragma unroll
+                                for (int g = 0; g < NG; ++g) pf_icdf4_fix(x[g], n[g], (uint32_t)(blk * 4 + q), 0u, k0, k1, z[g]);
+                            }
+#pragma unroll
+                            for (int g = 0; g < NG; ++g) {
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) usq[g] = fma(z[g][r], z[g][r], usq[g]);
                             }
@@ -459,7 +450,7 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
 // ---------------------------------------------------------------------------------------------------
 static size_t qf_lds_bytes(int ch_blocks, int nchunks, int kc, int rpad) {
     const size_t per = (size_t)ch_blocks * 16 * kc + (size_t)ch_blocks * 48;
-    return sizeof(double) * (per * (nchunks > 1 ? 2 : 1) + (size_t)kc * kc + qf_nconst(kc, rpad) + (size_t)rpad * rpad + 1 + 256 + 512);
+    return sizeof(double) * (per * (nchunks > 1 ? 2 : 1) + (size_t)kc * kc + qf_nconst(kc, rpad) + (size_t)rpad * rpad + 1 + 4 * PF_ICDF_LDS_ENTRIES);
 }
 
 template <int KC, int TGT, int RPAD, int NG>

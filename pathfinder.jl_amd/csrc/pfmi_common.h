@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/pfmi.h"
+#include "pfmi_icdftab.h"
 
 #define PF_LOG2PI 1.8378770664093454835606594728112352797227949472755668
 
@@ -183,17 +184,74 @@ __device__ __forceinline__ void pf_philox4x32_10(uint32_t c0, uint32_t c1, uint3
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// four standard normals for rows 4g..4g+3 of draw n (Box-Muller on 32-bit uniforms (x+0.5)2^-32)
-__device__ __forceinline__ void pf_randn4(uint64_t seed, uint32_t g, uint32_t n, uint32_t stream, double (&z)[4]) {
+// ---- the standard-normal generator ------------------------------------------------------------------------------
+// One 32-bit Philox word -> one normal through the piecewise-cubic inverse normal CDF of pfmi_icdftab.h (generated by
+// tools/gen_icdf_table.py, which documents the construction): exponent / top-5 mantissa bits of p = (mag + 1/2) 2^-32 select a
+// table entry, z = +-(c0 + dp (c1 + dp (c2 + dp c3))), dp = p - p_base.  Only exactly rounded IEEE operations (cvt, fma, sub)
+// => bit-identical to the CPU checker (pfo_randn4).  13 VALU instructions + two 16-byte LDS reads per normal (round 1's
+// Box-Muller: ~27 + Philox).  Words with mag < 2^PF_ICDF_TAILBITS (probability 2^-19) are refined with a second Philox word
+// (counter word 3 = 1) so that the tails reach |z| = 9.1 with >= 12 bits of resolution.
+static __device__ const double PF_ICDF_TAB_DEV[PF_ICDF_ENTRIES][4] = { PF_ICDF_TABLE_ROWS };
+
+// copy the common-case part of the table (binades 2^-2 .. 2^-20: 608 entries, 19 KB) into LDS; all threads, then a barrier
+__device__ __forceinline__ void pf_icdf_load(double2 *tab) {
+    const double2 *src = reinterpret_cast<const double2 *>(&PF_ICDF_TAB_DEV[0][0]);
+    for (int i = threadIdx.x; i < 2 * PF_ICDF_LDS_ENTRIES; i += blockDim.x) tab[i] = src[i];
+}
+// Q(p) ~ -Phi^-1(p), p in (2^-65, 1/2); `tab` holds at least `nent` entries (LDS copy or the full table)
+__device__ __forceinline__ double pf_icdf_q(double p, const double2 *tab, int nent) {
+    const unsigned hi = (unsigned)__double2hiint(p);
+    int idx = PF_ICDF_IDX0 - (int)(hi >> (20 - PF_ICDF_B));
+    idx = idx < nent - 1 ? idx : nent - 1;                         // tail words are fixed up by the caller
+    const double pb = __hiloint2double((int)(hi & ~((1u << (20 - PF_ICDF_B)) - 1u)), 0);
+    const double dp = p - pb;
+    const double2 c01 = tab[2 * idx], c23 = tab[2 * idx + 1];
+    return fma(fma(fma(c23.y, dp, c23.x), dp, c01.y), dp, c01.x);
+}
+// common case (mag >= 2^PF_ICDF_TAILBITS), table in LDS
+__device__ __forceinline__ double pf_icdf_main(uint32_t x, const double2 *lds_tab) {
+    const double p = fma((double)(x & 0x7FFFFFFFu), 0x1p-32, 0x1p-33);
+    const double q = pf_icdf_q(p, lds_tab, PF_ICDF_LDS_ENTRIES);
+    return __hiloint2double(__double2hiint(q) ^ (int)(x & 0x80000000u), __double2loint(q));
+}
+// any word, full table in global memory (rare path / kernels without an LDS copy)
+__device__ __forceinline__ double pf_icdf_any(uint32_t x, uint32_t x2) {
+    const uint32_t mag = x & 0x7FFFFFFFu;
+    double p;
+    if (mag >= (1u << PF_ICDF_TAILBITS)) p = fma((double)mag, 0x1p-32, 0x1p-33);
+    else p = ((double)(((uint64_t)mag << 32) | x2) + 0.5) * 0x1p-64;
+    const double q = pf_icdf_q(p, reinterpret_cast<const double2 *>(&PF_ICDF_TAB_DEV[0][0]), PF_ICDF_ENTRIES);
+    return (x >> 31) ? -q : q;
+}
+__device__ __forceinline__ bool pf_icdf_is_tail(uint32_t x) { return (x & 0x7FFFFFFFu) < (1u << PF_ICDF_TAILBITS); }
+
+__device__ __forceinline__ bool pf_icdf_tail4(const uint32_t (&x)[4]) {
+    const uint32_t m01 = min(x[0] & 0x7FFFFFFFu, x[1] & 0x7FFFFFFFu), m23 = min(x[2] & 0x7FFFFFFFu, x[3] & 0x7FFFFFFFu);
+    return min(m01, m23) < (1u << PF_ICDF_TAILBITS);
+}
+// rare path: replace the normals of tail words by their refined values (second Philox call, full table in global memory)
+__device__ __forceinline__ void pf_icdf4_fix(const uint32_t (&x)[4], uint32_t n, uint32_t g, uint32_t stream, uint32_t k0, uint32_t k1,
+                                          double (&z)[4]) {
+    if (!pf_icdf_tail4(x)) return;
+    uint32_t x2[4];
+    pf_philox4x32_10(n, g, stream, 1u, k0, k1, x2);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) if (pf_icdf_is_tail(x[t])) z[t] = pf_icdf_any(x[t], x2[t]);
+}
+// the four normals of Philox words x[0..3] (call (n, g, stream)), LDS table for the common case
+__device__ __forceinline__ void pf_icdf4(const uint32_t (&x)[4], uint32_t n, uint32_t g, uint32_t stream, uint32_t k0, uint32_t k1,
+                                         const double2 *lds_tab, double (&z)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) z[t] = pf_icdf_main(x[t], lds_tab);
+    if (__builtin_expect(__any(pf_icdf_tail4(x)), 0)) pf_icdf4_fix(x, n, g, stream, k0, k1, z);
+}
+// four standard normals for rows 4g..4g+3 of draw n
+__device__ __forceinline__ void pf_randn4(uint64_t seed, uint32_t g, uint32_t n, uint32_t stream, const double2 *lds_tab,
+                                          double (&z)[4]) {
     uint32_t x[4];
-    pf_philox4x32_10(n, g, stream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
-    const double S = 2.3283064365386962890625e-10;  // 2^-32
-    double u0 = ((double)x[0] + 0.5) * S, u1 = ((double)x[1] + 0.5) * S;
-    double u2 = ((double)x[2] + 0.5) * S, u3 = ((double)x[3] + 0.5) * S;
-    double r0 = sqrt(-2.0 * log(u0)), r1 = sqrt(-2.0 * log(u2));
-    double s, c;
-    sincospi(2.0 * u1, &s, &c); z[0] = r0 * c; z[1] = r0 * s;
-    sincospi(2.0 * u3, &s, &c); z[2] = r1 * c; z[3] = r1 * s;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    pf_philox4x32_10(n, g, stream, 0u, k0, k1, x);
+    pf_icdf4(x, n, g, stream, k0, k1, lds_tab, z);
 }
 
 __device__ __forceinline__ uint64_t pf_rand_u64(uint64_t seed, uint64_t t, uint32_t stream) {
