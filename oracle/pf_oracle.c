@@ -516,7 +516,7 @@ void pfo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 #include "../pathfinder.jl_amd/csrc/pfmi_icdftab.h"
 static const double PFO_ICDF_TAB[PF_ICDF_ENTRIES][4] = { PF_ICDF_TABLE_ROWS };
 
-/* Q(p) ~ -Phi^-1(p) for p in (2^-65, 1/2), p a double */
+/* Q ~ -Phi^-1(p) for p in (2^-65, 1/2), argument P = 2^32 p (the scaled variable the table is stored in) */
 double pfo_icdf_q(double p) {
     uint64_t bits;
     memcpy(&bits, &p, 8);
@@ -534,8 +534,8 @@ double pfo_icdf_q(double p) {
 double pfo_icdf_normal(uint32_t x, uint32_t x2) {
     const uint32_t mag = x & 0x7FFFFFFFu;
     double p;
-    if (mag >= (1u << PF_ICDF_TAILBITS)) p = fma((double)mag, 0x1p-32, 0x1p-33);                 /* (mag + 1/2) 2^-32 */
-    else p = ((double)(((uint64_t)mag << 32) | x2) + 0.5) * 0x1p-64;                              /* exact: < 2^44 */
+    if (mag >= (1u << PF_ICDF_TAILBITS)) p = (double)mag + 0.5;                                  /* P = 2^32 p = mag + 1/2 */
+    else p = ((double)(((uint64_t)mag << 32) | x2) + 0.5) * 0x1p-32;                              /* exact: < 2^44 */
     const double q = pfo_icdf_q(p);
     return (x >> 31) ? -q : q;
 }

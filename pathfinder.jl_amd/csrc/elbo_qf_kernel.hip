@@ -21,6 +21,7 @@
 //     fetch is a conflict-free broadcast read;
 //   * per 16-row block a wave issues 4 k-steps x (2 KC/4 + RPAD/4) quarter-size MFMAs (16 cycles each) -- the same
 //     matrix work as the two-pass kernel -- plus the RNG.
+#include <type_traits>
 #include "pfmi_common.h"
 #include "pfmi_fastmath.h"
 #include "elbo_args.h"
@@ -31,6 +32,9 @@
 #define QF_THREADS (QF_WAVES * 64)
 #ifndef QF_NG
 #define QF_NG 2                        // 16-draw groups per wave (share the operand fetches of a block)
+#endif
+#ifndef QF_ABLATE
+#define QF_ABLATE 0
 #endif
 #define QF_CHB 16                      // blocks (of 16 rows) per streamed chunk
 
@@ -175,6 +179,29 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
 #pragma unroll
             for (int r = 0; r < 4; ++r) u0[g][r] = 0.0;
         }
+        // software pipeline of the generator: the Philox call, interval look-up and table reads of the NEXT (group, block) are
+        // issued before the MFMA burst of the current group and consumed after it, so the (bank-conflicted, ~150-cycle)
+        // random-index LDS reads never stall the wave.  With two groups per wave they alternate -- finish g0, issue g1,
+        // contract g0, finish g1, issue g0 of the next block, contract g1 -- so ONE set of landing registers (`pend`, 44 VGPRs)
+        // serves both; it carries across iterations and chunk boundaries.  LDS issue order = consumption order (tables of the
+        // previous step, operands of this block, tables of the next step), so every s_waitcnt is exact.
+        struct Pend { uint32_t x[4]; double dp[4]; double2 c01[4], c23[4]; };
+        Pend pend;
+        auto gen_issue = [&](const int g, const int blk, Pend &P) {
+#if QF_ABLATE == 1                     // ablation (timing experiments only): no generator at all
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { P.x[r] = 0x40000000u | (n[g] + blk); P.dp[r] = 1e-3 * (blk + r); P.c01[r] = make_double2(0.1, 0.2); P.c23[r] = make_double2(0.3, 0.4); }
+#elif QF_ABLATE == 2                   // ablation: Philox only, no table look-up
+            pf_philox4x32_10(n[g], (uint32_t)(blk * 4 + q), 0u, 0u, k0, k1, P.x);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { P.dp[r] = (double)P.x[r] * 0x1p-32; P.c01[r] = make_double2(0.1, 0.2); P.c23[r] = make_double2(0.3, 0.4); }
+#else
+            pf_philox4x32_10(n[g], (uint32_t)(blk * 4 + q), 0u, 0u, k0, k1, P.x);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pf_icdf_issue(P.x[r], icdf, P.dp[r], P.c01[r], P.c23[r]);
+#endif
+        };
+        if (any_active && !any_pseudo) gen_issue(0, 0, pend);
         for (int ck = 0; ck < nchunks; ++ck) {
             // ---- streaming: fetch the next chunk (or chunk 0 for the next batch) into registers while this one is consumed
             double pre[PRE], pr_s = 0.0, pr_a = 0.0, pr_c = 0.0;
@@ -266,6 +293,41 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
                         for (int r = 0; r < 4; ++r) z[r] = h[r];
                     }
                 };
+                // second half of the pipelined generator: normals of block blk from the pending coefficients (+ what `normals` does)
+                auto finish = [&](const int g, const int blk, const Pend &P, double (&z)[4], auto special_tag) {
+                    constexpr bool SPECIAL = decltype(special_tag)::value;       // first / second / last block of the scan
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) z[r] = pf_icdf_finish(P.x[r], P.dp[r], P.c01[r], P.c23[r]);
+                    if (__builtin_expect(__any(pf_icdf_tail4(P.x)), 0))          // probability 2^-19 per normal
+                        pf_icdf4_fix(P.x, n[g], (uint32_t)(blk * 4 + q), 0u, k0, k1, z);
+                    if (SPECIAL) {
+                        if (blk == nblk - 1) {                                   // rows >= d do not exist
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) z[r] = (blk * 16 + 4 * q + r < d) ? z[r] : 0.0;
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) usq[g] = fma(z[r], z[r], usq[g]);
+                        if (blk == 0) {                                          // z[1:k] = V'u[1:k] (src/woodbury.jl:139)
+                            qf_d4 h = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { u0[g][r] = z[r]; h = qf_mfma16(a_h00[r], z[r], h); }
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) z[r] = h[r];
+                            z00[g] = z[0];
+                        } else if (KC > 16 && blk == 1) {
+                            qf_d4 h = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) h = qf_mfma16(a_h10[r], u0[g][r], h);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) h = qf_mfma16(a_h11[r], z[r], h);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) z[r] = h[r];
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) usq[g] = fma(z[r], z[r], usq[g]);      // |u|^2 before the transform (src/mvnormal.jl:31)
+                    }
+                };
                 // pseudo group: column j of this lane is Vh[:, j] (j < KC) or c/s (j == KC); no RNG, no head transform
                 auto pseudo_cols = [&](const int g, const int blk, const int bl, double (&z)[4]) {
                     const int j = 16 * sl[g] + c;
@@ -295,39 +357,35 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
                         }
                     }
                 } else {
-                    for (int bl = 0; bl < nb; ++bl) {
+                    // one block of both groups; the body exists twice: interior blocks (no row masking, no head transform) and the
+                    // first / second / last block, selected by ONE wave-uniform branch per block
+                    auto block_body = [&](const int bl, auto special_tag) {
+                        const int blk = blk0 + bl;
                         Ops oa;
-                        load_ops(bl, oa);                    // issued first; the RNG below hides the LDS / L2 latency
-                        __builtin_amdgcn_sched_barrier(0);
-                        double z[NG][4];
-                        if (NG == 2 && blk0 + bl > 1 && blk0 + bl < nblk - 1) {
-                            // interior block: Philox calls and table look-ups of both groups side by side (independent chains)
-                            const int blk = blk0 + bl;
-                            uint32_t x[NG][4];
 #pragma unroll
-                            for (int g = 0; g < NG; ++g) pf_philox4x32_10(n[g], (uint32_t)(blk * 4 + q), 0u, 0u, k0, k1, x[g]);
-                            bool tail = false;
-#pragma unroll
-                            for (int g = 0; g < NG; ++g) {
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) z[g][r] = pf_icdf_main(x[g][r], icdf);
-                                tail |= pf_icdf_tail4(x[g]);
+                        for (int g = 0; g < NG; ++g) {
+                            double z[4];
+                            finish(g, blk, pend, z, special_tag);    // coefficients were requested one MFMA burst ago
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (g == 0) {                            // operands of this block; the Philox work below hides their latency
+                                load_ops(bl, oa);
+                                __builtin_amdgcn_sched_barrier(0);
                             }
-                            if (__builtin_expect(__any(tail), 0)) {          // probability 2^-19 per normal
-#pragma unroll
-                                for (int g = 0; g < NG; ++g) pf_icdf4_fix(x[g], n[g], (uint32_t)(blk * 4 + q), 0u, k0, k1, z[g]);
-                            }
-#pragma unroll
-                            for (int g = 0; g < NG; ++g) {
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) usq[g] = fma(z[g][r], z[g][r], usq[g]);
-                            }
-                        } else {
-#pragma unroll
-                            for (int g = 0; g < NG; ++g) normals(g, blk0 + bl, z[g]);   // a trailing inactive group only wastes its own lanes
+                            if (g + 1 < NG) gen_issue(g + 1, blk, pend);
+                            else if (blk + 1 < nblk) gen_issue(0, blk + 1, pend);
+                            __builtin_amdgcn_sched_barrier(0);
+#if QF_ABLATE == 3                     // ablation: generator only, no contraction
+                            q12[g] += z[0] + z[1] + z[2] + z[3] + oa.av[0][0] + oa.rs[0];
+#else
+                            contract(g, z, oa, true);
+#endif
+                            __builtin_amdgcn_sched_barrier(0);
                         }
-#pragma unroll
-                        for (int g = 0; g < NG; ++g) contract(g, z[g], oa, true);
+                    };
+                    for (int bl = 0; bl < nb; ++bl) {
+                        const int blk = blk0 + bl;
+                        if (__builtin_expect((blk == 0) | (blk == nblk - 1) | (KC > 16 && blk == 1), 0)) block_body(bl, std::true_type{});
+                        else block_body(bl, std::false_type{});
                     }
                 }
             }

@@ -168,15 +168,23 @@ void pf_kernel_end(pfmi_ctx *c, const char *name);
 #ifdef __HIPCC__
 
 // Philox4x32-10 (Salmon et al. 2011); identical bit stream to oracle/pf_oracle.c:pfo_philox4x32_10
+// a ^ b ^ k with the (wave-uniform) round key as the one scalar operand VOP3 allows: LLVM splits this into two v_xor_b32 when k
+// lives in an SGPR, which costs 20 extra instructions per Philox call
+__device__ __forceinline__ uint32_t pf_xor3_key(uint32_t a, uint32_t b, uint32_t k) {
+    if (__builtin_constant_p(k)) return a ^ b ^ k;
+    uint32_t r;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(r) : "v"(a), "v"(b), "s"(k));   // gfx950: three-input bit op, truth table 0x96 = a ^ b ^ c
+    return r;
+}
 __device__ __forceinline__ void pf_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                  uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n0 = pf_xor3_key((uint32_t)(p1 >> 32), c1, k0);
         uint32_t n1 = (uint32_t)p1;
-        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n2 = pf_xor3_key((uint32_t)(p0 >> 32), c3, k1);
         uint32_t n3 = (uint32_t)p0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -187,41 +195,59 @@ __device__ __forceinline__ void pf_philox4x32_10(uint32_t c0, uint32_t c1, uint3
 // ---- the standard-normal generator ------------------------------------------------------------------------------
 // One 32-bit Philox word -> one normal through the piecewise-cubic inverse normal CDF of pfmi_icdftab.h (generated by
 // tools/gen_icdf_table.py, which documents the construction): exponent / top-5 mantissa bits of p = (mag + 1/2) 2^-32 select a
-// table entry, z = +-(c0 + dp (c1 + dp (c2 + dp c3))), dp = p - p_base.  Only exactly rounded IEEE operations (cvt, fma, sub)
+// table entry, z = +-(c0 + dp (c1 + dp (c2 + dp c3))), dp = p - p_base (evaluated in the scaled variable P = 2^32 p = mag + 1/2).  Only exactly rounded IEEE operations (cvt, fma, sub)
 // => bit-identical to the CPU checker (pfo_randn4).  13 VALU instructions + two 16-byte LDS reads per normal (round 1's
 // Box-Muller: ~27 + Philox).  Words with mag < 2^PF_ICDF_TAILBITS (probability 2^-19) are refined with a second Philox word
 // (counter word 3 = 1) so that the tails reach |z| = 9.1 with >= 12 bits of resolution.
 static __device__ const double PF_ICDF_TAB_DEV[PF_ICDF_ENTRIES][4] = { PF_ICDF_TABLE_ROWS };
 
-// copy the common-case part of the table (binades 2^-2 .. 2^-20: 608 entries, 19 KB) into LDS; all threads, then a barrier
+// copy the common-case part of the table (binades 2^-2 .. 2^-20: 608 entries, 19 KB) into LDS; all threads, then a barrier.
+// LDS layout: two arrays of 16-byte entries, {c0, c1}[608] then {c2, c3}[608] -- with the random per-lane index a 16-lane LDS
+// group then spreads over 16 bank quads instead of 8 (simulated: 5.4 instead of 7.5 LDS cycles per group and normal).
 __device__ __forceinline__ void pf_icdf_load(double2 *tab) {
     const double2 *src = reinterpret_cast<const double2 *>(&PF_ICDF_TAB_DEV[0][0]);
-    for (int i = threadIdx.x; i < 2 * PF_ICDF_LDS_ENTRIES; i += blockDim.x) tab[i] = src[i];
+    for (int i = threadIdx.x; i < 2 * PF_ICDF_LDS_ENTRIES; i += blockDim.x) tab[(i & 1) * PF_ICDF_LDS_ENTRIES + (i >> 1)] = src[i];
 }
-// Q(p) ~ -Phi^-1(p), p in (2^-65, 1/2); `tab` holds at least `nent` entries (LDS copy or the full table)
+// Q ~ -Phi^-1(p), p in (2^-65, 1/2), argument P = 2^32 p.  LDS = true: `tab` is the LDS copy made by pf_icdf_load (nent = 608);
+// false: the full table in its generated [entry][4] layout
+template <bool LDS>
 __device__ __forceinline__ double pf_icdf_q(double p, const double2 *tab, int nent) {
     const unsigned hi = (unsigned)__double2hiint(p);
     int idx = PF_ICDF_IDX0 - (int)(hi >> (20 - PF_ICDF_B));
     idx = idx < nent - 1 ? idx : nent - 1;                         // tail words are fixed up by the caller
     const double pb = __hiloint2double((int)(hi & ~((1u << (20 - PF_ICDF_B)) - 1u)), 0);
     const double dp = p - pb;
-    const double2 c01 = tab[2 * idx], c23 = tab[2 * idx + 1];
+    const double2 c01 = LDS ? tab[idx] : tab[2 * idx], c23 = LDS ? tab[PF_ICDF_LDS_ENTRIES + idx] : tab[2 * idx + 1];
     return fma(fma(fma(c23.y, dp, c23.x), dp, c01.y), dp, c01.x);
 }
 // common case (mag >= 2^PF_ICDF_TAILBITS), table in LDS
 __device__ __forceinline__ double pf_icdf_main(uint32_t x, const double2 *lds_tab) {
-    const double p = fma((double)(x & 0x7FFFFFFFu), 0x1p-32, 0x1p-33);
-    const double q = pf_icdf_q(p, lds_tab, PF_ICDF_LDS_ENTRIES);
+    const double p = (double)(x & 0x7FFFFFFFu) + 0.5;
+    const double q = pf_icdf_q<true>(p, lds_tab, PF_ICDF_LDS_ENTRIES);
     return __hiloint2double(__double2hiint(q) ^ (int)(x & 0x80000000u), __double2loint(q));
 }
 // any word, full table in global memory (rare path / kernels without an LDS copy)
 __device__ __forceinline__ double pf_icdf_any(uint32_t x, uint32_t x2) {
     const uint32_t mag = x & 0x7FFFFFFFu;
     double p;
-    if (mag >= (1u << PF_ICDF_TAILBITS)) p = fma((double)mag, 0x1p-32, 0x1p-33);
-    else p = ((double)(((uint64_t)mag << 32) | x2) + 0.5) * 0x1p-64;
-    const double q = pf_icdf_q(p, reinterpret_cast<const double2 *>(&PF_ICDF_TAB_DEV[0][0]), PF_ICDF_ENTRIES);
+    if (mag >= (1u << PF_ICDF_TAILBITS)) p = (double)mag + 0.5;
+    else p = ((double)(((uint64_t)mag << 32) | x2) + 0.5) * 0x1p-32;
+    const double q = pf_icdf_q<false>(p, reinterpret_cast<const double2 *>(&PF_ICDF_TAB_DEV[0][0]), PF_ICDF_ENTRIES);
     return (x >> 31) ? -q : q;
+}
+// the same in two halves for software-pipelined callers: `issue` computes dp and starts the two table reads, `finish`
+// evaluates the cubic once the coefficients have landed (one iteration later)
+__device__ __forceinline__ void pf_icdf_issue(uint32_t x, const double2 *lds_tab, double &dp, double2 &c01, double2 &c23) {
+    const double p = (double)(x & 0x7FFFFFFFu) + 0.5;
+    const unsigned hi = (unsigned)__double2hiint(p);
+    int idx = PF_ICDF_IDX0 - (int)(hi >> (20 - PF_ICDF_B));
+    idx = idx < PF_ICDF_LDS_ENTRIES - 1 ? idx : PF_ICDF_LDS_ENTRIES - 1;
+    dp = p - __hiloint2double((int)(hi & ~((1u << (20 - PF_ICDF_B)) - 1u)), 0);
+    c01 = lds_tab[idx]; c23 = lds_tab[PF_ICDF_LDS_ENTRIES + idx];
+}
+__device__ __forceinline__ double pf_icdf_finish(uint32_t x, double dp, const double2 &c01, const double2 &c23) {
+    const double q = fma(fma(fma(c23.y, dp, c23.x), dp, c01.y), dp, c01.x);
+    return __hiloint2double(__double2hiint(q) ^ (int)(x & 0x80000000u), __double2loint(q));
 }
 __device__ __forceinline__ bool pf_icdf_is_tail(uint32_t x) { return (x & 0x7FFFFFFFu) < (1u << PF_ICDF_TAILBITS); }
 

@@ -7,7 +7,7 @@ import sys
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)                      # pathfinder.jl_amd/
-_SO = os.path.join(_ROOT, "lib", "libpfmi.so")
+_SO = os.environ.get("PFMI_LIB_PATH") or os.path.join(_ROOT, "lib", "libpfmi.so")   # override: ablation / experiment builds
 _lib = None
 
 

@@ -1,0 +1,105 @@
+"""The standard-normal generator shared bit for bit by the oracle and the HIP kernels (round 2): one Philox4x32-10 word per
+normal through the tabulated piecewise-cubic inverse normal CDF (pathfinder.jl_amd/tools/gen_icdf_table.py ->
+csrc/pfmi_icdftab.h).  The reference draws with Julia's randn! (src/mvnormal.jl:30), whose stream cannot be reproduced
+outside Julia; what can be pinned is that THIS generator is N(0, 1) to far below Monte Carlo resolution, with
+tails beyond 8 sigma (VERDICT r1 weak #8 / ADVICE r1: the 32-bit Box-Muller of round 1 stopped at 6.66 sigma)."""
+import ctypes as C
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+from scipy import stats
+from scipy.special import ndtri
+
+from oracle import pf_oracle as po
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    lib = po.lib()
+    lib.pfo_icdf_q.restype = C.c_double
+    lib.pfo_icdf_q.argtypes = [C.c_double]
+    lib.pfo_icdf_normal.restype = C.c_double
+    lib.pfo_icdf_normal.argtypes = [C.c_uint32, C.c_uint32]
+    return lib
+
+
+def test_table_matches_inverse_normal_cdf(L):
+    """|Q(p) + Phi^-1(p)| <= 7.5e-10 on (2^-65, 1/2): log-uniform p (every binade) and uniform p (the bulk)."""
+    rng = np.random.default_rng(0)
+    ps = np.concatenate([np.exp(rng.uniform(np.log(2.0 ** -65), np.log(0.5), 60000)), rng.uniform(2.0 ** -20, 0.5, 60000)])
+    q = np.array([L.pfo_icdf_q(float(p) * 2.0 ** 32) for p in ps])          # the table is stored in the variable P = 2^32 p
+    assert np.max(np.abs(q + ndtri(ps))) <= 7.5e-10
+    assert np.all(q > 0)
+
+
+def test_committed_table_is_what_the_generator_script_produces():
+    spec = importlib.util.spec_from_file_location("gen_icdf", os.path.join(ROOT, "pathfinder.jl_amd", "tools", "gen_icdf_table.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    txt = open(os.path.join(ROOT, "pathfinder.jl_amd", "csrc", "pfmi_icdftab.h")).read()
+    rows = [l for l in txt.splitlines() if l.strip().startswith("{")]
+    assert len(rows) == 2048 == (g.E_TOP - g.E_BOT + 1) << g.B
+    k = np.arange(4)
+    xn = np.cos((2 * k + 1) * np.pi / 8)
+    for i in (0, 1, 31, 32, 607, 608, 1000, 2047):
+        a, h = g.interval(i)
+        t = (xn + 1) / 2
+        c = np.linalg.solve(np.vander(t, 4, increasing=True), -ndtri(a + h * t)) / h ** np.arange(4) * 2.0 ** (-32.0 * np.arange(4))
+        got = [float.fromhex(v.strip()) for v in rows[i].strip().rstrip("\\").strip().rstrip(",").strip("{}").split(",")]
+        np.testing.assert_allclose(got, c, rtol=1e-12)
+
+
+def test_word_to_normal_map(L):
+    f = L.pfo_icdf_normal
+    for x in (0, 1, 4095, 4096, 123456789, 0x7FFFFFFF):
+        assert f(x, 77) == -f(x | 0x80000000, 77)                          # sign bit = sign
+    mags = [0x7FFFFFFF, 0x40000000, 0x00100000, 4096, 4095, 100, 1, 0]
+    z = [f(m, 0x80000000) for m in mags]
+    assert all(b > a for a, b in zip(z, z[1:]))                              # smaller p -> larger |z|
+    assert abs(f(0x7FFFFFFF, 0)) < 1e-9                                      # p -> 1/2
+    # the second word only matters below 2^12 and refines continuously: p = (mag 2^32 + x2 + 1/2) 2^-64
+    assert f(4096, 0) == f(4096, 0xFFFFFFFF)
+    assert f(4095, 0) > f(4095, 0xFFFFFFFF) > f(4096, 0) and f(4095, 0xFFFFFFFF) - f(4096, 0) < 1e-4
+    assert abs(f(4095, 0x80000000) + ndtri((4095 * 2.0 ** 32 + 2.0 ** 31 + 0.5) * 2.0 ** -64)) < 7.5e-10
+    assert abs(f(0, 0) + ndtri(2.0 ** -65)) < 7.5e-10 and f(0, 0) > 9.0       # the support reaches 9.1 sigma (round 1: 6.66)
+
+
+def test_distribution_and_tail_mass():
+    """4 x 10^6 normals of the production stream: moments, Kolmogorov-Smirnov, and the mass beyond 4 / 4.5 sigma."""
+    U = po.randn_fill(20260928, 2000, 2000).ravel()
+    n = U.size
+    assert abs(U.mean()) < 5 / np.sqrt(n) and abs(U.var() - 1) < 5 * np.sqrt(2 / n)
+    assert abs(np.mean(U ** 3)) < 5 * np.sqrt(15 / n) and abs(np.mean(U ** 4) - 3) < 5 * np.sqrt(96 / n)
+    assert stats.kstest(U[:1_000_000], "norm").pvalue > 1e-3
+    for thr in (4.0, 4.5):
+        expect = n * 2 * stats.norm.sf(thr)
+        got = int(np.sum(np.abs(U) > thr))
+        assert abs(got - expect) < 5 * np.sqrt(expect) + 1, (thr, got, expect)
+    # counter-based: draws n0.. are a pure function of (seed, n); the four rows of a Philox call are rows 4g..4g+3
+    V = po.randn_fill(20260928, 2000, 10, n0=1990)
+    np.testing.assert_array_equal(V, po.randn_fill(20260928, 2000, 2000)[:, 1990:])
+
+
+def test_tail_refinement_occurs_in_the_stream():
+    """Words below 2^12 (probability 2^-19) really occur and take the second Philox call (counter word 3 = 1)."""
+    key = np.array([0x9ABCDEF0, 0x12345678], dtype=np.uint32)
+    seed = (int(key[1]) << 32) | int(key[0])
+    found = 0
+    for n in range(0, 3000):
+        for g in range(250):
+            x = po.philox4x32_10(np.array([n, g, 0, 0], dtype=np.uint32), key)
+            t = np.flatnonzero((x & 0x7FFFFFFF) < 4096)
+            if len(t):
+                x2 = po.philox4x32_10(np.array([n, g, 0, 1], dtype=np.uint32), key)
+                z = po.randn_fill(seed, 1000, 1, n0=n)[4 * g:4 * g + 4, 0]
+                for r in t:
+                    p = ((int(x[r]) & 0x7FFFFFFF) * 2.0 ** 32 + int(x2[r]) + 0.5) * 2.0 ** -64
+                    assert abs(abs(z[r]) + ndtri(p)) < 7.5e-10 and abs(z[r]) > 4.7
+                found += len(t)
+        if found >= 2:
+            break
+    assert found >= 1
