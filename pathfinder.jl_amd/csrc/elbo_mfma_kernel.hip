@@ -25,6 +25,9 @@
 
 #define MF_THREADS 512
 #define MF_WAVES 8
+// binades of the inverse-CDF table kept in LDS: 12 (12 KB) instead of 19 -- at d = 1000 this kernel uses 148 KB of LDS for the
+// factor block and its reduction buffers; words below 2^19 (probability 2^-12 per normal) take the global-table path
+#define MF_ICDF_NB 12
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
     double *gs = ssum + 32;                    // [RPAD][RPAD] target capacitance factor
     double *red2 = gs + RPAD * RPAD;           // [8][16][4] per-wave per-draw scalars
     double2 *icdf = reinterpret_cast<double2 *>(red2 + MF_WAVES * 64);     // [2 * 608] inverse-CDF table of the generator
-    double *zero_s = red2 + MF_WAVES * 64 + 4 * PF_ICDF_LDS_ENTRIES;       // [2] zeros (masked A-operand lanes)
+    double *zero_s = red2 + MF_WAVES * 64 + 4 * (MF_ICDF_NB << PF_ICDF_B);       // [2] zeros (masked A-operand lanes)
 
     {
         const double *Vh = A.vh + (size_t)p * d * KC;
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
         const double *T = A.tmat + (size_t)p * KC * KC;
         for (int i = tid; i < KC * KC; i += MF_THREADS) t_s[i] = T[i];
         if (TGT == 1 && RPAD > 0) for (int i = tid; i < RPAD * RPAD; i += MF_THREADS) gs[i] = A.t_g[i];
-        pf_icdf_load(icdf);
+        pf_icdf_load<MF_ICDF_NB>(icdf);
         if (tid < 2) zero_s[tid] = 0.0;
     }
     // head transform z_head = V' u_head as 4 MFMAs: A_r[i'][k] = M[rho(i')][4k + r], M = V' (identity padded)
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
     auto pass1_block = [&](const int blk, const uint32_t n, const bool head, double (&zz)[4]) {
         uint32_t x[4];
         pf_philox4x32_10(n, (uint32_t)(blk * 4 + q), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
-        pf_icdf4(x, n, (uint32_t)(blk * 4 + q), 0u, (uint32_t)seed, (uint32_t)(seed >> 32), icdf, zz);
+        pf_icdf4<MF_ICDF_NB>(x, n, (uint32_t)(blk * 4 + q), 0u, (uint32_t)seed, (uint32_t)(seed >> 32), icdf, zz);
         const int rowbase = blk * 16 + 4 * q;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -274,11 +277,16 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
             uint32_t c1 = (uint32_t)((nbv ? blk + 1 : wvs * NBW) * 4 + q), c2 = 0u, c3 = 0u;
             uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
             double zz[4], e4[4], xi4[4];
-            // P0: the normals of (next group, this block) from the Philox words xc = philox(n_next, 4 blk + q)
+            // P0: the normals of (next group, this block) come from the Philox words xc = philox(n_next, 4 blk + q): start the
+            // interval look-ups now, evaluate the cubics in P6 (the table reads land behind five phases of other work)
             xa = pf_mfma(a2v[0], ntv[0], xa);
-            pf_icdf4(xc, n_next, (uint32_t)(blk * 4 + q), 0u, (uint32_t)seed, (uint32_t)(seed >> 32), icdf, zz);
+            double dpv[4];
+            double2 c01v[4], c23v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pf_icdf_issue<MF_ICDF_NB>(xc[r], icdf, dpv[r], c01v[r], c23v[r]);
+            const uint32_t xw[4] = {xc[0], xc[1], xc[2], xc[3]};
             pf_philox_round(c0, c1, c2, c3, k0, k1);
-            PF_PIN_RNG(); PF_PIN(zz[0]); PF_PIN(zz[1]); PF_PIN(zz[2]); PF_PIN(zz[3]);
+            PF_PIN_RNG();
             PF_PHASE_END();
             // P1
             if (KC >= 8) xa = pf_mfma(a2v[KC >= 8 ? 1 : 0], ntv[KC >= 8 ? 1 : 0], xa);
@@ -326,7 +334,11 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
                 for (int I = 0; I < TR; ++I) acc3[I] = pf_mfma4(a3[0][I], e4[0], acc3[I]);
             }
             pf_philox_round(c0, c1, c2, c3, k0, k1);
-            PF_PIN_RNG();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) zz[r] = pf_icdf_finish(xw[r], dpv[r], c01v[r], c23v[r]);
+            if (__builtin_expect(__any(pf_icdf_miss4<MF_ICDF_NB>(xw)), 0))
+                pf_icdf4_fix<MF_ICDF_NB>(xw, n_next, (uint32_t)(blk * 4 + q), 0u, (uint32_t)seed, (uint32_t)(seed >> 32), zz);
+            PF_PIN_RNG(); PF_PIN(zz[0]); PF_PIN(zz[1]); PF_PIN(zz[2]); PF_PIN(zz[3]);
             PF_PHASE_END();
             // P7
             if (TGT == 1 && RPAD > 0) {
@@ -455,7 +467,7 @@ static size_t mf_lds_bytes(int d, int kc, int rpad) {
     const size_t rows = (size_t)((d + 15) / 16) * 16;
     return sizeof(double) * (rows * kc + 3 * rows + (size_t)kc * kc + MF_WAVES * 64 * (kc / 4) +
                              MF_WAVES * 64 * ((rpad + 3) / 4) + 256 + 64 * ((rpad + 3) / 4) + 32 + (size_t)rpad * rpad +
-                             MF_WAVES * 64 + 4 * PF_ICDF_LDS_ENTRIES + 2);
+                             MF_WAVES * 64 + 4 * (MF_ICDF_NB << PF_ICDF_B) + 2);
 }
 
 template <int KC, int NBW, int TGT, int RPAD, bool WX>

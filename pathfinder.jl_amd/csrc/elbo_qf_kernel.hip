@@ -298,7 +298,7 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
                     constexpr bool SPECIAL = decltype(special_tag)::value;       // first / second / last block of the scan
 #pragma unroll
                     for (int r = 0; r < 4; ++r) z[r] = pf_icdf_finish(P.x[r], P.dp[r], P.c01[r], P.c23[r]);
-                    if (__builtin_expect(__any(pf_icdf_tail4(P.x)), 0))          // probability 2^-19 per normal
+                    if (__builtin_expect(__any(pf_icdf_miss4(P.x)), 0))          // probability 2^-19 per normal
                         pf_icdf4_fix(P.x, n[g], (uint32_t)(blk * 4 + q), 0u, k0, k1, z);
                     if (SPECIAL) {
                         if (blk == nblk - 1) {                                   // rows >= d do not exist

@@ -201,83 +201,83 @@ __device__ __forceinline__ void pf_philox4x32_10(uint32_t c0, uint32_t c1, uint3
 // (counter word 3 = 1) so that the tails reach |z| = 9.1 with >= 12 bits of resolution.
 static __device__ const double PF_ICDF_TAB_DEV[PF_ICDF_ENTRIES][4] = { PF_ICDF_TABLE_ROWS };
 
-// copy the common-case part of the table (binades 2^-2 .. 2^-20: 608 entries, 19 KB) into LDS; all threads, then a barrier.
-// LDS layout: two arrays of 16-byte entries, {c0, c1}[608] then {c2, c3}[608] -- with the random per-lane index a 16-lane LDS
-// group then spreads over 16 bank quads instead of 8 (simulated: 5.4 instead of 7.5 LDS cycles per group and normal).
+// copy the first NB binades of the table (default 19: 2^-2 .. 2^-20 = everything a word with mag >= 2^12 can touch, 608 entries,
+// 19 KB) into LDS; all threads, then a barrier.  A kernel short of LDS may keep fewer binades (NB = 12: 12 KB): words below
+// 2^(31-NB) then take the slow path through the full table in global memory -- same values, probability 2^-NB per normal.
+// LDS layout: two arrays of 16-byte entries, {c0, c1}[32 NB] then {c2, c3}[32 NB] -- with the random per-lane index a 16-lane LDS
+// group then spreads over 16 bank quads instead of 8.
+template <int NB = PF_ICDF_NB_LDS>
 __device__ __forceinline__ void pf_icdf_load(double2 *tab) {
+    constexpr int NENT = NB << PF_ICDF_B;
     const double2 *src = reinterpret_cast<const double2 *>(&PF_ICDF_TAB_DEV[0][0]);
-    for (int i = threadIdx.x; i < 2 * PF_ICDF_LDS_ENTRIES; i += blockDim.x) tab[(i & 1) * PF_ICDF_LDS_ENTRIES + (i >> 1)] = src[i];
+    for (int i = threadIdx.x; i < 2 * NENT; i += blockDim.x) tab[(i & 1) * NENT + (i >> 1)] = src[i];
 }
-// Q ~ -Phi^-1(p), p in (2^-65, 1/2), argument P = 2^32 p.  LDS = true: `tab` is the LDS copy made by pf_icdf_load (nent = 608);
-// false: the full table in its generated [entry][4] layout
-template <bool LDS>
-__device__ __forceinline__ double pf_icdf_q(double p, const double2 *tab, int nent) {
-    const unsigned hi = (unsigned)__double2hiint(p);
-    int idx = PF_ICDF_IDX0 - (int)(hi >> (20 - PF_ICDF_B));
-    idx = idx < nent - 1 ? idx : nent - 1;                         // tail words are fixed up by the caller
-    const double pb = __hiloint2double((int)(hi & ~((1u << (20 - PF_ICDF_B)) - 1u)), 0);
-    const double dp = p - pb;
-    const double2 c01 = LDS ? tab[idx] : tab[2 * idx], c23 = LDS ? tab[PF_ICDF_LDS_ENTRIES + idx] : tab[2 * idx + 1];
-    return fma(fma(fma(c23.y, dp, c23.x), dp, c01.y), dp, c01.x);
-}
-// common case (mag >= 2^PF_ICDF_TAILBITS), table in LDS
-__device__ __forceinline__ double pf_icdf_main(uint32_t x, const double2 *lds_tab) {
-    const double p = (double)(x & 0x7FFFFFFFu) + 0.5;
-    const double q = pf_icdf_q<true>(p, lds_tab, PF_ICDF_LDS_ENTRIES);
-    return __hiloint2double(__double2hiint(q) ^ (int)(x & 0x80000000u), __double2loint(q));
-}
-// any word, full table in global memory (rare path / kernels without an LDS copy)
+// any word, full table in global memory (slow path / kernels without an LDS copy)
 __device__ __forceinline__ double pf_icdf_any(uint32_t x, uint32_t x2) {
     const uint32_t mag = x & 0x7FFFFFFFu;
     double p;
     if (mag >= (1u << PF_ICDF_TAILBITS)) p = (double)mag + 0.5;
     else p = ((double)(((uint64_t)mag << 32) | x2) + 0.5) * 0x1p-32;
-    const double q = pf_icdf_q<false>(p, reinterpret_cast<const double2 *>(&PF_ICDF_TAB_DEV[0][0]), PF_ICDF_ENTRIES);
+    const unsigned hi = (unsigned)__double2hiint(p);
+    const int idx = PF_ICDF_IDX0 - (int)(hi >> (20 - PF_ICDF_B));
+    const double dp = p - __hiloint2double((int)(hi & ~((1u << (20 - PF_ICDF_B)) - 1u)), 0);
+    const double *c = PF_ICDF_TAB_DEV[idx];
+    const double q = fma(fma(fma(c[3], dp, c[2]), dp, c[1]), dp, c[0]);
     return (x >> 31) ? -q : q;
 }
-// the same in two halves for software-pipelined callers: `issue` computes dp and starts the two table reads, `finish`
-// evaluates the cubic once the coefficients have landed (one iteration later)
+// the common case in two halves (software-pipelined callers put work between them): `issue` computes dp and starts the two
+// table reads from the LDS copy, `finish` evaluates the cubic once the coefficients have landed
+template <int NB = PF_ICDF_NB_LDS>
 __device__ __forceinline__ void pf_icdf_issue(uint32_t x, const double2 *lds_tab, double &dp, double2 &c01, double2 &c23) {
-    const double p = (double)(x & 0x7FFFFFFFu) + 0.5;
+    constexpr int NENT = NB << PF_ICDF_B;
+    const double p = (double)(x & 0x7FFFFFFFu) + 0.5;               // P = 2^32 p = mag + 1/2
     const unsigned hi = (unsigned)__double2hiint(p);
     int idx = PF_ICDF_IDX0 - (int)(hi >> (20 - PF_ICDF_B));
-    idx = idx < PF_ICDF_LDS_ENTRIES - 1 ? idx : PF_ICDF_LDS_ENTRIES - 1;
+    idx = idx < NENT - 1 ? idx : NENT - 1;                          // words beyond the LDS copy are fixed up by the caller
     dp = p - __hiloint2double((int)(hi & ~((1u << (20 - PF_ICDF_B)) - 1u)), 0);
-    c01 = lds_tab[idx]; c23 = lds_tab[PF_ICDF_LDS_ENTRIES + idx];
+    c01 = lds_tab[idx]; c23 = lds_tab[NENT + idx];
 }
 __device__ __forceinline__ double pf_icdf_finish(uint32_t x, double dp, const double2 &c01, const double2 &c23) {
     const double q = fma(fma(fma(c23.y, dp, c23.x), dp, c01.y), dp, c01.x);
     return __hiloint2double(__double2hiint(q) ^ (int)(x & 0x80000000u), __double2loint(q));
 }
-__device__ __forceinline__ bool pf_icdf_is_tail(uint32_t x) { return (x & 0x7FFFFFFFu) < (1u << PF_ICDF_TAILBITS); }
-
-__device__ __forceinline__ bool pf_icdf_tail4(const uint32_t (&x)[4]) {
+// true if one of the four words falls outside the LDS copy
+template <int NB = PF_ICDF_NB_LDS>
+__device__ __forceinline__ bool pf_icdf_miss4(const uint32_t (&x)[4]) {
     const uint32_t m01 = min(x[0] & 0x7FFFFFFFu, x[1] & 0x7FFFFFFFu), m23 = min(x[2] & 0x7FFFFFFFu, x[3] & 0x7FFFFFFFu);
-    return min(m01, m23) < (1u << PF_ICDF_TAILBITS);
+    return min(m01, m23) < (1u << (31 - NB));
 }
-// rare path: replace the normals of tail words by their refined values (second Philox call, full table in global memory)
+// slow path: replace the normals of words outside the LDS copy by their values from the full table; words below
+// 2^PF_ICDF_TAILBITS are first refined with the second Philox call (counter word 3 = 1)
+template <int NB = PF_ICDF_NB_LDS>
 __device__ __forceinline__ void pf_icdf4_fix(const uint32_t (&x)[4], uint32_t n, uint32_t g, uint32_t stream, uint32_t k0, uint32_t k1,
-                                          double (&z)[4]) {
-    if (!pf_icdf_tail4(x)) return;
-    uint32_t x2[4];
-    pf_philox4x32_10(n, g, stream, 1u, k0, k1, x2);
+                                             double (&z)[4]) {
+    uint32_t x2[4] = {0u, 0u, 0u, 0u};
+    if (__any(pf_icdf_miss4<PF_ICDF_NB_LDS>(x))) pf_philox4x32_10(n, g, stream, 1u, k0, k1, x2);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) if (pf_icdf_is_tail(x[t])) z[t] = pf_icdf_any(x[t], x2[t]);
+    for (int t = 0; t < 4; ++t) if ((x[t] & 0x7FFFFFFFu) < (1u << (31 - NB))) z[t] = pf_icdf_any(x[t], x2[t]);
 }
 // the four normals of Philox words x[0..3] (call (n, g, stream)), LDS table for the common case
+template <int NB = PF_ICDF_NB_LDS>
 __device__ __forceinline__ void pf_icdf4(const uint32_t (&x)[4], uint32_t n, uint32_t g, uint32_t stream, uint32_t k0, uint32_t k1,
                                          const double2 *lds_tab, double (&z)[4]) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) z[t] = pf_icdf_main(x[t], lds_tab);
-    if (__builtin_expect(__any(pf_icdf_tail4(x)), 0)) pf_icdf4_fix(x, n, g, stream, k0, k1, z);
+    for (int t = 0; t < 4; ++t) {
+        double dp;
+        double2 c01, c23;
+        pf_icdf_issue<NB>(x[t], lds_tab, dp, c01, c23);
+        z[t] = pf_icdf_finish(x[t], dp, c01, c23);
+    }
+    if (__builtin_expect(__any(pf_icdf_miss4<NB>(x)), 0)) pf_icdf4_fix<NB>(x, n, g, stream, k0, k1, z);
 }
 // four standard normals for rows 4g..4g+3 of draw n
+template <int NB = PF_ICDF_NB_LDS>
 __device__ __forceinline__ void pf_randn4(uint64_t seed, uint32_t g, uint32_t n, uint32_t stream, const double2 *lds_tab,
                                           double (&z)[4]) {
     uint32_t x[4];
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     pf_philox4x32_10(n, g, stream, 0u, k0, k1, x);
-    pf_icdf4(x, n, g, stream, k0, k1, lds_tab, z);
+    pf_icdf4<NB>(x, n, g, stream, k0, k1, lds_tab, z);
 }
 
 __device__ __forceinline__ uint64_t pf_rand_u64(uint64_t seed, uint64_t t, uint32_t stream) {
