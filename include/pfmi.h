@@ -42,6 +42,7 @@ typedef struct pfmi_ctx pfmi_ctx;
 #define PFMI_ERR_STATE (-3)
 #define PFMI_ERR_UNSUPPORTED (-4)
 #define PFMI_ERR_NUMERIC (-5)
+#define PFMI_ERR_COMM (-6)
 
 /* per-fit status (src/woodbury.jl:189-190, 202, 205) */
 #define PFMI_FIT_OK 0
@@ -198,6 +199,30 @@ int32_t pfmi_pool_gather(pfmi_ctx *ctx, int64_t ndraws, const int64_t *idx, int6
  * ranks (xGMI) assembles the result */
 int32_t pfmi_pool_gather_dev(pfmi_ctx *ctx, int64_t ndraws, const int64_t *idx, int64_t col_offset,
                              void *draws_dev);
+
+/* ---- multi-GPU: the pooled stage over paths sharded across GPUs (RCCL over xGMI) ----------------------------------- */
+/* Runs are independent until pooling (src/multipath.jl:190-208); draws_per_component = stack(draws), _compute_psis_result and
+ * _resample (src/multipath.jl:215-225) see every run.  Each GPU owns a contiguous block of paths (its ctx was fed only those
+ * traces; pool order stays k-major, src/resample.jl:93) and has called pfmi_pool_build.  A pfmi_comm joins the contexts:
+ *   pfmi_comm_init_all   ONE host process drives G contexts, one per GPU (ncclCommInitAll) -- a single Julia / C caller;
+ *   pfmi_comm_init_rank  one process per GPU: every process passes the same 128-byte id (pfmi_comm_unique_id on rank 0,
+ *                        shipped by the host's launcher) -- e.g. under torch.distributed.run or MPI.
+ * The result is identical for every G (extension of the ntasks invariance of test/multipath.jl:107-140). */
+typedef struct pfmi_comm pfmi_comm;
+int32_t pfmi_comm_unique_id(uint8_t *id128);
+int32_t pfmi_comm_init_all(int32_t ngpus, pfmi_ctx *const *ctxs, pfmi_comm **out);
+int32_t pfmi_comm_init_rank(pfmi_ctx *ctx, int32_t world, int32_t rank, const uint8_t *id128, pfmi_comm **out);
+int32_t pfmi_comm_destroy(pfmi_comm *comm);
+/* world = ranks RCCL itself reports (ncclCommCount), nlocal = contexts driven by this process, rccl_version = ncclGetVersion */
+int32_t pfmi_comm_info(pfmi_comm *comm, int32_t *world, int32_t *nlocal, int32_t *rccl_version);
+/* _compute_psis_result over all runs (src/multipath.jl:221): ONE all-gather of the fp64 log-ratio shards (K/G * N_r doubles per
+ * GPU), then PSIS.psis replicated on every GPU (weights stay device resident).  Shards must have equal size. */
+int32_t pfmi_comm_pool_psis(pfmi_comm *comm, double *pareto_k, int64_t *tail_len);
+/* _resample over all runs (src/multipath.jl:225, src/resample.jl:58-72): index selection replicated on every GPU (same
+ * arguments as pfmi_resample_indices; identical indices by construction, checked), every GPU gathers the columns it owns,
+ * one sum all-reduce assembles draws[d * ndraws].  idx: global 0-based pool columns (component id = idx / N_r). */
+int32_t pfmi_comm_resample(pfmi_comm *comm, int64_t ndraws, int32_t importance, int32_t replace, uint64_t seed,
+                           const double *uniforms, int64_t *idx, double *draws);
 
 /* ---- device utilities for hosts that keep buffers on the GPU (bench, multi-GPU) ---------------- */
 int32_t pfmi_malloc_dev(pfmi_ctx *ctx, int64_t bytes, void **dev_ptr);

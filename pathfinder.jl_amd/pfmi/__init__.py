@@ -7,7 +7,7 @@ from ._lib import PfmiError, build, lib  # noqa: F401
 from .api import (DEFAULT_HISTORY_LENGTH, DEFAULT_NDRAWS_ELBO, ELBOEstimate, MultiPathfinderResult,  # noqa: F401
                   MvNormal, PathfinderResult, PosDefException, PSISResult, UniformSampler, WoodburyPDMat,
                   fit_mvnormals, maximize_elbo, multipathfinder, pathfinder, resample)
-from .core import Engine, StaleHandleError  # noqa: F401
+from .core import Comm, Engine, StaleHandleError  # noqa: F401
 from .hostrng import HostRNG  # noqa: F401
 from .optimize import OptimizationTrace, optimize_with_trace  # noqa: F401
 from .targets import (CallbackTarget, FunnelTarget, GaussTarget, t_diag, t_funnel, t_iso, t_lowrank)  # noqa: F401

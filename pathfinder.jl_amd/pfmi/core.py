@@ -276,3 +276,57 @@ class Engine:
         idx = np.ascontiguousarray(idx, dtype=np.int64)
         check(self.L.pfmi_pool_gather_dev(self.ctx, C.c_int64(len(idx)), idx.ctypes.data_as(_i64p),
                                           C.c_int64(col_offset), C.c_void_p(dev_ptr)))
+
+
+class Comm:
+    """pfmi_comm: the RCCL group behind the C ABI (csrc/comm_rccl.hip).  Comm.init_all(engines) -- one process, one Engine per
+    GPU; Comm.init_rank(engine, world, rank, uid) -- one process per GPU, `uid` = Comm.unique_id() of rank 0 shipped by the
+    launcher."""
+
+    def __init__(self, handle, engines):
+        self.h, self.engines, self.L = handle, list(engines), _lib.lib()
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        check(_lib.lib().pfmi_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def init_all(cls, engines):
+        arr = (C.c_void_p * len(engines))(*[e.ctx for e in engines])
+        h = C.c_void_p()
+        check(_lib.lib().pfmi_comm_init_all(C.c_int32(len(engines)), arr, C.byref(h)))
+        return cls(h, engines)
+
+    @classmethod
+    def init_rank(cls, engine, world, rank, uid):
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        h = C.c_void_p()
+        check(_lib.lib().pfmi_comm_init_rank(engine.ctx, C.c_int32(world), C.c_int32(rank), buf, C.byref(h)))
+        return cls(h, [engine])
+
+    def info(self):
+        w, n, v = C.c_int32(), C.c_int32(), C.c_int32()
+        check(self.L.pfmi_comm_info(self.h, C.byref(w), C.byref(n), C.byref(v)))
+        return dict(world=w.value, nlocal=n.value, rccl_version=v.value)
+
+    def pool_psis(self):
+        k, M = C.c_double(), C.c_int64()
+        check(self.L.pfmi_comm_pool_psis(self.h, C.byref(k), C.byref(M)))
+        return dict(pareto_shape=k.value, tail_length=M.value)
+
+    def resample(self, ndraws, importance=True, replace=True, seed=0, uniforms=None, want_draws=True):
+        d = self.engines[0].d
+        idx = np.empty(ndraws, dtype=np.int64)
+        out = np.empty((d, ndraws), order="F") if want_draws else None
+        if uniforms is not None:
+            uniforms = np.ascontiguousarray(uniforms, dtype=np.float64)
+        check(self.L.pfmi_comm_resample(self.h, C.c_int64(ndraws), C.c_int32(int(importance)), C.c_int32(int(replace)),
+                                        C.c_uint64(int(seed)), _d(uniforms), idx.ctypes.data_as(_i64p), _d(out)))
+        return idx, out
+
+    def close(self):
+        if self.h:
+            self.L.pfmi_comm_destroy(self.h)
+            self.h = None

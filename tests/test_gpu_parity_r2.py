@@ -449,6 +449,54 @@ def test_stale_result_handles_raise(pfmi_mod):
     e.close()
 
 
+# ---- collectives behind the C ABI -------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["init_all", "init_rank"])
+def test_comm_rccl_world1_equals_local_path(pfmi_mod, eng, mode):
+    """pfmi_comm_* (csrc/comm_rccl.hip: ncclAllGather of the log-ratio shards, replicated PSIS / index selection, owner gather,
+    ncclAllReduce) in the only RCCL world a 1-GPU box allows.  Both ways of forming the group -- ncclCommInitAll (one process,
+    G contexts: a single Julia caller) and ncclCommInitRank with a shipped id (one process per GPU) -- must reproduce the
+    single-GPU calls bit for bit (result invariance under the GPU count, test/multipath.jl:107-140 extended to G)."""
+    tg = pfmi_mod.t_lowrank(50, r=8, seed=2)
+    traces = make_traces(tg, 4, 11)
+    eng.set_target(tg)
+    eng.set_traces([t.points for t in traces], [t.gradients for t in traces])
+    eng.fit_batch(6)
+    seeds = fit_seeds(eng.P, 4)
+    elbo, se, best = eng.elbo_batch(64, seeds)
+    pts = [int(eng.offsets[k]) + int(best[k]) for k in range(4)]
+    eng.pool_build(96, pts, seeds[pts])
+    pool, lr = eng.pool_get()
+    ref = eng.psis(lr)
+    ref_idx = eng.resample_indices(len(lr), 40, seed=9)
+    ref_norep = eng.resample_indices(len(lr), 40, replace=False, seed=9)
+    if mode == "init_all":
+        comm = pfmi_mod.Comm.init_all([eng])
+    else:
+        comm = pfmi_mod.Comm.init_rank(eng, 1, 0, pfmi_mod.Comm.unique_id())
+    try:
+        info = comm.info()
+        assert info["world"] == 1 and info["nlocal"] == 1 and info["rccl_version"] > 20000
+        res = comm.pool_psis()
+        assert res["pareto_shape"] == ref["pareto_shape"] and res["tail_length"] == ref["tail_length"]
+        idx, draws = comm.resample(40, seed=9)
+        np.testing.assert_array_equal(idx, ref_idx)
+        np.testing.assert_array_equal(draws, pool.reshape(tg.d, -1, order="F")[:, ref_idx])
+        idx2, draws2 = comm.resample(40, replace=False, seed=9)
+        np.testing.assert_array_equal(idx2, ref_norep)
+        np.testing.assert_array_equal(draws2, pool.reshape(tg.d, -1, order="F")[:, ref_norep])
+        u = np.random.default_rng(1).random(25)
+        idx3, _ = comm.resample(25, uniforms=u, want_draws=False)
+        np.testing.assert_array_equal(idx3, po.sample_weighted(ref["weights"], 25, uniforms=u))
+    finally:
+        comm.close()
+    with pytest.raises(pfmi_mod.PfmiError, match="share GPU"):
+        e2 = pfmi_mod.Engine(0)
+        try:
+            pfmi_mod.Comm.init_all([eng, e2])                          # one rank per GPU
+        finally:
+            e2.close()
+
+
 # ---- bench.py contract on the GPU box ---------------------------------------------------------------------------
 def test_bench_force_dist_counts_its_ranks():
     """bench.py --gpus 1 --force-dist: the N > 1 code path (RCCL all-gather + all-reduce) in a single-rank world; the JSON line
@@ -463,5 +511,5 @@ def test_bench_force_dist_counts_its_ranks():
                        env=env, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 1 and line["config"]["ranks_in_collective"] == 1 and line["config"]["collective_backend"].startswith("nccl")
+    assert line["n_gpus"] == 1 and line["config"]["ranks_in_collective"] == 1 and line["config"]["collective_backend"].startswith("RCCL")
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
