@@ -190,6 +190,14 @@ int32_t pfmi_psis(pfmi_ctx *ctx, const double *log_ratios, int64_t S, double *we
 int32_t pfmi_resample_indices(pfmi_ctx *ctx, int64_t S, int64_t ndraws, int32_t importance,
                               int32_t replace, uint64_t seed, const double *uniforms, int64_t *idx);
 
+/* StatsBase-compatible index selection for hosts that must match a live Julia run bit for bit: exactly
+ * StatsBase.direct_sample!(rng, 1:S, ProbabilityWeights(weights, 1), x) (the weighted branch of src/resample.jl:61-66 ->
+ * StatsBase.sample(rng, wv): t = rand(rng) * 1; i = 1; cw = w[1]; while cw < t && i < S: i += 1; cw += w[i]) on the ctx's
+ * current PSIS weights, with the running sum accumulated sequentially in fp64 like the Julia loop and uniforms[t] = the
+ * host's rand(rng) values in [0, 1).  idx is 0-based.  (pfmi_resample_indices is this library's own fixed-point
+ * inverse-CDF sampler: deterministic for any launch geometry / GPU count, but not StatsBase's algorithm.) */
+int32_t pfmi_resample_indices_direct(pfmi_ctx *ctx, int64_t S, int64_t ndraws, const double *uniforms, int64_t *idx);
+
 /* draws = draws_all[:, inds] (src/resample.jl:68).  Global pool column g = k_global*N_r + n is owned by this ctx iff
  * col_offset <= g < col_offset + K_local*N_r.  Host variant: every index must be owned (PFMI_ERR_ARG otherwise -- a
  * stale or out-of-range index is an error, never a silent zero column).  draws[d*ndraws]. */

@@ -738,6 +738,21 @@ int pfo_sample_weighted_norep(long S, const double *weights, long ndraws, uint64
     return 0;
 }
 
+/* StatsBase.direct_sample!(rng, 1:S, ProbabilityWeights(w, 1), x) -- the weighted branch StatsBase.sample takes for small
+ * requests (src/resample.jl:61-66 calls StatsBase.sample(rng, axes(draws_all, 2), pweights, ndraws; replace)); literal loop of
+ * StatsBase.sample(rng, wv):  t = rand(rng) * sum(wv); i = 1; cw = wv[1]; while cw < t && i < n; i += 1; cw += wv[i]; end.
+ * uniforms[t] plays rand(rng); sum(wv) = 1 by construction.  0-based output.  (StatsBase is third party: restated from its
+ * published source, parity unpinned -- see header.) */
+void pfo_sample_direct(long S, const double *w, long ndraws, const double *uniforms, int64_t *idx) {
+    for (long t = 0; t < ndraws; ++t) {
+        const double thr = uniforms[t] * 1.0;
+        long i = 0;
+        double cw = w[0];
+        while (cw < thr && i < S - 1) { i += 1; cw += w[i]; }
+        idx[t] = i;
+    }
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* Whole-path driver used for parity at scale and as the CPU baseline:                         */
 /* fit every point of one trace, run the ELBO over points 1..L with the Philox normals of      */

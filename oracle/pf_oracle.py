@@ -282,6 +282,14 @@ def sample_weighted(weights, ndraws, seed=0, uniforms=None):
     return idx
 
 
+def sample_direct(weights, uniforms):
+    """StatsBase.direct_sample! with the given rand(rng) values (0-based indices)."""
+    w, u = _f(weights), _f(uniforms)
+    idx = np.empty(len(u), dtype=np.int64)
+    lib().pfo_sample_direct(C.c_long(len(w)), _p(w), C.c_long(len(u)), _p(u), idx.ctypes.data_as(c_i64p))
+    return idx
+
+
 def sample_uniform(S, ndraws, seed=0, uniforms=None):
     idx = np.empty(ndraws, dtype=np.int64)
     up = _p(_f(uniforms)) if uniforms is not None else None

@@ -94,7 +94,7 @@ int32_t pfmi_destroy(pfmi_ctx *c) {
                       &c->elbo, &c->se, &c->best_iter, &c->fit_list, &c->ubuf, &c->xbuf, &c->scratch, &c->pool,
                       &c->pool_lr, &c->pool_lp, &c->pool_lq, &c->pool_points, &c->pool_seeds, &c->lw, &c->w,
                       &c->psis_out, &c->tailbuf, &c->cdf, &c->idx, &c->gbuf, &c->trace_lp, &c->st_theta, &c->st_grad,
-                      &c->st_lp, &c->st_npts, &c->lb_hs, &c->lb_hy, &c->lb_x0, &c->cl_counter, &c->cl_buf};
+                      &c->st_lp, &c->st_npts, &c->lb_hs, &c->lb_hy, &c->lb_x0, &c->cl_counter, &c->cl_buf, &c->sortk, &c->sorti};
     for (DevBuf *b : bufs) b->release();
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     (void)hipEventDestroy(c->kev0); (void)hipEventDestroy(c->kev1);
@@ -652,6 +652,22 @@ int32_t pfmi_resample_indices(pfmi_ctx *c, int64_t S, int64_t ndraws, int32_t im
     }
     PF_TRY(pf_launch_resample(c, S, ndraws, importance, replace, seed, d_uni));
     if (idx && ndraws > 0) PF_TRY(d2h(c, idx, c->idx.p, sizeof(int64_t) * ndraws));
+    return PFMI_OK;
+}
+
+int32_t pfmi_resample_indices_direct(pfmi_ctx *c, int64_t S, int64_t ndraws, const double *uniforms, int64_t *idx) {
+    PF_CTX(c);
+    PF_CHECK(S > 0 && ndraws >= 0 && (uniforms != nullptr || ndraws == 0), PFMI_ERR_ARG, "resample_direct: bad arguments");
+    PF_CHECK(c->S_w == S, PFMI_ERR_STATE, "resample_direct: importance weights for S=%lld not available (run pfmi_psis first)",
+             (long long)S);
+    if (ndraws == 0) return PFMI_OK;
+    for (int64_t t = 0; t < ndraws; ++t)
+        PF_CHECK(uniforms[t] >= 0.0 && uniforms[t] < 1.0, PFMI_ERR_ARG, "resample_direct: uniforms[%lld] = %g is not in [0, 1)", (long long)t,
+                 uniforms[t]);
+    PF_TRY(c->tailbuf.ensure(sizeof(double) * ndraws));
+    PF_TRY(h2d(c, c->tailbuf.p, uniforms, sizeof(double) * ndraws));
+    PF_TRY(pf_launch_resample_direct(c, S, ndraws, c->tailbuf.as<double>()));
+    if (idx) PF_TRY(d2h(c, idx, c->idx.p, sizeof(int64_t) * ndraws));
     return PFMI_OK;
 }
 

@@ -130,6 +130,7 @@ struct pfmi_ctx {
     DevBuf cdf;         // u64 [S]
     DevBuf idx;         // int64 [ndraws]
     DevBuf gbuf;        // gather output
+    DevBuf sortk, sorti; // (key, index) arrays of the large replace = false request
 };
 
 // ---- launch helpers (implemented in the .hip files) ----------------------------------------------
@@ -144,6 +145,7 @@ int32_t pf_launch_logpdf(pfmi_ctx *c, int64_t point, int64_t N, const double *d_
 int32_t pf_launch_psis(pfmi_ctx *c, const double *d_lr, int64_t S);
 int32_t pf_launch_resample(pfmi_ctx *c, int64_t S, int64_t ndraws, int importance, int replace,
                            uint64_t seed, const double *d_uniforms);
+int32_t pf_launch_resample_direct(pfmi_ctx *c, int64_t S, int64_t ndraws, const double *d_uniforms);
 int32_t pf_launch_gather(pfmi_ctx *c, int64_t ndraws, const int64_t *d_idx, int64_t col_offset, double *d_out);
 int32_t pf_launch_logratio(pfmi_ctx *c, int64_t n);
 int32_t pf_launch_lbfgs(pfmi_ctx *c, int K, int J, int maxiters, double g_tol, const double *d_x0);

@@ -330,6 +330,71 @@ __global__ __launch_bounds__(PSIS_THREADS) void pf_norep_select_kernel(long long
     }
 }
 
+// ---- replace = false beyond TAILCAP draws: full (key, index) bitonic sort in global memory ------------------------------------
+// keys[i] = order-preserving u64 of the Efraimidis-Spirakis key (-negkey), padded with ~0; ascending (key, index) order equals
+// the oracle's sort, so the first ndraws entries are the sample.  log2(n)(log2(n)+1)/2 launches: a rare, large-request path.
+__global__ void pf_sortkeys_init_kernel(long long S, long long n2, const double *__restrict__ negkey, uint64_t *__restrict__ keys,
+                                        uint32_t *__restrict__ ids) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n2) return;
+    keys[i] = (i < S) ? pf_key_of(-negkey[i]) : ~0ull;
+    ids[i] = (uint32_t)i;
+}
+__global__ void pf_bitonic_step_kernel(long long n2, long long j, long long k, uint64_t *__restrict__ keys, uint32_t *__restrict__ ids) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n2) return;
+    const long long l = i ^ j;
+    if (l <= i) return;
+    const uint64_t ka = keys[i], kb = keys[l];
+    const uint32_t ia = ids[i], ib = ids[l];
+    const bool a_gt_b = (ka > kb) || (ka == kb && ia > ib);
+    const bool up = (i & k) == 0;
+    if (a_gt_b == up) { keys[i] = kb; keys[l] = ka; ids[i] = ib; ids[l] = ia; }
+}
+__global__ void pf_sorted_take_kernel(long long ndraws, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ ids,
+                                      int64_t *__restrict__ idx, int *__restrict__ err) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ndraws) return;
+    idx[t] = (int64_t)ids[t];
+    if (!isfinite(pf_val_of(keys[t]))) *err = 1;                   // not enough positive weights
+}
+
+// ---- StatsBase.direct_sample! compatible index selection (src/resample.jl:61-66 -> StatsBase.sample(rng, wv)) ------------------
+//   t = rand(rng) * sum(wv);  i = 1; cw = wv[1];  while cw < t && i < n:  i += 1; cw += wv[i]
+// ProbabilityWeights(w, 1) fixes sum(wv) = 1.  The running sum is SEQUENTIAL fp64 (left to right), so the prefix sums are
+// produced by one thread in exactly that order (chunks staged through LDS by the whole workgroup); with cw non-decreasing the
+// loop's answer is the first i with cw_i >= t, found by binary search.  Given the uniforms a Julia host drew with its own
+// rng, the indices equal StatsBase's bit for bit.
+__global__ __launch_bounds__(PSIS_THREADS) void pf_seqcdf_kernel(long long S, const double *__restrict__ w, double *__restrict__ cw) {
+    __shared__ double buf[4096];
+    __shared__ double carry;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (tid == 0) carry = 0.0;
+    for (long long c0 = 0; c0 < S; c0 += 4096) {
+        const int n = (int)((S - c0 < 4096) ? S - c0 : 4096);
+        __syncthreads();
+        for (int i = tid; i < n; i += nt) buf[i] = w[c0 + i];
+        __syncthreads();
+        if (tid == 0) {
+            double acc = carry;
+            if (c0 == 0) { acc = buf[0]; buf[0] = acc; for (int i = 1; i < n; ++i) { acc += buf[i]; buf[i] = acc; } }   // cw = wv[1]
+            else for (int i = 0; i < n; ++i) { acc += buf[i]; buf[i] = acc; }
+            carry = acc;
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += nt) cw[c0 + i] = buf[i];
+    }
+}
+__global__ void pf_direct_sample_kernel(long long S, long long ndraws, const double *__restrict__ uniforms, const double *__restrict__ cw,
+                                        int64_t *__restrict__ idx) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ndraws) return;
+    const double thr = uniforms[t] * 1.0;                          // rand(rng) * wv.sum
+    long long lo = 0, hi = S - 1;                                  // first i with cw[i] >= thr, else the last index
+    while (lo < hi) { const long long mid = (lo + hi) >> 1; if (cw[mid] < thr) lo = mid + 1; else hi = mid; }
+    idx[t] = lo;
+}
+
 // out[:, t] = owned(idx[t]) ? pool[:, idx[t] - col_offset] : 0
 __global__ void pf_gather_kernel(int d, long long ndraws, long long ncols_local, long long col_offset,
                                  const int64_t *__restrict__ idx, const double *__restrict__ pool,
@@ -384,11 +449,26 @@ int32_t pf_launch_resample(pfmi_ctx *c, int64_t S, int64_t ndraws, int importanc
     } else {
         PF_CHECK(ndraws <= S, PFMI_ERR_ARG, "cannot draw %lld without replacement from %lld", (long long)ndraws,
                  (long long)S);
-        PF_CHECK(ndraws <= TAILCAP, PFMI_ERR_UNSUPPORTED, "replace=false supports at most %d draws", TAILCAP);
         hipLaunchKernelGGL(pf_norep_keys_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, c->stream,
                            (long long)S, importance, seed, c->w.as<double>(), c->scratch.as<double>());
-        hipLaunchKernelGGL(pf_norep_select_kernel, dim3(1), dim3(PSIS_THREADS), 0, c->stream, (long long)S,
-                           (int)ndraws, c->scratch.as<double>(), c->idx.as<int64_t>(), d_err);
+        if (ndraws <= TAILCAP) {                                   // radix select + LDS sort of the sample (one workgroup)
+            hipLaunchKernelGGL(pf_norep_select_kernel, dim3(1), dim3(PSIS_THREADS), 0, c->stream, (long long)S,
+                               (int)ndraws, c->scratch.as<double>(), c->idx.as<int64_t>(), d_err);
+        } else {                                                   // large request: sort every (key, index) pair
+            long long n2 = 1;
+            while (n2 < S) n2 <<= 1;
+            PF_TRY(c->sortk.ensure(sizeof(uint64_t) * (size_t)n2));
+            PF_TRY(c->sorti.ensure(sizeof(uint32_t) * (size_t)n2));
+            const dim3 grid((unsigned)((n2 + 255) / 256));
+            hipLaunchKernelGGL(pf_sortkeys_init_kernel, grid, dim3(256), 0, c->stream, (long long)S, n2, c->scratch.as<double>(),
+                               c->sortk.as<uint64_t>(), c->sorti.as<uint32_t>());
+            for (long long k = 2; k <= n2; k <<= 1)
+                for (long long j = k >> 1; j > 0; j >>= 1)
+                    hipLaunchKernelGGL(pf_bitonic_step_kernel, grid, dim3(256), 0, c->stream, n2, j, k, c->sortk.as<uint64_t>(),
+                                       c->sorti.as<uint32_t>());
+            hipLaunchKernelGGL(pf_sorted_take_kernel, dim3((unsigned)((ndraws + 255) / 256)), dim3(256), 0, c->stream,
+                               (long long)ndraws, c->sortk.as<uint64_t>(), c->sorti.as<uint32_t>(), c->idx.as<int64_t>(), d_err);
+        }
     }
     pf_kernel_end(c, "resample");
     PF_HIP(hipGetLastError());
@@ -396,6 +476,18 @@ int32_t pf_launch_resample(pfmi_ctx *c, int64_t S, int64_t ndraws, int importanc
     PF_HIP(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     PF_HIP(hipStreamSynchronize(c->stream));
     PF_CHECK(err == 0, PFMI_ERR_NUMERIC, "resample: weights are all zero / not enough positive weights");
+    return PFMI_OK;
+}
+
+int32_t pf_launch_resample_direct(pfmi_ctx *c, int64_t S, int64_t ndraws, const double *d_uniforms) {
+    PF_TRY(c->idx.ensure(sizeof(int64_t) * (ndraws > 0 ? ndraws : 1)));
+    PF_TRY(c->scratch.ensure(sizeof(double) * (size_t)S));
+    pf_kernel_begin(c);
+    hipLaunchKernelGGL(pf_seqcdf_kernel, dim3(1), dim3(PSIS_THREADS), 0, c->stream, (long long)S, c->w.as<double>(), c->scratch.as<double>());
+    hipLaunchKernelGGL(pf_direct_sample_kernel, dim3((unsigned)((ndraws + 255) / 256)), dim3(256), 0, c->stream, (long long)S,
+                       (long long)ndraws, d_uniforms, c->scratch.as<double>(), c->idx.as<int64_t>());
+    pf_kernel_end(c, "resample");
+    PF_HIP(hipGetLastError());
     return PFMI_OK;
 }
 

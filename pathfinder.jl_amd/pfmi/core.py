@@ -248,6 +248,14 @@ class Engine:
                                            idx.ctypes.data_as(_i64p)))
         return idx
 
+    def resample_indices_direct(self, S, uniforms):
+        """StatsBase.direct_sample! on the current PSIS weights with host-drawn uniforms (0-based indices)."""
+        uniforms = np.ascontiguousarray(uniforms, dtype=np.float64)
+        idx = np.empty(len(uniforms), dtype=np.int64)
+        check(self.L.pfmi_resample_indices_direct(self.ctx, C.c_int64(S), C.c_int64(len(uniforms)), _d(uniforms),
+                                                  idx.ctypes.data_as(_i64p)))
+        return idx
+
     def pool_gather(self, idx, col_offset=0):
         idx = np.ascontiguousarray(idx, dtype=np.int64)
         out = np.empty((self.d, len(idx)), order="F")

@@ -449,6 +449,38 @@ def test_stale_result_handles_raise(pfmi_mod):
     e.close()
 
 
+def test_statsbase_direct_index_mode_and_large_norep(pfmi_mod, eng):
+    """(a) pfmi_resample_indices_direct == StatsBase.direct_sample! (sequential fp64 running sum, `cw < t` scan) on
+    host-drawn uniforms: against the oracle's literal loop and an independent NumPy restatement (np.cumsum is sequential);
+    (b) replace = false beyond the 4096-draw LDS path: bit-exact against the oracle up to ndraws = S."""
+    import scipy.stats as st
+    for S, seed in ((64000, 3), (37, 4), (512000, 5)):
+        lr = st.t(4).rvs(S, random_state=np.random.default_rng(seed))
+        w = eng.psis(lr)["weights"]
+        u = np.random.default_rng(seed).random(3000)
+        u[:3] = [0.0, np.nextafter(1.0, 0.0), 0.5]
+        idx = eng.resample_indices_direct(S, u)
+        np.testing.assert_array_equal(idx, po.sample_direct(w, u))
+        cw = np.cumsum(w)
+        np.testing.assert_array_equal(idx, np.minimum(np.searchsorted(cw, u, side="left"), S - 1))
+    with pytest.raises(pfmi_mod.PfmiError, match="not in"):
+        eng.resample_indices_direct(S, np.array([1.0]))
+    S = 64000
+    lr = st.t(4).rvs(S, random_state=np.random.default_rng(1))
+    w = eng.psis(lr)["weights"]
+    for nd in (4096, 4097, 20000, S):
+        idx = eng.resample_indices(S, nd, replace=False, seed=7)
+        assert len(set(idx.tolist())) == nd
+        np.testing.assert_array_equal(idx, po.sample_weighted_norep(w, nd, seed=7))
+    idx = eng.resample_indices(S, 10000, importance=False, replace=False, seed=8)
+    assert len(set(idx.tolist())) == 10000
+    w0 = w.copy()
+    lr2 = lr.copy(); lr2[100:] = -np.inf                              # only 100 positive weights
+    eng.psis(lr2)
+    with pytest.raises(pfmi_mod.PfmiError):
+        eng.resample_indices(S, 5000, replace=False, seed=1)
+
+
 # ---- collectives behind the C ABI -------------------------------------------------------------------------------
 @pytest.mark.parametrize("mode", ["init_all", "init_rank"])
 def test_comm_rccl_world1_equals_local_path(pfmi_mod, eng, mode):
