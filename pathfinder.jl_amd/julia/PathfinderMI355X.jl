@@ -1,18 +1,28 @@
-# PathfinderMI355X.jl -- thin Julia `ccall` layer over libpfmi.so (include/pfmi.h).
+# PathfinderMI355X.jl -- Julia host package over libpfmi.so (include/pfmi.h): keeps Pathfinder.jl's `pathfinder()` /
+# `multipathfinder()` / `resample()` API and the LogDensityProblems callback surface on the Julia side and replaces the four
+# hot-path call sites of the reference (mlcolab/Pathfinder.jl v0.10.7) by batched GPU calls:
 #
-# STATUS: written to the C ABI's specification; NOT executed in this repository's CI because no Julia
-# toolchain exists in the build image (SURVEY.md hard part H1).  Everything numerical sits behind the C ABI
-# and is tested from Python (tests/test_gpu_parity.py); this file is the mechanical binding a maintainer of
-# mlcolab/Pathfinder.jl would add.  It keeps the public API (`pathfinder`, `multipathfinder`, `resample`) and
-# the LogDensityProblems callback surface in Julia and replaces the four hot-path call sites:
+#   fit_mvnormals(points, gradients; history_length)              src/singlepath.jl:301-303   -> fit_mvnormals(eng, traces; ...)
+#   maximize_elbo(rng, logp, fit_distributions[2:end], N, ntasks) src/singlepath.jl:306-308   -> maximize_elbo(eng, rngs, N)
+#   _compute_psis_result(logp, fit_distributions, draws; ntasks)  src/multipath.jl:221        -> _compute_psis_result(eng, ...)
+#   _resample(rng, draws_per_component, psis_result, ndraws)      src/multipath.jl:225        -> _resample(eng, rng, ...)
 #
-#   fit_mvnormals(points, gradients; history_length)              src/singlepath.jl:301-303
-#   maximize_elbo(rng, logp, fit_distributions[2:end], N, ntasks) src/singlepath.jl:306-308
-#   _compute_psis_result(logp, fit_distributions, draws; ntasks)  src/multipath.jl:221, src/resample.jl:35
-#   _resample(rng, draws_per_component, psis_result, ndraws)      src/multipath.jl:225, src/resample.jl:42-44
+# STATUS.  No Julia toolchain exists in this repository's build / GPU images (SURVEY.md H1), so this file has never been
+# executed here.  It is written to the C ABI's specification, every `ccall` signature is the header's, and the exact order of C
+# calls it makes is replayed and checked on the GPU by `examples/julia_sequence.c` (tests/test_gpu_parity_r2.py::
+# test_julia_call_sequence_in_c).  Everything numerical sits behind the C ABI and is tested from Python / C.
+#
+# Results.  `multipathfinder(eng, ...)` returns the reference's own `Pathfinder.MultiPathfinderResult` (its fields are
+# untyped); per-run results are `DevicePathfinderResult`s -- the reference's `PathfinderResult` requires
+# `fit_distributions::Vector{FD}` and an eager `elbo_estimates`, i.e. O(L d N) host memory (89 GB at the headline
+# configuration), so the same field names are served lazily instead:
+#   fit_distributions[i]   -> MvNormal(mu, WoodburyPDMat(A, B, D, WoodburyPDFactorization(U, Q, V)))   pfmi_get_fit
+#   elbo_estimates[i]      -> ELBOEstimate(value, std_err, draws, logp, logq, logr)                    pfmi_draws (regenerated)
+#   draws                  -> first ndraws ELBO draws of the winner (+ top-up)                         pfmi_draws
 module PathfinderMI355X
 
 using LinearAlgebra, Random
+import Distributions, PDMats, Pathfinder, SciMLBase, StatsBase
 
 const libpfmi = get(ENV, "PFMI_LIB", joinpath(@__DIR__, "..", "lib", "libpfmi.so"))
 
@@ -23,27 +33,32 @@ end
 last_error() = unsafe_string(ccall((:pfmi_last_error, libpfmi), Cstring, ()))
 check(rc::Int32) = rc == 0 ? nothing : throw(PfmiError(rc, last_error()))
 
-# ---- context ---------------------------------------------------------------------------------------
-mutable struct Context
+# ---- context ------------------------------------------------------------------------------------------------------------
+"One GPU, one HIP stream (pfmi_ctx).  One Engine per host thread."
+mutable struct Engine
     ptr::Ptr{Cvoid}
-    function Context(device::Integer=0)
+    device::Int
+    generation::Int                 # bumped whenever traces / fits change: lazy handles made earlier refuse to read
+    keepalive::Any                  # the boxed logp closure handed to the C side
+    function Engine(device::Integer=0)
         ref = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:pfmi_create, libpfmi), Int32, (Int32, Ref{Ptr{Cvoid}}), device, ref))
-        ctx = new(ref[])
-        finalizer(c -> ccall((:pfmi_destroy, libpfmi), Int32, (Ptr{Cvoid},), c.ptr), ctx)
-        return ctx
+        eng = new(ref[], device, 0, nothing)
+        finalizer(e -> ccall((:pfmi_destroy, libpfmi), Int32, (Ptr{Cvoid},), e.ptr), eng)
+        return eng
     end
 end
+struct StaleHandleError <: Exception end
+_live(eng::Engine, gen::Int) = eng.generation == gen || throw(StaleHandleError())
 
-# ---- target: built-in descriptors or an arbitrary Julia closure through @cfunction -------------------
+# ---- target: arbitrary Julia closure through @cfunction (the reference's general logp, src/elbo.jl:15) --------------------
 struct CTarget
     kind::Int32; d::Int32; r::Int32; reserved::Int32
     mean::Ptr{Float64}; a::Ptr{Float64}; Wd::Ptr{Float64}; G::Ptr{Float64}
     offset::Float64
     fn::Ptr{Cvoid}; user::Ptr{Cvoid}
 end
-
-# logp is called one column at a time, exactly like `logp.(eachcol(ϕ))` (src/elbo.jl:15)
+# logp is called one column at a time, exactly like `logp.(eachcol(phi))` (src/elbo.jl:15, src/resample.jl:90-92)
 function _logp_trampoline(X::Ptr{Float64}, d::Int32, n::Int64, out::Ptr{Float64}, user::Ptr{Cvoid})::Cvoid
     logp = unsafe_pointer_to_objref(user)[]
     Xm = unsafe_wrap(Array, X, (Int(d), Int(n)))
@@ -53,152 +68,407 @@ function _logp_trampoline(X::Ptr{Float64}, d::Int32, n::Int64, out::Ptr{Float64}
     end
     return nothing
 end
-
-function set_callback_target!(ctx::Context, logp, dim::Integer)
-    box = Ref{Any}(logp)                       # keep alive for the duration of the calls (caller holds `box`)
+function set_target!(eng::Engine, logp, dim::Integer)
+    box = Ref{Any}(logp)
+    eng.keepalive = box                                   # alive as long as the engine may call back
     cfn = @cfunction(_logp_trampoline, Cvoid, (Ptr{Float64}, Int32, Int64, Ptr{Float64}, Ptr{Cvoid}))
     t = Ref(CTarget(2, dim, 0, 0, C_NULL, C_NULL, C_NULL, C_NULL, 0.0, cfn, pointer_from_objref(box)))
-    check(ccall((:pfmi_set_target, libpfmi), Int32, (Ptr{Cvoid}, Ref{CTarget}), ctx.ptr, t))
-    return box
+    check(ccall((:pfmi_set_target, libpfmi), Int32, (Ptr{Cvoid}, Ref{CTarget}), eng.ptr, t))
+    return nothing
 end
 
-# ---- fit_mvnormals ------------------------------------------------------------------------------------
-"""
-    fit_batch!(ctx, traces; history_length) -> (status, j_eff, logdet, n_rejected)
+# ---- per-batch state --------------------------------------------------------------------------------------------------------
+struct Batch
+    eng::Engine
+    gen::Int
+    dim::Int
+    offsets::Vector{Int}            # 0-based offset of each path's first point, length K + 1
+    status::Vector{Int32}           # per point (src/woodbury.jl:202,205: 1 = A not PD, 2 = C not PD)
+    jeff::Vector{Int32}             # effective history length per point
+    nrej::Vector{Int64}             # rejected BFGS updates per path
+end
+npaths(b::Batch) = length(b.offsets) - 1
 
-`traces` is a vector of (points::Vector{Vector{Float64}}, gradients::Vector{Vector{Float64}}) -- one
-`OptimizationTrace` per path (src/optimize.jl:110-114).  Replaces `fit_mvnormals` for all paths at once.
+# ---- call site 1: fit_mvnormals ----------------------------------------------------------------------------------------------
 """
-function fit_batch!(ctx::Context, traces; history_length::Int=6, ϵ::Float64=1e-12)
+    fit_mvnormals(eng, traces; history_length, ϵ) -> Batch
+
+All runs at once.  `traces[k]` is the `OptimizationTrace` of run k (`.points`, `.gradients`: vectors of vectors,
+src/optimize.jl:94-114).  Replaces `fit_mvnormals` (src/mvnormal.jl:14-21) = `lbfgs_inverse_hessians` + `WoodburyPDMat` +
+`muladd(Σ, ∇logp, θ)` for every trace point.
+"""
+function fit_mvnormals(eng::Engine, traces; history_length::Int=Pathfinder.DEFAULT_HISTORY_LENGTH, ϵ::Float64=1e-12)
     K = length(traces)
-    npts = Int64[length(t[1]) for t in traces]
-    d = length(traces[1][1][1])
-    theta = reduce(hcat, reduce(vcat, [t[1] for t in traces]))   # d x P, column = point (point-major in memory)
-    grad = reduce(hcat, reduce(vcat, [t[2] for t in traces]))
+    npts = Int64[length(t.points) for t in traces]
+    d = length(first(first(traces).points))
+    theta = reduce(hcat, reduce(vcat, [t.points for t in traces]))        # d x P, column = trace point (point-major in memory)
+    grad = reduce(hcat, reduce(vcat, [t.gradients for t in traces]))
+    eng.generation += 1
     check(ccall((:pfmi_set_traces, libpfmi), Int32, (Ptr{Cvoid}, Int32, Ptr{Int64}, Int32, Ptr{Float64}, Ptr{Float64}),
-                ctx.ptr, K, npts, d, theta, grad))
-    check(ccall((:pfmi_fit_batch, libpfmi), Int32, (Ptr{Cvoid}, Int32, Float64), ctx.ptr, history_length, ϵ))
+                eng.ptr, K, npts, d, theta, grad))
+    check(ccall((:pfmi_fit_batch, libpfmi), Int32, (Ptr{Cvoid}, Int32, Float64), eng.ptr, history_length, ϵ))
     P = sum(npts)
-    status = Vector{Int32}(undef, P); jeff = Vector{Int32}(undef, P)
-    logdet = Vector{Float64}(undef, P); nrej = Vector{Int64}(undef, K)
+    status = Vector{Int32}(undef, P); jeff = Vector{Int32}(undef, P); nrej = Vector{Int64}(undef, K)
     check(ccall((:pfmi_get_fit_status, libpfmi), Int32, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ptr{Int64}),
-                ctx.ptr, status, jeff, logdet, nrej))
-    # per-fit failures become PosDefException at materialisation time, as in WoodburyPDMat's constructor
-    return status, jeff, logdet, nrej
+                eng.ptr, status, jeff, C_NULL, nrej))
+    return Batch(eng, eng.generation, d, vcat(0, cumsum(npts)), status, jeff, nrej)
 end
 
-"Materialise fit `p` (0-based) as the pieces of `MvNormal(μ, WoodburyPDMat(A, B, D, F))`."
-function get_fit(ctx::Context, p::Integer, d::Int, j::Int)
-    m = 2j; k = min(d, m)
+"Materialise fit `p` (0-based global point) as `MvNormal(μ, WoodburyPDMat(A, B, D, F))` (src/mvnormal.jl:18, src/woodbury.jl:12-21,246-257)."
+function fit_distribution(b::Batch, p::Integer)
+    _live(b.eng, b.gen)
+    b.status[p + 1] == 0 || throw(LinearAlgebra.PosDefException(Int(b.status[p + 1])))   # what WoodburyPDMat's constructor throws
+    d = b.dim; j = Int(b.jeff[p + 1]); m = 2j; k = min(d, m)
     α = Vector{Float64}(undef, d); B = Matrix{Float64}(undef, d, m); D = Matrix{Float64}(undef, m, m)
     qrf = Matrix{Float64}(undef, d, m); T = Matrix{Float64}(undef, k, k); V = Matrix{Float64}(undef, k, k)
     μ = Vector{Float64}(undef, d); ld = Ref{Float64}(NaN)
     check(ccall((:pfmi_get_fit, libpfmi), Int32,
                 (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
-                 Ptr{Float64}, Ref{Float64}), ctx.ptr, p, α, B, D, qrf, T, V, μ, ld))
-    # Pathfinder.WoodburyPDFactorization(U, Q, V) with U = Diagonal(sqrt.(α)), Q = QRCompactWYQ(qrf, T),
-    # V = UpperTriangular(V)   (src/woodbury.jl:12-21); Σ.B has size (d, 2j) as test/singlepath.jl:41 expects
-    return (; α, B, D, qr_factors=qrf, T, V, μ, logdet=ld[])
+                 Ptr{Float64}, Ref{Float64}), b.eng.ptr, p, α, B, D, qrf, T, V, μ, ld))
+    # qr(U' \ B) in LAPACK's compact-WY form, exactly what `qr(::Matrix{Float64})` returns (src/woodbury.jl:204)
+    Q = LinearAlgebra.QRCompactWYQ(qrf, T)
+    F = Pathfinder.WoodburyPDFactorization(Diagonal(sqrt.(α)), Q, UpperTriangular(V))
+    Σ = Pathfinder.WoodburyPDMat(Diagonal(α), B, D, F)                    # size(Σ.B) == (d, 2j), test/singlepath.jl:41
+    return Distributions.MvNormal(μ, Σ)
 end
 
-# ---- maximize_elbo --------------------------------------------------------------------------------------
-"""
-    elbo_batch!(ctx, ndraws, seeds) -> (elbo, se, best_iter)
+"`fit_distributions` of run k: built on first access."
+struct LazyFitDistributions <: AbstractVector{Any}
+    b::Batch
+    k::Int
+    cache::Dict{Int,Any}
+end
+Base.size(v::LazyFitDistributions) = (v.b.offsets[v.k + 1] - v.b.offsets[v.k],)
+Base.getindex(v::LazyFitDistributions, i::Int) = get!(() -> fit_distribution(v.b, v.b.offsets[v.k] + i - 1), v.cache, i)
 
-`seeds[p]` is the UInt64 of `rand!(rng, UInt64[L])` (src/elbo.jl:2) for point p.  `best_iter[k]` is the 1-based
-`iteration_opt` of `maximize_elbo` for path k (0 when the path has no iterations).
+# ---- call site 2: maximize_elbo ------------------------------------------------------------------------------------------------
+struct ElboBatch
+    b::Batch
+    ndraws::Int
+    seeds::Vector{UInt64}           # per point; seeds = rand!(rng_k, UInt64[L_k]) per run (src/elbo.jl:2)
+    value::Vector{Float64}
+    std_err::Vector{Float64}
+    iteration_opt::Vector{Int64}    # per run, 1-based like the reference's fit_iteration (0: the run has no iterations)
+end
 """
-function elbo_batch!(ctx::Context, ndraws::Integer, seeds::Vector{UInt64}, K::Integer)
-    P = length(seeds)
+    maximize_elbo(eng, batch, rngs, ndraws) -> ElboBatch
+
+`rngs[k]` is run k's own rng (already reseeded from `run_seeds[k]`, src/multipath.jl:190-193); it is advanced exactly like
+the reference does: ONE `rand!(rng, UInt64[L_k])` (src/elbo.jl:2).  The NaN-skipping first-max argmax (src/utils.jl:55-72)
+runs on the device.
+"""
+function maximize_elbo(b::Batch, rngs::AbstractVector{<:Random.AbstractRNG}, ndraws::Int;
+                       pending=1:npaths(b), run_seeds::Vector{Vector{UInt64}}=[UInt64[] for _ in 1:npaths(b)])
+    _live(b.eng, b.gen)
+    K = npaths(b); P = b.offsets[end]
+    seeds = zeros(UInt64, P)
+    for k in 1:K
+        L = b.offsets[k + 1] - b.offsets[k] - 1
+        # only runs that are (re)tried draw seeds; a finished run keeps its own, so the batched re-evaluation reproduces it bit for bit
+        k in pending && (run_seeds[k] = rand!(rngs[k], Vector{UInt64}(undef, L)))
+        seeds[(b.offsets[k] + 2):(b.offsets[k] + 1 + L)] .= run_seeds[k]
+    end
     elbo = Vector{Float64}(undef, P); se = similar(elbo); best = Vector{Int64}(undef, K)
     check(ccall((:pfmi_elbo_batch, libpfmi), Int32,
                 (Ptr{Cvoid}, Int64, Ptr{UInt64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}),
-                ctx.ptr, ndraws, seeds, C_NULL, elbo, se, best))
-    return elbo, se, best
+                b.eng.ptr, ndraws, seeds, C_NULL, elbo, se, best))
+    return ElboBatch(b, ndraws, seeds, elbo, se, best)
 end
 
-"ELBOEstimate.draws / rand(rng, fit_distribution, n) regenerated on demand (src/elbo.jl:19, src/singlepath.jl:226-233)"
-function draws(ctx::Context, p::Integer, seed::UInt64, n0::Integer, N::Integer, d::Integer)
-    X = Matrix{Float64}(undef, d, N); lp = Vector{Float64}(undef, N); lq = similar(lp)
+"`rand(rng, dist, n)` / `ELBOEstimate.draws`: draws n0 .. n0+N-1 of fit p, a pure function of (seed, n) (src/elbo.jl:19, src/singlepath.jl:226-233)."
+function draws(b::Batch, p::Integer, seed::UInt64, n0::Integer, N::Integer)
+    _live(b.eng, b.gen)
+    X = Matrix{Float64}(undef, b.dim, N); lp = Vector{Float64}(undef, N); lq = similar(lp)
     check(ccall((:pfmi_draws, libpfmi), Int32,
                 (Ptr{Cvoid}, Int64, UInt64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
-                ctx.ptr, p, seed, n0, N, C_NULL, X, lp, lq))
+                b.eng.ptr, p, seed, n0, N, C_NULL, X, lp, lq))
     return X, lp, lq
 end
 
-# ---- _compute_psis_result + _resample ----------------------------------------------------------------------
-"""
-    pool_psis_resample!(ctx, ndraws_per_run, points, seeds, ndraws; importance, replace, seed)
-
-Replaces `_compute_psis_result` + `_resample`: pools `ndraws_per_run` draws of fit `points[k]` per path on the
-device, runs PSIS on the log ratios, draws `ndraws` indices and gathers the columns.  Returns
-(draws, draw_component_ids (1-based), weights, pareto_shape).
-"""
-function pool_psis_resample!(ctx::Context, N_r::Integer, points::Vector{Int64}, seeds::Vector{UInt64}, ndraws::Integer,
-                             d::Integer; importance::Bool=true, replace::Bool=true, seed::UInt64=rand(UInt64))
-    K = length(points); S = K * N_r
-    check(ccall((:pfmi_pool_build, libpfmi), Int32, (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{UInt64}), ctx.ptr, N_r, points, seeds))
-    w = Vector{Float64}(undef, S); k̂ = Ref{Float64}(NaN); M = Ref{Int64}(0)
-    if importance
-        dev = Ref{Ptr{Cvoid}}(C_NULL); cnt = Ref{Int64}(0)
-        check(ccall((:pfmi_pool_log_ratios_dev, libpfmi), Int32, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Ref{Int64}), ctx.ptr, dev, cnt))
-        check(ccall((:pfmi_psis_dev, libpfmi), Int32,
-                    (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ref{Float64}, Ref{Int64}),
-                    ctx.ptr, dev[], S, w, C_NULL, k̂, M))
+"`elbo_estimates` of run k: `Pathfinder.ELBOEstimate`s whose draws are regenerated from the fit's seed on first access."
+struct LazyELBOEstimates <: AbstractVector{Any}
+    e::ElboBatch
+    k::Int
+    cache::Dict{Int,Any}
+end
+Base.size(v::LazyELBOEstimates) = (v.e.b.offsets[v.k + 1] - v.e.b.offsets[v.k] - 1,)
+function Base.getindex(v::LazyELBOEstimates, i::Int)
+    return get!(v.cache, i) do
+        p = v.e.b.offsets[v.k] + i                       # fit_distributions[i + 1]
+        ϕ, logpϕ, logqϕ = draws(v.e.b, p, v.e.seeds[p + 1], 0, v.e.ndraws)
+        Pathfinder.ELBOEstimate(v.e.value[p + 1], v.e.std_err[p + 1], ϕ, logpϕ, logqϕ, logpϕ - logqϕ)   # src/elbo.jl:22-29
     end
-    idx = Vector{Int64}(undef, ndraws)
-    check(ccall((:pfmi_resample_indices, libpfmi), Int32,
-                (Ptr{Cvoid}, Int64, Int64, Int32, Int32, UInt64, Ptr{Float64}, Ptr{Int64}),
-                ctx.ptr, S, ndraws, importance, replace, seed, C_NULL, idx))
-    X = Matrix{Float64}(undef, d, ndraws)
-    check(ccall((:pfmi_pool_gather, libpfmi), Int32, (Ptr{Cvoid}, Int64, Ptr{Int64}, Int64, Ptr{Float64}),
-                ctx.ptr, ndraws, idx, 0, X))
-    ids = cld.(idx .+ 1, N_r)                  # draw_component_ids (src/resample.jl:70); idx is 0-based
-    return X, ids, (importance ? w : nothing), k̂[]
 end
 
-# ---- optional: device L-BFGS for the built-in targets (plays optimize_with_trace, src/optimize.jl:35-59) ------
-function optimize_batch!(ctx::Context, x0::Matrix{Float64}; history_length::Int=6, maxiters::Int=1000, g_tol::Float64=1e-8)
+# ---- per-run result, field-compatible with Pathfinder.PathfinderResult (src/singlepath.jl:53-70) -----------------------------------
+mutable struct DevicePathfinderResult
+    input; optimizer; rng; optim_prob; logp
+    fit_iteration::Int
+    num_tries::Int
+    optim_solution; optim_trace
+    fit_distributions::LazyFitDistributions
+    elbo_estimates::LazyELBOEstimates
+    num_bfgs_updates_rejected::Int
+    success::Bool
+    draw_seed::UInt64
+    ndraws::Int
+    _draws::Union{Nothing,Matrix{Float64}}
+end
+function Base.getproperty(r::DevicePathfinderResult, s::Symbol)
+    if s === :fit_distribution || s === :fit_distribution_transformed
+        return getfield(r, :fit_distributions)[getfield(r, :fit_iteration) + 1]          # src/singlepath.jl:224
+    elseif s === :draws || s === :draws_transformed
+        if getfield(r, :_draws) === nothing                                             # src/singlepath.jl:226-233
+            e = getfield(r, :elbo_estimates).e
+            p = e.b.offsets[getfield(r, :elbo_estimates).k] + getfield(r, :fit_iteration)
+            setfield!(r, :_draws, draws(e.b, p, getfield(r, :draw_seed), 0, getfield(r, :ndraws))[1])
+        end
+        return getfield(r, :_draws)
+    end
+    return getfield(r, s)
+end
+
+# ---- PSIS result: the two fields the reference reads (src/resample.jl:64 `.weights`, src/multipath.jl:53 `.pareto_shape`) -----------
+struct DevicePSISResult
+    weights::Vector{Float64}
+    log_weights::Vector{Float64}
+    pareto_shape::Float64
+    tail_length::Int
+end
+
+# ---- call site 3: _compute_psis_result -----------------------------------------------------------------------------------------------
+"""
+    _compute_psis_result(elbos, fit_points, draw_seeds, ndraws_per_run) -> DevicePSISResult
+
+`draws_per_component = stack(draws)` stays on the device: N_r draws of fit `fit_points[k]` (0-based) with seed
+`draw_seeds[k]` per run, log ratios `logp - logpdf(component_k, ·)` in k-major / n-fastest order (src/resample.jl:81-95), then
+`PSIS.psis` (src/resample.jl:78).
+"""
+function _compute_psis_result(b::Batch, fit_points::Vector{Int64}, draw_seeds::Vector{UInt64}, N_r::Int; importance::Bool=true)
+    _live(b.eng, b.gen)
+    check(ccall((:pfmi_pool_build, libpfmi), Int32, (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{UInt64}), b.eng.ptr, N_r, fit_points, draw_seeds))
+    importance || return nothing
+    S = length(fit_points) * N_r
+    dev = Ref{Ptr{Cvoid}}(C_NULL); cnt = Ref{Int64}(0)
+    check(ccall((:pfmi_pool_log_ratios_dev, libpfmi), Int32, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Ref{Int64}), b.eng.ptr, dev, cnt))
+    w = Vector{Float64}(undef, S); lw = similar(w); k̂ = Ref{Float64}(NaN); M = Ref{Int64}(0)
+    check(ccall((:pfmi_psis_dev, libpfmi), Int32,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ref{Float64}, Ref{Int64}),
+                b.eng.ptr, dev[], S, w, lw, k̂, M))
+    return DevicePSISResult(w, lw, k̂[], Int(M[]))
+end
+
+# ---- call site 4: _resample ------------------------------------------------------------------------------------------------------------
+"""
+    _resample(b, rng, psis_result, N_r, K, ndraws; replace, statsbase=false) -> (draws, draw_component_ids)
+
+Index selection + gather on the device (src/resample.jl:58-72).  Default: the library's own deterministic sampler keyed by one
+`rand(rng, UInt64)`.  `statsbase = true` (weighted, with replacement): the indices ARE
+`StatsBase.direct_sample!(rng, 1:S, ProbabilityWeights(w, 1), x)` -- Julia draws the uniforms, the device does the scan.
+"""
+function _resample(b::Batch, rng::Random.AbstractRNG, psis_result, N_r::Int, K::Int, ndraws::Int; replace::Bool=true,
+                   statsbase::Bool=false)
+    _live(b.eng, b.gen)
+    S = K * N_r
+    idx = Vector{Int64}(undef, ndraws)
+    if statsbase && psis_result !== nothing && replace
+        u = rand(rng, ndraws)                                       # what direct_sample! consumes, one rand(rng) per draw
+        check(ccall((:pfmi_resample_indices_direct, libpfmi), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Ptr{Int64}),
+                    b.eng.ptr, S, ndraws, u, idx))
+    else
+        check(ccall((:pfmi_resample_indices, libpfmi), Int32,
+                    (Ptr{Cvoid}, Int64, Int64, Int32, Int32, UInt64, Ptr{Float64}, Ptr{Int64}),
+                    b.eng.ptr, S, ndraws, psis_result !== nothing, replace, rand(rng, UInt64), C_NULL, idx))
+    end
+    X = Matrix{Float64}(undef, b.dim, ndraws)
+    check(ccall((:pfmi_pool_gather, libpfmi), Int32, (Ptr{Cvoid}, Int64, Ptr{Int64}, Int64, Ptr{Float64}),
+                b.eng.ptr, ndraws, idx, 0, X))
+    return X, cld.(idx .+ 1, N_r)                                   # draw_component_ids (src/resample.jl:70); idx is 0-based
+end
+
+# ---- multipathfinder (src/multipath.jl:118-245), batched -------------------------------------------------------------------------------
+"""
+    multipathfinder(eng::Engine, fun, ndraws; kwargs...) -> Pathfinder.MultiPathfinderResult
+
+Same keywords as the reference.  The K optimisations run on the host exactly as in the reference (each with its own `copy(rng)`
+reseeded from `run_seeds[k]`); fits, ELBO scans, pooling, PSIS and resampling are ONE batched GPU call each.
+"""
+function multipathfinder(eng::Engine, optim_fun::SciMLBase.OptimizationFunction, ndraws::Int;
+                         init=nothing, input=optim_fun, dim::Int=-1,
+                         nruns::Int=init === nothing ? -1 : length(init),
+                         ndraws_elbo::Int=Pathfinder.DEFAULT_NDRAWS_ELBO,
+                         ndraws_per_run::Int=max(ndraws_elbo, cld(ndraws, max(nruns, 1))),
+                         rng::Random.AbstractRNG=Random.default_rng(),
+                         history_length::Int=Pathfinder.DEFAULT_HISTORY_LENGTH,
+                         optimizer=Pathfinder.default_optimizer(history_length),
+                         importance::Bool=true, ntries::Int=1_000, init_scale=2,
+                         init_sampler=Pathfinder.UniformSampler(init_scale), statsbase_indices::Bool=false, kwargs...)
+    _init = if init === nothing
+        nruns > 0 || throw(ArgumentError("A positive `nruns` must be set or `init` must be provided."))      # :148-150
+        dim > 0 || throw(ArgumentError("An initial point `init` or dimension `dim` must be provided."))     # src/singlepath.jl:171
+        [init_sampler(rng, Vector{Float64}(undef, dim)) for _ in 1:nruns]                                  # src/singlepath.jl:167-168
+    else
+        collect(init)
+    end
+    nruns = length(_init)
+    d = length(first(_init))
+    if ndraws > ndraws_per_run * nruns
+        @warn "More draws requested than total number of draws across replicas. Draws will not be unique."
+    end
+    logp(x) = -optim_fun.f(x, nothing)                                                                      # :159
+    set_target!(eng, logp, d)
+    run_seeds = rand!(rng, Vector{UInt64}(undef, nruns))                                                    # :162
+    rngs = [Random.seed!(copy(rng), s) for s in run_seeds]                                                  # :189-193
+    probs = [SciMLBase.OptimizationProblem(optim_fun, x0, nothing) for x0 in _init]
+    itry = ones(Int, nruns); pending = collect(1:nruns)
+    sols = Vector{Any}(undef, nruns); traces = Vector{Any}(undef, nruns)
+    local b::Batch, e::ElboBatch
+    success = falses(nruns)
+    fit_seeds = [UInt64[] for _ in 1:nruns]                           # seeds = rand!(rng_k, UInt64[L_k]) of each run's LAST try
+    while true                                                        # the retry loop of src/singlepath.jl:259-283, batched
+        for k in pending
+            sols[k], traces[k] = Pathfinder.optimize_with_trace(probs[k], deepcopy(optimizer); kwargs...)  # host, src/optimize.jl:35-59
+        end
+        b = fit_mvnormals(eng, traces; history_length)                # call site 1 (all runs: finished ones are refitted identically)
+        e = maximize_elbo(b, rngs, ndraws_elbo; pending, run_seeds=fit_seeds)   # call site 2
+        for k in pending
+            L = length(traces[k].points) - 1
+            it = e.iteration_opt[k]
+            v = it > 0 ? e.value[b.offsets[k] + it + 1] : NaN
+            success[k] = L > 0 && it > 0 && !isnan(v) && v != -Inf     # src/singlepath.jl:299, 309-314
+        end
+        pending = [k for k in pending if !success[k] && itry[k] < ntries]
+        isempty(pending) && break
+        for k in pending
+            itry[k] += 1
+            probs[k] = SciMLBase.remake(probs[k]; u0=init_sampler(rngs[k], copy(probs[k].u0)))              # :277
+        end
+    end
+    results = Vector{DevicePathfinderResult}(undef, nruns)
+    fit_points = Vector{Int64}(undef, nruns); draw_seeds = Vector{UInt64}(undef, nruns)
+    for k in 1:nruns
+        it = Int(e.iteration_opt[k])
+        success[k] || @warn "Pathfinder failed after $(itry[k]) tries. Increase `ntries`, inspect the model for numerical instability, or provide a more suitable `init_sampler`."
+        if b.nrej[k] > 0
+            perc = round(b.nrej[k] * (100 // length(traces[k].points)); digits=1)
+            @warn "$(b.nrej[k]) ($(perc)%) updates to the inverse Hessian estimate were rejected to keep it positive definite."
+        end
+        fit_points[k] = b.offsets[k] + it                             # fit_distributions[fit_iteration + 1], 0-based point
+        # draws = the winner's ELBO draws (+ top-up from the same counter-based stream), or fresh ones after a failure (:226-233)
+        draw_seeds[k] = success[k] ? e.seeds[fit_points[k] + 1] : rand(rngs[k], UInt64)
+        results[k] = DevicePathfinderResult(input, optimizer, rngs[k], probs[k], logp, it, itry[k], sols[k], traces[k],
+                                            LazyFitDistributions(b, k, Dict{Int,Any}()), LazyELBOEstimates(e, k, Dict{Int,Any}()),
+                                            Int(b.nrej[k]), success[k], draw_seeds[k], ndraws_per_run, nothing)
+    end
+    psis_result = _compute_psis_result(b, fit_points, draw_seeds, ndraws_per_run; importance)            # call site 3 (:220-224)
+    draws_, ids = _resample(b, rng, psis_result, ndraws_per_run, nruns, ndraws; statsbase=statsbase_indices)   # call site 4 (:225)
+    components = [fit_distribution(b, p) for p in fit_points]
+    fit_dist = Distributions.MixtureModel(components)                                                      # :215-216
+    return Pathfinder.MultiPathfinderResult(input, optimizer, rng, optim_fun, logp, fit_dist, draws_, ids, fit_dist, draws_,
+                                            results, psis_result)
+end
+
+"`pathfinder(eng, prob; ...)`: a single run through the same batched path (src/singlepath.jl:142-257)."
+function pathfinder(eng::Engine, optim_fun::SciMLBase.OptimizationFunction; init, ndraws_elbo::Int=Pathfinder.DEFAULT_NDRAWS_ELBO,
+                    ndraws::Int=ndraws_elbo, kwargs...)
+    res = multipathfinder(eng, optim_fun, ndraws; init=[init], ndraws_elbo, ndraws_per_run=ndraws, importance=false, kwargs...)
+    return res.pathfinder_results[1]
+end
+
+"""
+    resample(eng, result::Pathfinder.MultiPathfinderResult, ndraws; rng, replace, importance, ndraws_per_run)
+
+src/resample.jl:20-46 on the device: stored draws (re-pooled bit-identically from their seeds) or `ndraws_per_run` fresh
+candidates per component (seeds = `rand(rng, UInt64, K)`), PSIS, index selection, gather.
+"""
+function resample(result::Pathfinder.MultiPathfinderResult, ndraws::Int; rng::Random.AbstractRNG=result.rng, replace::Bool=true,
+                  importance::Bool=true, ndraws_per_run::Union{Nothing,Int}=nothing)
+    runs = result.pathfinder_results
+    b = first(runs).fit_distributions.b
+    K = length(runs)
+    pts = Int64[b.offsets[k] + runs[k].fit_iteration for k in 1:K]
+    if ndraws_per_run === nothing                                     # src/resample.jl:97-101
+        N_r = first(runs).ndraws; seeds = UInt64[r.draw_seed for r in runs]
+    else                                                              # src/resample.jl:102-109
+        N_r = ndraws_per_run; seeds = rand(rng, UInt64, K)
+    end
+    psis_result = _compute_psis_result(b, pts, seeds, N_r; importance)
+    draws_, ids = _resample(b, rng, psis_result, N_r, K, ndraws; replace)
+    return Pathfinder.MultiPathfinderResult(result.input, result.optimizer, result.rng, result.optim_fun, result.logp,
+                                            result.fit_distribution, draws_, ids, result.fit_distribution, draws_, runs, psis_result)
+end
+
+# ---- multi-GPU: one Julia process, G engines (pfmi_comm_init_all = ncclCommInitAll), paths in contiguous blocks -------------------------
+mutable struct Comm
+    ptr::Ptr{Cvoid}
+    engines::Vector{Engine}
+    function Comm(engines::Vector{Engine})
+        ref = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:pfmi_comm_init_all, libpfmi), Int32, (Int32, Ptr{Ptr{Cvoid}}, Ref{Ptr{Cvoid}}),
+                    length(engines), [e.ptr for e in engines], ref))
+        c = new(ref[], engines)
+        finalizer(x -> ccall((:pfmi_comm_destroy, libpfmi), Int32, (Ptr{Cvoid},), x.ptr), c)
+        return c
+    end
+end
+"pooled PSIS over every GPU's runs: one RCCL all-gather of the log-ratio shards, PSIS replicated (src/multipath.jl:221)"
+function pool_psis(c::Comm)
+    k̂ = Ref{Float64}(NaN); M = Ref{Int64}(0)
+    check(ccall((:pfmi_comm_pool_psis, libpfmi), Int32, (Ptr{Cvoid}, Ref{Float64}, Ref{Int64}), c.ptr, k̂, M))
+    return k̂[], Int(M[])
+end
+"replicated index selection, owner gather, one sum all-reduce (src/multipath.jl:225)"
+function resample(c::Comm, rng::Random.AbstractRNG, dim::Int, N_r::Int, ndraws::Int; importance::Bool=true, replace::Bool=true)
+    idx = Vector{Int64}(undef, ndraws); X = Matrix{Float64}(undef, dim, ndraws)
+    check(ccall((:pfmi_comm_resample, libpfmi), Int32, (Ptr{Cvoid}, Int64, Int32, Int32, UInt64, Ptr{Float64}, Ptr{Int64}, Ptr{Float64}),
+                c.ptr, ndraws, importance, replace, rand(rng, UInt64), C_NULL, idx, X))
+    return X, cld.(idx .+ 1, N_r)
+end
+
+# ---- optional: device L-BFGS for the built-in targets (plays optimize_with_trace, src/optimize.jl:35-59) -------------------------------
+function optimize_batch!(eng::Engine, x0::Matrix{Float64}; history_length::Int=6, maxiters::Int=1000, g_tol::Float64=1e-8)
     K = size(x0, 2)                              # x0 is d x K column-major == K x d point-major for the C side
     npts = Vector{Int64}(undef, K)
+    eng.generation += 1
     check(ccall((:pfmi_optimize_batch, libpfmi), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Int32, Int32, Float64, Ptr{Int64}),
-                ctx.ptr, K, x0, history_length, maxiters, g_tol, npts))
+                eng.ptr, K, x0, history_length, maxiters, g_tol, npts))
     return npts
 end
-function get_trace(ctx::Context, k::Integer, npoints::Integer, d::Integer)   # OptimizationTrace, src/optimize.jl:94-100
+function get_trace(eng::Engine, k::Integer, npoints::Integer, d::Integer)   # OptimizationTrace, src/optimize.jl:94-100
     θ = Matrix{Float64}(undef, d, npoints); g = similar(θ); lp = Vector{Float64}(undef, npoints)
-    check(ccall((:pfmi_get_trace, libpfmi), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), ctx.ptr, k, θ, lp, g))
-    return (points=collect(eachcol(θ)), log_densities=lp, gradients=collect(eachcol(g)))
+    check(ccall((:pfmi_get_trace, libpfmi), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), eng.ptr, k, θ, lp, g))
+    return Pathfinder.OptimizationTrace(collect(eachcol(θ)), lp, collect(eachcol(g)))
 end
 
-# ---- the PDMats surface of a fitted covariance (src/woodbury.jl:326-423), as the HMC extensions use it -------
+# ---- the PDMats surface of a fitted covariance on the device (src/woodbury.jl:326-423), as the HMC extensions use it ----------------------
 # (ext/PathfinderAdvancedHMCExt.jl:17-23 builds a metric from Σ; its sampling calls unwhiten!/mul!/quad on it)
-struct DeviceWoodbury
-    ctx::Context
+struct DeviceWoodbury <: PDMats.AbstractPDMat{Float64}
+    b::Batch
     point::Int64      # 0-based global trace-point index of the fit
-    dim::Int
 end
 const OP = (unwhiten=Int32(0), whiten=Int32(1), rmul=Int32(2), invunwhiten=Int32(3), mul=Int32(4), solve=Int32(5),
             quad=Int32(6), invquad=Int32(7))
-
 function _apply(W::DeviceWoodbury, op::Int32, x::AbstractVecOrMat{Float64})
-    X = Matrix{Float64}(reshape(x, W.dim, :))
+    _live(W.b.eng, W.b.gen)
+    X = Matrix{Float64}(reshape(x, W.b.dim, :))
     N = size(X, 2)
     out = op >= OP.quad ? Vector{Float64}(undef, N) : similar(X)
     check(ccall((:pfmi_woodbury_apply, libpfmi), Int32, (Ptr{Cvoid}, Int64, Int32, Int64, Ptr{Float64}, Ptr{Float64}),
-                W.ctx.ptr, W.point, op, N, X, out))
-    return (x isa AbstractVector && op < OP.quad) ? vec(out) : out
+                W.b.eng.ptr, W.point, op, N, X, out))
+    return (x isa AbstractVector && op < OP.quad) ? vec(out) : (x isa AbstractVector ? out[1] : out)
 end
-unwhiten(W::DeviceWoodbury, x) = _apply(W, OP.unwhiten, x)          # PDMats.unwhiten!   src/woodbury.jl:401-406
-whiten(W::DeviceWoodbury, x) = _apply(W, OP.whiten, x)              # PDMats.whiten!     src/woodbury.jl:410-415
-invunwhiten(W::DeviceWoodbury, x) = _apply(W, OP.invunwhiten, x)    # PDMats.invunwhiten! src/woodbury.jl:417-422
-Base.:*(W::DeviceWoodbury, x::AbstractVecOrMat{Float64}) = _apply(W, OP.mul, x)    # src/woodbury.jl:340-349
+Base.size(W::DeviceWoodbury) = (W.b.dim, W.b.dim)
+PDMats.unwhiten(W::DeviceWoodbury, x::AbstractVecOrMat{Float64}) = _apply(W, OP.unwhiten, x)          # src/woodbury.jl:401-406
+PDMats.whiten(W::DeviceWoodbury, x::AbstractVecOrMat{Float64}) = _apply(W, OP.whiten, x)              # src/woodbury.jl:410-415
+PDMats.invunwhiten(W::DeviceWoodbury, x::AbstractVecOrMat{Float64}) = _apply(W, OP.invunwhiten, x)    # src/woodbury.jl:417-422
+Base.:*(W::DeviceWoodbury, x::AbstractVecOrMat{Float64}) = _apply(W, OP.mul, x)                       # src/woodbury.jl:340-349
 Base.:\(W::DeviceWoodbury, x::AbstractVecOrMat{Float64}) = _apply(W, OP.solve, x)
-quad(W::DeviceWoodbury, x) = _apply(W, OP.quad, x)                  # src/woodbury.jl:384-397
-invquad(W::DeviceWoodbury, x) = _apply(W, OP.invquad, x)            # src/woodbury.jl:369-382
-function diag(W::DeviceWoodbury)                                    # src/woodbury.jl:326-329
-    out = Vector{Float64}(undef, W.dim)
-    check(ccall((:pfmi_woodbury_diag, libpfmi), Int32, (Ptr{Cvoid}, Int64, Ptr{Float64}), W.ctx.ptr, W.point, out))
+PDMats.quad(W::DeviceWoodbury, x::AbstractVecOrMat{Float64}) = _apply(W, OP.quad, x)                  # src/woodbury.jl:384-397
+PDMats.invquad(W::DeviceWoodbury, x::AbstractVecOrMat{Float64}) = _apply(W, OP.invquad, x)            # src/woodbury.jl:369-382
+function LinearAlgebra.diag(W::DeviceWoodbury)                                                        # src/woodbury.jl:326-329
+    _live(W.b.eng, W.b.gen)
+    out = Vector{Float64}(undef, W.b.dim)
+    check(ccall((:pfmi_woodbury_diag, libpfmi), Int32, (Ptr{Cvoid}, Int64, Ptr{Float64}), W.b.eng.ptr, W.point, out))
     return out
 end
 

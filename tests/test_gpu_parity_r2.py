@@ -529,6 +529,25 @@ def test_comm_rccl_world1_equals_local_path(pfmi_mod, eng, mode):
             e2.close()
 
 
+def test_julia_call_sequence_in_c(tmp_path):
+    """examples/julia_sequence.c replays, call for call, what pathfinder.jl_amd/julia/PathfinderMI355X.jl does for
+    multipathfinder / resample / Comm (callback target through the trampoline, batched fit + ELBO, lazy materialisation with
+    pfmi_get_fit / pfmi_draws, pooled PSIS, both index modes, fresh candidates, the RCCL group, the batched retry) and checks
+    every result the Julia side relies on -- the executed stand-in for the wrapper (no Julia toolchain exists here)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc on this box")
+    exe = str(tmp_path / "julia_sequence")
+    libdir = os.path.join(root, "pathfinder.jl_amd", "lib")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "julia_sequence.c"), "-o", exe,
+                           "-L", libdir, "-lpfmi", f"-Wl,-rpath,{libdir}", "-lm"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.strip().splitlines()[-1].startswith("OK julia_sequence")
+
+
 # ---- bench.py contract on the GPU box ---------------------------------------------------------------------------
 def test_bench_force_dist_counts_its_ranks():
     """bench.py --gpus 1 --force-dist: the N > 1 code path (RCCL all-gather + all-reduce) in a single-rank world; the JSON line
