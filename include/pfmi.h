@@ -141,6 +141,11 @@ int32_t pfmi_get_fit(pfmi_ctx *ctx, int64_t point, double *alpha, double *B, dou
 int32_t pfmi_elbo_batch(pfmi_ctx *ctx, int64_t N, const uint64_t *seeds, const double *u_host,
                         double *elbo, double *se, int64_t *best_iter);
 
+/* HOST_CALLBACK targets only: wall time spent inside the user's callback and bytes of draws handed to it (device -> pinned host)
+ * during the last pfmi_elbo_batch.  The draws of a block of fits are generated and downloaded while the host evaluates the
+ * previous block, so elbo_batch time ~ max(callback time, generation + PCIe time). */
+int32_t pfmi_callback_stats(pfmi_ctx *ctx, double *callback_seconds, double *bytes_to_host);
+
 /* per-draw log densities of one fit from the last pfmi_elbo_batch: logp[N], logq[N] */
 int32_t pfmi_get_elbo_logs(pfmi_ctx *ctx, int64_t point, double *logp, double *logq);
 

@@ -249,6 +249,16 @@ __global__ void pf_logratio_kernel(int64_t n, const double *__restrict__ lp, con
     if (i < n) lr[i] = lp[i] - lq[i];
 }
 
+// dst[points[s] * N + n] = src[s * N + n]: the callback path's per-fit log densities into the point-indexed table (one launch
+// instead of one device-to-device copy per fit)
+__global__ void pf_scatter_rows_kernel(int64_t ns, int64_t N, const int32_t *__restrict__ points, const double *__restrict__ src,
+                                       double *__restrict__ dst) {
+    const int64_t s = blockIdx.y;
+    if (s >= ns) return;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x)
+        dst[(size_t)points[s] * N + n] = src[(size_t)s * N + n];
+}
+
 // ---------------------------------------------------------------------------------------------------
 // logpdf(MvNormal(mu, W), x) = -(d log2pi + logdet)/2 - |L \ (x - mu)|^2 / 2, one lane per column.
 // ldiv!(L): z = U'^{-1}(x - mu); z <- Q'z = z - Vh T'(Vh' z); z[1:k] <- V'^{-1} z[1:k]  (src/woodbury.jl:158-165)
@@ -405,6 +415,14 @@ int32_t pf_launch_elbo_reduce(pfmi_ctx *c) {
     hipLaunchKernelGGL(pf_elbo_argmax_kernel, dim3((unsigned)((c->K + 63) / 64)), dim3(64), 0, c->stream, c->K,
                        c->d_off.as<int64_t>(), c->elbo.as<double>(), c->best_iter.as<int64_t>());
     pf_kernel_end(c, "elbo_reduce");
+    PF_HIP(hipGetLastError());
+    return PFMI_OK;
+}
+
+int32_t pf_launch_scatter_rows(pfmi_ctx *c, int64_t ns, int64_t N, const int32_t *d_points, const double *d_src, double *d_dst) {
+    if (ns <= 0 || N <= 0) return PFMI_OK;
+    const unsigned gx = (unsigned)((N + 255) / 256 < 64 ? (N + 255) / 256 : 64);
+    hipLaunchKernelGGL(pf_scatter_rows_kernel, dim3(gx, (unsigned)ns), dim3(256), 0, c->stream, ns, N, d_points, d_src, d_dst);
     PF_HIP(hipGetLastError());
     return PFMI_OK;
 }

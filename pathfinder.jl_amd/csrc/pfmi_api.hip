@@ -1,6 +1,7 @@
 // pfmi_api.hip -- the extern "C" boundary declared in include/pfmi.h (host side of libpfmi.so).
 #include "pfmi_common.h"
 
+#include <chrono>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -39,6 +40,25 @@ static int32_t d2h(pfmi_ctx *c, void *dst, const void *src, size_t bytes) {
     if (bytes == 0) return PFMI_OK;
     PF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     PF_HIP(hipStreamSynchronize(c->stream));
+    return PFMI_OK;
+}
+// pinned host staging of the callback path (grown on demand, freed in pfmi_destroy)
+static int32_t ensure_pinned(pfmi_ctx *c, size_t x_bytes, size_t lp_bytes) {
+    for (int b = 0; b < 2; ++b) {
+        if (x_bytes > c->pin_x_cap) {
+            if (c->pin_x[b]) (void)hipHostFree(c->pin_x[b]);
+            c->pin_x[b] = nullptr;
+            PF_HIP(hipHostMalloc(&c->pin_x[b], x_bytes, hipHostMallocDefault));
+        }
+        if (lp_bytes > c->pin_lp_cap) {
+            if (c->pin_lp[b]) (void)hipHostFree(c->pin_lp[b]);
+            c->pin_lp[b] = nullptr;
+            PF_HIP(hipHostMalloc(&c->pin_lp[b], lp_bytes, hipHostMallocDefault));
+        }
+        if (!c->cb_ev[b]) PF_HIP(hipEventCreateWithFlags(&c->cb_ev[b], hipEventDisableTiming));
+    }
+    if (x_bytes > c->pin_x_cap) c->pin_x_cap = x_bytes;
+    if (lp_bytes > c->pin_lp_cap) c->pin_lp_cap = lp_bytes;
     return PFMI_OK;
 }
 #define PF_CTX(c)                                                          \
@@ -96,6 +116,12 @@ int32_t pfmi_destroy(pfmi_ctx *c) {
                       &c->psis_out, &c->tailbuf, &c->cdf, &c->idx, &c->gbuf, &c->trace_lp, &c->st_theta, &c->st_grad,
                       &c->st_lp, &c->st_npts, &c->lb_hs, &c->lb_hy, &c->lb_x0, &c->cl_counter, &c->cl_buf, &c->sortk, &c->sorti};
     for (DevBuf *b : bufs) b->release();
+    for (int b = 0; b < 2; ++b) {
+        c->cb_x[b].release(); c->cb_lp[b].release();
+        if (c->pin_x[b]) (void)hipHostFree(c->pin_x[b]);
+        if (c->pin_lp[b]) (void)hipHostFree(c->pin_lp[b]);
+        if (c->cb_ev[b]) (void)hipEventDestroy(c->cb_ev[b]);
+    }
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     (void)hipEventDestroy(c->kev0); (void)hipEventDestroy(c->kev1);
     (void)hipStreamDestroy(c->stream);
@@ -388,13 +414,20 @@ int32_t pfmi_get_fit(pfmi_ctx *c, int64_t p, double *alpha, double *B, double *D
 }
 
 // ---- ELBO ---------------------------------------------------------------------------------------------
-// evaluate the host-callback target on `n` columns stored at device pointer d_x; results to d_lp
+// evaluate the host-callback target on `n` columns stored at device pointer d_x; results to d_lp (pinned staging, 64 MB blocks)
 static int32_t callback_logp(pfmi_ctx *c, const double *d_x, int64_t n, double *d_lp) {
     const TargetDev &T = c->target;
-    std::vector<double> hx((size_t)n * c->d), hl((size_t)n);
-    PF_TRY(d2h(c, hx.data(), d_x, sizeof(double) * hx.size()));
-    T.fn(hx.data(), c->d, n, hl.data(), T.user);
-    PF_TRY(h2d(c, d_lp, hl.data(), sizeof(double) * hl.size()));
+    const int d = c->d;
+    int64_t chunk = (int64_t)((64ll << 20) / (sizeof(double) * (size_t)d));
+    if (chunk < 1) chunk = 1;
+    if (chunk > n) chunk = n;
+    PF_TRY(ensure_pinned(c, sizeof(double) * (size_t)chunk * d, sizeof(double) * (size_t)chunk));
+    for (int64_t s0 = 0; s0 < n; s0 += chunk) {
+        const int64_t ns = (n - s0 < chunk) ? n - s0 : chunk;
+        PF_TRY(d2h(c, c->pin_x[0], d_x + (size_t)s0 * d, sizeof(double) * (size_t)ns * d));
+        T.fn(reinterpret_cast<const double *>(c->pin_x[0]), d, ns, reinterpret_cast<double *>(c->pin_lp[0]), T.user);
+        PF_TRY(h2d(c, d_lp + s0, c->pin_lp[0], sizeof(double) * (size_t)ns));
+    }
     return PFMI_OK;
 }
 
@@ -438,22 +471,39 @@ int32_t pfmi_elbo_batch(pfmi_ctx *c, int64_t N, const uint64_t *seeds, const dou
         PF_TRY(pf_launch_elbo_draws(c, d_list, d_lseeds, nf, 0, N, d_u, ustride, nullptr, 0, c->logp.as<double>(),
                                     c->logq.as<double>(), N, true, true));
     } else {
-        // host closure: materialise the draws of a chunk of fits, copy to the host, evaluate, upload
+        // host closure (the reference's general logp, src/elbo.jl:15): the draws of a block of fits are materialised on the device,
+        // handed to the callback through PINNED staging and the log densities scattered back by one kernel.  Double buffered:
+        // while the host evaluates block i, the device already generates and downloads block i + 1.
         const int64_t per = (int64_t)d * N;
-        int64_t chunk = (int64_t)((256ll << 20) / (sizeof(double) * (size_t)per));
+        int64_t chunk = (int64_t)((64ll << 20) / (sizeof(double) * (size_t)per));
         if (chunk < 1) chunk = 1;
         if (chunk > nf) chunk = nf > 0 ? nf : 1;
-        PF_TRY(c->xbuf.ensure(sizeof(double) * (size_t)chunk * per));
-        PF_TRY(c->scratch.ensure(sizeof(double) * (size_t)chunk * N));
-        for (int64_t s0 = 0; s0 < nf; s0 += chunk) {
-            const int64_t ns = (nf - s0 < chunk) ? nf - s0 : chunk;
-            PF_TRY(pf_launch_elbo_draws(c, d_list + s0, d_lseeds + s0, ns, 0, N, d_u, ustride, c->xbuf.as<double>(), per,
+        const size_t xb = sizeof(double) * (size_t)chunk * per, lb = sizeof(double) * (size_t)chunk * N;
+        PF_TRY(ensure_pinned(c, xb, lb));
+        for (int b = 0; b < 2; ++b) { PF_TRY(c->cb_x[b].ensure(xb)); PF_TRY(c->cb_lp[b].ensure(lb)); }
+        c->cb_seconds = 0.0; c->cb_bytes_d2h = 0.0;
+        const int64_t nblocks = (nf + chunk - 1) / chunk;
+        auto enqueue = [&](int64_t i) -> int32_t {                  // generate block i and start its download
+            const int b = (int)(i & 1);
+            const int64_t s0 = i * chunk, ns = (nf - s0 < chunk) ? nf - s0 : chunk;
+            PF_TRY(pf_launch_elbo_draws(c, d_list + s0, d_lseeds + s0, ns, 0, N, d_u, ustride, c->cb_x[b].as<double>(), per,
                                         c->logp.as<double>(), c->logq.as<double>(), N, false, true));
-            PF_TRY(callback_logp(c, c->xbuf.as<double>(), ns * N, c->scratch.as<double>()));
-            for (int64_t s = 0; s < ns; ++s)   // scatter into the point-indexed logp table
-                PF_HIP(hipMemcpyAsync(c->logp.as<double>() + (size_t)list[(size_t)(s0 + s)] * N,
-                                      c->scratch.as<double>() + (size_t)s * N, sizeof(double) * N,
-                                      hipMemcpyDeviceToDevice, c->stream));
+            PF_HIP(hipMemcpyAsync(c->pin_x[b], c->cb_x[b].p, sizeof(double) * (size_t)ns * per, hipMemcpyDeviceToHost, c->stream));
+            PF_HIP(hipEventRecord(c->cb_ev[b], c->stream));
+            return PFMI_OK;
+        };
+        if (nblocks > 0) PF_TRY(enqueue(0));
+        for (int64_t i = 0; i < nblocks; ++i) {
+            const int b = (int)(i & 1);
+            const int64_t s0 = i * chunk, ns = (nf - s0 < chunk) ? nf - s0 : chunk;
+            if (i + 1 < nblocks) PF_TRY(enqueue(i + 1));
+            PF_HIP(hipEventSynchronize(c->cb_ev[b]));
+            const auto t0 = std::chrono::steady_clock::now();
+            c->target.fn(reinterpret_cast<const double *>(c->pin_x[b]), d, ns * N, reinterpret_cast<double *>(c->pin_lp[b]), c->target.user);
+            c->cb_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            c->cb_bytes_d2h += (double)sizeof(double) * (double)ns * (double)per;
+            PF_HIP(hipMemcpyAsync(c->cb_lp[b].p, c->pin_lp[b], sizeof(double) * (size_t)ns * N, hipMemcpyHostToDevice, c->stream));
+            PF_TRY(pf_launch_scatter_rows(c, ns, N, d_list + s0, c->cb_lp[b].as<double>(), c->logp.as<double>()));
         }
     }
     PF_TRY(pf_launch_elbo_reduce(c));
@@ -462,6 +512,13 @@ int32_t pfmi_elbo_batch(pfmi_ctx *c, int64_t N, const uint64_t *seeds, const dou
     if (se) PF_TRY(d2h(c, se, c->se.p, sizeof(double) * P));
     if (best_iter) PF_TRY(d2h(c, best_iter, c->best_iter.p, sizeof(int64_t) * c->K));
     PF_HIP(hipStreamSynchronize(c->stream));
+    return PFMI_OK;
+}
+
+int32_t pfmi_callback_stats(pfmi_ctx *c, double *callback_seconds, double *bytes_to_host) {
+    PF_CTX(c);
+    if (callback_seconds) *callback_seconds = c->cb_seconds;
+    if (bytes_to_host) *bytes_to_host = c->cb_bytes_d2h;
     return PFMI_OK;
 }
 

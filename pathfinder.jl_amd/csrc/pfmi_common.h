@@ -131,6 +131,13 @@ struct pfmi_ctx {
     DevBuf idx;         // int64 [ndraws]
     DevBuf gbuf;        // gather output
     DevBuf sortk, sorti; // (key, index) arrays of the large replace = false request
+    // host-callback targets: double-buffered device blocks, pinned host staging, one event per buffer
+    DevBuf cb_x[2], cb_lp[2];
+    void *pin_x[2] = {nullptr, nullptr}, *pin_lp[2] = {nullptr, nullptr};
+    size_t pin_x_cap = 0, pin_lp_cap = 0;
+    hipEvent_t cb_ev[2] = {nullptr, nullptr};
+    double cb_seconds = 0.0;      // wall time spent inside the user's callback during the last elbo_batch
+    double cb_bytes_d2h = 0.0;    // bytes of draws handed to the callback
 };
 
 // ---- launch helpers (implemented in the .hip files) ----------------------------------------------
@@ -148,6 +155,7 @@ int32_t pf_launch_resample(pfmi_ctx *c, int64_t S, int64_t ndraws, int importanc
 int32_t pf_launch_resample_direct(pfmi_ctx *c, int64_t S, int64_t ndraws, const double *d_uniforms);
 int32_t pf_launch_gather(pfmi_ctx *c, int64_t ndraws, const int64_t *d_idx, int64_t col_offset, double *d_out);
 int32_t pf_launch_logratio(pfmi_ctx *c, int64_t n);
+int32_t pf_launch_scatter_rows(pfmi_ctx *c, int64_t ns, int64_t N, const int32_t *d_points, const double *d_src, double *d_dst);
 int32_t pf_launch_lbfgs(pfmi_ctx *c, int K, int J, int maxiters, double g_tol, const double *d_x0);
 int32_t pf_launch_trace_pack(pfmi_ctx *c, int64_t cap);
 int32_t pf_launch_woodbury_prim(pfmi_ctx *c, int mode, int64_t p, int64_t N, const double *d_in, double *d_out);

@@ -29,7 +29,7 @@ SYMBOLS = [
     "pfmi_last_error", "pfmi_version", "pfmi_device_count", "pfmi_create", "pfmi_destroy", "pfmi_sync",
     "pfmi_timer_start", "pfmi_timer_stop", "pfmi_profile", "pfmi_kernel_time", "pfmi_set_target",
     "pfmi_set_traces", "pfmi_optimize_batch", "pfmi_get_trace", "pfmi_fit_batch", "pfmi_get_fit_status", "pfmi_get_fit", "pfmi_elbo_batch",
-    "pfmi_get_elbo_logs", "pfmi_draws", "pfmi_logpdf", "pfmi_woodbury_apply", "pfmi_woodbury_diag", "pfmi_pool_build", "pfmi_pool_get",
+    "pfmi_get_elbo_logs", "pfmi_callback_stats", "pfmi_draws", "pfmi_logpdf", "pfmi_woodbury_apply", "pfmi_woodbury_diag", "pfmi_pool_build", "pfmi_pool_get",
     "pfmi_pool_log_ratios_dev", "pfmi_psis_dev", "pfmi_psis", "pfmi_resample_indices", "pfmi_resample_indices_direct", "pfmi_pool_gather",
     "pfmi_pool_gather_dev", "pfmi_malloc_dev", "pfmi_free_dev", "pfmi_memcpy_h2d", "pfmi_memcpy_d2h",
     "pfmi_comm_unique_id", "pfmi_comm_init_all", "pfmi_comm_init_rank", "pfmi_comm_destroy", "pfmi_comm_info",

@@ -378,11 +378,12 @@ def _run_paths(eng, target, inits, run_rngs, *, dim, history_length, ndraws_elbo
                     state[k]["trace"].materialise()
         else:
             eng.set_traces([s["trace"].points for s in state], [s["trace"].gradients for s in state])
+        # one batched fit + ELBO over every path (finished paths are recomputed identically from their seeds).  fit_batch only
+        # ENQUEUES the history walk and the fits; the per-fit seeds are drawn on the host while they run
+        eng.fit_batch(history_length)
         fresh = rand_u64_multi([run_rngs[k] for k in pending], [len(state[k]["trace"]) - 1 for k in pending])
         for k, sd in zip(pending, fresh):                           # seeds = rand!(rng_k, UInt64[L_k])  (src/elbo.jl:2)
             state[k]["seeds"] = np.concatenate([[np.uint64(0)], sd]).astype(np.uint64)
-        # one batched fit + ELBO over every path (finished paths are recomputed identically from their seeds)
-        eng.fit_batch(history_length)
         status, jeff, logdet, nrej = eng.fit_status()
         seeds = np.concatenate([s["seeds"] for s in state])
         elbo, se, best = eng.elbo_batch(ndraws_elbo, seeds)

@@ -158,6 +158,11 @@ class Engine:
                                      best.ctypes.data_as(_i64p)))
         return elbo, se, best
 
+    def callback_stats(self):
+        sec, nb = C.c_double(), C.c_double()
+        check(self.L.pfmi_callback_stats(self.ctx, C.byref(sec), C.byref(nb)))
+        return dict(callback_seconds=sec.value, bytes_to_host=nb.value)
+
     def elbo_logs(self, p, N):
         lp, lq = np.empty(N), np.empty(N)
         check(self.L.pfmi_get_elbo_logs(self.ctx, C.c_int64(p), _d(lp), _d(lq)))
