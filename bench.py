@@ -275,15 +275,29 @@ def main():
                 traffic = pmc["traffic_bytes_per_launch"]
         except Exception:
             pass
+        # the kernel's real bound is instruction issue (f64 MFMA shares the fp64 lanes with the VALU on gfx950): report
+        # the matrix rate beside the contract's figure.  Per 16 rows x 16 draws a group issues 4 x (2 KC/4 + RPAD/4) MFMA 4x4x4 (512 flop)
+        kc = next(o for o in (4, 8, 12, 16, 20, 32) if m <= o)
+        rpad = (8 if getattr(tg, "r", 0) <= 8 else 16) if getattr(tg, "r", 0) > 0 else 0
+        ncols = 2 * kc + rpad          # w = Vh'z, A3 = Vh'(a s^2 z), A4 = Wd'(s z)
+        nblk = -(-d // 16)
+        mfma_flops = draws_local / 16.0 * nblk * 4 * (ncols // 4) * 512.0
+        mfma_tf = mfma_flops / (ms / max(n, 1) * 1e-3) / 1e12 if ms > 0 else 0.0
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                    "label": "equivalent materialised-draw bandwidth: algorithmic bytes of SURVEY 8(d) / measured launch time "
+                             "(the fused kernel moves < 3 % of them; HBM is idle)",
+                    "mfma_f64": {"achieved": round(mfma_tf, 2), "peak": 78.6, "unit": "TFLOP/s", "frac": round(mfma_tf / 78.6, 4),
+                                 "note": "f64 MFMA flops of the scan / launch time; the kernel's floor is the SUM of its MFMA and VALU "
+                                         "issue streams (no co-issue on gfx950, profiles/r02_coissue_microbench.txt): ~80 % of that floor"},
                     "kernel": "pf_elbo_qf_kernel (single-pass ELBO scan)",
                     "launches": int(n), "avg_launch_ms": round(ms / max(n, 1), 4),
                     "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_draw": bytes_per_draw,
                     "note": "achieved = algorithmic bytes (16*d + factor bytes per draw, SURVEY 8d) / measured launch time. The "
                             "kernel is fused: normals are generated in registers and draws of non-winning fits are never "
-                            "written, so measured HBM traffic (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json) "
-                            "is <1% of the algorithmic bytes; the real bound is the fp64 VALU / f64 MFMA issue rate."}
+                            "written, so measured HBM traffic (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, two separate --pmc passes, "
+                            "profiles/pmc_traffic.json) is <3% of the algorithmic bytes; the real bound is the fp64 VALU / f64 MFMA "
+                            "issue rate (see mfma_f64)."}
 
     # ---- CPU baseline: the oracle (a port of the reference algorithm) on this box's host cores ------------
     cpu = None

@@ -342,7 +342,7 @@ def _use_device_optimizer(target, optimizer):
 
 # ---- batched driver shared by pathfinder / multipathfinder ------------------------------------------------
 def _run_paths(eng, target, inits, run_rngs, *, dim, history_length, ndraws_elbo, ntries, init_sampler,
-               optimizer_kwargs, materialise, optimizer="auto"):
+               optimizer_kwargs, materialise, optimizer="auto", strict=True):
     """Runs every path to success (or ntries), batching the GPU work.  Returns per-path dicts.
     The K optimisations run on the device for built-in targets (pfmi_optimize_batch, all paths in one launch) and
     through the host driver for callback targets (the reference's general case, src/optimize.jl:35-59)."""
@@ -385,6 +385,14 @@ def _run_paths(eng, target, inits, run_rngs, *, dim, history_length, ndraws_elbo
         for k, sd in zip(pending, fresh):                           # seeds = rand!(rng_k, UInt64[L_k])  (src/elbo.jl:2)
             state[k]["seeds"] = np.concatenate([[np.uint64(0)], sd]).astype(np.uint64)
         status, jeff, logdet, nrej = eng.fit_status()
+        bad = np.flatnonzero(status)
+        if len(bad) and strict:
+            # WoodburyPDMat's constructor throws inside fit_mvnormals (src/woodbury.jl:202,205) and nothing in
+            # _pathfinder / the retry loop catches it (src/singlepath.jl:259-314): the reference's call fails as a whole
+            p = int(bad[0])
+            k = int(np.searchsorted(eng.offsets, p, side="right") - 1)
+            raise PosDefException(f"run {k + 1}, fit {p - int(eng.offsets[k]) + 1}: {_STATUS_MSG.get(int(status[p]), 'failed')} "
+                                  f"({len(bad)} of {len(status)} fits failed; strict=False keeps them as NaN ELBOs instead)")
         seeds = np.concatenate([s["seeds"] for s in state])
         elbo, se, best = eng.elbo_batch(ndraws_elbo, seeds)
         new_pending = []
@@ -438,9 +446,10 @@ def _assemble_path(eng, target, st, rng, ndraws, ndraws_elbo, input_, status, je
 
 def pathfinder(target, *, rng=None, init=None, dim=-1, init_scale=2, init_sampler=None, input=None,
                history_length=DEFAULT_HISTORY_LENGTH, ndraws_elbo=DEFAULT_NDRAWS_ELBO, ndraws=None, ntries=1000,
-               ntasks=1, engine=None, materialise=True, optimizer="auto", **optimizer_kwargs):
+               ntasks=1, engine=None, materialise=True, optimizer="auto", strict=True, **optimizer_kwargs):
     """Single-path Pathfinder (reference src/singlepath.jl:142-257).  optimizer: "auto" (device L-BFGS for built-in
-    targets, host driver for callbacks), "device" or "host"."""
+    targets, host driver for callbacks), "device" or "host".  strict: a non-positive-definite fit raises PosDefException like
+    the reference (src/woodbury.jl:202,205); strict=False keeps the library's per-fit status / NaN-ELBO behaviour."""
     rng = rng if rng is not None else HostRNG(0)
     ndraws = ndraws_elbo if ndraws is None else ndraws
     init_sampler = init_sampler or UniformSampler(init_scale)
@@ -455,7 +464,7 @@ def pathfinder(target, *, rng=None, init=None, dim=-1, init_scale=2, init_sample
     eng.set_target(target)
     state, status, jeff = _run_paths(eng, target, [init], [rng], dim=dim, history_length=history_length,
                                      ndraws_elbo=ndraws_elbo, ntries=ntries, init_sampler=init_sampler,
-                                     optimizer_kwargs=optimizer_kwargs, materialise=materialise, optimizer=optimizer)
+                                     optimizer_kwargs=optimizer_kwargs, materialise=materialise, optimizer=optimizer, strict=strict)
     st = state[0]
     a = _assemble_path(eng, target, st, rng, ndraws, ndraws_elbo, input, status, jeff, materialise)
     X = eng.draws(a["fit_point"], a["draw_seed"], ndraws)[0]     # src/singlepath.jl:226-233
@@ -467,8 +476,8 @@ def pathfinder(target, *, rng=None, init=None, dim=-1, init_scale=2, init_sample
 def multipathfinder(target, ndraws, *, init=None, nruns=-1, ndraws_elbo=DEFAULT_NDRAWS_ELBO, ndraws_per_run=None,
                     rng=None, history_length=DEFAULT_HISTORY_LENGTH, importance=True, dim=-1, init_scale=2,
                     init_sampler=None, ntries=1000, ntasks=1, ntasks_per_run=1, input=None, engine=None,
-                    materialise=False, optimizer="auto", **optimizer_kwargs):
-    """Multi-path Pathfinder (reference src/multipath.jl:118-245).  optimizer: see pathfinder()."""
+                    materialise=False, optimizer="auto", strict=True, **optimizer_kwargs):
+    """Multi-path Pathfinder (reference src/multipath.jl:118-245).  optimizer, strict: see pathfinder()."""
     if init is None:
         if nruns <= 0:
             raise ValueError("A positive `nruns` must be set or `init` must be provided.")     # :148-150
@@ -490,7 +499,7 @@ def multipathfinder(target, ndraws, *, init=None, nruns=-1, ndraws_elbo=DEFAULT_
     eng.set_target(target)
     state, status, jeff = _run_paths(eng, target, inits, run_rngs, dim=dim, history_length=history_length,
                                      ndraws_elbo=ndraws_elbo, ntries=ntries, init_sampler=init_sampler,
-                                     optimizer_kwargs=optimizer_kwargs, materialise=materialise, optimizer=optimizer)
+                                     optimizer_kwargs=optimizer_kwargs, materialise=materialise, optimizer=optimizer, strict=strict)
     parts = [_assemble_path(eng, target, st, r, ndraws_per_run, ndraws_elbo, input, status, jeff, materialise)
              for st, r in zip(state, run_rngs)]
     # draws_per_component = stack(draws)   (:217) -- device resident
