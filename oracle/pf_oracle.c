@@ -497,15 +497,20 @@ static inline void philox_round(uint32_t c[4], const uint32_t k[2]) {
     uint32_t n3 = (uint32_t)p0;
     c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
 }
-void pfo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+/* Philox4x32-R (Salmon, Moraes, Dror, Shaw 2011).  R = 10 everywhere a host can see the bits (seeds, resampling uniforms; pinned by
+ * the Random123 known answers in tests/test_oracle_elbo_psis.py); the normal-generation stream uses R = PFO_NORMAL_ROUNDS = 7,
+ * the crush-resistant minimum of the paper's table 2 (same round function and key schedule, three rounds fewer). */
+#define PFO_NORMAL_ROUNDS 7
+void pfo_philox4x32_r(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]) {
     uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
     uint32_t k[2] = {key[0], key[1]};
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < rounds; ++r) {
         philox_round(c, k);
         k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
     }
     out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
 }
+void pfo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { pfo_philox4x32_r(ctr, key, 10, out); }
 /* The standard-normal generator (replaces Julia's randn! of src/mvnormal.jl:30, whose Xoshiro/ziggurat stream cannot be
  * reproduced outside Julia -- SURVEY.md H3).  One 32-bit Philox word -> one normal through the piecewise-cubic inverse normal
  * CDF tabulated in pathfinder.jl_amd/csrc/pfmi_icdftab.h (generated by pathfinder.jl_amd/tools/gen_icdf_table.py, which
@@ -543,10 +548,10 @@ void pfo_randn4(uint64_t seed, uint32_t g, uint32_t n, uint32_t stream, double z
     uint32_t ctr[4] = {n, g, stream, 0u};
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     uint32_t x[4], x2[4] = {0u, 0u, 0u, 0u};
-    pfo_philox4x32_10(ctr, key, x);
+    pfo_philox4x32_r(ctr, key, PFO_NORMAL_ROUNDS, x);
     int tail = 0;
     for (int t = 0; t < 4; ++t) tail |= (x[t] & 0x7FFFFFFFu) < (1u << PF_ICDF_TAILBITS);
-    if (tail) { ctr[3] = 1u; pfo_philox4x32_10(ctr, key, x2); }
+    if (tail) { ctr[3] = 1u; pfo_philox4x32_r(ctr, key, PFO_NORMAL_ROUNDS, x2); }
     for (int t = 0; t < 4; ++t) z[t] = pfo_icdf_normal(x[t], x2[t]);
 }
 /* fill U (d x N col-major) with the standard normals of draws n0 .. n0+N-1 of `seed` */

@@ -244,6 +244,18 @@ def philox4x32_10(ctr, key):
     return out
 
 
+def philox4x32(ctr, key, rounds):
+    ctr = np.asarray(ctr, dtype=np.uint32)
+    key = np.asarray(key, dtype=np.uint32)
+    out = np.zeros(4, dtype=np.uint32)
+    u32p = C.POINTER(C.c_uint32)
+    lib().pfo_philox4x32_r(ctr.ctypes.data_as(u32p), key.ctypes.data_as(u32p), C.c_int(rounds), out.ctypes.data_as(u32p))
+    return out
+
+
+NORMAL_ROUNDS = 7       # rounds of the normal-generation stream (pfo_randn4); seeds / resampling use 10
+
+
 def randn_fill(seed, d, N, n0=0):
     U = np.empty((d, N), order="F")
     lib().pfo_randn_fill(C.c_uint64(int(seed)), d, C.c_long(n0), C.c_long(N), _p(U))

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
     // normals of rows 16 blk + 4q + {0..3} of draw n (+ head transform for block 0) and their pass-1 MFMAs
     auto pass1_block = [&](const int blk, const uint32_t n, const bool head, double (&zz)[4]) {
         uint32_t x[4];
-        pf_philox4x32_10(n, (uint32_t)(blk * 4 + q), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+        pf_philox_normals(n, (uint32_t)(blk * 4 + q), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
         pf_icdf4<MF_ICDF_NB>(x, n, (uint32_t)(blk * 4 + q), 0u, (uint32_t)seed, (uint32_t)(seed >> 32), icdf, zz);
         const int rowbase = blk * 16 + 4 * q;
 #pragma unroll
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        pf_philox4x32_10(n + 16u, (uint32_t)(wvs * NBW * 4 + q), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), xc);
+        pf_philox_normals(n + 16u, (uint32_t)(wvs * NBW * 4 + q), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), xc);
 #pragma unroll
         for (int reg = 0; reg < WR; ++reg) red[wv * 64 * WR + reg * 64 + lane] = accw[reg];   // entry (j = q + 4 reg, c)
         __syncthreads();
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
 #pragma unroll
                 for (int I = 0; I < TR; ++I) acc3[I] = pf_mfma4(a3[1][I], e4[1], acc3[I]);
             }
-            pf_philox_round(c0, c1, c2, c3, k0, k1);
+            if (PF_NORMAL_ROUNDS > 7) pf_philox_round(c0, c1, c2, c3, k0, k1);
             if (blk == nblk - 1) {                                                      // rows >= d exist only in the last block
 #pragma unroll
                 for (int r = 0; r < 4; ++r) zz[r] = (rowbase + r < d) ? zz[r] : 0.0;
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
 #pragma unroll
                 for (int I = 0; I < TR; ++I) acc3[I] = pf_mfma4(a3[2][I], e4[2], acc3[I]);
             }
-            pf_philox_round(c0, c1, c2, c3, k0, k1);
+            if (PF_NORMAL_ROUNDS > 8) pf_philox_round(c0, c1, c2, c3, k0, k1);
             PF_PIN_RNG();
             PF_PHASE_END();
             // P9
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
 #pragma unroll
                 for (int I = 0; I < TR; ++I) acc3[I] = pf_mfma4(a3[3][I], e4[3], acc3[I]);
             }
-            pf_philox_round(c0, c1, c2, c3, k0, k1);
+            if (PF_NORMAL_ROUNDS > 9) pf_philox_round(c0, c1, c2, c3, k0, k1);
             if (head) {                                                                 // z[1:k] = V' u[1:k]  (src/woodbury.jl:139)
                 d4 h = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll

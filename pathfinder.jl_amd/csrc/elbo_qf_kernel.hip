@@ -192,11 +192,11 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
 #pragma unroll
             for (int r = 0; r < 4; ++r) { P.x[r] = 0x40000000u | (n[g] + blk); P.dp[r] = 1e-3 * (blk + r); P.c01[r] = make_double2(0.1, 0.2); P.c23[r] = make_double2(0.3, 0.4); }
 #elif QF_ABLATE == 2                   // ablation: Philox only, no table look-up
-            pf_philox4x32_10(n[g], (uint32_t)(blk * 4 + q), 0u, 0u, k0, k1, P.x);
+            pf_philox_normals(n[g], (uint32_t)(blk * 4 + q), 0u, 0u, k0, k1, P.x);
 #pragma unroll
             for (int r = 0; r < 4; ++r) { P.dp[r] = (double)P.x[r] * 0x1p-32; P.c01[r] = make_double2(0.1, 0.2); P.c23[r] = make_double2(0.3, 0.4); }
 #else
-            pf_philox4x32_10(n[g], (uint32_t)(blk * 4 + q), 0u, 0u, k0, k1, P.x);
+            pf_philox_normals(n[g], (uint32_t)(blk * 4 + q), 0u, 0u, k0, k1, P.x);
 #pragma unroll
             for (int r = 0; r < 4; ++r) pf_icdf_issue(P.x[r], icdf, P.dp[r], P.c01[r], P.c23[r]);
 #endif
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
                 // normals of rows 16 blk + 4q + {0..3} of draw n[g], head transform included
                 auto normals = [&](const int g, const int blk, double (&z)[4]) {
                     uint32_t x[4];
-                    pf_philox4x32_10(n[g], (uint32_t)(blk * 4 + q), 0u, 0u, k0, k1, x);
+                    pf_philox_normals(n[g], (uint32_t)(blk * 4 + q), 0u, 0u, k0, k1, x);
                     pf_icdf4(x, n[g], (uint32_t)(blk * 4 + q), 0u, k0, k1, icdf, z);
                     if (blk == nblk - 1) {
 #pragma unroll

@@ -186,10 +186,16 @@ __device__ __forceinline__ uint32_t pf_xor3_key(uint32_t a, uint32_t b, uint32_t
     asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(r) : "v"(a), "v"(b), "s"(k));   // gfx950: three-input bit op, truth table 0x96 = a ^ b ^ c
     return r;
 }
-__device__ __forceinline__ void pf_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                                 uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+// Rounds of the NORMAL-generation stream.  Philox4x32 is crush-resistant from 7 rounds (Salmon et al. 2011, table 2: 7 is the
+// minimum that passes BigCrush, 10 the default with a safety margin); the 1.1e10 normals of a step are the kernel's second
+// largest issue stream and each round costs 24 SIMD cycles (two 64-bit multiplies), so the normals use 7.  Seeds, resampling
+// uniforms and everything a host sees keep the 10-round function with its published known answers.
+#define PF_NORMAL_ROUNDS 7
+template <int ROUNDS>
+__device__ __forceinline__ void pf_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < ROUNDS; ++r) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         uint32_t n0 = pf_xor3_key((uint32_t)(p1 >> 32), c1, k0);
@@ -200,6 +206,14 @@ __device__ __forceinline__ void pf_philox4x32_10(uint32_t c0, uint32_t c1, uint3
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ void pf_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                                 uint32_t (&out)[4]) {
+    pf_philox4x32<10>(c0, c1, c2, c3, k0, k1, out);
+}
+__device__ __forceinline__ void pf_philox_normals(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                                  uint32_t (&out)[4]) {
+    pf_philox4x32<PF_NORMAL_ROUNDS>(c0, c1, c2, c3, k0, k1, out);
 }
 
 // ---- the standard-normal generator ------------------------------------------------------------------------------
@@ -263,7 +277,7 @@ template <int NB = PF_ICDF_NB_LDS>
 __device__ __forceinline__ void pf_icdf4_fix(const uint32_t (&x)[4], uint32_t n, uint32_t g, uint32_t stream, uint32_t k0, uint32_t k1,
                                              double (&z)[4]) {
     uint32_t x2[4] = {0u, 0u, 0u, 0u};
-    if (__any(pf_icdf_miss4<PF_ICDF_NB_LDS>(x))) pf_philox4x32_10(n, g, stream, 1u, k0, k1, x2);
+    if (__any(pf_icdf_miss4<PF_ICDF_NB_LDS>(x))) pf_philox_normals(n, g, stream, 1u, k0, k1, x2);
 #pragma unroll
     for (int t = 0; t < 4; ++t) if ((x[t] & 0x7FFFFFFFu) < (1u << (31 - NB))) z[t] = pf_icdf_any(x[t], x2[t]);
 }
@@ -286,7 +300,7 @@ __device__ __forceinline__ void pf_randn4(uint64_t seed, uint32_t g, uint32_t n,
                                           double (&z)[4]) {
     uint32_t x[4];
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    pf_philox4x32_10(n, g, stream, 0u, k0, k1, x);
+    pf_philox_normals(n, g, stream, 0u, k0, k1, x);
     pf_icdf4<NB>(x, n, g, stream, k0, k1, lds_tab, z);
 }
 

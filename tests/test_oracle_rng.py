@@ -84,6 +84,36 @@ def test_distribution_and_tail_mass():
     np.testing.assert_array_equal(V, po.randn_fill(20260928, 2000, 2000)[:, 1990:])
 
 
+def test_seven_round_philox_is_the_ten_round_function_truncated():
+    """The normal stream uses Philox4x32-7 (the paper's crush-resistant minimum): same round function / key schedule as the
+    KAT-pinned 10-round generator (tests/test_oracle_elbo_psis.py), checked against an independent NumPy restatement, plus the
+    avalanche behaviour one expects from 7 rounds (flipping one counter bit flips ~half of the 128 output bits)."""
+    import pfmi.hostrng as hr
+    rng = np.random.default_rng(3)
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+
+    def ref(ctr, key, rounds):
+        c = [int(v) for v in ctr]; k = [int(v) for v in key]
+        for _ in range(rounds):
+            p0, p1 = M0 * c[0], M1 * c[2]
+            c = [((p1 >> 32) ^ c[1] ^ k[0]) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c[3] ^ k[1]) & 0xFFFFFFFF, p0 & 0xFFFFFFFF]
+            k = [(k[0] + W0) & 0xFFFFFFFF, (k[1] + W1) & 0xFFFFFFFF]
+        return np.array(c, dtype=np.uint32)
+
+    flips = []
+    for _ in range(200):
+        ctr = rng.integers(0, 2 ** 32, 4, dtype=np.uint64).astype(np.uint32)
+        key = rng.integers(0, 2 ** 32, 2, dtype=np.uint64).astype(np.uint32)
+        for r in (7, 10):
+            np.testing.assert_array_equal(po.philox4x32(ctr, key, r), ref(ctr, key, r))
+        np.testing.assert_array_equal(po.philox4x32(ctr, key, 10), po.philox4x32_10(ctr, key))
+        np.testing.assert_array_equal(po.philox4x32(ctr, key, 10), hr.philox4x32_10(ctr[None, :], (int(key[0]), int(key[1])))[0])
+        c2 = ctr.copy(); c2[0] ^= np.uint32(1 << int(rng.integers(0, 32)))
+        a, b = po.philox4x32(ctr, key, 7), po.philox4x32(c2, key, 7)
+        flips.append(sum(bin(int(x) ^ int(y)).count("1") for x, y in zip(a, b)))
+    assert 60 < np.mean(flips) < 68 and min(flips) > 35
+
+
 def test_tail_refinement_occurs_in_the_stream():
     """Words below 2^12 (probability 2^-19) really occur and take the second Philox call (counter word 3 = 1)."""
     key = np.array([0x9ABCDEF0, 0x12345678], dtype=np.uint32)
@@ -91,10 +121,10 @@ def test_tail_refinement_occurs_in_the_stream():
     found = 0
     for n in range(0, 3000):
         for g in range(250):
-            x = po.philox4x32_10(np.array([n, g, 0, 0], dtype=np.uint32), key)
+            x = po.philox4x32(np.array([n, g, 0, 0], dtype=np.uint32), key, po.NORMAL_ROUNDS)
             t = np.flatnonzero((x & 0x7FFFFFFF) < 4096)
             if len(t):
-                x2 = po.philox4x32_10(np.array([n, g, 0, 1], dtype=np.uint32), key)
+                x2 = po.philox4x32(np.array([n, g, 0, 1], dtype=np.uint32), key, po.NORMAL_ROUNDS)
                 z = po.randn_fill(seed, 1000, 1, n0=n)[4 * g:4 * g + 4, 0]
                 for r in t:
                     p = ((int(x[r]) & 0x7FFFFFFF) * 2.0 ** 32 + int(x2[r]) + 0.5) * 2.0 ** -64
