@@ -179,14 +179,12 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
 #pragma unroll
             for (int r = 0; r < 4; ++r) u0[g][r] = 0.0;
         }
-        // software pipeline of the generator: the Philox call, interval look-up and table reads of the NEXT (group, block) are
-        // issued before the MFMA burst of the current group and consumed after it, so the (bank-conflicted, ~150-cycle)
-        // random-index LDS reads never stall the wave.  With two groups per wave they alternate -- finish g0, issue g1,
-        // contract g0, finish g1, issue g0 of the next block, contract g1 -- so ONE set of landing registers (`pend`, 44 VGPRs)
-        // serves both; it carries across iterations and chunk boundaries.  LDS issue order = consumption order (tables of the
-        // previous step, operands of this block, tables of the next step), so every s_waitcnt is exact.
+        // generator in two halves: `gen_issue` = Philox call, interval index, start of the two table reads per normal; `finish` =
+        // the cubics + everything `normals` does.  Issuing every group's look-ups before finishing any keeps 8 (two groups) random
+        // LDS reads in flight per lane.  (A deeper software pipeline -- look-ups issued one MFMA burst ahead, landing registers
+        // shared by the alternating groups -- was built and measured in round 2: 25.3 vs 24.7 ms for two groups, 121 vs 95 ms for
+        // one group at d = 10^4; with no MFMA / VALU co-issue on gfx950 there is nothing to hide the look-ups behind.)
         struct Pend { uint32_t x[4]; double dp[4]; double2 c01[4], c23[4]; };
-        Pend pend;
         auto gen_issue = [&](const int g, const int blk, Pend &P) {
 #if QF_ABLATE == 1                     // ablation (timing experiments only): no generator at all
 #pragma unroll
@@ -201,7 +199,6 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
             for (int r = 0; r < 4; ++r) pf_icdf_issue(P.x[r], icdf, P.dp[r], P.c01[r], P.c23[r]);
 #endif
         };
-        if (any_active && !any_pseudo) gen_issue(0, 0, pend);
         for (int ck = 0; ck < nchunks; ++ck) {
             // ---- streaming: fetch the next chunk (or chunk 0 for the next batch) into registers while this one is consumed
             double pre[PRE], pr_s = 0.0, pr_a = 0.0, pr_c = 0.0;
@@ -362,24 +359,21 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
                     auto block_body = [&](const int bl, auto special_tag) {
                         const int blk = blk0 + bl;
                         Ops oa;
+                        load_ops(bl, oa);                        // operands first: the generator below hides their latency
+                        __builtin_amdgcn_sched_barrier(0);
+                        Pend pp[NG];
+                        double z[NG][4];
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) gen_issue(g, blk, pp[g]);
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) finish(g, blk, pp[g], z[g], special_tag);
 #pragma unroll
                         for (int g = 0; g < NG; ++g) {
-                            double z[4];
-                            finish(g, blk, pend, z, special_tag);    // coefficients were requested one MFMA burst ago
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (g == 0) {                            // operands of this block; the Philox work below hides their latency
-                                load_ops(bl, oa);
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
-                            if (g + 1 < NG) gen_issue(g + 1, blk, pend);
-                            else if (blk + 1 < nblk) gen_issue(0, blk + 1, pend);
-                            __builtin_amdgcn_sched_barrier(0);
 #if QF_ABLATE == 3                     // ablation: generator only, no contraction
-                            q12[g] += z[0] + z[1] + z[2] + z[3] + oa.av[0][0] + oa.rs[0];
+                            q12[g] += z[g][0] + z[g][1] + z[g][2] + z[g][3] + oa.av[0][0] + oa.rs[0];
 #else
-                            contract(g, z, oa, true);
+                            contract(g, z[g], oa, true);
 #endif
-                            __builtin_amdgcn_sched_barrier(0);
                         }
                     };
                     for (int bl = 0; bl < nb; ++bl) {
