@@ -32,37 +32,42 @@ __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
     const int k = blockIdx.x, tid = threadIdx.x;
     const int64_t p0 = off[k];
     const int L = (int)(off[k + 1] - p0 - 1);
-    __shared__ double red[4 * (HIST_NT / 64)];
-    __shared__ int s_slot[64];
-    __shared__ int s_ind, s_eff, s_rej;
+    __shared__ double red[2 * 4 * (HIST_NT / 64)];          // two halves: one barrier per iteration (pf_block_sum_pp)
+    int flip = 0;
+    // ring bookkeeping (src/inverse_hessian.jl:49-52, 105): every thread sees the same `accept` (the block sums are bit-identical
+    // in every lane), so the LAST thread keeps the state by itself (counters in registers, slots in LDS nobody else touches) and
+    // writes hist_len / hist_src with plain stores -- no serial section the other waves have to wait for
+    __shared__ int ring[64];                                 // touched by the keeper thread only (dynamic indexing: LDS, not scratch)
+    int r_ind = 0, r_eff = 0, r_rej = 0;
+    const bool keeper = tid == HIST_NT - 1;
 
-    double al[EPT], t0[EPT], g0[EPT], t1[EPT], g1[EPT];
+    // The walk is sequential in l and every iteration needs two fresh rows (theta_l, grad_l) that nobody has touched before: with
+    // the loads issued one iteration ahead the iteration time WAS the DRAM latency (3 us at config 3).  Round 2 keeps the rows of
+    // points l, l+1, l+2 in three register sets (rotated by a 3-way unrolled loop, so all indices are static) and issues the
+    // loads of point l+3 as soon as set l has been consumed: three iterations for a load to land.  (EPT > 6: two sets -- 1024
+    // threads have 128 VGPRs.)
+    constexpr int NSET = EPT <= 6 ? 3 : 2;
+    double al[EPT], t0[EPT], g0[EPT], tq[NSET][EPT], gq[NSET][EPT];
+    auto load_point = [&](const int pt, double (&tt)[EPT], double (&gg)[EPT]) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = tid + HIST_NT * e;
+            tt[e] = gg[e] = 0.0;
+            if (i < d && pt <= L) { tt[e] = theta[(size_t)(p0 + pt) * d + i]; gg[e] = grad[(size_t)(p0 + pt) * d + i]; }
+        }
+    };
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int i = tid + HIST_NT * e;
         al[e] = 1.0;                                                           // H0 = I  (:38-39)
-        t0[e] = g0[e] = t1[e] = g1[e] = 0.0;
-        if (i < d) {
-            alpha_all[(size_t)p0 * d + i] = 1.0;
-            t0[e] = theta[(size_t)p0 * d + i];
-            g0[e] = grad[(size_t)p0 * d + i];
-            if (L >= 1) { t1[e] = theta[(size_t)(p0 + 1) * d + i]; g1[e] = grad[(size_t)(p0 + 1) * d + i]; }
-        }
+        if (i < d) alpha_all[(size_t)p0 * d + i] = 1.0;
     }
-    if (tid == 0) { hist_len[p0] = 0; s_ind = 0; s_eff = 0; s_rej = 0; }
-    for (int l = 1; l <= L; ++l) {                                              // :43
-        // prefetch point l + 1 while step l is reduced -- only when the third row set fits the register budget
-        // (1024 threads: 128 VGPRs; at EPT >= 8 it spilled 80..616 B per lane and the walk ran 10x slower)
-        constexpr bool PREF = EPT <= 6;
-        double tn[PREF ? EPT : 1], gn[PREF ? EPT : 1];
-        if (PREF) {
+    load_point(0, t0, g0);
 #pragma unroll
-            for (int e = 0; e < EPT; ++e) {
-                const int i = tid + HIST_NT * e;
-                tn[e] = gn[e] = 0.0;
-                if (i < d && l < L) { tn[e] = theta[(size_t)(p0 + l + 1) * d + i]; gn[e] = grad[(size_t)(p0 + l + 1) * d + i]; }
-            }
-        }
+    for (int q = 0; q < NSET; ++q) load_point(1 + q, tq[q], gq[q]);              // points 1 .. NSET
+    if (keeper) hist_len[p0] = 0;
+    // one trace step: (t0, g0) = point l - 1, (t1, g1) = point l; afterwards (t0, g0) = point l and the set is refilled
+    auto step = [&](const int l, double (&t1)[EPT], double (&g1)[EPT]) {
         double v[4] = {0.0, 0.0, 0.0, 0.0};   // y.s, y.y, y'diag(a)y, s'diag(1/a)s
         double ial[EPT];                                                        // 1 / alpha: one division serves the c sum and the update
 #pragma unroll
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
             v[2] += y * al[e] * y;
             v[3] += s * ial[e] * s;
         }
-        pf_block_sum<4>(v, red);
+        pf_block_sum_pp<4, 4>(v, red, flip);
         const bool accept = v[0] > eps * v[1];                                  // :47
         if (accept) {                                                           // gilbert_init :5-10
             const double a = v[2], b = v[0], c = v[3], aoc = a / c;
@@ -90,27 +95,28 @@ __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
             const int i = tid + HIST_NT * e;
             if (i < d) alpha_all[(size_t)(p0 + l) * d + i] = al[e];
             t0[e] = t1[e]; g0[e] = g1[e];
-            if (PREF) { t1[e] = tn[e]; g1[e] = gn[e]; }
-            else {
-                t1[e] = g1[e] = 0.0;
-                if (i < d && l < L) { t1[e] = theta[(size_t)(p0 + l + 1) * d + i]; g1[e] = grad[(size_t)(p0 + l + 1) * d + i]; }
-            }
         }
-        if (tid == 0) {
+        load_point(l + NSET, t1, g1);                                           // refill this set: needed NSET iterations from now
+        if (keeper) {
             if (accept) {
-                s_ind = (s_ind % J) + 1;                                        // mod1 :49
-                if (s_ind > s_eff) s_eff = s_ind;                               // :50
-                s_slot[s_ind - 1] = l - 1;
+                r_ind = (r_ind % J) + 1;                                        // mod1 :49
+                if (r_ind > r_eff) r_eff = r_ind;                               // :50
+                ring[r_ind - 1] = l - 1;
             } else {
-                s_rej += 1;                                                     // :57
+                r_rej += 1;                                                     // :57
             }
-            hist_len[p0 + l] = s_eff;
+            hist_len[p0 + l] = r_eff;
             int c = 0;                                                          // hist_inds :105
-            for (int t = s_ind + 1; t <= s_eff; ++t) hist_src[(size_t)(p0 + l) * J + c++] = s_slot[t - 1];
-            for (int t = 1; t <= s_ind; ++t) hist_src[(size_t)(p0 + l) * J + c++] = s_slot[t - 1];
+            for (int t = r_ind + 1; t <= r_eff; ++t) hist_src[(size_t)(p0 + l) * J + c++] = ring[t - 1];
+            for (int t = 1; t <= r_ind; ++t) hist_src[(size_t)(p0 + l) * J + c++] = ring[t - 1];
         }
+    };
+    for (int l = 1; l <= L; l += NSET) {                                        // :43
+#pragma unroll
+        for (int q = 0; q < NSET; ++q)
+            if (l + q <= L) step(l + q, tq[q], gq[q]);
     }
-    if (tid == 0) n_rej[k] = s_rej;
+    if (keeper) n_rej[k] = r_rej;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -498,7 +504,9 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
     constexpr int NP = KPAD * (KPAD + 1) / 2;            // Gram entries (upper triangle)
     constexpr int CH = NP < 26 ? NP : 26;                // entries per block reduction
     constexpr int NCH = (NP + CH - 1) / CH;
-    __shared__ double red[(NT / 64) * (CH > KPAD ? CH : KPAD)];
+    constexpr int NVMAX = CH > KPAD ? CH : KPAD;
+    __shared__ double red[2 * (NT / 64) * NVMAX];       // two halves: one barrier per block reduction (pf_block_sum_pp)
+    int flip = 0;
     __shared__ double sRow[2][KPAD], sHead[KPAD];
     __shared__ double sD[KPAD * KPAD], sR[KPAD * KPAD], sT[KPAD * KPAD], sV[KPAD * KPAD], sG[KPAD * KPAD];
     __shared__ double sLogdetV;
@@ -519,7 +527,7 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
     }
     {
         double v[2] = {bad, ldu};
-        pf_block_sum<2>(v, red);
+        pf_block_sum_pp<2, NVMAX>(v, red, flip);
         bad = v[0]; ldu = v[1];
     }
     for (int t = tid; t < KPAD * KPAD; t += NT) { sD[t] = 0.0; sR[t] = 0.0; sT[t] = 0.0; sV[t] = 0.0; sG[t] = 0.0; }
@@ -584,7 +592,7 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
                     ++e;
                 }
         }
-        pf_block_sum<CH>(g2, red);
+        pf_block_sum_pp<CH, NVMAX>(g2, red, flip);
         if (tid == 0) {
             int e = 0;
 #pragma unroll
@@ -672,7 +680,7 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
                 for (int cc = 0; cc < KPAD; ++cc) acc[cc] += xc * a[i][cc];
             }
         }
-        pf_block_sum<KPAD>(acc, red);       // its barriers also publish srow (double buffered: no trailing barrier)
+        pf_block_sum_pp<KPAD, NVMAX>(acc, red, flip);       // its barriers also publish srow (double buffered: no trailing barrier)
         double xn2 = 0.0;
 #pragma unroll
         for (int cc = 0; cc < KPAD; ++cc) if (cc == c) xn2 = acc[cc];
@@ -805,7 +813,7 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
     for (int i = 0; i < RPT; ++i)
 #pragma unroll
         for (int cc = 0; cc < KPAD; ++cc) acc[cc] += agv[i] * a[i][cc];
-    pf_block_sum<KPAD>(acc, red);
+    pf_block_sum_pp<KPAD, NVMAX>(acc, red, flip);
     double t1[KPAD];                          // t1 = T' w1 (every thread, from LDS T)
 #pragma unroll
     for (int aa = 0; aa < KPAD; ++aa) {
@@ -849,7 +857,7 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
             for (int cc = 0; cc < KPAD; ++cc) acc[cc] += bv[i] * a[i][cc];
         }
     }
-    pf_block_sum<KPAD>(acc, red);
+    pf_block_sum_pp<KPAD, NVMAX>(acc, red, flip);
 #pragma unroll
     for (int aa = 0; aa < KPAD; ++aa) {       // t2 = T w2
         double v = 0.0;

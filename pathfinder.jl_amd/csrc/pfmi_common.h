@@ -357,6 +357,28 @@ __device__ __forceinline__ void pf_block_sum(double (&v)[NV], double *red) {
         v[i] = s;
     }
 }
+// Same with ONE barrier per reduction: consecutive reductions alternate between two scratch halves (`flip`), so the barrier
+// that publishes reduction n + 1 also guarantees that everybody finished reading reduction n's half before reduction n + 2
+// overwrites it.  `red` holds 2 * (blockDim.x / 64) * NVMAX doubles; every thread must make the same sequence of calls.
+template <int NV, int NVMAX>
+__device__ __forceinline__ void pf_block_sum_pp(double (&v)[NV], double *red, int &flip) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    double *buf = red + flip * (nw * NVMAX);
+    flip ^= 1;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = pf_wave_sum(v[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) buf[wave * NV + i] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double s = buf[i];
+        for (int w = 1; w < nw; ++w) s += buf[w * NV + i];
+        v[i] = s;
+    }
+}
 __device__ __forceinline__ double pf_block_sum1(double x, double *red) {
     double v[1] = {x};
     pf_block_sum<1>(v, red);
