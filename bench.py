@@ -33,6 +33,12 @@ for _p in (ROOT, os.path.join(ROOT, "pathfinder.jl_amd"), os.path.join(ROOT, "te
 import numpy as np  # noqa: E402
 
 
+class _DevArray:
+    """zero-copy view of a libpfmi device buffer for torch (CUDA array interface); fallback collective path only"""
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
 def _self_launch(ngpus):
     """`python bench.py --gpus N` outside a torch.distributed.run world: launch the N ranks (one per GPU) ourselves and
     relay their output; returns the launcher's exit code."""
@@ -142,11 +148,35 @@ def main():
     if use_dist:
         # the data-path collectives go through the C ABI (pfmi_comm_*: ncclAllGather / ncclAllReduce on the engine's stream,
         # csrc/comm_rccl.hip); torch.distributed only ships the 128-byte RCCL id, the barrier and the timing reduction
-        uid = [pfmi.Comm.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        comm = pfmi.Comm.init_rank(eng, world, rank, uid[0])
-        info = comm.info()
-        assert info["world"] == world, info
+        comm_note = "RCCL through the C ABI (pfmi_comm_*), torch nccl group for barrier / timing"
+        try:
+            if os.environ.get("PFMI_BENCH_COMM") == "torch":        # test hook: exercise the fallback branch
+                raise RuntimeError("PFMI_BENCH_COMM=torch")
+            uid = [None]
+            if rank == 0:
+                try:
+                    uid = [pfmi.Comm.unique_id()]
+                except Exception as ex0:                            # every rank must still reach the broadcast
+                    uid = [("error", repr(ex0))]
+            dist.broadcast_object_list(uid, src=0)
+            if not isinstance(uid[0], (bytes, bytearray)):
+                raise RuntimeError(f"rank 0 could not create an RCCL id: {uid[0]}")
+            comm = pfmi.Comm.init_rank(eng, world, rank, uid[0])
+            info = comm.info()
+            assert info["world"] == world, info
+            ok = 1.0
+        except Exception as ex:                                     # reported in the JSON line, never silent
+            comm, ok, comm_note = None, 0.0, f"torch.distributed nccl collectives on engine memory (pfmi_comm_init_rank failed: {ex!r})"
+        import torch
+        flag = torch.tensor([ok], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)                 # all ranks take the same path
+        if float(flag[0]) < 1.0:
+            if comm is not None:
+                comm.close()
+                comm = None
+                comm_note = "torch.distributed nccl collectives on engine memory (pfmi_comm_init_rank failed on another rank)"
+            lr_all = torch.empty(K * N_r, dtype=torch.float64, device=f"cuda:{local_rank}")
+            out_dev = torch.zeros(ndraws * d, dtype=torch.float64, device=f"cuda:{local_rank}")
 
     state = {}
 
@@ -155,9 +185,21 @@ def main():
         elbo, se, best = eng.elbo_batch(N_e, seeds)
         pts = [int(eng.offsets[k]) + int(best[k]) for k in range(Kl)]
         eng.pool_build(N_r, pts, seeds[pts])
-        if use_dist:
+        if use_dist and comm is not None:
             res = comm.pool_psis()                                  # ONE RCCL all-gather of the log-ratio shards + replicated PSIS
             idx, state["draws"] = comm.resample(ndraws, seed=master)   # replicated indices, owner gather, sum all-reduce, D2H
+        elif use_dist:                                              # fallback: the same orchestration through torch.distributed
+            import torch
+            from pfmi.distributed import pooled_psis_resample
+            ptr, cnt = eng.pool_log_ratios_dev()
+            shard = torch.as_tensor(_DevArray(ptr, cnt), device=f"cuda:{local_rank}")
+            res, idx = pooled_psis_resample(
+                dist, shard, lr_all, out_dev,
+                psis_fn=lambda t: eng.psis_dev(t.data_ptr(), t.numel(), want_weights=False),
+                sample_fn=lambda S: eng.resample_indices(S, ndraws, seed=master),
+                gather_fn=lambda ix, o: eng.pool_gather_dev(ix, k0 * N_r, o.data_ptr()),
+                sync_fn=torch.cuda.synchronize, min_world=1)
+            state["draws"] = out_dev
         else:
             ptr, cnt = eng.pool_log_ratios_dev()                    # syncs the engine stream
             res = eng.psis_dev(ptr, cnt, want_weights=False)
@@ -360,7 +402,7 @@ def main():
                        "npaths": K, "paths_per_gpu": Kl, "fits_total": int(total_draws // N_e),
                        "elbo_draws_per_step": int(total_draws), "parallelism": f"paths sharded x{G}",
                        "ranks_in_collective": ranks_seen,
-                       "collective_backend": "RCCL through the C ABI (pfmi_comm_*), torch nccl group for barrier / timing" if use_dist else None},
+                       "collective_backend": comm_note if use_dist else None},
             "multipathfinder_hot_path_ms": round(ms_per_step, 3),
             "multipathfinder_wall_ms_incl_device_lbfgs": None if wall_e2e is None else round(wall_e2e, 3),
             "multipathfinder_api_wall_ms": None if api_wall is None else round(api_wall, 3),
@@ -373,7 +415,8 @@ def main():
         }
     if use_dist:
         dist.barrier()
-        comm.close()
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
     eng.close()
     if rank == 0:

@@ -549,7 +549,8 @@ def test_julia_call_sequence_in_c(tmp_path):
 
 
 # ---- bench.py contract on the GPU box ---------------------------------------------------------------------------
-def test_bench_force_dist_counts_its_ranks():
+@pytest.mark.parametrize("comm_mode", ["c_abi", "torch"])
+def test_bench_force_dist_counts_its_ranks(comm_mode):
     """bench.py --gpus 1 --force-dist: the N > 1 code path (RCCL all-gather + all-reduce) in a single-rank world; the JSON line
     reports the ranks counted through the collective (VERDICT r1 #1)."""
     import json
@@ -557,10 +558,13 @@ def test_bench_force_dist_counts_its_ranks():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    if comm_mode == "torch":
+        env["PFMI_BENCH_COMM"] = "torch"                              # the reported fallback: torch.distributed collectives
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "1", "--warmup", "1",
                         "--npaths", "8", "--dim", "100", "--target", "diag", "--no-cpu-baseline"], capture_output=True, text=True,
                        env=env, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 1 and line["config"]["ranks_in_collective"] == 1 and line["config"]["collective_backend"].startswith("RCCL")
+    assert line["n_gpus"] == 1 and line["config"]["ranks_in_collective"] == 1
+    assert line["config"]["collective_backend"].startswith("RCCL" if comm_mode == "c_abi" else "torch.distributed")
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
