@@ -237,6 +237,12 @@ int32_t pfmi_comm_pool_psis(pfmi_comm *comm, double *pareto_k, int64_t *tail_len
 int32_t pfmi_comm_resample(pfmi_comm *comm, int64_t ndraws, int32_t importance, int32_t replace, uint64_t seed,
                            const double *uniforms, int64_t *idx, double *draws);
 
+/* ---- host utility --------------------------------------------------------------------------------------------------- */
+/* The counter-based generator the Python / C host mirrors use for the reference's seed hierarchy (run_seeds =
+ * rand!(rng, UInt64[nruns]) src/multipath.jl:162; seeds = rand!(rng, UInt64[L]) src/elbo.jl:2): out[i] = low 64 bits of
+ * Philox4x32-10(counter (t0 + i, stream), key seed).  Host code only (a Julia host uses its own rng instead). */
+int32_t pfmi_host_rand_u64(uint64_t seed, uint64_t t0, int64_t n, uint32_t stream, uint64_t *out);
+
 /* ---- device utilities for hosts that keep buffers on the GPU (bench, multi-GPU) ---------------- */
 int32_t pfmi_malloc_dev(pfmi_ctx *ctx, int64_t bytes, void **dev_ptr);
 int32_t pfmi_free_dev(pfmi_ctx *ctx, void *dev_ptr);

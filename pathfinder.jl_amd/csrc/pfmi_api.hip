@@ -755,6 +755,26 @@ int32_t pfmi_pool_gather(pfmi_ctx *c, int64_t ndraws, const int64_t *idx, int64_
     return PFMI_OK;
 }
 
+// ---- host utility: the seed-hierarchy generator of the Python / C mirrors ------------------------------------------
+// out[i] = low 64 bits of Philox4x32-10(counter = (t0 + i, stream), key = seed) -- bit-identical to pf_rand_u64 on the device
+// and to pfmi/hostrng.py (which falls back to NumPy when the library predates this entry).  Pure host code, no ctx.
+int32_t pfmi_host_rand_u64(uint64_t seed, uint64_t t0, int64_t n, uint32_t stream, uint64_t *out) {
+    PF_CHECK(n >= 0 && (out != nullptr || n == 0), PFMI_ERR_ARG, "host_rand_u64: bad arguments");
+    const uint32_t key0 = (uint32_t)seed, key1 = (uint32_t)(seed >> 32);
+    for (int64_t i = 0; i < n; ++i) {
+        const uint64_t t = t0 + (uint64_t)i;
+        uint32_t c0 = (uint32_t)t, c1 = (uint32_t)(t >> 32), c2 = stream, c3 = 0u, k0 = key0, k1 = key1;
+        for (int r = 0; r < 10; ++r) {
+            const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+            const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+            c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+        out[i] = (uint64_t)c0 | ((uint64_t)c1 << 32);
+    }
+    return PFMI_OK;
+}
+
 // ---- device utilities ----------------------------------------------------------------------------------
 int32_t pfmi_malloc_dev(pfmi_ctx *c, int64_t bytes, void **dev_ptr) {
     PF_CTX(c);

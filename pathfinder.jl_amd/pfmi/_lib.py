@@ -33,7 +33,7 @@ SYMBOLS = [
     "pfmi_pool_log_ratios_dev", "pfmi_psis_dev", "pfmi_psis", "pfmi_resample_indices", "pfmi_resample_indices_direct", "pfmi_pool_gather",
     "pfmi_pool_gather_dev", "pfmi_malloc_dev", "pfmi_free_dev", "pfmi_memcpy_h2d", "pfmi_memcpy_d2h",
     "pfmi_comm_unique_id", "pfmi_comm_init_all", "pfmi_comm_init_rank", "pfmi_comm_destroy", "pfmi_comm_info",
-    "pfmi_comm_pool_psis", "pfmi_comm_resample",
+    "pfmi_comm_pool_psis", "pfmi_comm_resample", "pfmi_host_rand_u64",
 ]
 
 

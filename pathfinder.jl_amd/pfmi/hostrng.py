@@ -31,12 +31,40 @@ def philox4x32_10(ctr, key):
     return np.stack([c0, c1, c2, c3], axis=-1).astype(np.uint32)
 
 
+def _native():
+    """pfmi_host_rand_u64 of libpfmi.so (plain host code) when the library is built; None -> NumPy below."""
+    global _NATIVE
+    if _NATIVE is None:
+        try:
+            import ctypes as C
+            from . import _lib
+            f = _lib.lib().pfmi_host_rand_u64
+            f.argtypes = [C.c_uint64, C.c_uint64, C.c_int64, C.c_uint32, C.POINTER(C.c_uint64)]
+            _NATIVE = f
+        except Exception:
+            _NATIVE = False
+    return _NATIVE or None
+
+
+_NATIVE = None
+
+
 def rand_u64_multi(rngs, counts):
     """[r.rand_u64(n) for r, n in zip(rngs, counts)] in ONE vectorised Philox evaluation (advances every rng)."""
     counts = [int(n) for n in counts]
     tot = sum(counts)
     if tot == 0:
         return [np.zeros(0, dtype=np.uint64) for _ in counts]
+    f = _native()
+    if f is not None:
+        import ctypes as C
+        res = []
+        for r, n in zip(rngs, counts):
+            out = np.empty(n, dtype=np.uint64)
+            f(C.c_uint64(r.seed), C.c_uint64(r.counter), C.c_int64(n), C.c_uint32(HostRNG.STREAM), out.ctypes.data_as(C.POINTER(C.c_uint64)))
+            r.counter += n
+            res.append(out)
+        return res
     t = np.concatenate([np.arange(r.counter, r.counter + n, dtype=np.uint64) for r, n in zip(rngs, counts)])
     sd = np.concatenate([np.full(n, r.seed, dtype=np.uint64) for r, n in zip(rngs, counts)])
     ctr = np.stack([t & _MASK, t >> np.uint64(32), np.full_like(t, HostRNG.STREAM), np.zeros_like(t)], axis=-1)
@@ -52,6 +80,13 @@ def rand_u64_multi(rngs, counts):
 def rand_u64(seed, t, stream):
     """64 random bits for counters t (array) of `seed` on `stream` (== pf_rand_u64)."""
     t = np.atleast_1d(np.asarray(t, dtype=np.uint64))
+    f = _native()
+    if f is not None and t.ndim == 1 and len(t) > 0 and np.array_equal(t, np.arange(t[0], t[0] + np.uint64(len(t)), dtype=np.uint64)):
+        import ctypes as C
+        out = np.empty(len(t), dtype=np.uint64)
+        f(C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), C.c_uint64(int(t[0])), C.c_int64(len(t)), C.c_uint32(int(stream)),
+          out.ctypes.data_as(C.POINTER(C.c_uint64)))
+        return out
     ctr = np.stack([t & _MASK, t >> np.uint64(32), np.full_like(t, stream), np.zeros_like(t)], axis=-1)
     seed = int(seed)
     x = philox4x32_10(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)).astype(np.uint64)
