@@ -927,11 +927,9 @@ int32_t pf_launch_fit(pfmi_ctx *c) {
     a.vh = c->vh.as<double>(); a.tmat = c->tmat.as<double>(); a.vchol = c->vchol.as<double>();
     a.rq = c->rq.as<double>(); a.dmat = c->dmat.as<double>(); a.sqrt_alpha = c->sqrt_alpha.as<double>();
     a.mu = c->mu.as<double>(); a.logdet = c->logdet.as<double>(); a.status = c->status.as<int32_t>();
-    a.P = c->P; a.cl_counter = nullptr; a.cl_buf = nullptr; a.cl_nwg = 1; a.cl_nclusters = 0;
+    a.P = c->P;
     pf_kernel_begin(c);
-    bool handled = false;                                     // large d: one cluster of workgroups per fit
-    PF_TRY(pf_launch_fit_cluster(c, a, &handled));
-    if (!handled) switch (c->kpad) {
+    switch (c->kpad) {
         case 4: launch_fit_t<4>(c, a); break;
         case 8: launch_fit_t<8>(c, a); break;
         case 12: launch_fit_t<12>(c, a); break;

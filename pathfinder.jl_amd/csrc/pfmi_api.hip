@@ -114,7 +114,7 @@ int32_t pfmi_destroy(pfmi_ctx *c) {
                       &c->elbo, &c->se, &c->best_iter, &c->fit_list, &c->ubuf, &c->xbuf, &c->scratch, &c->pool,
                       &c->pool_lr, &c->pool_lp, &c->pool_lq, &c->pool_points, &c->pool_seeds, &c->lw, &c->w,
                       &c->psis_out, &c->tailbuf, &c->cdf, &c->idx, &c->gbuf, &c->trace_lp, &c->st_theta, &c->st_grad,
-                      &c->st_lp, &c->st_npts, &c->lb_hs, &c->lb_hy, &c->lb_x0, &c->cl_counter, &c->cl_buf, &c->sortk, &c->sorti};
+                      &c->st_lp, &c->st_npts, &c->lb_hs, &c->lb_hy, &c->lb_x0, &c->sortk, &c->sorti};
     for (DevBuf *b : bufs) b->release();
     for (int b = 0; b < 2; ++b) {
         c->cb_x[b].release(); c->cb_lp[b].release();

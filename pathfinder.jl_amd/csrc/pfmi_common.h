@@ -100,7 +100,6 @@ struct pfmi_ctx {
     DevBuf mu;          // [P][d]
     DevBuf logdet;      // [P]
     DevBuf status;      // int32 [P]
-    DevBuf cl_counter, cl_buf;   // cluster fit kernel: arrival counters, partial-sum exchange
 
     // ELBO state
     bool elbo_done = false;

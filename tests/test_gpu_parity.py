@@ -858,45 +858,32 @@ def test_rccl_collectives_on_engine_memory_world1(pfmi_mod, eng):
 
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("tname,d,J", [("diag", 2100, 6), ("lr", 1500, 6), ("funnel", 2500, 10)])
-def test_fit_kernel_variants_agree_at_large_d(pfmi_mod, eng, tname, d, J):
-    """d > 1024 fits: the memory-resident kernel (default; fused reflector-apply + next-column dots, two Gram rows per sweep)
-    and the opt-in cluster kernel (PFMI_FIT_KERNEL=cluster: the block lives in the registers of several cooperating
-    workgroups, cross-workgroup sums through device-scope atomics, cooperative launch) produce the same factorisation;
-    the memory-resident one is additionally checked against the oracle's dense W / logdet / mu."""
+def test_memory_resident_fit_kernel_at_large_d(pfmi_mod, eng, tname, d, J):
+    """d > 1024 fits take the memory-resident kernel (fused reflector-apply + next-column dots, two Gram rows per sweep): dense
+    W / logdet / mu against the oracle at four fits of the first path."""
     tg = {"diag": lambda d: pfmi_mod.t_diag(d, 1), "lr": lambda d: pfmi_mod.t_lowrank(d, 8, 2), "funnel": pfmi_mod.t_funnel}[tname](d)
     eng.set_target(tg)
     x0 = pfmi_mod.HostRNG(3).rand(2 * d).reshape(2, d) * (20 if tname == "funnel" else 4) - (10 if tname == "funnel" else 2)
     eng.optimize_batch(x0, J, 25)
-    out = {}
-    old = os.environ.get("PFMI_FIT_KERNEL")
-    try:
-        for mode in ("mem", "cluster"):
-            os.environ["PFMI_FIT_KERNEL"] = mode
-            eng.fit_batch(J)
-            st, je, ld, nr = eng.fit_status()
-            pts = sorted({1, 2, eng.P // 2, eng.P - 1})
-            out[mode] = (st, ld, [eng.get_fit(p, int(je[p])) for p in pts], pts)
-    finally:
-        if old is None:
-            os.environ.pop("PFMI_FIT_KERNEL", None)
-        else:
-            os.environ["PFMI_FIT_KERNEL"] = old
-    a, b = out["mem"], out["cluster"]
-    np.testing.assert_array_equal(a[0], b[0])
-    ok = a[0] == 0
-    assert np.max(np.abs(a[1][ok] - b[1][ok]) / (1 + np.abs(a[1][ok]))) <= 1e-10
+    eng.fit_batch(J)
+    st, je, ld, nr = eng.fit_status()
     th, _, gr = eng.get_trace(0, logp=False)
     alpha_all, hl, hs, _ = po.lbfgs_history(th, gr, J)
-    for fa, fb, p in zip(a[2], b[2], a[3]):
+    n_checked = 0
+    for p in sorted({1, 2, len(th) // 2, len(th) - 1}):
+        if st[p] != 0:
+            continue
+        fa = eng.get_fit(p, int(je[p]))
+        F = _oracle_factor(type("T", (), {"points": th, "gradients": gr})(), alpha_all, hl, hs, p, d)
+        assert int(je[p]) == int(hl[p])
+        assert abs(F.logdet - fa["logdet"]) <= 1e-9 * (1 + abs(F.logdet))
+        mu_o = F.fit_mean(th[p], gr[p])
+        np.testing.assert_allclose(fa["mu"], mu_o, rtol=1e-7, atol=1e-8 * (1 + np.abs(mu_o).max()))
         Wa = np.diag(fa["alpha"]) + fa["B"] @ fa["D"] @ fa["B"].T if fa["B"].size else np.diag(fa["alpha"])
-        Wb = np.diag(fb["alpha"]) + fb["B"] @ fb["D"] @ fb["B"].T if fb["B"].size else np.diag(fb["alpha"])
-        np.testing.assert_allclose(Wa, Wb, rtol=1e-10, atol=1e-12 * np.abs(Wa).max())
-        np.testing.assert_allclose(fa["mu"], fb["mu"], rtol=1e-8, atol=1e-9 * (1 + np.abs(fa["mu"]).max()))
-        if p < len(th):                                              # point of path 0: compare with the oracle's fit
-            F = _oracle_factor(type("T", (), {"points": th, "gradients": gr})(), alpha_all, hl, hs, p, d)
-            assert abs(F.logdet - fa["logdet"]) <= 1e-9 * (1 + abs(F.logdet))
-            mu_o = F.fit_mean(th[p], gr[p])
-            np.testing.assert_allclose(fa["mu"], mu_o, rtol=1e-7, atol=1e-8 * (1 + np.abs(mu_o).max()))
+        Wo = F.dense()
+        assert np.max(np.abs(Wa - Wo)) <= 1e-10 * np.abs(Wo).max() * max(1.0, np.linalg.cond(fa["D"]) ** 0.5 if fa["D"].size else 1.0)
+        n_checked += 1
+    assert n_checked >= 3
 
 
 @pytest.mark.parametrize("name,K,J", [("iso10", 2, 6), ("lr50", 2, 6), ("diag30", 2, 10), ("funnel12", 2, 6)])
