@@ -406,8 +406,7 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
                 if (!pseudo[g]) continue;
                 const int j = 16 * sl[g] + c;
                 double *vv = cn_s + 4, *Mm = cn_s + 4 + KC, *t0 = Mm + KC * KC, *Nn = t0 + RPAD;
-                const double q3 = q12[g] + __shfl_xor(q12[g], 16, 64);
-                const double q4 = q3 + __shfl_xor(q3, 32, 64);
+                const double q4 = pf_sum_q(q12[g]);
 #pragma unroll
                 for (int T = 0; T < NT; ++T) {
                     const int a = 4 * T + q;
@@ -430,18 +429,18 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
         for (int g = 0; g < NG; ++g) {
             if (!active[g] || pseudo[g]) continue;
             double us = usq[g];
-            us += __shfl_xor(us, 16, 64); us += __shfl_xor(us, 32, 64);
+            us = pf_sum_q(us);
             double lp = NAN;
             if (TGT != 0) {
                 double qs = q12[g];
-                qs += __shfl_xor(qs, 16, 64); qs += __shfl_xor(qs, 32, 64);
+                qs = pf_sum_q(qs);
                 double tv[KC];
 #pragma unroll
                 for (int a = 0; a < KC; ++a) {
                     double s = 0.0;
 #pragma unroll
                     for (int T = 0; T < NT; ++T) s = fma(t_s[a * KC + 4 * T + q], accw[g][T], s);
-                    s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+                    s = pf_sum_q(s);
                     tv[a] = s;
                 }
                 const double *vv = cn_s + 4, *Mm = cn_s + 4 + KC, *t0 = Mm + KC * KC, *Nn = t0 + RPAD, *vh0 = Nn + RPAD * KC;
@@ -456,7 +455,7 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
                     for (int qq = 0; qq < 4; ++qq) tva = (q == qq) ? tv[4 * T + qq] : tva;
                     qa = fma(tva, mt - 2.0 * (vv[a] + acc3[g][T]), qa);
                 }
-                qa += __shfl_xor(qa, 16, 64); qa += __shfl_xor(qa, 32, 64);
+                qa = pf_sum_q(qa);
                 const double q1 = cn_s[0] + qs + qa;
                 if (TGT == 1) {
                     double corr = 0.0;

@@ -330,6 +330,23 @@ __device__ __forceinline__ double pf_wave_sum(double v) {
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
     return __hiloint2double(hi, lo);
 }
+// s + (s of lane ^ 16) and s + (s of lane ^ 32) on the VALU (gfx950: v_permlane16_swap / v_permlane32_swap) instead of
+// ds_bpermute round trips through the LDS crossbar.  swap(A, A') with A = A' = s leaves A = [r0 r0 r2 r2], A' = [r1 r1 r3 r3] by
+// rows of 16 (resp. [lo lo], [hi hi] by halves), so A + A' is the pairwise sum in every lane -- bit-identical to the shuffle form.
+__device__ __forceinline__ double pf_add_xor16(double s) {
+    const unsigned lo = (unsigned)__double2loint(s), hi = (unsigned)__double2hiint(s);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ double pf_add_xor32(double s) {
+    const unsigned lo = (unsigned)__double2loint(s), hi = (unsigned)__double2hiint(s);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+// sum over the four lanes {c, c + 16, c + 32, c + 48}
+__device__ __forceinline__ double pf_sum_q(double s) { return pf_add_xor32(pf_add_xor16(s)); }
 __device__ __forceinline__ double pf_wave_max(double v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
