@@ -262,16 +262,27 @@ end
 """
     _resample(b, rng, psis_result, N_r, K, ndraws; replace, statsbase=false) -> (draws, draw_component_ids)
 
-Index selection + gather on the device (src/resample.jl:58-72).  Default: the library's own deterministic sampler keyed by one
-`rand(rng, UInt64)`.  `statsbase = true` (weighted, with replacement): the indices ARE
-`StatsBase.direct_sample!(rng, 1:S, ProbabilityWeights(w, 1), x)` -- Julia draws the uniforms, the device does the scan.
+Index selection + gather (src/resample.jl:58-72).  `statsbase` chooses who draws the indices:
+* `false` (default): the library's own deterministic sampler on the device, keyed by one `rand(rng, UInt64)`;
+* `:host`: EXACTLY the reference -- `StatsBase.sample(rng, 1:S, ProbabilityWeights(w, 1), ndraws; replace)` runs in Julia on
+  the downloaded PSIS weights (whatever algorithm the installed StatsBase picks: direct, alias, Efraimidis-Spirakis) and only
+  the gather of the selected columns happens on the device;
+* `true` (weighted, with replacement): the indices ARE `StatsBase.direct_sample!(rng, 1:S, ProbabilityWeights(w, 1), x)` --
+  Julia draws the uniforms, the device does the scan (no weight download).
 """
 function _resample(b::Batch, rng::Random.AbstractRNG, psis_result, N_r::Int, K::Int, ndraws::Int; replace::Bool=true,
-                   statsbase::Bool=false)
+                   statsbase::Union{Bool,Symbol}=false)
     _live(b.eng, b.gen)
     S = K * N_r
     idx = Vector{Int64}(undef, ndraws)
-    if statsbase && psis_result !== nothing && replace
+    if statsbase === :host
+        inds = if psis_result === nothing
+            StatsBase.sample(rng, 1:S, ndraws; replace)                                                   # src/resample.jl:61
+        else
+            StatsBase.sample(rng, 1:S, StatsBase.ProbabilityWeights(psis_result.weights, 1.0), ndraws; replace)   # :63-66
+        end
+        idx .= inds .- 1
+    elseif statsbase === true && psis_result !== nothing && replace
         u = rand(rng, ndraws)                                       # what direct_sample! consumes, one rand(rng) per draw
         check(ccall((:pfmi_resample_indices_direct, libpfmi), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Ptr{Int64}),
                     b.eng.ptr, S, ndraws, u, idx))
@@ -302,7 +313,7 @@ function multipathfinder(eng::Engine, optim_fun::SciMLBase.OptimizationFunction,
                          history_length::Int=Pathfinder.DEFAULT_HISTORY_LENGTH,
                          optimizer=Pathfinder.default_optimizer(history_length),
                          importance::Bool=true, ntries::Int=1_000, init_scale=2,
-                         init_sampler=Pathfinder.UniformSampler(init_scale), statsbase_indices::Bool=false, kwargs...)
+                         init_sampler=Pathfinder.UniformSampler(init_scale), statsbase_indices::Union{Bool,Symbol}=false, kwargs...)
     _init = if init === nothing
         nruns > 0 || throw(ArgumentError("A positive `nruns` must be set or `init` must be provided."))      # :148-150
         dim > 0 || throw(ArgumentError("An initial point `init` or dimension `dim` must be provided."))     # src/singlepath.jl:171
