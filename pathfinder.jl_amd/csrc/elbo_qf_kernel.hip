@@ -36,6 +36,7 @@
 #ifndef QF_ABLATE
 #define QF_ABLATE 0
 #endif
+#define QF_MIN_FRONT 1024             // doubles in front of the inverse-CDF table (>= (32 - 19) * 32 * 2 = 832)
 #define QF_CHB 16                      // blocks (of 16 rows) per streamed chunk
 
 typedef double qf_d4 __attribute__((ext_vector_type(4)));
@@ -91,7 +92,10 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
     // ---- LDS carve-up (offsets in doubles from `lds`; plain offsets keep every access a ds_ instruction)
     const int vh_sz = ch_blocks * 16 * KC, rs_sz = ch_blocks * 48;
     const int buf_stride = (nchunks > 1) ? vh_sz + rs_sz : 0;       // second staging buffer only when streaming
-    const int fix_off = (nchunks > 1 ? 2 : 1) * (vh_sz + rs_sz);
+    // the clamp-free interval look-up may read up to 13 binades x 32 x 16 B = 6.5 KB in FRONT of the table: keep at least that much
+    // staged data before it (only matters for d < 64)
+    const int stage_sz = (nchunks > 1 ? 2 : 1) * (vh_sz + rs_sz);
+    const int fix_off = stage_sz > QF_MIN_FRONT ? stage_sz : QF_MIN_FRONT;
     double *t_s = lds + fix_off;                   // [KC][KC]
     double *cn_s = t_s + KC * KC;                  // [NC]
     double *g_s = cn_s + NC;                       // [RPAD][RPAD]
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
 #else
             pf_philox_normals(n[g], (uint32_t)(blk * 4 + q), 0u, 0u, k0, k1, P.x);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pf_icdf_issue(P.x[r], icdf, P.dp[r], P.c01[r], P.c23[r]);
+            for (int r = 0; r < 4; ++r) pf_icdf_issue<PF_ICDF_NB_LDS, false>(P.x[r], icdf, P.dp[r], P.c01[r], P.c23[r]);
 #endif
         };
         for (int ck = 0; ck < nchunks; ++ck) {
@@ -501,7 +505,9 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
 // ---------------------------------------------------------------------------------------------------
 static size_t qf_lds_bytes(int ch_blocks, int nchunks, int kc, int rpad) {
     const size_t per = (size_t)ch_blocks * 16 * kc + (size_t)ch_blocks * 48;
-    return sizeof(double) * (per * (nchunks > 1 ? 2 : 1) + (size_t)kc * kc + qf_nconst(kc, rpad) + (size_t)rpad * rpad + 1 + 4 * PF_ICDF_LDS_ENTRIES);
+    size_t stage = per * (nchunks > 1 ? 2 : 1);
+    if (stage < QF_MIN_FRONT) stage = QF_MIN_FRONT;
+    return sizeof(double) * (stage + (size_t)kc * kc + qf_nconst(kc, rpad) + (size_t)rpad * rpad + 1 + 4 * PF_ICDF_LDS_ENTRIES);
 }
 
 template <int KC, int TGT, int RPAD, int NG>

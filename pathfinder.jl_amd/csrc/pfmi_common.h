@@ -233,7 +233,9 @@ template <int NB = PF_ICDF_NB_LDS>
 __device__ __forceinline__ void pf_icdf_load(double2 *tab) {
     constexpr int NENT = NB << PF_ICDF_B;
     const double2 *src = reinterpret_cast<const double2 *>(&PF_ICDF_TAB_DEV[0][0]);
-    for (int i = threadIdx.x; i < 2 * NENT; i += blockDim.x) tab[(i & 1) * NENT + (i >> 1)] = src[i];
+    // LDS order is ASCENDING in p (entry NENT - 1 - i of the generated table at slot i): the slot is then (hi32(P) >> 15) minus a
+    // constant, one shift + one shift-add per look-up
+    for (int i = threadIdx.x; i < 2 * NENT; i += blockDim.x) tab[(i & 1) * NENT + (NENT - 1 - (i >> 1))] = src[i];
 }
 // any word, full table in global memory (slow path / kernels without an LDS copy)
 __device__ __forceinline__ double pf_icdf_any(uint32_t x, uint32_t x2) {
@@ -250,15 +252,18 @@ __device__ __forceinline__ double pf_icdf_any(uint32_t x, uint32_t x2) {
 }
 // the common case in two halves (software-pipelined callers put work between them): `issue` computes dp and starts the two
 // table reads from the LDS copy, `finish` evaluates the cubic once the coefficients have landed
-template <int NB = PF_ICDF_NB_LDS>
+// CLAMP = false: words beyond the LDS copy (fixed up by the caller anyway) read whatever lies up to 2^(PF_ICDF_B) * (32 - NB) * 16
+// bytes BELOW the table -- the caller guarantees that much LDS in front of it (the ELBO scan: >= 40 KB of staged factor block)
+template <int NB = PF_ICDF_NB_LDS, bool CLAMP = true>
 __device__ __forceinline__ void pf_icdf_issue(uint32_t x, const double2 *lds_tab, double &dp, double2 &c01, double2 &c23) {
     constexpr int NENT = NB << PF_ICDF_B;
+    constexpr int SLOT0 = PF_ICDF_IDX0 - (NENT - 1);                // (hi32(P) >> 15) of the lowest interval kept in LDS
     const double p = (double)(x & 0x7FFFFFFFu) + 0.5;               // P = 2^32 p = mag + 1/2
     const unsigned hi = (unsigned)__double2hiint(p);
-    int idx = PF_ICDF_IDX0 - (int)(hi >> (20 - PF_ICDF_B));
-    idx = idx < NENT - 1 ? idx : NENT - 1;                          // words beyond the LDS copy are fixed up by the caller
+    int slot = (int)(hi >> (20 - PF_ICDF_B)) - SLOT0;
+    if (CLAMP) slot = slot > 0 ? slot : 0;                          // words beyond the LDS copy are fixed up by the caller
     dp = p - __hiloint2double((int)(hi & ~((1u << (20 - PF_ICDF_B)) - 1u)), 0);
-    c01 = lds_tab[idx]; c23 = lds_tab[NENT + idx];
+    c01 = lds_tab[slot]; c23 = lds_tab[NENT + slot];
 }
 __device__ __forceinline__ double pf_icdf_finish(uint32_t x, double dp, const double2 &c01, const double2 &c23) {
     const double q = fma(fma(fma(c23.y, dp, c23.x), dp, c01.y), dp, c01.x);
