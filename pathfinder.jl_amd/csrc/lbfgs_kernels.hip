@@ -33,7 +33,7 @@ struct LbfgsState {
 
 // f = -logp at xn = x + a p, gn = grad f(xn), dphi = gn . p
 template <int EPT, int NT, int RPAD>
-__device__ __forceinline__ void lb_eval(const LbfgsArgs &A, LbfgsState<EPT, NT, RPAD> &S, double a, double *red, double &f,
+__device__ __forceinline__ void lb_eval(const LbfgsArgs &A, LbfgsState<EPT, NT, RPAD> &S, double a, double *red, int &flip, double &f,
                                         double &dphi) {
     const int tid = threadIdx.x, d = A.d;
     double v[RPAD + 2];
@@ -47,7 +47,7 @@ __device__ __forceinline__ void lb_eval(const LbfgsArgs &A, LbfgsState<EPT, NT, 
             if (i == 0) v[1] = S.xn[e];
             else if (i < d) v[0] += S.xn[e] * S.xn[e];
         }
-        pf_block_sum<RPAD + 2>(v, red);
+        pf_block_sum_pp<RPAD + 2, RPAD + 4>(v, red, flip);
         const double tau = v[1], ss = v[0], ee = exp(-tau), dm1 = (double)(d - 1);
         f = 0.5 * ((tau / 3.0) * (tau / 3.0) + dm1 * tau + ee * ss);
 #pragma unroll
@@ -69,7 +69,7 @@ __device__ __forceinline__ void lb_eval(const LbfgsArgs &A, LbfgsState<EPT, NT, 
                 for (int j = 0; j < RPAD; ++j) v[2 + j] += row[j] * ev[e];
             }
         }
-        pf_block_sum<RPAD + 2>(v, red);
+        pf_block_sum_pp<RPAD + 2, RPAD + 4>(v, red, flip);
         double corr = 0.0;
         double hh[RPAD > 0 ? RPAD : 1];
         if (RPAD > 0) {
@@ -106,18 +106,18 @@ __device__ __forceinline__ void lb_eval(const LbfgsArgs &A, LbfgsState<EPT, NT, 
     double dp = 0.0;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) dp += S.gn[e] * S.p[e];
-    dphi = pf_block_sum1(dp, red);
+    dphi = pf_block_sum1_pp<RPAD + 4>(dp, red, flip);
     S.fn = f;
 }
 
 template <int EPT, int NT, int RPAD>
-__device__ __forceinline__ void lb_zoom(const LbfgsArgs &A, LbfgsState<EPT, NT, RPAD> &S, double *red, double lo, double hi,
+__device__ __forceinline__ void lb_zoom(const LbfgsArgs &A, LbfgsState<EPT, NT, RPAD> &S, double *red, int &flip, double lo, double hi,
                                         double f_lo, double f0, double g0) {
     const double c1 = 1e-4, c2 = 0.9;
     for (int it = 0; it < 30; ++it) {
         const double a = 0.5 * (lo + hi);
         double f, g;
-        lb_eval<EPT, NT, RPAD>(A, S, a, red, f, g);
+        lb_eval<EPT, NT, RPAD>(A, S, a, red, flip, f, g);
         if ((f > f0 + c1 * a * g0) || (f >= f_lo)) {
             hi = a;
         } else {
@@ -129,17 +129,17 @@ __device__ __forceinline__ void lb_zoom(const LbfgsArgs &A, LbfgsState<EPT, NT, 
 }
 
 template <int EPT, int NT, int RPAD>
-__device__ __forceinline__ void lb_search(const LbfgsArgs &A, LbfgsState<EPT, NT, RPAD> &S, double *red, double f0, double g0,
+__device__ __forceinline__ void lb_search(const LbfgsArgs &A, LbfgsState<EPT, NT, RPAD> &S, double *red, int &flip, double f0, double g0,
                                           double a_init) {
     const double c1 = 1e-4, c2 = 0.9, amax = 1e10;
     double a_prev = 0.0, f_prev = f0, a = a_init;
     for (int it = 0; it < 25; ++it) {
         double f, g;
-        lb_eval<EPT, NT, RPAD>(A, S, a, red, f, g);
+        lb_eval<EPT, NT, RPAD>(A, S, a, red, flip, f, g);
         if (!isfinite(f)) { a = 0.5 * (a_prev + a); continue; }
-        if ((f > f0 + c1 * a * g0) || (it > 0 && f >= f_prev)) { lb_zoom<EPT, NT, RPAD>(A, S, red, a_prev, a, f_prev, f0, g0); return; }
+        if ((f > f0 + c1 * a * g0) || (it > 0 && f >= f_prev)) { lb_zoom<EPT, NT, RPAD>(A, S, red, flip, a_prev, a, f_prev, f0, g0); return; }
         if (fabs(g) <= -c2 * g0) return;
-        if (g >= 0) { lb_zoom<EPT, NT, RPAD>(A, S, red, a, a_prev, f, f0, g0); return; }
+        if (g >= 0) { lb_zoom<EPT, NT, RPAD>(A, S, red, flip, a, a_prev, f, f0, g0); return; }
         a_prev = a; f_prev = f;
         a = fmin(2 * a, amax);
     }
@@ -148,7 +148,8 @@ __device__ __forceinline__ void lb_search(const LbfgsArgs &A, LbfgsState<EPT, NT
 template <int EPT, int NT, int RPAD>
 __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
     extern __shared__ double lb_dyn[];
-    __shared__ double red[(NT / 64) * (RPAD + 4)];
+    __shared__ double red[2 * (NT / 64) * (RPAD + 4)];   // two halves: one barrier per block reduction (pf_block_sum_pp)
+    int flip = 0;
     __shared__ double s_rho[16], s_al[16];
     const int k = blockIdx.x, tid = threadIdx.x, d = A.d, J = A.J;
     double *hs = A.hist_in_lds ? lb_dyn : A.hs + (size_t)k * J * d;
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
         S.av[e] = (act && A.kind == PFMI_TARGET_GAUSS) ? A.a[i] : 0.0;
     }
     double f, dphi;
-    lb_eval<EPT, NT, RPAD>(A, S, 0.0, red, f, dphi);
+    lb_eval<EPT, NT, RPAD>(A, S, 0.0, red, flip, f, dphi);
 #pragma unroll
     for (int e = 0; e < EPT; ++e) S.g[e] = S.gn[e];
     int n = 0, h = 0, head = 0;
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
         double gm = 0.0;
 #pragma unroll
         for (int e = 0; e < EPT; ++e) gm = fmax(gm, isfinite(S.g[e]) ? fabs(S.g[e]) : INFINITY);
-        gm = pf_block_max1(gm, red);
+        gm = pf_block_max1_pp<RPAD + 4>(gm, red, flip);
         if (!isfinite(f) || !(gm < INFINITY)) break;                   // src/optimize.jl:103-105
         if (gm <= A.g_tol) break;
         // ---- two-loop recursion: q = H g
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
                 yv[e] = i < d ? y[i] : 0.0;
                 sq += (i < d ? s[i] : 0.0) * q[e];
             }
-            sq = pf_block_sum1(sq, red);
+            sq = pf_block_sum1_pp<RPAD + 4>(sq, red, flip);
             const double al = s_rho[slot] * sq;
             if (tid == 0) s_al[slot] = al;
 #pragma unroll
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
                 sv[e] = i < d ? s[i] : 0.0;
                 yq += (i < d ? y[i] : 0.0) * q[e];
             }
-            yq = pf_block_sum1(yq, red);
+            yq = pf_block_sum1_pp<RPAD + 4>(yq, red, flip);
             const double co = s_al[slot] - s_rho[slot] * yq;
 #pragma unroll
             for (int e = 0; e < EPT; ++e) q[e] += co * sv[e];
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
         double v2[2] = {0.0, 0.0};
 #pragma unroll
         for (int e = 0; e < EPT; ++e) { S.p[e] = -q[e]; v2[0] += S.g[e] * S.p[e]; v2[1] += S.g[e] * S.g[e]; }
-        pf_block_sum<2>(v2, red);
+        pf_block_sum_pp<2, RPAD + 4>(v2, red, flip);
         double g0 = v2[0];
         if (g0 >= 0) {                                                  // not a descent direction: restart
             h = 0; head = 0;
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
         }
         double a0 = 1.0;
         if (!h) a0 = fmin(1.0, 1.0 / fmax(sqrt(v2[1]), 1e-300));
-        lb_search<EPT, NT, RPAD>(A, S, red, f, g0, a0);
+        lb_search<EPT, NT, RPAD>(A, S, red, flip, f, g0, a0);
         // ---- accept the last evaluated point
         double v4[4] = {0.0, 0.0, 0.0, 0.0};
         double sv[EPT], yv[EPT];
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
             v4[2] += (S.xn[e] != S.x[e]) ? 1.0 : 0.0;
             v4[3] += isfinite(S.gn[e]) ? 0.0 : 1.0;
         }
-        pf_block_sum<4>(v4, red);
+        pf_block_sum_pp<4, RPAD + 4>(v4, red, flip);
         if (!isfinite(S.fn) || v4[3] > 0.0) break;
         if (v4[0] > 1e-10 * v4[1]) {
             if (h == J) { head = (head + 1) % J; h = J - 1; }

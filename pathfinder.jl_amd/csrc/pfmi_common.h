@@ -400,6 +400,24 @@ __device__ __forceinline__ void pf_block_sum_pp(double (&v)[NV], double *red, in
         v[i] = s;
     }
 }
+template <int NVMAX>
+__device__ __forceinline__ double pf_block_sum1_pp(double x, double *red, int &flip) {
+    double v[1] = {x};
+    pf_block_sum_pp<1, NVMAX>(v, red, flip);
+    return v[0];
+}
+template <int NVMAX>
+__device__ __forceinline__ double pf_block_max1_pp(double x, double *red, int &flip) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    double *buf = red + flip * (nw * NVMAX);
+    flip ^= 1;
+    x = pf_wave_max(x);
+    if (lane == 0) buf[wave] = x;
+    __syncthreads();
+    double s = buf[0];
+    for (int w = 1; w < nw; ++w) s = fmax(s, buf[w]);
+    return s;
+}
 __device__ __forceinline__ double pf_block_sum1(double x, double *red) {
     double v[1] = {x};
     pf_block_sum<1>(v, red);
