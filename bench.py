@@ -297,14 +297,15 @@ def main():
         eng.profile(True)
     if not args.host_traces:
         eng.optimize_batch(x0s, J, args.maxiters)
-    step()                      # every rank takes part (collectives); only rank 0 records kernel events
+    for _ in range(3):          # every rank takes part (collectives); only rank 0 records kernel events; 3 steps: launch averages
+        step()
     barrier()
     if rank == 0:
         for name in ("optimize", "trace_pack", "history", "fit", "elbo_draws", "elbo_draws_x", "elbo_reduce", "psis", "resample"):
             ms, n = eng.kernel_time(name)
-            stages[name] = {"ms": round(ms, 4), "launches": int(n)}
+            stages[name] = {"ms": round(ms / max(n, 1), 4), "launches": int(n)}      # average per launch
+        ms, n = eng.kernel_time("elbo_draws")                                      # the ELBO-scan launches only (total, count)
         eng.profile(False)
-        ms, n = stages["elbo_draws"]["ms"], stages["elbo_draws"]["launches"]      # the ELBO-scan launch only
         m = 2 * J
         bytes_per_draw = 16.0 * d + 8.0 * d * (m + 2) / N_e           # algorithmic bytes per ELBO draw
         alg_bytes = bytes_per_draw * draws_local                       # one launch = every ELBO draw of this rank
