@@ -344,7 +344,7 @@ def main():
 
     # ---- CPU baseline: the oracle (a port of the reference algorithm) on this box's host cores ------------
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and G == 1 and not args.no_cpu_baseline:          # contract: rank 0 at N = 1 only
         try:
             from helpers import oracle_target
             from oracle import pf_oracle as po
