@@ -1,7 +1,7 @@
 // microbench.hip -- gfx950 micro-benchmarks that size the ELBO kernel design (not part of libpfmi.so).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/microbench.hip -o build/microbench && build/microbench
-// Measures: fp64 VALU FMA rate, v_mfma_f64_16x16x4 rate, Philox4x32-10 rate, Box-Muller (ocml vs custom)
-// rate, and MFMA/VALU co-issue.
+// Measures: fp64 VALU FMA rate, v_mfma_f64_16x16x4 rate, Philox4x32-10 rate, the round-2 normal generator (Philox4x32-7 +
+// table inverse CDF) and MFMA/VALU co-issue (see also coissue.hip).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -63,63 +63,41 @@ __global__ void k_philox(double *out, int iters) {
     out[n] = (double)acc;
 }
 
-__global__ void k_randn_ocml(double *out, int iters) {
-    double acc = 0;
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    for (int i = 0; i < iters; ++i) {
-        double z[4];
-        pf_randn4(0x123456789abcdefull, (uint32_t)i, n, 0u, z);
-        acc += z[0] + z[1] + z[2] + z[3];
-    }
-    out[n] = acc;
-}
-
-__global__ void k_randn_fast(double *out, int iters) {
-    __shared__ double2 tab[128];
-    pf_logtab_load(tab);
+// round-2 generator: Philox4x32-7 + table inverse CDF (LDS copy of the common-case table), 4 normals per call
+__global__ void k_randn_icdf(double *out, int iters) {
+    __shared__ double2 tab[2 * PF_ICDF_LDS_ENTRIES];
+    pf_icdf_load(tab);
     __syncthreads();
     double acc = 0;
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     for (int i = 0; i < iters; ++i) {
         double z[4];
-        pf_randn4_fast(0x123456789abcdefull, (uint32_t)i, n, 0u, tab, z);
+        pf_randn4(0x123456789abcdefull, (uint32_t)i, n, 0u, tab, z);
         acc += z[0] + z[1] + z[2] + z[3];
     }
     out[n] = acc;
 }
 
-// Box-Muller only (no Philox): transcendental cost in isolation
-__global__ void k_bm_fast(double *out, int iters) {
-    __shared__ double2 tab[128];
-    pf_logtab_load(tab);
+// table inverse CDF only (no Philox): look-up + cubic cost in isolation
+__global__ void k_icdf_only(double *out, int iters) {
+    __shared__ double2 tab[2 * PF_ICDF_LDS_ENTRIES];
+    pf_icdf_load(tab);
     __syncthreads();
     double acc = 0;
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t s = n * 2654435761u + 12345u;
     for (int i = 0; i < iters; ++i) {
         s = s * 1664525u + 1013904223u;
-        uint32_t x[4] = {s, s ^ 0x9E3779B9u, s * 3u + 1u, ~s};
-        double z[4];
-        pf_boxmuller4_fast(x, tab, z);
-        acc += z[0] + z[1] + z[2] + z[3];
+        const uint32_t x[4] = {s | 0x00100000u, (s ^ 0x9E3779B9u) | 0x00100000u, (s * 3u + 1u) | 0x00100000u, (~s) | 0x00100000u};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            double dp;
+            double2 c01, c23;
+            pf_icdf_issue(x[t], tab, dp, c01, c23);
+            acc += pf_icdf_finish(x[t], dp, c01, c23);
+        }
     }
     out[n] = acc;
-}
-
-// accuracy check of the fast path against the ocml path
-__global__ void k_acc(double *maxerr, int iters) {
-    __shared__ double2 tab[128];
-    pf_logtab_load(tab);
-    __syncthreads();
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    double me = 0;
-    for (int i = 0; i < iters; ++i) {
-        double z[4], y[4];
-        pf_randn4(777ull, (uint32_t)i, n, 0u, z);
-        pf_randn4_fast(777ull, (uint32_t)i, n, 0u, tab, y);
-        for (int t = 0; t < 4; ++t) me = fmax(me, fabs(z[t] - y[t]));
-    }
-    atomicMax((unsigned long long *)maxerr, (unsigned long long)__double_as_longlong(me));
 }
 
 template <typename F>
@@ -158,18 +136,9 @@ int main() {
     const int it2 = 1024;
     ms = time_kernel([&] { hipLaunchKernelGGL(k_philox, dim3(blocks), dim3(threads), 0, 0, out, it2); }, 3);
     printf("Philox4x32-10      : %8.3f ms  -> %7.2f G calls/s (%.2f G u32/s)\n", ms, (double)it2 * nthr / ms / 1e6, 4.0 * it2 * nthr / ms / 1e6);
-    ms = time_kernel([&] { hipLaunchKernelGGL(k_randn_ocml, dim3(blocks), dim3(threads), 0, 0, out, it2); }, 3);
-    printf("randn4 (ocml)      : %8.3f ms  -> %7.2f G normals/s\n", ms, 4.0 * it2 * nthr / ms / 1e6);
-    ms = time_kernel([&] { hipLaunchKernelGGL(k_randn_fast, dim3(blocks), dim3(threads), 0, 0, out, it2); }, 3);
-    printf("randn4 (fast)      : %8.3f ms  -> %7.2f G normals/s\n", ms, 4.0 * it2 * nthr / ms / 1e6);
-    ms = time_kernel([&] { hipLaunchKernelGGL(k_bm_fast, dim3(blocks), dim3(threads), 0, 0, out, it2); }, 3);
-    printf("box-muller4 (fast) : %8.3f ms  -> %7.2f G normals/s\n", ms, 4.0 * it2 * nthr / ms / 1e6);
-    double *merr;
-    CHECK(hipMalloc(&merr, 8));
-    CHECK(hipMemset(merr, 0, 8));
-    hipLaunchKernelGGL(k_acc, dim3(256), dim3(256), 0, 0, merr, 256);
-    double h = 0;
-    CHECK(hipMemcpy(&h, merr, 8, hipMemcpyDeviceToHost));
-    printf("max |randn_fast - randn_ocml| over %d normals: %.3e\n", 256 * 256 * 256 * 4, h);
+    ms = time_kernel([&] { hipLaunchKernelGGL(k_randn_icdf, dim3(blocks), dim3(threads), 0, 0, out, it2); }, 3);
+    printf("randn4 (Philox-7 + table inverse CDF): %8.3f ms  -> %7.2f G normals/s\n", ms, 4.0 * it2 * nthr / ms / 1e6);
+    ms = time_kernel([&] { hipLaunchKernelGGL(k_icdf_only, dim3(blocks), dim3(threads), 0, 0, out, it2); }, 3);
+    printf("table inverse CDF only               : %8.3f ms  -> %7.2f G normals/s\n", ms, 4.0 * it2 * nthr / ms / 1e6);
     return 0;
 }
