@@ -918,6 +918,8 @@ static void launch_fit_t(pfmi_ctx *c, const FitArgs &a) {
     hipLaunchKernelGGL(pf_fit_kernel<KPAD>, grid, block, 0, c->stream, a);
 }
 
+int32_t pf_launch_fit_panel(pfmi_ctx *c, const FitArgs &a, bool *handled);   // fit_panel_kernel.hip
+
 int32_t pf_launch_fit(pfmi_ctx *c) {
     FitArgs a;
     a.d = c->d; a.J = c->J;
@@ -929,6 +931,16 @@ int32_t pf_launch_fit(pfmi_ctx *c) {
     a.mu = c->mu.as<double>(); a.logdet = c->logdet.as<double>(); a.status = c->status.as<int32_t>();
     a.P = c->P;
     pf_kernel_begin(c);
+    {
+        const char *force = getenv("PFMI_FIT_KERNEL");        // "mem": column-by-column memory-resident kernel also for d > 1024
+        bool handled = false;
+        if (!(force && force[0] == 'm')) PF_TRY(pf_launch_fit_panel(c, a, &handled));
+        if (handled) {
+            pf_kernel_end(c, "fit");
+            PF_HIP(hipGetLastError());
+            return PFMI_OK;
+        }
+    }
     switch (c->kpad) {
         case 4: launch_fit_t<4>(c, a); break;
         case 8: launch_fit_t<8>(c, a); break;

@@ -100,6 +100,7 @@ struct pfmi_ctx {
     DevBuf mu;          // [P][d]
     DevBuf logdet;      // [P]
     DevBuf status;      // int32 [P]
+    DevBuf fit_scratch; // per-workgroup column-major working block of the panel fit kernel (d > 1024) + its work counter
 
     // ELBO state
     bool elbo_done = false;

@@ -858,9 +858,11 @@ def test_rccl_collectives_on_engine_memory_world1(pfmi_mod, eng):
 
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("tname,d,J", [("diag", 2100, 6), ("lr", 1500, 6), ("funnel", 2500, 10)])
-def test_memory_resident_fit_kernel_at_large_d(pfmi_mod, eng, tname, d, J):
-    """d > 1024 fits take the memory-resident kernel (fused reflector-apply + next-column dots, two Gram rows per sweep): dense
-    W / logdet / mu against the oracle at four fits of the first path."""
+def test_memory_resident_fit_kernel_at_large_d(pfmi_mod, eng, tname, d, J, monkeypatch):
+    """the column-by-column memory-resident kernel (fused reflector-apply + next-column dots, two Gram rows per sweep; the large-d
+    default of round 1, now behind PFMI_FIT_KERNEL=mem and for d > 16384): dense W / logdet / mu against the oracle at four fits
+    of the first path."""
+    monkeypatch.setenv("PFMI_FIT_KERNEL", "mem")
     tg = {"diag": lambda d: pfmi_mod.t_diag(d, 1), "lr": lambda d: pfmi_mod.t_lowrank(d, 8, 2), "funnel": pfmi_mod.t_funnel}[tname](d)
     eng.set_target(tg)
     x0 = pfmi_mod.HostRNG(3).rand(2 * d).reshape(2, d) * (20 if tname == "funnel" else 4) - (10 if tname == "funnel" else 2)
@@ -884,6 +886,84 @@ def test_memory_resident_fit_kernel_at_large_d(pfmi_mod, eng, tname, d, J):
         assert np.max(np.abs(Wa - Wo)) <= 1e-10 * np.abs(Wo).max() * max(1.0, np.linalg.cond(fa["D"]) ** 0.5 if fa["D"].size else 1.0)
         n_checked += 1
     assert n_checked >= 3
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("tname,d,J,maxit", [("diag", 1500, 4, 12), ("lr", 3000, 6, 14), ("funnel", 6000, 10, 16), ("diag", 12000, 10, 14),
+                                               ("diag", 2000, 16, 22), ("funnel", 10000, 10, 14)])
+def test_panel_fit_kernel_variants(pfmi_mod, eng, tname, d, J, maxit):
+    """The panel-blocked fit kernel (the default for 1024 < d <= 16384: register panels of 4 / 2 columns, MFMA cross products,
+    G = R'R, mean without a sweep) in every instantiation: rows per thread 5 / 10 / 20 / 32, one and two MFMA column tiles
+    (KPAD 8, 12, 20, 32), panels with 2 valid columns (odd history lengths at the start of a path).  Against the oracle:
+    status, logdet, mu, reflector-level QR / T / V where the QR is well conditioned, W x through the factor; and against the
+    column-by-column memory-resident kernel (PFMI_FIT_KERNEL=mem) on every fit."""
+    tg = {"diag": lambda d: pfmi_mod.t_diag(d, 1), "lr": lambda d: pfmi_mod.t_lowrank(d, 8, 2), "funnel": pfmi_mod.t_funnel}[tname](d)
+    eng.set_target(tg)
+    x0 = pfmi_mod.HostRNG(4).rand(2 * d).reshape(2, d) * (20 if tname == "funnel" else 4) - (10 if tname == "funnel" else 2)
+    eng.optimize_batch(x0, J, maxit)
+    eng.fit_batch(J)
+    st, je, ld, nr = eng.fit_status()
+    fits = {p: eng.get_fit(p, int(je[p])) for p in range(eng.P)}
+    old = os.environ.get("PFMI_FIT_KERNEL")
+    os.environ["PFMI_FIT_KERNEL"] = "mem"
+    try:
+        eng.fit_batch(J)
+        st2, je2, ld2, _ = eng.fit_status()
+        fits2 = {p: eng.get_fit(p, int(je2[p])) for p in range(eng.P)}
+    finally:
+        if old is None:
+            os.environ.pop("PFMI_FIT_KERNEL", None)
+        else:
+            os.environ["PFMI_FIT_KERNEL"] = old
+    np.testing.assert_array_equal(st, st2)
+    np.testing.assert_array_equal(je, je2)
+    seen_m = set()
+    n_strict = 0
+    rng = np.random.default_rng(0)
+    for k in range(2):
+        th, _, gr = eng.get_trace(k, logp=False)
+        p0 = int(eng.offsets[k])
+        alpha_all, hl, hs, _ = po.lbfgs_history(th, gr, J)
+        tr = type("T", (), {"points": th, "gradients": gr})()
+        for l in range(len(th)):
+            p = p0 + l
+            if st[p] != 0:
+                continue
+            fa, fb = fits[p], fits2[p]
+            j = int(je[p])
+            seen_m.add(2 * j)
+            assert abs(ld[p] - ld2[p]) <= 1e-9 * (1 + abs(ld2[p]))
+            if l in (1, 2, 3, len(th) // 2, len(th) - 1):
+                F = _oracle_factor(tr, alpha_all, hl, hs, l, d)
+                assert j == int(hl[l]) and F.status == 0
+                assert abs(F.logdet - fa["logdet"]) <= 1e-9 * (1 + abs(F.logdet))
+                mu_o = F.fit_mean(th[l], gr[l])
+                np.testing.assert_allclose(fa["mu"], mu_o, rtol=1e-7, atol=1e-8 * (1 + np.abs(mu_o).max()))
+                np.testing.assert_allclose(fa["D"], F.D, rtol=1e-6, atol=1e-9 * np.abs(F.D).max())
+                if j:
+                    X = rng.normal(size=(d, 3))
+                    Wx = fa["alpha"][:, None] * X + fa["B"] @ (fa["D"] @ (fa["B"].T @ X))
+                    np.testing.assert_allclose(Wx, F.mul_W(X), rtol=1e-8, atol=1e-9 * np.abs(Wx).max())
+                    Vh = np.tril(fa["qr_factors"], -1) + np.eye(d, 2 * j)
+                    G = Vh.T @ Vh                                        # Q'Q = I  <=>  T^-1 + T^-T = Vh'Vh
+                    assert np.all(np.diag(fa["T"]) > 0)
+                    np.testing.assert_allclose(np.linalg.inv(fa["T"]) + np.linalg.inv(fa["T"]).T, G, rtol=1e-9, atol=1e-10 * np.abs(G).max())
+                    if _well_conditioned(F):
+                        n_strict += 1
+                        amp = 1e-13 / _qr_ratio(F)
+                        np.testing.assert_allclose(fa["V"], F.V[:2 * j, :2 * j], rtol=1e-8, atol=max(1e-9, amp) * np.abs(F.V).max())
+                        np.testing.assert_allclose(fa["qr_factors"], F.QR[:, :2 * j], rtol=1e-8, atol=max(1e-9, amp) * np.abs(F.QR).max())
+                        np.testing.assert_allclose(np.diag(fa["T"]), F.tau[:2 * j], rtol=1e-9, atol=1e-12)
+            # panel kernel vs column-by-column kernel: same reflectors up to the conditioning of the block
+            scale = max(np.abs(fb["qr_factors"]).max(), 1e-300) if j else 1.0
+            Rd = np.abs(np.diag(fb["qr_factors"][:2 * j, :2 * j])) if j else np.ones(1)
+            amp = 1e-12 * (Rd.max() / max(Rd.min(), 1e-300)) if j else 0.0
+            if j and amp < 1e-6:
+                np.testing.assert_allclose(fa["qr_factors"], fb["qr_factors"], rtol=1e-7, atol=max(1e-10, amp) * scale)
+                np.testing.assert_allclose(fa["T"], fb["T"], rtol=1e-7, atol=max(1e-10, amp))
+            np.testing.assert_allclose(fa["mu"], fb["mu"], rtol=1e-7, atol=1e-8 * (1 + np.abs(fb["mu"]).max()))
+    assert n_strict >= 2, n_strict
+    assert any(mm % 4 == 2 for mm in seen_m) and max(seen_m) == 2 * J, seen_m      # ragged last panel and the full history both ran
 
 
 @pytest.mark.parametrize("name,K,J", [("iso10", 2, 6), ("lr50", 2, 6), ("diag30", 2, 10), ("funnel12", 2, 6)])
