@@ -516,32 +516,30 @@ void pfo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
  * CDF tabulated in pathfinder.jl_amd/csrc/pfmi_icdftab.h (generated by pathfinder.jl_amd/tools/gen_icdf_table.py, which
  * documents the construction; |Q(p) + Phi^-1(p)| <= 7.5e-10).  That header is DATA shared with the device code on purpose: the
  * table IS the definition of the generator, and because the evaluation uses only exactly rounded IEEE operations
- * (int -> double, fma, subtraction) the GPU reproduces these normals BIT FOR BIT.  The table itself is pinned against
+ * (int -> double, fma) the GPU reproduces these normals BIT FOR BIT.  The table itself is pinned against
  * scipy.special.ndtri and by distribution tests in tests/test_oracle_rng.py. */
 #include "../pathfinder.jl_amd/csrc/pfmi_icdftab.h"
 static const double PFO_ICDF_TAB[PF_ICDF_ENTRIES][4] = { PF_ICDF_TABLE_ROWS };
 
-/* Q ~ -Phi^-1(p) for p in (2^-65, 1/2), argument P = 2^32 p (the scaled variable the table is stored in) */
-double pfo_icdf_q(double p) {
+/* Q ~ -Phi^-1(p) for p in (2^-65, 1/2); argument v = the polynomial variable of the table (gen_icdf_table.py): mag in the common
+ * case (p = (mag + 1/2) 2^-32, the half is folded into the coefficients), 2^32 p in the tail.  The interval is read off the exponent
+ * and the top PF_ICDF_B mantissa bits of v; the cubic is stored in global monomial form: three fma. */
+double pfo_icdf_q(double v) {
     uint64_t bits;
-    memcpy(&bits, &p, 8);
+    memcpy(&bits, &v, 8);
     uint32_t hi = (uint32_t)(bits >> 32);
     int idx = PF_ICDF_IDX0 - (int)(hi >> (20 - PF_ICDF_B));
-    uint64_t bb = (uint64_t)(hi & ~((1u << (20 - PF_ICDF_B)) - 1u)) << 32;      /* p with the low mantissa bits cleared */
-    double pb;
-    memcpy(&pb, &bb, 8);
-    const double dp = p - pb;
     const double *c = PFO_ICDF_TAB[idx];
-    return fma(fma(fma(c[3], dp, c[2]), dp, c[1]), dp, c[0]);
+    return fma(fma(fma(c[3], v, c[2]), v, c[1]), v, c[0]);
 }
 /* one normal from the Philox word x; x2 = the matching word of the refinement call (counter word 3 = 1), only read when
  * mag < 2^PF_ICDF_TAILBITS (probability 2^-19) */
 double pfo_icdf_normal(uint32_t x, uint32_t x2) {
     const uint32_t mag = x & 0x7FFFFFFFu;
-    double p;
-    if (mag >= (1u << PF_ICDF_TAILBITS)) p = (double)mag + 0.5;                                  /* P = 2^32 p = mag + 1/2 */
-    else p = ((double)(((uint64_t)mag << 32) | x2) + 0.5) * 0x1p-32;                              /* exact: < 2^44 */
-    const double q = pfo_icdf_q(p);
+    double v;
+    if (mag >= (1u << PF_ICDF_TAILBITS)) v = (double)mag;                                        /* p = (mag + 1/2) 2^-32 */
+    else v = ((double)(((uint64_t)mag << 32) | x2) + 0.5) * 0x1p-32;                              /* exact: < 2^44 */
+    const double q = pfo_icdf_q(v);
     return (x >> 31) ? -q : q;
 }
 void pfo_randn4(uint64_t seed, uint32_t g, uint32_t n, uint32_t stream, double z[4]) {

@@ -189,6 +189,7 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
         // shared by the alternating groups -- was built and measured in round 2: 25.3 vs 24.7 ms for two groups, 121 vs 95 ms for
         // one group at d = 10^4; with no MFMA / VALU co-issue on gfx950 there is nothing to hide the look-ups behind.)
         struct Pend { uint32_t x[4]; double dp[4]; double2 c01[4], c23[4]; };
+        const uint32_t icdf_adj = pf_icdf_adj<PF_ICDF_NB_LDS>(icdf);
         auto gen_issue = [&](const int g, const int blk, Pend &P) {
 #if QF_ABLATE == 1                     // ablation (timing experiments only): no generator at all
 #pragma unroll
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
 #else
             pf_philox_normals(n[g], (uint32_t)(blk * 4 + q), 0u, 0u, k0, k1, P.x);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pf_icdf_issue<PF_ICDF_NB_LDS, false>(P.x[r], icdf, P.dp[r], P.c01[r], P.c23[r]);
+            for (int r = 0; r < 4; ++r) pf_icdf_issue_adj<PF_ICDF_NB_LDS>(P.x[r], icdf_adj, P.dp[r], P.c01[r], P.c23[r]);
 #endif
         };
         for (int ck = 0; ck < nchunks; ++ck) {

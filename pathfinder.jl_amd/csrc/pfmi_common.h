@@ -241,34 +241,60 @@ __device__ __forceinline__ void pf_icdf_load(double2 *tab) {
 // any word, full table in global memory (slow path / kernels without an LDS copy)
 __device__ __forceinline__ double pf_icdf_any(uint32_t x, uint32_t x2) {
     const uint32_t mag = x & 0x7FFFFFFFu;
-    double p;
-    if (mag >= (1u << PF_ICDF_TAILBITS)) p = (double)mag + 0.5;
-    else p = ((double)(((uint64_t)mag << 32) | x2) + 0.5) * 0x1p-32;
-    const unsigned hi = (unsigned)__double2hiint(p);
+    double v;                                                       // the polynomial variable (tools/gen_icdf_table.py)
+    if (mag >= (1u << PF_ICDF_TAILBITS)) v = (double)mag;
+    else v = ((double)(((uint64_t)mag << 32) | x2) + 0.5) * 0x1p-32;
+    const unsigned hi = (unsigned)__double2hiint(v);
     const int idx = PF_ICDF_IDX0 - (int)(hi >> (20 - PF_ICDF_B));
-    const double dp = p - __hiloint2double((int)(hi & ~((1u << (20 - PF_ICDF_B)) - 1u)), 0);
     const double *c = PF_ICDF_TAB_DEV[idx];
-    const double q = fma(fma(fma(c[3], dp, c[2]), dp, c[1]), dp, c[0]);
+    const double q = fma(fma(fma(c[3], v, c[2]), v, c[1]), v, c[0]);
     return (x >> 31) ? -q : q;
 }
-// the common case in two halves (software-pipelined callers put work between them): `issue` computes dp and starts the two
+// the common case in two halves (software-pipelined callers put work between them): `issue` converts the word and starts the two
 // table reads from the LDS copy, `finish` evaluates the cubic once the coefficients have landed
 // CLAMP = false: words beyond the LDS copy (fixed up by the caller anyway) read whatever lies up to 2^(PF_ICDF_B) * (32 - NB) * 16
 // bytes BELOW the table -- the caller guarantees that much LDS in front of it (the ELBO scan: >= 40 KB of staged factor block)
 template <int NB = PF_ICDF_NB_LDS, bool CLAMP = true>
-__device__ __forceinline__ void pf_icdf_issue(uint32_t x, const double2 *lds_tab, double &dp, double2 &c01, double2 &c23) {
+__device__ __forceinline__ void pf_icdf_issue(uint32_t x, const double2 *lds_tab, double &v, double2 &c01, double2 &c23) {
     constexpr int NENT = NB << PF_ICDF_B;
-    constexpr int SLOT0 = PF_ICDF_IDX0 - (NENT - 1);                // (hi32(P) >> 15) of the lowest interval kept in LDS
-    const double p = (double)(x & 0x7FFFFFFFu) + 0.5;               // P = 2^32 p = mag + 1/2
-    const unsigned hi = (unsigned)__double2hiint(p);
+    constexpr int SLOT0 = PF_ICDF_IDX0 - (NENT - 1);                // (hi32(v) >> 15) of the lowest interval kept in LDS
+    v = (double)(x & 0x7FFFFFFFu);                                  // polynomial variable of the common case: mag
+    const unsigned hi = (unsigned)__double2hiint(v);
     int slot = (int)(hi >> (20 - PF_ICDF_B)) - SLOT0;
     if (CLAMP) slot = slot > 0 ? slot : 0;                          // words beyond the LDS copy are fixed up by the caller
-    dp = p - __hiloint2double((int)(hi & ~((1u << (20 - PF_ICDF_B)) - 1u)), 0);
     c01 = lds_tab[slot]; c23 = lds_tab[NENT + slot];
 }
-__device__ __forceinline__ double pf_icdf_finish(uint32_t x, double dp, const double2 &c01, const double2 &c23) {
-    const double q = fma(fma(fma(c23.y, dp, c23.x), dp, c01.y), dp, c01.x);
-    return __hiloint2double(__double2hiint(q) ^ (int)(x & 0x80000000u), __double2loint(q));
+// The same look-up with the address arithmetic folded into one v_lshl_add_u32: `adj` is the LDS byte address the interval index
+// (hi32(P) >> 15) = 0 would have (loop-invariant, kept opaque so that the compiler does not split the constant off again -- it
+// emitted three v_add_u32 per normal), the second coefficient pair sits NENT entries further (immediate ds_read offset).  Only for
+// callers that guarantee readable LDS below the table (CLAMP = false above).
+typedef double pf_v2d __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) pf_v2d *pf_lds_d2;
+template <int NB = PF_ICDF_NB_LDS>
+__device__ __forceinline__ uint32_t pf_icdf_adj(const double2 *lds_tab) {
+    constexpr int NENT = NB << PF_ICDF_B;
+    constexpr int SLOT0 = PF_ICDF_IDX0 - (NENT - 1);
+    uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(uintptr_t)(pf_lds_d2)lds_tab - (uint32_t)SLOT0 * 16u));   // wave-uniform
+    asm volatile("" : "+s"(off));
+    return off;
+}
+template <int NB = PF_ICDF_NB_LDS>
+__device__ __forceinline__ void pf_icdf_issue_adj(uint32_t x, uint32_t adj, double &v, double2 &c01, double2 &c23) {
+    constexpr int NENT = NB << PF_ICDF_B;
+    v = (double)(x & 0x7FFFFFFFu);
+    const unsigned hi = (unsigned)__double2hiint(v);
+    unsigned idx = hi >> (20 - PF_ICDF_B);
+    asm("" : "+v"(idx));                                            // keeps (idx << 4) + adj one v_lshl_add_u32 (else: shift, mask, add)
+    const pf_lds_d2 e = (pf_lds_d2)(uintptr_t)(adj + (idx << 4));
+    const pf_v2d a = e[0], b = e[NENT];
+    c01 = make_double2(a.x, a.y); c23 = make_double2(b.x, b.y);
+}
+// the table holds magnitudes (> 0 on every interval), so "apply the sign of the word" is a bit-field insert (one v_bfi_b32)
+__device__ __forceinline__ double pf_icdf_finish(uint32_t x, double v, const double2 &c01, const double2 &c23) {
+    const double q = fma(fma(fma(c23.y, v, c23.x), v, c01.y), v, c01.x);
+    unsigned hq;                                                    // (mask & hi(q)) | (~mask & x); spelled out because the compiler
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hq) : "s"(0x7FFFFFFFu), "v"((unsigned)__double2hiint(q)), "v"(x));   // only matched half of the sites
+    return __hiloint2double((int)hq, __double2loint(q));
 }
 // true if one of the four words falls outside the LDS copy
 template <int NB = PF_ICDF_NB_LDS>

@@ -31,7 +31,11 @@ def test_table_matches_inverse_normal_cdf(L):
     """|Q(p) + Phi^-1(p)| <= 7.5e-10 on (2^-65, 1/2): log-uniform p (every binade) and uniform p (the bulk)."""
     rng = np.random.default_rng(0)
     ps = np.concatenate([np.exp(rng.uniform(np.log(2.0 ** -65), np.log(0.5), 60000)), rng.uniform(2.0 ** -20, 0.5, 60000)])
-    q = np.array([L.pfo_icdf_q(float(p) * 2.0 ** 32) for p in ps])          # the table is stored in the variable P = 2^32 p
+    P = ps * 2.0 ** 32
+    keep = (P < 4096.0) | (P >= 4096.5)          # words have P = mag + 1/2 with integer mag: [4096, 4096.5) cannot occur
+    ps, P = ps[keep], P[keep]
+    # the table is stored in the polynomial variable v: mag = P - 1/2 in the common case (P >= 2^12), P = 2^32 p in the tail
+    q = np.array([L.pfo_icdf_q(float(v)) for v in np.where(P >= 4096.0, P - 0.5, P)])
     assert np.max(np.abs(q + ndtri(ps))) <= 7.5e-10
     assert np.all(q > 0)
 
@@ -43,14 +47,19 @@ def test_committed_table_is_what_the_generator_script_produces():
     txt = open(os.path.join(ROOT, "pathfinder.jl_amd", "csrc", "pfmi_icdftab.h")).read()
     rows = [l for l in txt.splitlines() if l.strip().startswith("{")]
     assert len(rows) == 2048 == (g.E_TOP - g.E_BOT + 1) << g.B
+    tab, worst = g.coefficients()
+    assert worst < 7.5e-10
+    got = np.array([[float.fromhex(v.strip()) for v in r.strip().rstrip("\\").strip().rstrip(",").strip("{}").split(",")] for r in rows])
+    np.testing.assert_array_equal(got, tab)
+    # independent of the script's local -> global conversion: the stored global cubic reproduces -Phi^-1 at the Chebyshev nodes
     k = np.arange(4)
     xn = np.cos((2 * k + 1) * np.pi / 8)
     for i in (0, 1, 31, 32, 607, 608, 1000, 2047):
         a, h = g.interval(i)
-        t = (xn + 1) / 2
-        c = np.linalg.solve(np.vander(t, 4, increasing=True), -ndtri(a + h * t)) / h ** np.arange(4) * 2.0 ** (-32.0 * np.arange(4))
-        got = [float.fromhex(v.strip()) for v in rows[i].strip().rstrip("\\").strip().rstrip(",").strip("{}").split(",")]
-        np.testing.assert_allclose(got, c, rtol=1e-12)
+        pn = a + h * (xn + 1) / 2
+        v = pn * 2.0 ** 32 - (0.5 if pn[0] * 2.0 ** 32 >= 4096.0 else 0.0)
+        q = ((got[i, 3] * v + got[i, 2]) * v + got[i, 1]) * v + got[i, 0]
+        np.testing.assert_allclose(q, -ndtri(pn), rtol=0, atol=1e-12)
 
 
 def test_word_to_normal_map(L):
