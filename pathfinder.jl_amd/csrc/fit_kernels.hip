@@ -501,14 +501,12 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
     double *mu = A.mu + (size_t)p * d;
     const double *theta_p = A.theta + (size_t)p * d, *grad_p = A.grad + (size_t)p * d;
 
-    constexpr int NP = KPAD * (KPAD + 1) / 2;            // Gram entries (upper triangle)
-    constexpr int CH = NP < 26 ? NP : 26;                // entries per block reduction
-    constexpr int NCH = (NP + CH - 1) / CH;
-    constexpr int NVMAX = CH > KPAD ? CH : KPAD;
+    constexpr int NVMAX = KPAD;
     __shared__ double red[2 * (NT / 64) * NVMAX];       // two halves: one barrier per block reduction (pf_block_sum_pp)
     int flip = 0;
     __shared__ double sRow[2][KPAD], sHead[KPAD];
     __shared__ double sD[KPAD * KPAD], sR[KPAD * KPAD], sT[KPAD * KPAD], sV[KPAD * KPAD], sG[KPAD * KPAD];
+    __shared__ double sX1[(KPAD / 2) * KPAD], sX2[(KPAD / 2) * KPAD], sX3[(KPAD / 2) * KPAD];     // j x j scratch of the D computation
     __shared__ double sLogdetV;
     __shared__ int sStatus;
 
@@ -572,92 +570,6 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
         }
     }
     double acc[KPAD];
-    // ---- Gram matrix G = B~'B~: all KPAD(KPAD+1)/2 entries with compile-time column indices (pure FMAs), CH entries
-    //      per block reduction (3 reductions at KPAD = 12 instead of one per row)
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-        double g2[CH];
-#pragma unroll
-        for (int e = 0; e < CH; ++e) g2[e] = 0.0;
-        {
-            int e = 0;
-#pragma unroll
-            for (int ca = 0; ca < KPAD; ++ca)
-#pragma unroll
-                for (int cb = ca; cb < KPAD; ++cb) {
-                    if (e / CH == ch) {
-#pragma unroll
-                        for (int i = 0; i < RPT; ++i) g2[e % CH] += a[i][ca] * a[i][cb];
-                    }
-                    ++e;
-                }
-        }
-        pf_block_sum_pp<CH, NVMAX>(g2, red, flip);
-        if (tid == 0) {
-            int e = 0;
-#pragma unroll
-            for (int ca = 0; ca < KPAD; ++ca)
-#pragma unroll
-                for (int cb = ca; cb < KPAD; ++cb) {
-                    if (e / CH == ch) { sG[ca * KPAD + cb] = g2[e % CH]; sG[cb * KPAD + ca] = g2[e % CH]; }
-                    ++e;
-                }
-        }
-    }
-    __syncthreads();
-    // ---- D (m x m)   (src/inverse_hessian.jl:119-130)
-    if (j > 0) {
-        double *R = sT, *nRinv = sV;
-        for (int t = tid; t < j * j; t += NT) {
-            const int aa = t / j, b = t % j;
-            R[aa * KPAD + b] = (b >= aa) ? sG[(j + aa) * KPAD + b] : 0.0;      // triu(S'Y)   :119-121
-            nRinv[aa * KPAD + b] = 0.0;
-        }
-    }
-    __syncthreads();
-    if (tid < j) {                                   // -R^{-1}: lane c solves column c by back substitution :122-124
-        const double *R = sT;
-        double *nRinv = sV;
-        const int c = tid;
-        for (int r = c; r >= 0; --r) {
-            double rhs = (r == c) ? -1.0 : 0.0;
-            for (int t = r + 1; t <= c; ++t) rhs -= R[r * KPAD + t] * nRinv[t * KPAD + c];
-            nRinv[r * KPAD + c] = rhs / R[r * KPAD + r];
-        }
-    }
-    __syncthreads();
-    if (j > 0) {   // M = Y'alpha Y + diag(R); D12, D21 -- one entry per thread
-        for (int t = tid; t < j * j; t += NT) {
-            const int aa = t / j, b = t % j;
-            sD[aa * KPAD + (j + b)] = sV[aa * KPAD + b];
-            sD[(j + aa) * KPAD + b] = sV[b * KPAD + aa];
-            double v = (aa <= b) ? sG[aa * KPAD + b] : sG[b * KPAD + aa];
-            if (aa == b) v += sT[aa * KPAD + aa];
-            sR[aa * KPAD + b] = v;                                   // M
-        }
-    }
-    __syncthreads();
-    if (j > 0) {   // T1 = M nRinv  -> sG (G is no longer needed)
-        for (int t = tid; t < j * j; t += NT) {
-            const int aa = t / j, b = t % j;
-            double v = 0.0;
-            for (int u = 0; u <= b; ++u) v += sR[aa * KPAD + u] * sV[u * KPAD + b];
-            sG[aa * KPAD + b] = v;
-        }
-    }
-    __syncthreads();
-    if (j > 0) {   // D22 = nRinv' T1
-        for (int t = tid; t < j * j; t += NT) {
-            const int aa = t / j, b = t % j;
-            double v = 0.0;
-            for (int u = 0; u <= aa; ++u) v += sV[u * KPAD + aa] * sG[u * KPAD + b];
-            sD[(j + aa) * KPAD + (j + b)] = v;
-        }
-    }
-    __syncthreads();
-    for (int t = tid; t < KPAD * KPAD; t += NT) { sT[t] = 0.0; sV[t] = 0.0; sR[t] = 0.0; }
-    __syncthreads();
-
     // ---- Householder QR, one block reduction per column.  Thread aa < KPAD keeps row aa of the compact-WY T in
     //      registers (dlarft: T[0:c, c] = -tau T[0:c,0:c] (Vh' v_c)), so the column loop has no serial section.
     // (row aa of T lives in LDS and is only ever touched by thread aa: no barrier needed, and 2 KPAD fewer VGPRs)
@@ -735,6 +647,65 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
                 sR[tid * KPAD + cc] = (cc < m) ? a[0][cc] : 0.0;
                 a[0][cc] = (cc == tid) ? 1.0 : 0.0;
             }
+        }
+    }
+    __syncthreads();
+    // ---- Gram matrix from the triangular factor: G = B~'B~ = R'R (G[c][b], c, b < j: Y'alpha Y; G[j + a][b]: S'Y) -- round 1 swept
+    //      the register block for it (KPAD (KPAD + 1) / 2 products per row and three block reductions, 15 % of the kernel)
+    for (int t = tid; t < m * m; t += NT) {
+        const int aa = t / m, b = t % m, u1 = (aa < b ? aa : b) < k - 1 ? (aa < b ? aa : b) : k - 1;
+        double v = 0.0;
+        for (int u = 0; u <= u1; ++u) v += sR[u * KPAD + aa] * sR[u * KPAD + b];
+        sG[aa * KPAD + b] = v;
+    }
+    __syncthreads();
+    // ---- D (m x m)   (src/inverse_hessian.jl:119-130)
+    if (j > 0) {
+        double *R = sX1, *nRinv = sX2;
+        for (int t = tid; t < j * j; t += NT) {
+            const int aa = t / j, b = t % j;
+            R[aa * KPAD + b] = (b >= aa) ? sG[(j + aa) * KPAD + b] : 0.0;      // triu(S'Y)   :119-121
+            nRinv[aa * KPAD + b] = 0.0;
+        }
+    }
+    __syncthreads();
+    if (tid < j) {                                   // -R^{-1}: lane c solves column c by back substitution :122-124
+        const double *R = sX1;
+        double *nRinv = sX2;
+        const int c = tid;
+        for (int r = c; r >= 0; --r) {
+            double rhs = (r == c) ? -1.0 : 0.0;
+            for (int t = r + 1; t <= c; ++t) rhs -= R[r * KPAD + t] * nRinv[t * KPAD + c];
+            nRinv[r * KPAD + c] = rhs / R[r * KPAD + r];
+        }
+    }
+    __syncthreads();
+    if (j > 0) {   // M = Y'alpha Y + diag(R); D12, D21 -- one entry per thread
+        for (int t = tid; t < j * j; t += NT) {
+            const int aa = t / j, b = t % j;
+            sD[aa * KPAD + (j + b)] = sX2[aa * KPAD + b];
+            sD[(j + aa) * KPAD + b] = sX2[b * KPAD + aa];
+            double v = (aa <= b) ? sG[aa * KPAD + b] : sG[b * KPAD + aa];
+            if (aa == b) v += sX1[aa * KPAD + aa];
+            sX3[aa * KPAD + b] = v;                                  // M
+        }
+    }
+    __syncthreads();
+    if (j > 0) {   // T1 = M nRinv  -> sG (G is no longer needed)
+        for (int t = tid; t < j * j; t += NT) {
+            const int aa = t / j, b = t % j;
+            double v = 0.0;
+            for (int u = 0; u <= b; ++u) v += sX3[aa * KPAD + u] * sX2[u * KPAD + b];
+            sG[aa * KPAD + b] = v;
+        }
+    }
+    __syncthreads();
+    if (j > 0) {   // D22 = nRinv' T1
+        for (int t = tid; t < j * j; t += NT) {
+            const int aa = t / j, b = t % j;
+            double v = 0.0;
+            for (int u = 0; u <= aa; ++u) v += sX2[u * KPAD + aa] * sG[u * KPAD + b];
+            sD[(j + aa) * KPAD + (j + b)] = v;
         }
     }
     __syncthreads();
