@@ -332,7 +332,7 @@ def main():
                              "(the fused kernel moves < 3 % of them; HBM is idle)",
                     "mfma_f64": {"achieved": round(mfma_tf, 2), "peak": 78.6, "unit": "TFLOP/s", "frac": round(mfma_tf / 78.6, 4),
                                  "note": "f64 MFMA flops of the scan / launch time; the kernel's floor is the SUM of its MFMA and VALU "
-                                         "issue streams (no co-issue on gfx950, profiles/r02_coissue_microbench.txt): ~90 % of that floor, DESIGN.md 4.1"},
+                                         "issue streams (no co-issue on gfx950, profiles/r02_coissue_microbench.txt): ~80 % of that floor, DESIGN.md 4.1"},
                     "kernel": "pf_elbo_qf_kernel (single-pass ELBO scan)",
                     "launches": int(n), "avg_launch_ms": round(ms / max(n, 1), 4),
                     "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_draw": bytes_per_draw,
