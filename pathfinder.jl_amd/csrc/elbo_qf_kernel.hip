@@ -371,9 +371,8 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
 #pragma unroll
                         for (int g = 0; g < NG; ++g) gen_issue(g, blk, pp[g]);
 #pragma unroll
-                        for (int g = 0; g < NG; ++g) finish(g, blk, pp[g], z[g], special_tag);
-#pragma unroll
-                        for (int g = 0; g < NG; ++g) {
+                        for (int g = 0; g < NG; ++g) {           // the MFMA burst of group g hides the look-up latency of group g + 1
+                            finish(g, blk, pp[g], z[g], special_tag);
 #if QF_ABLATE == 3                     // ablation: generator only, no contraction
                             q12[g] += z[g][0] + z[g][1] + z[g][2] + z[g][3] + oa.av[0][0] + oa.rs[0];
 #else

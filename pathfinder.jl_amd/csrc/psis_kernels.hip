@@ -271,24 +271,41 @@ __device__ __forceinline__ uint64_t pf_weight_to_fixed(double w) {
 __device__ __forceinline__ uint64_t pf_uniform_to_bits(double u) {
     return ((uint64_t)floor(u * 9007199254740992.0)) << 11;
 }
-// single workgroup; uniform != 0 -> every weight is 1 (importance = false)
+// inclusive scan of a u64 across the wave (lane i gets the sum of lanes 0..i)
+__device__ __forceinline__ uint64_t pf_wave_scan_u64(uint64_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned lo = __shfl_up((unsigned)v, off, 64), hi = __shfl_up((unsigned)(v >> 32), off, 64);
+        if (lane >= off) v += ((uint64_t)hi << 32) | lo;
+    }
+    return v;
+}
+// single workgroup.  Wave w owns a contiguous run of 64-element tiles: coalesced loads, a wave-level scan per tile and a running
+// carry (integer sums: the table does not depend on the order of these partial sums); pass 1 = run totals, pass 2 = scan + store.
+// (Round 1 gave every thread a contiguous chunk: 64 different cache lines per load instruction, 0.15 ms at S = 64 000.)
 __global__ __launch_bounds__(PSIS_THREADS) void pf_cdf_kernel(long long S, const double *__restrict__ w,
                                                               uint64_t *__restrict__ cdf) {
-    const int tid = threadIdx.x, nt = blockDim.x;
-    __shared__ uint64_t part[PSIS_THREADS];
-    const long long chunk = (S + nt - 1) / nt;
-    const long long i0 = (long long)tid * chunk, i1 = (i0 + chunk < S) ? i0 + chunk : S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    __shared__ uint64_t part[PSIS_THREADS / 64];
+    const long long ntile = (S + 63) >> 6, per = (ntile + nw - 1) / nw;
+    const long long t0 = (long long)wave * per, t1 = (t0 + per < ntile) ? t0 + per : ntile;
     uint64_t s = 0;
-    for (long long i = i0; i < i1; ++i) s += pf_weight_to_fixed(w[i]);
-    part[tid] = s;
-    __syncthreads();
-    if (tid == 0) {
-        uint64_t acc = 0;
-        for (int t = 0; t < nt; ++t) { const uint64_t v = part[t]; part[t] = acc; acc += v; }
+    for (long long t = t0; t < t1; ++t) {
+        const long long i = (t << 6) + lane;
+        s += (i < S) ? pf_weight_to_fixed(w[i]) : 0ull;
     }
+    s = pf_wave_scan_u64(s, lane);
+    if (lane == 63) part[wave] = s;
     __syncthreads();
-    uint64_t acc = part[tid];
-    for (long long i = i0; i < i1; ++i) { acc += pf_weight_to_fixed(w[i]); cdf[i] = acc; }
+    uint64_t carry = 0;
+    for (int v = 0; v < wave; ++v) carry += part[v];
+    for (long long t = t0; t < t1; ++t) {
+        const long long i = (t << 6) + lane;
+        const uint64_t x = (i < S) ? pf_weight_to_fixed(w[i]) : 0ull;
+        const uint64_t incl = pf_wave_scan_u64(x, lane);
+        if (i < S) cdf[i] = carry + incl;
+        carry += ((uint64_t)__shfl((unsigned)(incl >> 32), 63, 64) << 32) | (uint64_t)__shfl((unsigned)incl, 63, 64);
+    }
 }
 
 __global__ void pf_sample_kernel(long long S, long long ndraws, int weighted, uint64_t seed,
