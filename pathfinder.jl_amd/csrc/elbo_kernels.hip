@@ -225,21 +225,30 @@ __global__ __launch_bounds__(256) void pf_elbo_reduce_kernel(int64_t N, const in
 
 // _findmax_skipnan over the iterations 1..L of each path (first element seeds the state even if NaN,
 // later NaNs are skipped, strict > so the first maximum wins).  1-based result, 0 when L == 0.
-__global__ void pf_elbo_argmax_kernel(int K, const int64_t *__restrict__ off, const double *__restrict__ elbo,
-                                      int64_t *__restrict__ best_iter) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per path (round 1 walked each path with one thread: ~175 dependent loads, 65 us): lane-local candidates, then a
+// butterfly that keeps the larger value and, among equal values, the smaller index.
+__global__ __launch_bounds__(64) void pf_elbo_argmax_kernel(int K, const int64_t *__restrict__ off, const double *__restrict__ elbo,
+                                                           int64_t *__restrict__ best_iter) {
+    const int k = blockIdx.x, lane = threadIdx.x;
     if (k >= K) return;
     const int64_t p0 = off[k];
     const int L = (int)(off[k + 1] - p0 - 1);
-    if (L <= 0) { best_iter[k] = 0; return; }
-    double xmax = elbo[p0 + 1];
-    int64_t imax = 1;
-    for (int l = 2; l <= L; ++l) {
+    if (L <= 0) { if (lane == 0) best_iter[k] = 0; return; }
+    double xmax = 0.0;
+    int imax = 0x7FFFFFFF, have = 0;
+    for (int l = 1 + lane; l <= L; l += 64) {
         const double xi = elbo[p0 + l];
         if (isnan(xi)) continue;
-        if (isnan(xmax) || xi > xmax) { xmax = xi; imax = l; }
+        if (!have || xi > xmax) { xmax = xi; imax = l; have = 1; }
     }
-    best_iter[k] = imax;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const double xo = __shfl_xor(xmax, o, 64);
+        const int io = __shfl_xor(imax, o, 64), ho = __shfl_xor(have, o, 64);
+        const bool take = ho && (!have || xo > xmax || (xo == xmax && io < imax));
+        if (take) { xmax = xo; imax = io; have = 1; }
+    }
+    if (lane == 0) best_iter[k] = have ? imax : 1;       // all NaN: the first element seeded the state
 }
 
 // log_ratios = logp - logq
@@ -412,7 +421,7 @@ int32_t pf_launch_elbo_reduce(pfmi_ctx *c) {
     hipLaunchKernelGGL(pf_elbo_reduce_kernel, dim3((unsigned)c->P), dim3(256), 0, c->stream, c->N_e,
                        c->d_off.as<int64_t>(), c->d_path_of.as<int32_t>(), c->status.as<int32_t>(),
                        c->logp.as<double>(), c->logq.as<double>(), c->elbo.as<double>(), c->se.as<double>());
-    hipLaunchKernelGGL(pf_elbo_argmax_kernel, dim3((unsigned)((c->K + 63) / 64)), dim3(64), 0, c->stream, c->K,
+    hipLaunchKernelGGL(pf_elbo_argmax_kernel, dim3((unsigned)c->K), dim3(64), 0, c->stream, c->K,
                        c->d_off.as<int64_t>(), c->elbo.as<double>(), c->best_iter.as<int64_t>());
     pf_kernel_end(c, "elbo_reduce");
     PF_HIP(hipGetLastError());

@@ -42,18 +42,23 @@ __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
     const bool keeper = tid == HIST_NT - 1;
 
     // The walk is sequential in l and every iteration needs two fresh rows (theta_l, grad_l) that nobody has touched before: with
-    // the loads issued one iteration ahead the iteration time WAS the DRAM latency (3 us at config 3).  Round 2 keeps the rows of
-    // points l, l+1, l+2 in three register sets (rotated by a 3-way unrolled loop, so all indices are static) and issues the
-    // loads of point l+3 as soon as set l has been consumed: three iterations for a load to land.  (EPT > 6: two sets -- 1024
-    // threads have 128 VGPRs.)
-    constexpr int NSET = EPT <= 6 ? 3 : 2;
-    double al[EPT], t0[EPT], g0[EPT], tq[NSET][EPT], gq[NSET][EPT];
+    // the loads issued one iteration ahead the iteration time WAS the DRAM latency (3 us at config 3).  The rows of NS consecutive
+    // points live in NS register sets used round-robin (set p % NS holds point p): step l reads sets (l - 1) % NS and l % NS and
+    // then refills the older one with point l - 1 + NS, i.e. NS - 2 steps ahead of its first use.  The loop is unrolled NS times so
+    // that every set index is static and NO value is ever copied between sets, and its body is branch-free: round 2's first version
+    // (predicated loads, a conditional per unrolled step, t0 <- t1 copies) made the compiler wait with vmcnt(0) / copy registers of
+    // pending loads at every join, so each step still paid a full memory round trip.
+    // (EPT > 6: three sets -- 1024 threads have 128 VGPRs.)
+    constexpr int NS = EPT <= 6 ? 4 : 3;
+    double al[EPT], tq[NS][EPT], gq[NS][EPT];
+    // unconditional loads from clamped addresses; points beyond L are never consumed, coordinates beyond d are zeroed where s and
+    // y are formed (masking here would make the load's first use immediate)
     auto load_point = [&](const int pt, double (&tt)[EPT], double (&gg)[EPT]) {
+        const size_t row = (size_t)(p0 + (pt <= L ? pt : L)) * d;
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
-            const int i = tid + HIST_NT * e;
-            tt[e] = gg[e] = 0.0;
-            if (i < d && pt <= L) { tt[e] = theta[(size_t)(p0 + pt) * d + i]; gg[e] = grad[(size_t)(p0 + pt) * d + i]; }
+            const int i = tid + HIST_NT * e, ic = i < d ? i : d - 1;
+            tt[e] = theta[row + ic]; gg[e] = grad[row + ic];
         }
     };
 #pragma unroll
@@ -62,41 +67,40 @@ __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
         al[e] = 1.0;                                                           // H0 = I  (:38-39)
         if (i < d) alpha_all[(size_t)p0 * d + i] = 1.0;
     }
-    load_point(0, t0, g0);
 #pragma unroll
-    for (int q = 0; q < NSET; ++q) load_point(1 + q, tq[q], gq[q]);              // points 1 .. NSET
+    for (int q = 0; q < NS; ++q) load_point(q, tq[q], gq[q]);                    // points 0 .. NS - 1
     if (keeper) hist_len[p0] = 0;
-    // one trace step: (t0, g0) = point l - 1, (t1, g1) = point l; afterwards (t0, g0) = point l and the set is refilled
-    auto step = [&](const int l, double (&t1)[EPT], double (&g1)[EPT]) {
+    // one trace step: (t0, g0) = point l - 1, (t1, g1) = point l; afterwards the set of point l - 1 is refilled
+    auto step = [&](const int l, double (&t0)[EPT], double (&g0)[EPT], const double (&t1)[EPT], const double (&g1)[EPT]) {
         double v[4] = {0.0, 0.0, 0.0, 0.0};   // y.s, y.y, y'diag(a)y, s'diag(1/a)s
-        double ial[EPT];                                                        // 1 / alpha: one division serves the c sum and the update
+        double ial[EPT], sv[EPT], yv[EPT];                                      // 1 / alpha: one division serves the c sum and the update
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
-            const double s = t1[e] - t0[e], y = g0[e] - g1[e];                  // :45-46 (zero beyond d)
+            const bool in = tid + HIST_NT * e < d;
+            const double s = in ? t1[e] - t0[e] : 0.0, y = in ? g0[e] - g1[e] : 0.0;   // :45-46
+            sv[e] = s; yv[e] = y;
             ial[e] = 1.0 / al[e];
             v[0] += y * s;
             v[1] += y * y;
             v[2] += y * al[e] * y;
             v[3] += s * ial[e] * s;
         }
+        load_point(l - 1 + NS, t0, g0);                                         // refill: first needed NS - 2 steps from now
         pf_block_sum_pp<4, 4>(v, red, flip);
         const bool accept = v[0] > eps * v[1];                                  // :47
         if (accept) {                                                           // gilbert_init :5-10
             const double a = v[2], b = v[0], c = v[3], aoc = a / c;
 #pragma unroll
             for (int e = 0; e < EPT; ++e) {
-                const double s = t1[e] - t0[e], y = g0[e] - g1[e];
-                const double sa = s * ial[e];
-                al[e] = b / (a * ial[e] + y * y - aoc * sa * sa);
+                const double sa = sv[e] * ial[e];
+                al[e] = b / (a * ial[e] + yv[e] * yv[e] - aoc * sa * sa);
             }
         }
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             const int i = tid + HIST_NT * e;
             if (i < d) alpha_all[(size_t)(p0 + l) * d + i] = al[e];
-            t0[e] = t1[e]; g0[e] = g1[e];
         }
-        load_point(l + NSET, t1, g1);                                           // refill this set: needed NSET iterations from now
         if (keeper) {
             if (accept) {
                 r_ind = (r_ind % J) + 1;                                        // mod1 :49
@@ -111,11 +115,15 @@ __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
             for (int t = 1; t <= r_ind; ++t) hist_src[(size_t)(p0 + l) * J + c++] = ring[t - 1];
         }
     };
-    for (int l = 1; l <= L; l += NSET) {                                        // :43
+    int l = 1;
+    for (; l + NS - 1 <= L; l += NS) {                                          // :43
 #pragma unroll
-        for (int q = 0; q < NSET; ++q)
-            if (l + q <= L) step(l + q, tq[q], gq[q]);
+        for (int q = 0; q < NS; ++q) step(l + q, tq[q], gq[q], tq[(q + 1) % NS], gq[(q + 1) % NS]);
     }
+    const int rem = L - l + 1;                                                  // 0 .. NS - 1 steps left
+#pragma unroll
+    for (int q = 0; q < NS - 1; ++q)
+        if (q < rem) step(l + q, tq[q], gq[q], tq[(q + 1) % NS], gq[(q + 1) % NS]);
     if (keeper) n_rej[k] = r_rej;
 }
 
