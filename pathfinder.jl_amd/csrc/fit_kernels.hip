@@ -28,18 +28,19 @@ template <int EPT, int HIST_NT>
 __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
     int d, int J, double eps, const int64_t *__restrict__ off, const double *__restrict__ theta,
     const double *__restrict__ grad, double *__restrict__ alpha_all, int *__restrict__ hist_len,
-    int *__restrict__ hist_src, int *__restrict__ n_rej) {
+    int *__restrict__ hist_src, int *__restrict__ n_rej, int *__restrict__ acc_list) {
     const int k = blockIdx.x, tid = threadIdx.x;
     const int64_t p0 = off[k];
     const int L = (int)(off[k + 1] - p0 - 1);
     __shared__ double red[2 * 4 * (HIST_NT / 64)];          // two halves: one barrier per iteration (pf_block_sum_pp)
     int flip = 0;
     // ring bookkeeping (src/inverse_hessian.jl:49-52, 105): every thread sees the same `accept` (the block sums are bit-identical
-    // in every lane), so the LAST thread keeps the state by itself (counters in registers, slots in LDS nobody else touches) and
-    // writes hist_len / hist_src with plain stores -- no serial section the other waves have to wait for
-    __shared__ int ring[64];                                 // touched by the keeper thread only (dynamic indexing: LDS, not scratch)
-    int r_ind = 0, r_eff = 0, r_rej = 0;
-    const bool keeper = tid == HIST_NT - 1;
+    // in every lane).  During the walk thread 0 only appends the accepted step to a list and stores the running count (two plain
+    // stores, nothing to wait for); the ring contents of every point -- the last min(count, J) accepted steps, oldest first, which
+    // is what mod1 / hist_inds produce -- are expanded from that list by all threads after the walk.  (Until round 2 a keeper
+    // thread rebuilt the ring row by row inside the loop: up to J dependent LDS reads + stores per step on the critical wave.)
+    int n_acc = 0;
+    int *const acc = acc_list + p0;                          // acc[k] = source index (l - 1) of the k-th accepted update of this path
 
     // The walk is sequential in l and every iteration needs two fresh rows (theta_l, grad_l) that nobody has touched before: with
     // the loads issued one iteration ahead the iteration time WAS the DRAM latency (3 us at config 3).  The rows of NS consecutive
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
     // pending loads at every join, so each step still paid a full memory round trip.
     // (EPT > 6: three sets -- 1024 threads have 128 VGPRs.)
     constexpr int NS = EPT <= 6 ? 4 : 3;
-    double al[EPT], tq[NS][EPT], gq[NS][EPT];
+    double al[EPT], ial[EPT], tq[NS][EPT], gq[NS][EPT];
     // unconditional loads from clamped addresses; points beyond L are never consumed, coordinates beyond d are zeroed where s and
     // y are formed (masking here would make the load's first use immediate)
     auto load_point = [&](const int pt, double (&tt)[EPT], double (&gg)[EPT]) {
@@ -64,22 +65,21 @@ __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int i = tid + HIST_NT * e;
-        al[e] = 1.0;                                                           // H0 = I  (:38-39)
+        al[e] = 1.0; ial[e] = 1.0;                                             // H0 = I  (:38-39)
         if (i < d) alpha_all[(size_t)p0 * d + i] = 1.0;
     }
 #pragma unroll
     for (int q = 0; q < NS; ++q) load_point(q, tq[q], gq[q]);                    // points 0 .. NS - 1
-    if (keeper) hist_len[p0] = 0;
+    if (tid == 0) hist_len[p0] = 0;
     // one trace step: (t0, g0) = point l - 1, (t1, g1) = point l; afterwards the set of point l - 1 is refilled
     auto step = [&](const int l, double (&t0)[EPT], double (&g0)[EPT], const double (&t1)[EPT], const double (&g1)[EPT]) {
         double v[4] = {0.0, 0.0, 0.0, 0.0};   // y.s, y.y, y'diag(a)y, s'diag(1/a)s
-        double ial[EPT], sv[EPT], yv[EPT];                                      // 1 / alpha: one division serves the c sum and the update
+        double sv[EPT], yv[EPT];
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             const bool in = tid + HIST_NT * e < d;
             const double s = in ? t1[e] - t0[e] : 0.0, y = in ? g0[e] - g1[e] : 0.0;   // :45-46
             sv[e] = s; yv[e] = y;
-            ial[e] = 1.0 / al[e];
             v[0] += y * s;
             v[1] += y * y;
             v[2] += y * al[e] * y;
@@ -89,30 +89,25 @@ __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
         pf_block_sum_pp<4, 4>(v, red, flip);
         const bool accept = v[0] > eps * v[1];                                  // :47
         if (accept) {                                                           // gilbert_init :5-10
-            const double a = v[2], b = v[0], c = v[3], aoc = a / c;
+            const double a = v[2], b = v[0], c = v[3], aoc = a / c, rb = 1.0 / b;
 #pragma unroll
             for (int e = 0; e < EPT; ++e) {
                 const double sa = sv[e] * ial[e];
-                al[e] = b / (a * ial[e] + yv[e] * yv[e] - aoc * sa * sa);
+                const double x = a * ial[e] + yv[e] * yv[e] - aoc * sa * sa;
+                al[e] = b / x;                                                  // the reference's formula, bit for bit
+                ial[e] = x * rb;                                                // 1 / alpha for the next step without a second division
             }
+            n_acc += 1;
         }
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             const int i = tid + HIST_NT * e;
             if (i < d) alpha_all[(size_t)(p0 + l) * d + i] = al[e];
         }
-        if (keeper) {
-            if (accept) {
-                r_ind = (r_ind % J) + 1;                                        // mod1 :49
-                if (r_ind > r_eff) r_eff = r_ind;                               // :50
-                ring[r_ind - 1] = l - 1;
-            } else {
-                r_rej += 1;                                                     // :57
-            }
-            hist_len[p0 + l] = r_eff;
-            int c = 0;                                                          // hist_inds :105
-            for (int t = r_ind + 1; t <= r_eff; ++t) hist_src[(size_t)(p0 + l) * J + c++] = ring[t - 1];
-            for (int t = 1; t <= r_ind; ++t) hist_src[(size_t)(p0 + l) * J + c++] = ring[t - 1];
+        if (tid == 0) {
+            if (accept) acc[n_acc - 1] = l - 1;
+            hist_len[p0 + l] = n_acc < J ? n_acc : J;                           // r_eff = max r_ind so far (:49-50)
+            hist_src[(size_t)(p0 + l) * J] = n_acc;                             // parked in the row's first slot until the expansion below
         }
     };
     int l = 1;
@@ -124,7 +119,20 @@ __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
 #pragma unroll
     for (int q = 0; q < NS - 1; ++q)
         if (q < rem) step(l + q, tq[q], gq[q], tq[(q + 1) % NS], gq[(q + 1) % NS]);
-    if (keeper) n_rej[k] = r_rej;
+    if (tid == 0) n_rej[k] = L > 0 ? L - n_acc : 0;                             // :57
+    // ---- hist_inds (:105) of every point from the accepted list: row l = the last min(n_acc(l), J) accepted steps, oldest first
+    __threadfence_block();
+    __syncthreads();
+    for (int q = 1 + tid; q <= L; q += HIST_NT) {
+        int *row = hist_src + (size_t)(p0 + q) * J;
+        const int na = row[0], re = na < J ? na : J;
+        int first = 0;
+        for (int c = 0; c < re; ++c) {
+            const int v = acc[na - re + c];
+            if (c == 0) first = v; else row[c] = v;
+        }
+        row[0] = re > 0 ? first : 0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -868,7 +876,8 @@ int32_t pf_launch_history(pfmi_ctx *c, double eps) {
 #define PF_HIST(E, NT)                                                                                           \
     hipLaunchKernelGGL((pf_history_kernel<E, NT>), dim3(c->K), dim3(NT), 0, c->stream, c->d, c->J, eps,           \
                        c->d_off.as<int64_t>(), c->theta.as<double>(), c->grad.as<double>(),                      \
-                       c->alpha_all.as<double>(), c->hist_len.as<int>(), c->hist_src.as<int>(), c->n_rej.as<int>())
+                       c->alpha_all.as<double>(), c->hist_len.as<int>(), c->hist_src.as<int>(), c->n_rej.as<int>(),          \
+                       c->hist_acc.as<int>())
     // the walk is sequential in l: one block reduction per iteration, cheaper across 4 waves than across 16
     // (a single wave for d <= 256: no cross-wave exchange at all)
     if (c->d <= 64) PF_HIST(1, 64); else if (c->d <= 128) PF_HIST(2, 64); else if (c->d <= 256) PF_HIST(4, 64);

@@ -109,7 +109,7 @@ int32_t pfmi_destroy(pfmi_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->theta, &c->grad, &c->d_off, &c->d_path_of, &c->target.mean, &c->target.a, &c->target.wd,
-                      &c->target.g, &c->target.wd16, &c->alpha_all, &c->hist_len, &c->hist_src, &c->n_rej, &c->vh, &c->tmat, &c->vchol,
+                      &c->target.g, &c->target.wd16, &c->alpha_all, &c->hist_len, &c->hist_src, &c->hist_acc, &c->n_rej, &c->vh, &c->tmat, &c->vchol,
                       &c->rq, &c->dmat, &c->sqrt_alpha, &c->mu, &c->logdet, &c->status, &c->seeds, &c->logp, &c->logq,
                       &c->elbo, &c->se, &c->best_iter, &c->fit_list, &c->ubuf, &c->xbuf, &c->scratch, &c->fit_scratch, &c->pool,
                       &c->pool_lr, &c->pool_lp, &c->pool_lq, &c->pool_points, &c->pool_seeds, &c->lw, &c->w,
@@ -318,6 +318,7 @@ int32_t pfmi_fit_batch(pfmi_ctx *c, int32_t J, double eps) {
     PF_TRY(c->alpha_all.ensure(sizeof(double) * P * d));
     PF_TRY(c->hist_len.ensure(sizeof(int32_t) * P));
     PF_TRY(c->hist_src.ensure(sizeof(int32_t) * P * J));
+    PF_TRY(c->hist_acc.ensure(sizeof(int32_t) * P));
     PF_TRY(c->n_rej.ensure(sizeof(int32_t) * c->K));
     PF_TRY(c->vh.ensure(sizeof(double) * P * d * kpad));
     PF_TRY(c->tmat.ensure(sizeof(double) * P * kk));

@@ -90,6 +90,7 @@ struct pfmi_ctx {
     DevBuf alpha_all;   // [P][d]
     DevBuf hist_len;    // int32 [P]
     DevBuf hist_src;    // int32 [P][J]
+    DevBuf hist_acc;    // int32 [P]: per path, the accepted updates in order (scratch of the history walk)
     DevBuf n_rej;       // int32 [K]
     DevBuf vh;          // [P][d][kpad] row-major Householder vectors (explicit unit diagonal)
     DevBuf tmat;        // [P][kpad][kpad] compact-WY T (row-major, upper)
