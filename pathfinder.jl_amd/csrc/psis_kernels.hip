@@ -25,6 +25,21 @@ __device__ __forceinline__ double pf_val_of(uint64_t k) {
     return __longlong_as_double((long long)b);
 }
 
+// for (i = tid; i < S; i += nt) f(i, vals[i]) with PF_SB loads in flight per thread: a single workgroup walks S = 64 000 values
+// a dozen times, and with one load per trip every trip cost an L2 round trip (0.30 ms for the whole kernel)
+#define PF_SB 8
+template <typename F>
+__device__ __forceinline__ void pf_foreach_batched(const double *vals, long long S, F f) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (long long i0 = tid; i0 < S; i0 += (long long)PF_SB * nt) {
+        double v[PF_SB];
+#pragma unroll
+        for (int u = 0; u < PF_SB; ++u) { const long long i = i0 + (long long)u * nt; v[u] = vals[i < S ? i : S - 1]; }
+#pragma unroll
+        for (int u = 0; u < PF_SB; ++u) { const long long i = i0 + (long long)u * nt; if (i < S) f(i, v[u]); }
+    }
+}
+
 struct SelectState {
     unsigned hist[256];
     unsigned long long prefix;
@@ -76,7 +91,7 @@ __device__ void pf_select_top_sorted(const double *__restrict__ vals, long long 
     int top_pass = 7;
     {
         uint64_t kmin = ~0ull, kmax = 0ull;
-        for (long long i = tid; i < S; i += nt) { const uint64_t k = pf_key_of(vals[i]); kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax; }
+        pf_foreach_batched(vals, S, [&](long long, double x) { const uint64_t k = pf_key_of(x); kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax; });
         for (int off = 32; off > 0; off >>= 1) {
             const uint64_t a = __shfl_xor(kmin, off, 64), b = __shfl_xor(kmax, off, 64);
             kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax;
@@ -96,10 +111,10 @@ __device__ void pf_select_top_sorted(const double *__restrict__ vals, long long 
         __syncthreads();
         const unsigned long long prefix = st->prefix;
         const unsigned long long himask = (pass == 7) ? 0ull : (~0ull << (8 * (pass + 1)));
-        for (long long i = tid; i < S; i += nt) {
-            const uint64_t k = pf_key_of(vals[i]);
+        pf_foreach_batched(vals, S, [&](long long, double x) {
+            const uint64_t k = pf_key_of(x);
             if ((k & himask) == prefix) atomicAdd(&st->hist[(unsigned)((k >> (8 * pass)) & 0xFF)], 1u);
-        }
+        });
         __syncthreads();
         pf_hist_pick(st, prefix, pass);
     }
@@ -115,10 +130,10 @@ __device__ void pf_select_top_sorted(const double *__restrict__ vals, long long 
         __syncthreads();
         const unsigned long long prefix = st->prefix;
         const unsigned long long himask = (pass == 3) ? 0ull : ((~0ull << (8 * (pass + 1))) & 0xFFFFFFFFull);
-        for (long long i = tid; i < S; i += nt) {
-            if (pf_key_of(vals[i]) == tk && (((unsigned long long)i) & himask) == prefix)
+        pf_foreach_batched(vals, S, [&](long long i, double x) {
+            if (pf_key_of(x) == tk && (((unsigned long long)i) & himask) == prefix)
                 atomicAdd(&st->hist[(unsigned)((i >> (8 * pass)) & 0xFF)], 1u);
-        }
+        });
         __syncthreads();
         pf_hist_pick(st, prefix, pass);
     }
@@ -129,13 +144,13 @@ __device__ void pf_select_top_sorted(const double *__restrict__ vals, long long 
     for (int t = tid; t < npow; t += nt) { tkeys[t] = ~0ull; tidx[t] = 0xFFFFFFFFu; }
     if (tid == 0) st->count = 0u;
     __syncthreads();
-    for (long long i = tid; i < S; i += nt) {
-        const uint64_t k = pf_key_of(vals[i]);
+    pf_foreach_batched(vals, S, [&](long long i, double x) {
+        const uint64_t k = pf_key_of(x);
         if (k > tk || (k == tk && (unsigned long long)i >= ti)) {
             const unsigned slot = atomicAdd(&st->count, 1u);
             if (slot < (unsigned)TAILCAP) { tkeys[slot] = k; tidx[slot] = (uint32_t)i; }
         }
-    }
+    });
     __syncthreads();
     for (int size = 2; size <= npow; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -165,8 +180,10 @@ __global__ __launch_bounds__(PSIS_THREADS) void pf_psis_kernel(long long S, cons
     __shared__ double s_theta[128], s_ll[128];
     __shared__ double s_sigma, s_mu;
 
-    for (long long i = tid; i < S; i += nt) lw[i] = lr[i];
     double pareto_k = NAN;
+    // lw is written once, at the end: everything but the M tail entries is lr - logsumexp, and the smoothed tail sits in LDS until then
+    bool have_sel = false, replaced = false;
+    uint64_t tk0 = 0; uint32_t ti0 = 0; double lmax_all = NAN, logu_all = NAN;
     if (tid == 0) s_sigma = NAN;
     __syncthreads();
     if (M >= 5 && M + 1 <= TAILCAP && (long long)(M + 1) <= S) {
@@ -175,6 +192,7 @@ __global__ __launch_bounds__(PSIS_THREADS) void pf_psis_kernel(long long S, cons
         double *w = reinterpret_cast<double *>(tkeys);
         const double logu = pf_val_of(tkeys[0]);
         const double lmax = pf_val_of(tkeys[M]);
+        have_sel = true; tk0 = tkeys[0]; ti0 = tidx[0]; lmax_all = lmax; logu_all = logu;
         double bad = 0.0;
         for (int t = 1 + tid; t <= M; t += nt) if (!isfinite(pf_val_of(tkeys[t]))) bad = 1.0;
         bad = pf_block_sum1(bad, red);
@@ -213,12 +231,14 @@ __global__ __launch_bounds__(PSIS_THREADS) void pf_psis_kernel(long long S, cons
                     }
                 }
                 __syncthreads();
-                if (tid == 0) {
+                if (tid < 64) {                                    // posterior-mean theta: wave 0, lanes over the grid
                     double lmx = -INFINITY;
-                    for (int i = 0; i < mest; ++i) if (s_ll[i] > lmx) lmx = s_ll[i];
+                    for (int i = lane; i < mest; i += 64) lmx = fmax(lmx, s_ll[i]);
+                    lmx = pf_wave_max(lmx);
                     double ws = 0.0, ts = 0.0;
-                    for (int i = 0; i < mest; ++i) { const double e = exp(s_ll[i] - lmx); ws += e; ts += e * s_theta[i]; }
-                    s_mu = ts / ws;   // posterior-mean theta
+                    for (int i = lane; i < mest; i += 64) { const double e = exp(s_ll[i] - lmx); ws += e; ts += e * s_theta[i]; }
+                    ws = pf_wave_sum(ws); ts = pf_wave_sum(ts);
+                    if (lane == 0) s_mu = ts / ws;
                 }
                 __syncthreads();
                 const double th = s_mu;
@@ -230,14 +250,16 @@ __global__ __launch_bounds__(PSIS_THREADS) void pf_psis_kernel(long long S, cons
                 if (isfinite(kk)) kadj = (kk * (double)M + 5.0) / ((double)M + 10.0);   // prior adjustment
                 pareto_k = kadj;
                 if (isfinite(kadj) && isfinite(sigma)) {
+                    __syncthreads();                               // everybody is done reading w[] (the kk sum above)
                     for (int t = tid; t < M; t += nt) {
                         const double p = ((double)(t + 1) - 0.5) / (double)M;
                         const double nl = -log1p(-p);
                         const double z = (kadj == 0.0) ? nl : expm1(kadj * nl) / kadj;
                         double v = log(sigma * z + mu_s);
                         if (v > 0.0) v = 0.0;
-                        lw[tidx[t + 1]] = v + lmax;
+                        w[t] = v + lmax;                           // smoothed log weight of element tidx[t + 1]
                     }
+                    replaced = true;
                 }
                 if (tid == 0) s_sigma = sigma;
             }
@@ -245,19 +267,41 @@ __global__ __launch_bounds__(PSIS_THREADS) void pf_psis_kernel(long long S, cons
     }
     __threadfence_block();
     __syncthreads();
-    // ---- log-normalise: lw -= logsumexp(lw); weights = exp(lw)
+    // ---- log-normalise: lw = (smoothed) log ratios - logsumexp; weights = exp(lw).  Two passes over lr: the maximum needs none --
+    //      the largest untouched element is the cutoff (or the overall maximum when nothing was replaced).
+    const double *wt = reinterpret_cast<const double *>(tkeys);
+    auto is_tail = [&](long long i, double x) {
+        const uint64_t k = pf_key_of(x);
+        return replaced && (k > tk0 || (k == tk0 && (uint64_t)i > (uint64_t)ti0));
+    };
     double mx = -INFINITY;
-    for (long long i = tid; i < S; i += nt) mx = fmax(mx, lw[i]);
-    mx = pf_block_max1(mx, red);
+    if (replaced) {
+        for (int t = tid; t < M; t += nt) mx = fmax(mx, wt[t]);
+        mx = fmax(pf_block_max1(mx, red), logu_all);
+    } else if (have_sel) mx = lmax_all;
+    else {
+        pf_foreach_batched(lr, S, [&](long long, double x) { mx = fmax(mx, x); });
+        mx = pf_block_max1(mx, red);
+    }
     __syncthreads();
     double se = 0.0;
-    if (isfinite(mx)) for (long long i = tid; i < S; i += nt) se += exp(lw[i] - mx);
+    if (isfinite(mx)) {
+        pf_foreach_batched(lr, S, [&](long long i, double x) { if (!is_tail(i, x)) se += exp(x - mx); });
+        if (replaced) for (int t = tid; t < M; t += nt) se += exp(wt[t] - mx);
+    }
     se = pf_block_sum1(se, red);
     const double lse = isfinite(mx) ? mx + log(se) : mx;
-    for (long long i = tid; i < S; i += nt) {
-        const double v = lw[i] - lse;
-        lw[i] = v;
-        wout[i] = exp(v);
+    pf_foreach_batched(lr, S, [&](long long i, double x) {
+        if (!is_tail(i, x)) {
+            const double v = x - lse;
+            lw[i] = v;
+            wout[i] = exp(v);
+        }
+    });
+    if (replaced) for (int t = tid; t < M; t += nt) {
+        const double v = wt[t] - lse;
+        lw[tidx[t + 1]] = v;
+        wout[tidx[t + 1]] = exp(v);
     }
     if (tid == 0) { out[0] = pareto_k; out[1] = (double)M; out[2] = s_sigma; out[3] = lse; }
 }
