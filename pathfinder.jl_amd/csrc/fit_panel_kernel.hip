@@ -283,7 +283,8 @@ __global__ __launch_bounds__(FP_NT, 1) void pf_fit_panel_kernel(FitArgs A, const
 #pragma unroll
                     for (int cc = 0; cc < PW; ++cc) srow[cc] = P[0][cc];
                 }
-                pf_block_sum_pp<PW, FP_NVMAX>(dots, red, flip);     // its barrier also publishes srow (double buffered)
+                if constexpr (PW % 4 == 0) pf_block_sum_mv<PW, FP_NVMAX>(dots, red, flip);     // its barrier also publishes srow (double buffered)
+                else pf_block_sum_pp<PW, FP_NVMAX>(dots, red, flip);
                 const double xn2 = dots[cl];
                 const double alpha_c = srow[cl];
                 const double xnorm = sqrt(xn2);
