@@ -589,7 +589,11 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
     // ---- Householder QR, one block reduction per column.  Thread aa < KPAD keeps row aa of the compact-WY T in
     //      registers (dlarft: T[0:c, c] = -tau T[0:c,0:c] (Vh' v_c)), so the column loop has no serial section.
     // (row aa of T lives in LDS and is only ever touched by thread aa: no barrier needed, and 2 KPAD fewer VGPRs)
-    for (int c = 0; c < k; ++c) {
+    // (fully unrolled: with a run-time column index every "column c of my rows" is a chain of KPAD v_cndmask pairs per row --
+    //  a quarter of the kernel's instructions at KPAD = 12, and the kernel is issue-bound with 3 waves per SIMD)
+#pragma unroll
+    for (int c = 0; c < KPAD; ++c) {
+        if (c >= k) continue;                 // (not `break`: an early exit keeps the optimizer from unrolling around the barrier)
         double *srow = sRow[c & 1];
         if (tid == c) {                       // row c belongs to thread c (slot 0): publish it
 #pragma unroll
