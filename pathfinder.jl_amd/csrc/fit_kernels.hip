@@ -575,11 +575,13 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
                     const double y = A.grad[q0] - A.grad[q1];
                     const double s = A.theta[q1] - A.theta[q0];
                     const double by = (al * y) * isa, bs = s * isa;
-                    // columns c and j + c (j is runtime: select statically unrolled targets)
+                    // columns c and j + c.  j is a run-time value: the usual full history (j = KPAD / 2: all but the first points of a
+                    // path) takes a static slot, shorter ones select among the statically unrolled targets
+                    a[i][c] = by;
+                    if (j == KPAD / 2) a[i][KPAD / 2 + c] = bs;
+                    else {
 #pragma unroll
-                    for (int cc = 0; cc < KPAD; ++cc) {
-                        if (cc == c) a[i][cc] = by;
-                        if (cc == j + c) a[i][cc] = bs;
+                        for (int cc = 0; cc < KPAD; ++cc) if (cc == j + c) a[i][cc] = bs;
                     }
                 }
             }
