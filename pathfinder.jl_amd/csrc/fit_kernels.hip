@@ -86,7 +86,7 @@ __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
             v[3] += s * ial[e] * s;
         }
         load_point(l - 1 + NS, t0, g0);                                         // refill: first needed NS - 2 steps from now
-        pf_block_sum_mv<4, 4>(v, red, flip);
+        pf_block_sum_mv<4, 4, HIST_NT / 64>(v, red, flip);
         const bool accept = v[0] > eps * v[1];                                  // :47
         if (accept) {                                                           // gilbert_init :5-10
             const double a = v[2], b = v[0], c = v[3], aoc = a / c, rb = 1.0 / b;
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
                 for (int cc = 0; cc < KPAD; ++cc) acc[cc] += xc * a[i][cc];
             }
         }
-        pf_block_sum_mv<KPAD, NVMAX>(acc, red, flip);       // its barriers also publish srow (double buffered: no trailing barrier)
+        pf_block_sum_mv<KPAD, NVMAX>(acc, red, flip);     // (run-time wave count on purpose: the static form makes the compiler hoist 4 KPAD LDS reads and spill)       // its barriers also publish srow (double buffered: no trailing barrier)
         double xn2 = 0.0;
 #pragma unroll
         for (int cc = 0; cc < KPAD; ++cc) if (cc == c) xn2 = acc[cc];
@@ -806,7 +806,7 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
     for (int i = 0; i < RPT; ++i)
 #pragma unroll
         for (int cc = 0; cc < KPAD; ++cc) acc[cc] += agv[i] * a[i][cc];
-    pf_block_sum_mv<KPAD, NVMAX>(acc, red, flip);
+    pf_block_sum_mv<KPAD, NVMAX>(acc, red, flip);     // (run-time wave count on purpose: the static form makes the compiler hoist 4 KPAD LDS reads and spill)
     double t1[KPAD];                          // t1 = T' w1 (every thread, from LDS T)
 #pragma unroll
     for (int aa = 0; aa < KPAD; ++aa) {
@@ -850,7 +850,7 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
             for (int cc = 0; cc < KPAD; ++cc) acc[cc] += bv[i] * a[i][cc];
         }
     }
-    pf_block_sum_mv<KPAD, NVMAX>(acc, red, flip);
+    pf_block_sum_mv<KPAD, NVMAX>(acc, red, flip);     // (run-time wave count on purpose: the static form makes the compiler hoist 4 KPAD LDS reads and spill)
 #pragma unroll
     for (int aa = 0; aa < KPAD; ++aa) {       // t2 = T w2
         double v = 0.0;

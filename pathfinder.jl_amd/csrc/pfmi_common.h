@@ -409,9 +409,11 @@ __device__ __forceinline__ void pf_block_sum(double (&v)[NV], double *red) {
 // Same with ONE barrier per reduction: consecutive reductions alternate between two scratch halves (`flip`), so the barrier
 // that publishes reduction n + 1 also guarantees that everybody finished reading reduction n's half before reduction n + 2
 // overwrites it.  `red` holds 2 * (blockDim.x / 64) * NVMAX doubles; every thread must make the same sequence of calls.
-template <int NV, int NVMAX>
+// NW = number of waves of the workgroup when it is a compile-time constant (0: read blockDim): with a run-time wave count the
+// cross-wave sum is a loop of dependent LDS reads with an s_waitcnt each; a static count lets all reads fly at once.
+template <int NV, int NVMAX, int NW = 0>
 __device__ __forceinline__ void pf_block_sum_pp(double (&v)[NV], double *red, int &flip) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = NW ? NW : (int)(blockDim.x >> 6);
     double *buf = red + flip * (nw * NVMAX);
     flip ^= 1;
 #pragma unroll
@@ -421,11 +423,21 @@ __device__ __forceinline__ void pf_block_sum_pp(double (&v)[NV], double *red, in
         for (int i = 0; i < NV; ++i) buf[wave * NV + i] = v[i];
     }
     __syncthreads();
+    if (NW) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        double s = buf[i];
-        for (int w = 1; w < nw; ++w) s += buf[w * NV + i];
-        v[i] = s;
+        for (int i = 0; i < NV; ++i) {
+            double s = buf[i];
+#pragma unroll
+            for (int w = 1; w < (NW ? NW : 1); ++w) s += buf[w * NV + i];
+            v[i] = s;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            double s = buf[i];
+            for (int w = 1; w < nw; ++w) s += buf[w * NV + i];
+            v[i] = s;
+        }
     }
 }
 // ---- multi-value butterfly (NV % 4 == 0): the wave sums of NV values in NV/2 + NV/4 permlane-swap steps plus 4 DPP steps on NV/4
@@ -446,10 +458,10 @@ __device__ __forceinline__ double pf_swap16_add(double a, double b) {
     const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
     return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
 }
-template <int NV, int NVMAX>
+template <int NV, int NVMAX, int NW = 0>
 __device__ __forceinline__ void pf_block_sum_mv(double (&v)[NV], double *red, int &flip) {
     static_assert(NV % 4 == 0, "pf_block_sum_mv: NV must be a multiple of 4");
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = NW ? NW : (int)(blockDim.x >> 6);
     double *buf = red + flip * (nw * NVMAX);
     flip ^= 1;
     double r[NV / 2], q[NV / 4];
@@ -469,27 +481,46 @@ __device__ __forceinline__ void pf_block_sum_mv(double (&v)[NV], double *red, in
         for (int j = 0; j < NV / 4; ++j) buf[wave * NV + (lane >> 4) * (NV / 4) + j] = q[j];
     }
     __syncthreads();
+    if (NW) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        double s = buf[i];
-        for (int w = 1; w < nw; ++w) s += buf[w * NV + i];
-        v[i] = s;
+        for (int i = 0; i < NV; ++i) {
+            double s = buf[i];
+#pragma unroll
+            for (int w = 1; w < (NW ? NW : 1); ++w) s += buf[w * NV + i];      // same order as the run-time loop
+            v[i] = s;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            double s = buf[i];
+            for (int w = 1; w < nw; ++w) s += buf[w * NV + i];
+            v[i] = s;
+        }
     }
 }
-template <int NVMAX>
+template <int NVMAX, int NW = 0>
 __device__ __forceinline__ double pf_block_sum1_pp(double x, double *red, int &flip) {
     double v[1] = {x};
-    pf_block_sum_pp<1, NVMAX>(v, red, flip);
+    pf_block_sum_pp<1, NVMAX, NW>(v, red, flip);
     return v[0];
 }
-template <int NVMAX>
+template <int NVMAX, int NW = 0>
 __device__ __forceinline__ double pf_block_max1_pp(double x, double *red, int &flip) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = NW ? NW : (int)(blockDim.x >> 6);
     double *buf = red + flip * (nw * NVMAX);
     flip ^= 1;
     x = pf_wave_max(x);
     if (lane == 0) buf[wave] = x;
     __syncthreads();
+    if (NW) {
+        double t[NW ? NW : 1];
+#pragma unroll
+        for (int w = 0; w < (NW ? NW : 1); ++w) t[w] = buf[w];
+        double s = t[0];
+#pragma unroll
+        for (int w = 1; w < (NW ? NW : 1); ++w) s = fmax(s, t[w]);
+        return s;
+    }
     double s = buf[0];
     for (int w = 1; w < nw; ++w) s = fmax(s, buf[w]);
     return s;
