@@ -28,6 +28,11 @@ struct LbfgsArgs {
 template <int EPT, int NT, int RPAD>
 struct LbfgsState {
     double x[EPT], g[EPT], p[EPT], xn[EPT], gn[EPT], mean[EPT], av[EPT];
+    // this thread's rows of the low-rank target factor, when they fit in registers (256-thread workgroups run one wave per SIMD: 512
+    // registers each): both sweeps of every function evaluation used to re-load them from L2 inside the line search's critical path
+    static constexpr bool WD_REG = (RPAD > 0) && (EPT * RPAD <= 64);
+    double wdr[WD_REG ? EPT : 1][WD_REG ? RPAD : 1];
+    const double *gm;                        // r x r factor (LDS copy)
     double fn;
 };
 
@@ -36,9 +41,10 @@ template <int EPT, int NT, int RPAD>
 __device__ __forceinline__ void lb_eval(const LbfgsArgs &A, LbfgsState<EPT, NT, RPAD> &S, double a, double *red, int &flip, double &f,
                                         double &dphi) {
     const int tid = threadIdx.x, d = A.d;
-    double v[RPAD + 2];
+    constexpr int NVP = (RPAD + 2 + 3) / 4 * 4;            // padded to a multiple of 4: multi-value butterfly reduction
+    double v[NVP];
 #pragma unroll
-    for (int j = 0; j < RPAD + 2; ++j) v[j] = 0.0;
+    for (int j = 0; j < NVP; ++j) v[j] = 0.0;
     if (A.kind == PFMI_TARGET_FUNNEL) {
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
@@ -47,7 +53,7 @@ __device__ __forceinline__ void lb_eval(const LbfgsArgs &A, LbfgsState<EPT, NT, 
             if (i == 0) v[1] = S.xn[e];
             else if (i < d) v[0] += S.xn[e] * S.xn[e];
         }
-        pf_block_sum_pp<RPAD + 2, RPAD + 4, NT / 64>(v, red, flip);
+        pf_block_sum_pp<NVP, RPAD + 4, NT / 64>(v, red, flip);
         const double tau = v[1], ss = v[0], ee = exp(-tau), dm1 = (double)(d - 1);
         f = 0.5 * ((tau / 3.0) * (tau / 3.0) + dm1 * tau + ee * ss);
 #pragma unroll
@@ -64,12 +70,17 @@ __device__ __forceinline__ void lb_eval(const LbfgsArgs &A, LbfgsState<EPT, NT, 
             ev[e] = S.xn[e] - S.mean[e];
             v[0] += S.av[e] * ev[e] * ev[e];
             if (RPAD > 0 && i < d) {
-                const double *row = A.wd + (size_t)i * RPAD;
+                if constexpr (LbfgsState<EPT, NT, RPAD>::WD_REG) {
 #pragma unroll
-                for (int j = 0; j < RPAD; ++j) v[2 + j] += row[j] * ev[e];
+                    for (int j = 0; j < RPAD; ++j) v[2 + j] += S.wdr[e][j] * ev[e];
+                } else {
+                    const double *row = A.wd + (size_t)i * RPAD;
+#pragma unroll
+                    for (int j = 0; j < RPAD; ++j) v[2 + j] += row[j] * ev[e];
+                }
             }
         }
-        pf_block_sum_pp<RPAD + 2, RPAD + 4, NT / 64>(v, red, flip);
+        pf_block_sum_pp<NVP, RPAD + 4, NT / 64>(v, red, flip);
         double corr = 0.0;
         double hh[RPAD > 0 ? RPAD : 1];
         if (RPAD > 0) {
@@ -78,7 +89,7 @@ __device__ __forceinline__ void lb_eval(const LbfgsArgs &A, LbfgsState<EPT, NT, 
             for (int j = 0; j < RPAD; ++j) {
                 double s = 0.0;
 #pragma unroll
-                for (int l = 0; l <= j; ++l) s += A.gm[j * RPAD + l] * v[2 + l];
+                for (int l = 0; l <= j; ++l) s += S.gm[j * RPAD + l] * v[2 + l];
                 gg[j] = s;
                 corr += s * s;
             }
@@ -86,7 +97,7 @@ __device__ __forceinline__ void lb_eval(const LbfgsArgs &A, LbfgsState<EPT, NT, 
             for (int l = 0; l < RPAD; ++l) {
                 double s = 0.0;
 #pragma unroll
-                for (int j = l; j < RPAD; ++j) s += A.gm[j * RPAD + l] * gg[j];
+                for (int j = l; j < RPAD; ++j) s += S.gm[j * RPAD + l] * gg[j];
                 hh[l] = s;
             }
         }
@@ -96,9 +107,14 @@ __device__ __forceinline__ void lb_eval(const LbfgsArgs &A, LbfgsState<EPT, NT, 
             const int i = tid + e * NT;
             double gv = S.av[e] * ev[e];
             if (RPAD > 0 && i < d) {
-                const double *row = A.wd + (size_t)i * RPAD;
+                if constexpr (LbfgsState<EPT, NT, RPAD>::WD_REG) {
 #pragma unroll
-                for (int j = 0; j < RPAD; ++j) gv -= row[j] * hh[j];
+                    for (int j = 0; j < RPAD; ++j) gv -= S.wdr[e][j] * hh[j];
+                } else {
+                    const double *row = A.wd + (size_t)i * RPAD;
+#pragma unroll
+                    for (int j = 0; j < RPAD; ++j) gv -= row[j] * hh[j];
+                }
             }
             S.gn[e] = gv;
         }
@@ -151,6 +167,8 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
     __shared__ double red[2 * (NT / 64) * (RPAD + 4)];   // two halves: one barrier per block reduction (pf_block_sum_pp)
     int flip = 0;
     __shared__ double s_rho[16], s_al[16];
+    __shared__ double s_gm[RPAD > 0 ? RPAD * RPAD : 1];      // the target's r x r Cholesky factor: read in every function evaluation
+    if (RPAD > 0) { for (int t = threadIdx.x; t < RPAD * RPAD; t += NT) s_gm[t] = A.gm[t]; __syncthreads(); }
     const int k = blockIdx.x, tid = threadIdx.x, d = A.d, J = A.J;
     double *hs = A.hist_in_lds ? lb_dyn : A.hs + (size_t)k * J * d;
     double *hy = A.hist_in_lds ? lb_dyn + (size_t)J * d : A.hy + (size_t)k * J * d;
@@ -159,6 +177,7 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
     double *tr_lp = A.tr_lp + (size_t)k * tcap;
 
     LbfgsState<EPT, NT, RPAD> S;
+    S.gm = s_gm;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int i = tid + e * NT;
@@ -167,6 +186,10 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
         S.p[e] = 0.0;
         S.mean[e] = (act && A.kind == PFMI_TARGET_GAUSS) ? A.mean[i] : 0.0;
         S.av[e] = (act && A.kind == PFMI_TARGET_GAUSS) ? A.a[i] : 0.0;
+        if constexpr (LbfgsState<EPT, NT, RPAD>::WD_REG) {
+#pragma unroll
+            for (int j = 0; j < RPAD; ++j) S.wdr[e][j] = act ? A.wd[(size_t)i * RPAD + j] : 0.0;
+        }
     }
     double f, dphi;
     lb_eval<EPT, NT, RPAD>(A, S, 0.0, red, flip, f, dphi);
