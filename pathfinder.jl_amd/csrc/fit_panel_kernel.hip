@@ -3,8 +3,8 @@
 // Same outputs and the same LAPACK reflector convention as pf_fit_kernel (fit_kernels.hip; reference
 // src/inverse_hessian.jl:98-133, src/woodbury.jl:201-207, src/mvnormal.jl:14-21), organised around HBM traffic: at
 // d = 10^4, J = 10 the d x 2J block is 1.6 MB per fit, lives in HBM, and the column-by-column kernel sweeps it ~50 times
-// (80 MB per fit).  Here a persistent 1024-thread workgroup per CU factors the block in panels of PW columns that live in
-// REGISTERS (thread t owns rows t + 1024 i), left-looking:
+// (80 MB per fit).  Here a persistent 512-thread workgroup per CU factors the block in panels of PW columns that live in
+// REGISTERS (thread t owns rows t + 512 i), left-looking:
 //
 //   phase A   inputs -> scaled block B~ = U'\[alpha.Y  S], column-major into a per-workgroup scratch (panel 0 stays in
 //             registers); sqrt(alpha), log det U

@@ -690,13 +690,16 @@ def test_woodbury_operator_surface(pfmi_mod, eng, name, K, J):
 
 # ---- device trajectory generation -----------------------------------------------------
 @pytest.mark.parametrize("name,d,scale,maxit", [("iso", 10, 2, 1000), ("diag", 30, 2, 1000), ("lr", 50, 2, 1000), ("funnel", 12, 10, 60),
-                                               ("lr", 1000, 2, 1000), ("diag", 3000, 2, 200)])
+                                               ("lr", 1000, 2, 1000), ("diag", 3000, 2, 200), ("lr16", 600, 2, 1000), ("lr11", 200, 2, 1000),
+                                               ("lr", 1500, 2, 300)])
 def test_device_lbfgs_traces_match_oracle_driver(pfmi_mod, eng, name, d, scale, maxit):
     """pfmi_optimize_batch vs oracle pfo_optimize_trace (same algorithm, scalar C): early iterates agree to roundoff
     (later ones drift apart through line-search branches, as between any two L-BFGS implementations), every recorded
     (logp, grad) belongs to its recorded point, the objective never increases, Gaussian targets converge to g_tol.
-    d = 1000 exercises the LDS ring, d = 3000 the global ring and the 1024-thread variant."""
+    d = 1000 exercises the LDS ring, d = 3000 the global ring and the 1024-thread variant; rank 16 / 11 the 16-column padding of the
+    low-rank factor (its rows cached in registers), d = 1500 the low-rank target with rows re-read from memory."""
     tg = {"iso": pfmi_mod.t_iso, "diag": lambda d: pfmi_mod.t_diag(d, 1), "lr": lambda d: pfmi_mod.t_lowrank(d, 8, 2),
+          "lr16": lambda d: pfmi_mod.t_lowrank(d, 16, 3), "lr11": lambda d: pfmi_mod.t_lowrank(d, 11, 4),
           "funnel": pfmi_mod.t_funnel}[name](d)
     ot = oracle_target(tg)
     K = 3
