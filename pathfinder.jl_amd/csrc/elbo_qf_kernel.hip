@@ -438,58 +438,59 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
             if (TGT != 0) {
                 double qs = q12[g];
                 qs = pf_sum_q(qs);
-                double tv[KC];
+                // The small matrix-vector products of the 16 draws run on v_mfma_f64_16x16x4: lane (q, c) holds entries 4T + q of
+                // draw c, which is both the B-operand layout (k = q, column = draw) and -- rows q + 4 reg -- the result layout, so
+                // y = Mat x needs no cross-lane step at all; the A operand is Mat[row 16 rt + c][4 s + q] straight from LDS.  (Until
+                // round 2 every entry of T w was a 4-lane shuffle sum and M tv, Nn tv ran on the VALU with tv replicated: 375 VALU +
+                // 86 LDS instructions per group.)
+                auto matvec = [&](const double *Mat, const int ld, const int nrows, auto nx_tag, auto ny_tag, auto lower_tag,
+                                  const double (&x)[decltype(nx_tag)::value], double (&y)[decltype(ny_tag)::value]) {
+                    constexpr int NX = decltype(nx_tag)::value, NY = decltype(ny_tag)::value;
+                    constexpr bool LOWER = decltype(lower_tag)::value;
 #pragma unroll
-                for (int a = 0; a < KC; ++a) {
-                    double s = 0.0;
+                    for (int rt = 0; rt < (NY + 3) / 4; ++rt) {
+                        qf_d4 acc = {0.0, 0.0, 0.0, 0.0};
+                        const int row = 16 * rt + c;
 #pragma unroll
-                    for (int T = 0; T < NT; ++T) s = fma(t_s[a * KC + 4 * T + q], accw[g][T], s);
-                    s = pf_sum_q(s);
-                    tv[a] = s;
-                }
+                        for (int st = 0; st < NX; ++st) {
+                            const int col = 4 * st + q;
+                            const bool ok = row < nrows && (!LOWER || col <= row);
+                            const double av = ok ? Mat[row * ld + col] : 0.0;
+                            acc = qf_mfma16(av, x[st], acc);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (4 * rt + r < NY) y[4 * rt + r] = acc[r];
+                    }
+                };
                 const double *vv = cn_s + 4, *Mm = cn_s + 4 + KC, *t0 = Mm + KC * KC, *Nn = t0 + RPAD, *vh0 = Nn + RPAD * KC;
+                double tvd[NT], mt[NT];                                   // entries 4T + q of tv = T w and of M tv
+                matvec(t_s, KC, KC, std::integral_constant<int, NT>{}, std::integral_constant<int, NT>{}, std::false_type{}, accw[g], tvd);
+                matvec(Mm, KC, KC, std::integral_constant<int, NT>{}, std::integral_constant<int, NT>{}, std::false_type{}, tvd, mt);
                 double qa = 0.0;
 #pragma unroll
-                for (int T = 0; T < NT; ++T) {
-                    const int a = 4 * T + q;
-                    double mt = 0.0, tva = 0.0;
-#pragma unroll
-                    for (int b = 0; b < KC; ++b) mt = fma(Mm[a * KC + b], tv[b], mt);
-#pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) tva = (q == qq) ? tv[4 * T + qq] : tva;
-                    qa = fma(tva, mt - 2.0 * (vv[a] + acc3[g][T]), qa);
-                }
+                for (int T = 0; T < NT; ++T) qa = fma(tvd[T], mt[T] - 2.0 * (vv[4 * T + q] + acc3[g][T]), qa);
                 qa = pf_sum_q(qa);
                 const double q1 = cn_s[0] + qs + qa;
                 if (TGT == 1) {
                     double corr = 0.0;
                     if (RPAD > 0) {
-                        double tt[TR > 0 ? TR : 1];
+                        constexpr int TRr = TR > 0 ? TR : 1;
+                        double nt[TRr], tt[TRr], gg[TRr];
+                        matvec(Nn, KC, RPAD, std::integral_constant<int, NT>{}, std::integral_constant<int, TRr>{}, std::false_type{}, tvd, nt);
 #pragma unroll
-                        for (int T = 0; T < TR; ++T) {
-                            const int j = 4 * T + q;
-                            double s = t0[j] + acc4[g][T];
+                        for (int T = 0; T < TR; ++T) tt[T] = t0[4 * T + q] + acc4[g][T] - nt[T];
+                        matvec(g_s, RPAD, RPAD, std::integral_constant<int, TRr>{}, std::integral_constant<int, TRr>{}, std::true_type{}, tt, gg);
 #pragma unroll
-                            for (int b = 0; b < KC; ++b) s = fma(-Nn[j * KC + b], tv[b], s);
-                            tt[T] = s;
-                        }
-                        double tall[RPAD > 0 ? RPAD : 1];
-#pragma unroll
-                        for (int j = 0; j < RPAD; ++j) tall[j] = __shfl(tt[j >> 2], (j & 3) * 16 + c, 64);
-#pragma unroll
-                        for (int j = 0; j < RPAD; ++j) {
-                            double gg = 0.0;
-#pragma unroll
-                            for (int l = 0; l <= j; ++l) gg = fma(g_s[j * RPAD + l], tall[l], gg);
-                            corr = fma(gg, gg, corr);
-                        }
+                        for (int T = 0; T < TR; ++T) corr = fma(gg[T], gg[T], corr);
+                        corr = pf_sum_q(corr);
                     }
                     lp = A.t_offset - 0.5 * (q1 - corr);
                 } else {                                                   // funnel: tau = x_1, ss = sum_{i>=2} x_i^2
                     const double zh = __shfl(z00[g], c, 64);
                     double pr = 0.0;
 #pragma unroll
-                    for (int b = 0; b < KC; ++b) pr = fma(vh0[b], tv[b], pr);
+                    for (int T = 0; T < NT; ++T) pr = fma(vh0[4 * T + q], tvd[T], pr);
+                    pr = pf_sum_q(pr);
                     const double ta = cn_s[1] + cn_s[2] * (zh - pr), t3 = ta / 3.0;
                     lp = (t3 * t3 + (double)(d - 1) * ta + q1 * exp(-ta)) / -2.0;
                 }

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
             v[3] += s * ial[e] * s;
         }
         load_point(l - 1 + NS, t0, g0);                                         // refill: first needed NS - 2 steps from now
-        pf_block_sum_mv<4, 4, HIST_NT / 64>(v, red, flip);
+        pf_block_sum_mv<4, 4, (HIST_NT <= 256 ? HIST_NT / 64 : 0)>(v, red, flip);   // static wave count only for <= 4 waves (16 waves: register pressure)
         const bool accept = v[0] > eps * v[1];                                  // :47
         if (accept) {                                                           // gilbert_init :5-10
             const double a = v[2], b = v[0], c = v[3], aoc = a / c, rb = 1.0 / b;

@@ -53,7 +53,7 @@ __device__ __forceinline__ void lb_eval(const LbfgsArgs &A, LbfgsState<EPT, NT, 
             if (i == 0) v[1] = S.xn[e];
             else if (i < d) v[0] += S.xn[e] * S.xn[e];
         }
-        pf_block_sum_pp<NVP, RPAD + 4, NT / 64>(v, red, flip);
+        pf_block_sum_pp<NVP, RPAD + 4, (NT <= 256 ? NT / 64 : 0)>(v, red, flip);
         const double tau = v[1], ss = v[0], ee = exp(-tau), dm1 = (double)(d - 1);
         f = 0.5 * ((tau / 3.0) * (tau / 3.0) + dm1 * tau + ee * ss);
 #pragma unroll
@@ -80,7 +80,7 @@ __device__ __forceinline__ void lb_eval(const LbfgsArgs &A, LbfgsState<EPT, NT, 
                 }
             }
         }
-        pf_block_sum_pp<NVP, RPAD + 4, NT / 64>(v, red, flip);
+        pf_block_sum_pp<NVP, RPAD + 4, (NT <= 256 ? NT / 64 : 0)>(v, red, flip);
         double corr = 0.0;
         double hh[RPAD > 0 ? RPAD : 1];
         if (RPAD > 0) {
@@ -122,7 +122,7 @@ __device__ __forceinline__ void lb_eval(const LbfgsArgs &A, LbfgsState<EPT, NT, 
     double dp = 0.0;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) dp += S.gn[e] * S.p[e];
-    dphi = pf_block_sum1_pp<RPAD + 4, NT / 64>(dp, red, flip);
+    dphi = pf_block_sum1_pp<RPAD + 4, (NT <= 256 ? NT / 64 : 0)>(dp, red, flip);
     S.fn = f;
 }
 
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
         double gm = 0.0;
 #pragma unroll
         for (int e = 0; e < EPT; ++e) gm = fmax(gm, isfinite(S.g[e]) ? fabs(S.g[e]) : INFINITY);
-        gm = pf_block_max1_pp<RPAD + 4, NT / 64>(gm, red, flip);
+        gm = pf_block_max1_pp<RPAD + 4, (NT <= 256 ? NT / 64 : 0)>(gm, red, flip);
         if (!isfinite(f) || !(gm < INFINITY)) break;                   // src/optimize.jl:103-105
         if (gm <= A.g_tol) break;
         // ---- two-loop recursion: q = H g
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
                 yv[e] = i < d ? y[i] : 0.0;
                 sq += (i < d ? s[i] : 0.0) * q[e];
             }
-            sq = pf_block_sum1_pp<RPAD + 4, NT / 64>(sq, red, flip);
+            sq = pf_block_sum1_pp<RPAD + 4, (NT <= 256 ? NT / 64 : 0)>(sq, red, flip);
             const double al = s_rho[slot] * sq;
             if (tid == 0) s_al[slot] = al;
 #pragma unroll
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
                 sv[e] = i < d ? s[i] : 0.0;
                 yq += (i < d ? y[i] : 0.0) * q[e];
             }
-            yq = pf_block_sum1_pp<RPAD + 4, NT / 64>(yq, red, flip);
+            yq = pf_block_sum1_pp<RPAD + 4, (NT <= 256 ? NT / 64 : 0)>(yq, red, flip);
             const double co = s_al[slot] - s_rho[slot] * yq;
 #pragma unroll
             for (int e = 0; e < EPT; ++e) q[e] += co * sv[e];
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
         double v2[2] = {0.0, 0.0};
 #pragma unroll
         for (int e = 0; e < EPT; ++e) { S.p[e] = -q[e]; v2[0] += S.g[e] * S.p[e]; v2[1] += S.g[e] * S.g[e]; }
-        pf_block_sum_pp<2, RPAD + 4, NT / 64>(v2, red, flip);
+        pf_block_sum_pp<2, RPAD + 4, (NT <= 256 ? NT / 64 : 0)>(v2, red, flip);
         double g0 = v2[0];
         if (g0 >= 0) {                                                  // not a descent direction: restart
             h = 0; head = 0;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
             v4[2] += (S.xn[e] != S.x[e]) ? 1.0 : 0.0;
             v4[3] += isfinite(S.gn[e]) ? 0.0 : 1.0;
         }
-        pf_block_sum_pp<4, RPAD + 4, NT / 64>(v4, red, flip);
+        pf_block_sum_pp<4, RPAD + 4, (NT <= 256 ? NT / 64 : 0)>(v4, red, flip);
         if (!isfinite(S.fn) || v4[3] > 0.0) break;
         if (v4[0] > 1e-10 * v4[1]) {
             if (h == J) { head = (head + 1) % J; h = J - 1; }
