@@ -329,10 +329,10 @@ def main():
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                     "label": "equivalent materialised-draw bandwidth: algorithmic bytes of SURVEY 8(d) / measured launch time "
-                             "(the fused kernel moves < 3 % of them; HBM is idle)",
+                             "(the fused kernel moves < 3 % of them; HBM is idle, so the fraction can pass 1.0 -- the real bound is instruction issue, see mfma_f64)",
                     "mfma_f64": {"achieved": round(mfma_tf, 2), "peak": 78.6, "unit": "TFLOP/s", "frac": round(mfma_tf / 78.6, 4),
                                  "note": "f64 MFMA flops of the scan / launch time; the kernel's floor is the SUM of its MFMA and VALU "
-                                         "issue streams (no co-issue on gfx950, profiles/r02_coissue_microbench.txt): ~80 % of that floor, DESIGN.md 4.1"},
+                                         "issue streams (no co-issue on gfx950, profiles/r02_coissue_microbench.txt): ~84 % of that floor, DESIGN.md 4.1"},
                     "kernel": "pf_elbo_qf_kernel (single-pass ELBO scan)",
                     "launches": int(n), "avg_launch_ms": round(ms / max(n, 1), 4),
                     "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_draw": bytes_per_draw,
