@@ -483,4 +483,11 @@ function LinearAlgebra.diag(W::DeviceWoodbury)                                  
     return out
 end
 
+# inv(W) and W * c (src/woodbury.jl:317-321, 357-360) build new Pathfinder.WoodburyPDMat objects on the host: materialise the fit
+# (pfmi_get_fit -> Pathfinder.WoodburyPDMat with its WoodburyPDFactorization) and let the reference's own methods do the rest.
+materialise(W::DeviceWoodbury) = fit_distribution(W.b, W.point).Σ
+Base.inv(W::DeviceWoodbury) = inv(materialise(W))
+Base.:*(W::DeviceWoodbury, c::Real) = materialise(W) * c
+Base.:*(c::Real, W::DeviceWoodbury) = W * c
+
 end # module

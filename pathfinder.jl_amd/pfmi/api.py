@@ -79,6 +79,8 @@ class WoodburyPDMat:                # src/woodbury.jl:246-257
         return np.diag(self.A) + self.B @ self.D @ self.B.T
 
     def _op(self, op, x):
+        if self.engine is None:
+            raise RuntimeError("this WoodburyPDMat was built on the host (inv / scaling): it has no device factor")
         self.engine.check_token(self.token, "WoodburyPDMat")
         return self.engine.woodbury_apply(self.point, op, x)
 
@@ -92,8 +94,41 @@ class WoodburyPDMat:                # src/woodbury.jl:246-257
     def invquad(self, x): return self._op("invquad", x)
 
     def diag(self):
+        if self.engine is None:
+            return self.A + np.einsum("ij,jk,ik->i", self.B, self.D, self.B)
         self.engine.check_token(self.token, "WoodburyPDMat")
         return self.engine.woodbury_diag(self.point)
+
+    # inv(W) and W * c build NEW WoodburyPDMat objects on the host from the downloaded pieces, exactly as the reference does
+    # (src/woodbury.jl:50-52, 218-223, 317-321, 357-360); they carry no engine handle (dense() / diag() work, the device operators do not).
+    def thin_Q(self):
+        """first k columns of Q = I - Vh T Vh' (Vh = unit-lower Householder vectors of F.Q_factors)"""
+        d, k = self.B.shape[0], self.F.V.shape[0]
+        Vh = np.tril(self.F.Q_factors[:, :k], -1) + np.eye(d, k)
+        Q1 = -Vh @ (self.F.Q_T @ Vh[:k, :].T)
+        Q1[:k, :] += np.eye(k)
+        return Q1
+
+    def inv(self):
+        """inv(W) = WoodburyPDMat(pdunfactorize(inv(F))...): F^-1 = (U'^-1, Q, V'^-1), A = U'U, B = U'Q, D = V'V - I"""
+        Ui = 1.0 / self.F.U                                       # inv(U') of the diagonal U
+        k = self.F.V.shape[0]
+        Vi = np.linalg.solve(self.F.V.T, np.eye(k)) if k else np.zeros((0, 0))     # inv(V'): lower triangular
+        Fi = WoodburyPDFactorization(Ui, self.F.Q_factors, self.F.Q_T, Vi)
+        B = Ui[:, None] * self.thin_Q()
+        D = Vi.T @ Vi - np.eye(k)
+        return WoodburyPDMat(Ui * Ui, B, D, Fi, -self.logdet)
+
+    def __mul__(self, c):
+        """W * c (src/woodbury.jl:357-360): c > 0 -> WoodburyPDMat(A c, B, D c), otherwise the dense matrix times c"""
+        c = float(c)
+        if not c > 0:
+            return self.dense() * c
+        sc = np.sqrt(c)
+        F = WoodburyPDFactorization(self.F.U * sc, self.F.Q_factors, self.F.Q_T, None)     # V of the scaled matrix is not formed
+        return WoodburyPDMat(self.A * c, self.B.copy(), self.D * c, F, self.logdet + len(self.A) * np.log(c))
+
+    __rmul__ = __mul__
 
 
 @dataclass

@@ -568,3 +568,32 @@ def test_bench_force_dist_counts_its_ranks(comm_mode):
     assert line["n_gpus"] == 1 and line["config"]["ranks_in_collective"] == 1
     assert line["config"]["collective_backend"].startswith("RCCL" if comm_mode == "c_abi" else "torch.distributed")
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
+
+
+@pytest.mark.gpu
+def test_woodbury_inv_and_scaling_build_host_objects(pfmi_mod):
+    """inv(W) and W * c (reference src/woodbury.jl:317-321, 357-360, test/woodbury.jl inv / * testsets): new WoodburyPDMat objects built
+    on the host from the downloaded factor -- inv(F) = (U'^-1, Q, V'^-1), (A, B, D) = pdunfactorize -- against dense algebra."""
+    tg = pfmi_mod.t_lowrank(40, r=8, seed=5)
+    res = pfmi_mod.pathfinder(tg, ndraws=10, rng=pfmi_mod.HostRNG(3), history_length=6, ndraws_elbo=20)
+    n_checked = 0
+    for dist_ in (res.fit_distributions[2], res.fit_distributions[len(res.fit_distributions) - 1], res.fit_distribution):
+        W = dist_.Sigma
+        Wd = W.dense()
+        Wi = W.inv()
+        assert Wi.B.shape == W.B.shape and Wi.D.shape == W.D.shape
+        np.testing.assert_allclose(Wi.dense(), np.linalg.inv(Wd), rtol=1e-8, atol=1e-10 * np.abs(np.linalg.inv(Wd)).max())
+        np.testing.assert_allclose(Wi.diag(), np.diag(np.linalg.inv(Wd)), rtol=1e-8)
+        assert abs(Wi.logdet + W.logdet) < 1e-12 and abs(W.logdet - np.linalg.slogdet(Wd)[1]) < 1e-8 * (1 + abs(W.logdet))
+        Q1 = W.thin_Q()
+        np.testing.assert_allclose(Q1.T @ Q1, np.eye(Q1.shape[1]), atol=1e-12)
+        W3 = W * 3.0
+        np.testing.assert_allclose(W3.dense(), 3.0 * Wd, rtol=1e-12, atol=1e-13 * np.abs(Wd).max())
+        assert abs(W3.logdet - np.linalg.slogdet(3.0 * Wd)[1]) < 1e-8 * (1 + abs(W3.logdet))
+        np.testing.assert_allclose((2.0 * W).dense(), 2.0 * Wd, rtol=1e-12, atol=1e-13 * np.abs(Wd).max())
+        np.testing.assert_allclose(W * -1.0, -Wd, rtol=1e-13)            # c <= 0: the dense matrix (src/woodbury.jl:358)
+        with pytest.raises(RuntimeError):
+            Wi.mul(np.ones(40))
+        n_checked += 1
+    assert n_checked == 3
+
