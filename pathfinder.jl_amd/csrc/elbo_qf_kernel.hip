@@ -530,14 +530,32 @@ static int32_t launch_qf_ng(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
     if (split > 1) gpw = ((gpw + NPG + QF_WAVES * NG - 1) / (QF_WAVES * NG)) * (QF_WAVES * NG) - NPG;   // fill the last batch
     if (gpw < 1) gpw = 1;
     const int gx = (ngroups + gpw - 1) / gpw;
-    for (int64_t s0 = 0; s0 < nfits; s0 += 32768) {
-        const int64_t ns = (nfits - s0 < 32768) ? (nfits - s0) : 32768;
-        ElboArgs b = a;
-        b.points = a.points + s0; b.seeds = a.seeds + s0;
-        if (!a.by_point) { b.logp += s0 * a.log_stride; b.logq += s0 * a.log_stride; }
-        hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)ns), dim3(QF_THREADS), lds_bytes, c->stream, b, ch_blocks, nchunks, gpw,
-                           ngroups);
+    auto launch = [&](int64_t f0, int64_t nf, int gpw_, int gx_) {
+        for (int64_t s0 = f0; s0 < f0 + nf; s0 += 32768) {
+            const int64_t ns = (f0 + nf - s0 < 32768) ? (f0 + nf - s0) : 32768;
+            ElboArgs b = a;
+            b.points = a.points + s0; b.seeds = a.seeds + s0;
+            if (!a.by_point) { b.logp += s0 * a.log_stride; b.logq += s0 * a.log_stride; }
+            hipLaunchKernelGGL(kern, dim3((unsigned)gx_, (unsigned)ns), dim3(QF_THREADS), lds_bytes, c->stream, b, ch_blocks, nchunks, gpw_,
+                               ngroups);
+        }
+    };
+    // Workgroups of one launch all take the same time, so the fits beyond the last full round of CUs (nfits mod #CU) would keep a
+    // few CUs busy for a whole workgroup time while the rest idle.  Those fits go into a second launch cut into one-batch pieces
+    // (each piece recomputes the per-fit constants in its pseudo-group slot) whenever that finishes sooner.
+    int64_t tail = 0;
+    int gpw_t = gpw, gx_t = gx;
+    if (split == 1 && TGT != 0) {
+        int ncu = 0;
+        PF_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device));
+        const int slots = QF_WAVES * NG, nb_full = (ngroups + NPG + slots - 1) / slots;
+        const int64_t rem = ncu > 0 ? nfits % ncu : 0;
+        gpw_t = slots - NPG;
+        gx_t = gpw_t > 0 ? (ngroups + gpw_t - 1) / gpw_t : 0;
+        if (rem > 0 && nfits > ncu && gpw_t > 0 && nb_full > 1 && (rem * gx_t + ncu - 1) / ncu < nb_full) tail = rem;
     }
+    if (nfits - tail > 0) launch(0, nfits - tail, gpw, gx);
+    if (tail > 0) launch(nfits - tail, tail, gpw_t, gx_t);
     return PFMI_OK;
 }
 
