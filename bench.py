@@ -333,7 +333,8 @@ def main():
                     "mfma_f64": {"achieved": round(mfma_tf, 2), "peak": 78.6, "unit": "TFLOP/s", "frac": round(mfma_tf / 78.6, 4),
                                  "note": "f64 MFMA flops of the scan / launch time; the kernel's floor is the SUM of its MFMA and VALU "
                                          "issue streams (no co-issue on gfx950, profiles/r02_coissue_microbench.txt): ~84 % of that floor, DESIGN.md 4.1"},
-                    "kernel": "pf_elbo_qf_kernel (single-pass ELBO scan)",
+                    "kernel": "pf_elbo_qf_kernel (single-pass ELBO scan; one scan = the main launch + a short tail launch for the fits beyond "
+                              "the last full round of CUs, timed together: profiles/r02_bench_kernel_stats.md lists both grids)",
                     "launches": int(n), "avg_launch_ms": round(ms / max(n, 1), 4),
                     "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_draw": bytes_per_draw,
                     "note": "achieved = algorithmic bytes (16*d + factor bytes per draw, SURVEY 8d) / measured launch time. The "
