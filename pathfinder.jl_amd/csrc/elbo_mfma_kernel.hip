@@ -477,9 +477,13 @@ static int32_t launch_mf(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
     auto kern = pf_elbo_mfma_kernel<KC, NBW, TGT, RPAD, WX>;
     PF_TRY(pf_raise_lds_limit(c, reinterpret_cast<const void *>(kern), 160 * 1024));
     const int ngroups = (int)((a.N + 15) / 16);
-    // one fit per workgroup; split a fit's draw groups over several workgroups only when there are few fits
+    // one fit per workgroup; split a fit's draw groups over several workgroups only when there are few fits -- until every CU has a
+    // workgroup, not further: each piece stages the whole factor (97 KB at d = 1000) into LDS again (pool_build of config 3, 64 fits:
+    // 16 pieces per fit 0.33 ms, 8 pieces 0.28 ms, 4 pieces 0.26 ms)
+    int ncu = 0;
+    PF_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device));
     int split = 1;
-    while ((int64_t)split * nfits < 1024 && split * 2 <= ngroups) split *= 2;
+    while ((int64_t)split * nfits < ncu && split * 2 <= ngroups) split *= 2;
     const int gpb = (ngroups + split - 1) / split;
     const int gx = (ngroups + gpb - 1) / gpb;
     for (int64_t s0 = 0; s0 < nfits; s0 += 32768) {
