@@ -113,7 +113,7 @@ int32_t pfmi_destroy(pfmi_ctx *c) {
                       &c->rq, &c->dmat, &c->sqrt_alpha, &c->mu, &c->logdet, &c->status, &c->seeds, &c->logp, &c->logq,
                       &c->elbo, &c->se, &c->best_iter, &c->fit_list, &c->ubuf, &c->xbuf, &c->scratch, &c->fit_scratch, &c->pool,
                       &c->pool_lr, &c->pool_lp, &c->pool_lq, &c->pool_points, &c->pool_seeds, &c->lw, &c->w,
-                      &c->psis_out, &c->tailbuf, &c->cdf, &c->idx, &c->gbuf, &c->trace_lp, &c->st_theta, &c->st_grad,
+                      &c->psis_out, &c->psis_aux, &c->tailbuf, &c->cdf, &c->idx, &c->gbuf, &c->trace_lp, &c->st_theta, &c->st_grad,
                       &c->st_lp, &c->st_npts, &c->lb_hs, &c->lb_hy, &c->lb_x0, &c->sortk, &c->sorti};
     for (DevBuf *b : bufs) b->release();
     for (int b = 0; b < 2; ++b) {

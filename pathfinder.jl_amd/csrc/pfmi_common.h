@@ -127,6 +127,7 @@ struct pfmi_ctx {
     DevBuf lw;          // [S] smoothed, normalised log weights
     DevBuf w;           // [S] weights
     DevBuf psis_out;    // [4] pareto_k, tail_len, ...
+    DevBuf psis_aux;    // PsisAux: histogram, candidate list, smoothed tail and normalisation constants of the multi-workgroup PSIS
     DevBuf tailbuf;     // tail keys / idx
     DevBuf cdf;         // u64 [S]
     DevBuf idx;         // int64 [ndraws]

@@ -12,6 +12,8 @@
 //   pf_norep_kernel    : Efraimidis-Spirakis sampling without replacement (replace = false).
 //   pf_gather_kernel   : draws = draws_all[:, inds] (src/resample.jl:68).
 #include "pfmi_common.h"
+#include <stdlib.h>
+#include <stddef.h>
 
 #define PSIS_THREADS 1024
 #define TAILCAP 4096
@@ -168,10 +170,138 @@ __device__ void pf_select_top_sorted(const double *__restrict__ vals, long long 
     }
 }
 
+// ---- multi-workgroup PSIS (S >= PSIS_MULTI_MIN) ------------------------------------------------------------------------------
+// The single-workgroup kernel walks the S log ratios ~10 times (select) + 2 x exp (normalisation): 0.26 ms at S = 64 000, none of
+// which shrinks with the number of GPUs.  The passes over S move to short multi-workgroup kernels; what is left for the single
+// workgroup is the sort of <= 4096 candidates and the GPD fit.
+//   pf_psis_minmax_kernel   key range (atomicMax on the key and on its complement: one memset initialises both)
+//   pf_psis_hist_kernel     4096-bin histogram of the 12 key bits below the highest differing bit (LDS histogram per workgroup)
+//   pf_psis_compact_kernel  every workgroup scans the histogram from the top for the bin that holds the (M+1)-th largest key; if that
+//                           bin and everything above are <= TAILCAP elements they are appended to the candidate list (any order:
+//                           the tail kernel sorts by (key, index)); otherwise `done` stays 0 and the tail kernel selects by itself
+//   pf_psis_kernel<true>    candidates -> sorted tail, Zhang-Stephens fit, smoothed tail + normalisation constants to `aux`
+//   pf_psis_sum_kernel      partial sums of exp(lr - max) over the untouched elements (fixed slice per workgroup)
+//   pf_psis_norm_kernel     lse from the partials in a fixed order; lw, w
+#define PSIS_MULTI_MIN 8192
+#define PSIS_MW 64                      // workgroups of the multi-workgroup passes
+#define PSIS_MT 256
+struct PsisAux {
+    unsigned long long kmax, kmin_inv;  // max key, max ~key
+    unsigned hist[4096];
+    unsigned cand_count, done, replaced, ti0;
+    unsigned long long tk0;
+    double mx, se_tail, pareto_k, sigma;
+    int M, pad;
+    double partial[PSIS_MW];
+    unsigned long long cand_key[TAILCAP];
+    unsigned cand_idx[TAILCAP];
+    double tail_val[TAILCAP];
+    unsigned tail_idx[TAILCAP];
+};
+__device__ __forceinline__ int pf_psis_shift0(unsigned long long kmin, unsigned long long kmax) {
+    const unsigned long long diff = kmin ^ kmax;
+    const int top = diff ? 63 - __clzll((long long)diff) : 0;
+    return top >= 11 ? top - 11 : 0;
+}
+__global__ __launch_bounds__(PSIS_MT) void pf_psis_minmax_kernel(long long S, const double *__restrict__ lr, PsisAux *aux) {
+    unsigned long long kmax = 0ull, kinv = 0ull;
+    for (long long i = (long long)blockIdx.x * PSIS_MT + threadIdx.x; i < S; i += (long long)PSIS_MW * PSIS_MT) {
+        const unsigned long long k = pf_key_of(lr[i]);
+        kmax = k > kmax ? k : kmax; kinv = ~k > kinv ? ~k : kinv;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long a = __shfl_xor(kmax, off, 64), b = __shfl_xor(kinv, off, 64);
+        kmax = a > kmax ? a : kmax; kinv = b > kinv ? b : kinv;
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMax(&aux->kmax, kmax); atomicMax(&aux->kmin_inv, kinv); }
+}
+__global__ __launch_bounds__(PSIS_MT) void pf_psis_hist_kernel(long long S, const double *__restrict__ lr, PsisAux *aux) {
+    __shared__ unsigned h[4096];
+    for (int b = threadIdx.x; b < 4096; b += PSIS_MT) h[b] = 0u;
+    __syncthreads();
+    const int sh = pf_psis_shift0(~aux->kmin_inv, aux->kmax);
+    for (long long i = (long long)blockIdx.x * PSIS_MT + threadIdx.x; i < S; i += (long long)PSIS_MW * PSIS_MT)
+        atomicAdd(&h[(unsigned)((pf_key_of(lr[i]) >> sh) & 0xFFFull)], 1u);
+    __syncthreads();
+    for (int b = threadIdx.x; b < 4096; b += PSIS_MT) if (h[b]) atomicAdd(&aux->hist[b], h[b]);
+}
+__global__ __launch_bounds__(PSIS_MT) void pf_psis_compact_kernel(long long S, const double *__restrict__ lr, PsisAux *aux, int R) {
+    __shared__ unsigned part[PSIS_MT];
+    __shared__ int s_bin, s_ok;
+    const int tid = threadIdx.x;
+    // bins 4095 .. 0, 16 per thread from the top: thread t owns bins 4095 - 16 t .. 4080 - 16 t
+    unsigned loc[16], sum = 0u;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { loc[j] = aux->hist[4095 - 16 * tid - j]; sum += loc[j]; }
+    part[tid] = sum;
+    if (tid == 0) { s_bin = -1; s_ok = 0; }
+    __syncthreads();
+    unsigned above = 0u;
+    for (int t = 0; t < tid; ++t) above += part[t];              // elements in the bins above this thread's
+    if (above < (unsigned)R && above + sum >= (unsigned)R) {      // exactly one thread
+        unsigned cum = above;
+        for (int j = 0; j < 16; ++j) {
+            if (cum < (unsigned)R && cum + loc[j] >= (unsigned)R) { s_bin = 4095 - 16 * tid - j; s_ok = (cum + loc[j] <= (unsigned)TAILCAP); break; }
+            cum += loc[j];
+        }
+    }
+    __syncthreads();
+    const int bin = s_bin;
+    if (blockIdx.x == 0 && tid == 0) aux->done = (bin >= 0 && s_ok) ? 1u : 0u;
+    if (bin < 0 || !s_ok) return;
+    const int sh = pf_psis_shift0(~aux->kmin_inv, aux->kmax);
+    for (long long i = (long long)blockIdx.x * PSIS_MT + tid; i < S; i += (long long)PSIS_MW * PSIS_MT) {
+        const unsigned long long k = pf_key_of(lr[i]);
+        if ((int)((k >> sh) & 0xFFFull) >= bin) {
+            const unsigned slot = atomicAdd(&aux->cand_count, 1u);
+            if (slot < (unsigned)TAILCAP) { aux->cand_key[slot] = k; aux->cand_idx[slot] = (unsigned)i; }
+        }
+    }
+}
+__device__ __forceinline__ bool pf_psis_is_tail(const PsisAux *aux, long long i, double x) {
+    const unsigned long long k = pf_key_of(x);
+    return aux->replaced && (k > aux->tk0 || (k == aux->tk0 && (unsigned long long)i > (unsigned long long)aux->ti0));
+}
+__global__ __launch_bounds__(PSIS_MT) void pf_psis_sum_kernel(long long S, const double *__restrict__ lr, PsisAux *aux) {
+    __shared__ double red[PSIS_MT / 64];
+    const double mx = aux->mx;
+    double se = 0.0;
+    if (isfinite(mx))
+        for (long long i = (long long)blockIdx.x * PSIS_MT + threadIdx.x; i < S; i += (long long)PSIS_MW * PSIS_MT) {
+            const double x = lr[i];
+            if (!pf_psis_is_tail(aux, i, x)) se += exp(x - mx);
+        }
+    se = pf_block_sum1(se, red);
+    if (threadIdx.x == 0) aux->partial[blockIdx.x] = se;
+}
+__global__ __launch_bounds__(PSIS_MT) void pf_psis_norm_kernel(long long S, const double *__restrict__ lr, const PsisAux *aux,
+                                                              double *__restrict__ lw, double *__restrict__ wout,
+                                                              double *__restrict__ out) {
+    const double mx = aux->mx;
+    double se = aux->se_tail;
+    for (int b = 0; b < PSIS_MW; ++b) se += aux->partial[b];      // fixed order: identical in every thread
+    const double lse = isfinite(mx) ? mx + log(se) : mx;
+    for (long long i = (long long)blockIdx.x * PSIS_MT + threadIdx.x; i < S; i += (long long)PSIS_MW * PSIS_MT) {
+        const double x = lr[i];
+        if (!pf_psis_is_tail(aux, i, x)) { const double v = x - lse; lw[i] = v; wout[i] = exp(v); }
+    }
+    if (blockIdx.x == 0) {
+        if (aux->replaced)
+            for (int t = threadIdx.x; t < aux->M; t += PSIS_MT) {
+                const double v = aux->tail_val[t] - lse;
+                lw[aux->tail_idx[t]] = v; wout[aux->tail_idx[t]] = exp(v);
+            }
+        if (threadIdx.x == 0) { out[0] = aux->pareto_k; out[1] = (double)aux->M; out[2] = aux->sigma; out[3] = lse; }
+    }
+}
+
 // out[0] = pareto_k, out[1] = tail length M, out[2] = sigma (scaled), out[3] = logsumexp
+// MULTI: the passes over S run in the multi-workgroup kernels above; this workgroup sorts the candidates (or selects by itself when
+// the candidate list overflowed), fits the tail and leaves the smoothed tail + normalisation constants in `aux`.
+template <bool MULTI>
 __global__ __launch_bounds__(PSIS_THREADS) void pf_psis_kernel(long long S, const double *__restrict__ lr,
                                                                double *__restrict__ lw, double *__restrict__ wout,
-                                                               double *__restrict__ out, int M) {
+                                                               double *__restrict__ out, int M, PsisAux *aux) {
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
     __shared__ uint64_t tkeys[TAILCAP];   // reused as double w[] after the sort
     __shared__ uint32_t tidx[TAILCAP];
@@ -187,7 +317,44 @@ __global__ __launch_bounds__(PSIS_THREADS) void pf_psis_kernel(long long S, cons
     if (tid == 0) s_sigma = NAN;
     __syncthreads();
     if (M >= 5 && M + 1 <= TAILCAP && (long long)(M + 1) <= S) {
-        pf_select_top_sorted(lr, S, M + 1, tkeys, tidx, &st);
+        if (MULTI && aux->done) {
+            // candidates (everything from the threshold bin upwards, <= TAILCAP, any order) -> ascending by (key, index); the M + 1
+            // largest move to the front
+            const int R = M + 1, cnt = (int)aux->cand_count;
+            int npow = 1;
+            while (npow < cnt) npow <<= 1;
+            for (int t = tid; t < npow; t += nt) {
+                tkeys[t] = t < cnt ? aux->cand_key[t] : ~0ull;
+                tidx[t] = t < cnt ? aux->cand_idx[t] : 0xFFFFFFFFu;
+            }
+            __syncthreads();
+            for (int size = 2; size <= npow; size <<= 1)
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    for (int t = tid; t < npow / 2; t += nt) {
+                        const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                        const bool up = ((lo & size) == 0);
+                        const uint64_t ka = tkeys[lo], kb = tkeys[hi];
+                        const uint32_t ia = tidx[lo], ib = tidx[hi];
+                        const bool a_gt_b = (ka > kb) || (ka == kb && ia > ib);
+                        if (a_gt_b == up) { tkeys[lo] = kb; tkeys[hi] = ka; tidx[lo] = ib; tidx[hi] = ia; }
+                    }
+                    __syncthreads();
+                }
+            uint64_t mk[(TAILCAP + PSIS_THREADS - 1) / PSIS_THREADS];
+            uint32_t mi[(TAILCAP + PSIS_THREADS - 1) / PSIS_THREADS];
+#pragma unroll
+            for (int q = 0; q < (TAILCAP + PSIS_THREADS - 1) / PSIS_THREADS; ++q) {
+                const int t = tid + q * nt;
+                if (t < R) { mk[q] = tkeys[cnt - R + t]; mi[q] = tidx[cnt - R + t]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < (TAILCAP + PSIS_THREADS - 1) / PSIS_THREADS; ++q) {
+                const int t = tid + q * nt;
+                if (t < R) { tkeys[t] = mk[q]; tidx[t] = mi[q]; }
+            }
+            __syncthreads();
+        } else pf_select_top_sorted(lr, S, M + 1, tkeys, tidx, &st);
         // tkeys[0] = cutoff, tkeys[1..M] = the M largest, ascending
         double *w = reinterpret_cast<double *>(tkeys);
         const double logu = pf_val_of(tkeys[0]);
@@ -284,6 +451,17 @@ __global__ __launch_bounds__(PSIS_THREADS) void pf_psis_kernel(long long S, cons
         mx = pf_block_max1(mx, red);
     }
     __syncthreads();
+    if (MULTI) {                                                   // hand over to pf_psis_sum_kernel / pf_psis_norm_kernel
+        double se = 0.0;
+        if (replaced && isfinite(mx)) for (int t = tid; t < M; t += nt) se += exp(wt[t] - mx);
+        se = pf_block_sum1(se, red);
+        if (replaced) for (int t = tid; t < M; t += nt) { aux->tail_val[t] = wt[t]; aux->tail_idx[t] = tidx[t + 1]; }
+        if (tid == 0) {
+            aux->mx = mx; aux->se_tail = se; aux->replaced = replaced ? 1u : 0u; aux->tk0 = tk0; aux->ti0 = ti0;
+            aux->pareto_k = pareto_k; aux->sigma = s_sigma; aux->M = M;
+        }
+        return;
+    }
     double se = 0.0;
     if (isfinite(mx)) {
         pf_foreach_batched(lr, S, [&](long long i, double x) { if (!is_tail(i, x)) se += exp(x - mx); });
@@ -483,8 +661,22 @@ int32_t pf_launch_psis(pfmi_ctx *c, const double *d_lr, int64_t S) {
     PF_TRY(c->w.ensure(sizeof(double) * S));
     PF_TRY(c->psis_out.ensure(sizeof(double) * 4));
     pf_kernel_begin(c);
-    hipLaunchKernelGGL(pf_psis_kernel, dim3(1), dim3(PSIS_THREADS), 0, c->stream, (long long)S, d_lr,
-                       c->lw.as<double>(), c->w.as<double>(), c->psis_out.as<double>(), (int)M);
+    const char *force = getenv("PFMI_PSIS_KERNEL");              // "single": the one-workgroup kernel for every S (tests)
+    if (S >= PSIS_MULTI_MIN && M >= 5 && !(force && force[0] == 's')) {
+        PF_TRY(c->psis_aux.ensure(sizeof(PsisAux)));
+        PsisAux *aux = c->psis_aux.as<PsisAux>();
+        PF_HIP(hipMemsetAsync(aux, 0, offsetof(PsisAux, cand_key), c->stream));
+        hipLaunchKernelGGL(pf_psis_minmax_kernel, dim3(PSIS_MW), dim3(PSIS_MT), 0, c->stream, (long long)S, d_lr, aux);
+        hipLaunchKernelGGL(pf_psis_hist_kernel, dim3(PSIS_MW), dim3(PSIS_MT), 0, c->stream, (long long)S, d_lr, aux);
+        hipLaunchKernelGGL(pf_psis_compact_kernel, dim3(PSIS_MW), dim3(PSIS_MT), 0, c->stream, (long long)S, d_lr, aux, (int)M + 1);
+        hipLaunchKernelGGL(pf_psis_kernel<true>, dim3(1), dim3(PSIS_THREADS), 0, c->stream, (long long)S, d_lr,
+                           c->lw.as<double>(), c->w.as<double>(), c->psis_out.as<double>(), (int)M, aux);
+        hipLaunchKernelGGL(pf_psis_sum_kernel, dim3(PSIS_MW), dim3(PSIS_MT), 0, c->stream, (long long)S, d_lr, aux);
+        hipLaunchKernelGGL(pf_psis_norm_kernel, dim3(PSIS_MW), dim3(PSIS_MT), 0, c->stream, (long long)S, d_lr, aux,
+                           c->lw.as<double>(), c->w.as<double>(), c->psis_out.as<double>());
+    } else
+        hipLaunchKernelGGL(pf_psis_kernel<false>, dim3(1), dim3(PSIS_THREADS), 0, c->stream, (long long)S, d_lr,
+                           c->lw.as<double>(), c->w.as<double>(), c->psis_out.as<double>(), (int)M, (PsisAux *)nullptr);
     pf_kernel_end(c, "psis");
     PF_HIP(hipGetLastError());
     c->S_w = S;

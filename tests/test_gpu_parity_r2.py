@@ -597,3 +597,51 @@ def test_woodbury_inv_and_scaling_build_host_objects(pfmi_mod):
         n_checked += 1
     assert n_checked == 3
 
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["t4", "ties", "all_equal", "narrow", "with_inf", "big"])
+def test_psis_multi_workgroup_equals_single_workgroup_and_oracle(pfmi_mod, case, monkeypatch):
+    """S >= 8192 takes the multi-workgroup PSIS (key range, 4096-bin histogram, candidate compaction, sorted tail + GPD fit in one
+    workgroup, multi-workgroup normalisation).  Same selection as the one-workgroup kernel (PFMI_PSIS_KERNEL=single) on every input,
+    including the ones that overflow the candidate list (heavy ties, all values equal -> the tail kernel selects by itself), and the
+    oracle's numbers."""
+    rng = np.random.default_rng(11)
+    S = 64000
+    if case == "t4":
+        import scipy.stats as st
+        lr = st.t(4).rvs(S, random_state=rng) * 2.0 - 1.0
+    elif case == "ties":
+        lr = np.round(rng.normal(size=S), 1)                      # ~70 distinct values: thousands of ties at the cutoff
+    elif case == "all_equal":
+        lr = np.full(S, -3.25)
+    elif case == "narrow":
+        lr = -1000.0 + 1e-9 * rng.normal(size=S)                  # all keys share their leading 30+ bits
+    elif case == "with_inf":
+        lr = rng.normal(size=S)
+        lr[rng.integers(0, S, 50)] = -np.inf                      # zero-weight draws (logp = -Inf)
+    else:
+        S = 300000
+        lr = rng.standard_t(3, size=S) * 3.0
+    eng = pfmi_mod.Engine(0)
+    try:
+        a = eng.psis(lr)
+        monkeypatch.setenv("PFMI_PSIS_KERNEL", "single")
+        b = eng.psis(lr)
+        monkeypatch.delenv("PFMI_PSIS_KERNEL")
+    finally:
+        eng.close()
+    assert a["tail_length"] == b["tail_length"]
+    if np.isnan(b["pareto_shape"]):
+        assert np.isnan(a["pareto_shape"])
+    else:
+        assert abs(a["pareto_shape"] - b["pareto_shape"]) <= 1e-13 * (1 + abs(b["pareto_shape"]))
+    fin = np.isfinite(b["log_weights"])
+    np.testing.assert_array_equal(np.isfinite(a["log_weights"]), fin)
+    assert np.max(np.abs(a["log_weights"][fin] - b["log_weights"][fin])) <= 1e-12 * (1 + np.abs(b["log_weights"][fin]).max())
+    np.testing.assert_allclose(a["weights"], b["weights"], rtol=1e-11, atol=1e-300)
+    lw, w, k, M = po.psis(lr)
+    assert a["tail_length"] == M
+    if np.isfinite(k):
+        assert abs(a["pareto_shape"] - k) <= 1e-8
+    assert np.max(np.abs(a["log_weights"][fin] - lw[fin])) <= 1e-10 * (1 + np.abs(lw[fin]).max())
+
