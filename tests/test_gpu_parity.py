@@ -773,18 +773,24 @@ def test_multipathfinder_device_and_host_optimizers_agree(pfmi_mod):
 @pytest.mark.parametrize("tname,d,K,J,N,scale,maxit", [
     ("iso", 10, 2, 6, 100, 2, 1000), ("diag", 30, 2, 6, 200, 2, 1000), ("lr", 50, 2, 6, 200, 2, 1000), ("lr", 300, 2, 6, 500, 2, 1000),
     ("funnel", 12, 2, 6, 100, 10, 40), ("diag", 30, 2, 10, 200, 2, 1000), ("lr", 50, 2, 16, 200, 2, 1000),
-    ("diag", 3000, 2, 6, 200, 2, 30), ("funnel", 2500, 2, 10, 300, 10, 30), ("lr", 1100, 2, 8, 130, 2, 40)])
+    ("diag", 3000, 2, 6, 200, 2, 30), ("funnel", 2500, 2, 10, 300, 10, 30), ("lr", 1100, 2, 8, 130, 2, 40),
+    ("lr", 64, 8, 6, 1000, 2, 45), ("diag", 48, 7, 4, 500, 2, 50)])
 def test_single_pass_scan_matches_lane_kernel(pfmi_mod, eng, tname, d, K, J, N, scale, maxit):
     """the single-pass quadratic-form scan (elbo_qf_kernel.hip: logp from per-draw contractions, x never formed; Vh resident or
     streamed through LDS; KC up to 32) against the lane-per-draw kernel that evaluates logp(x) on the materialised draw, same
     seeds: per-draw logp / logq and the per-fit ELBO agree to fp64 roundoff.  Covers the head transform spilling into
-    block 1 (J = 10, 16), chunked streaming (d = 2500, 3000), ragged last block / last group and the low-rank target."""
+    block 1 (J = 10, 16), chunked streaming (d = 2500, 3000), ragged last block / last group and the low-rank target; the two
+    K = 8 / 7 cases have more fits than the GPU has CUs and not a multiple of them, so the fits of the last partial round take the
+    second, one-batch-per-workgroup launch (two groups per wave at N = 1000, one at N = 500)."""
     tg = {"iso": pfmi_mod.t_iso, "diag": lambda d: pfmi_mod.t_diag(d, 1), "lr": lambda d: pfmi_mod.t_lowrank(d, 8, 2),
           "funnel": pfmi_mod.t_funnel}[tname](d)
     eng.set_target(tg)
     x0 = pfmi_mod.HostRNG(3).rand(K * d).reshape(K, d) * 2 * scale - scale
     eng.optimize_batch(x0, J, maxit)
     eng.fit_batch(J)
+    if K >= 7:
+        nfits = eng.P - K
+        assert nfits > 256 and nfits % 256 != 0, nfits               # the tail launch really runs
     seeds = fit_seeds(eng.P, 1)
     out = {}
     old = os.environ.get("PFMI_ELBO_KERNEL")
@@ -792,7 +798,7 @@ def test_single_pass_scan_matches_lane_kernel(pfmi_mod, eng, tname, d, K, J, N, 
         for mode in ("lane", "qf"):
             os.environ["PFMI_ELBO_KERNEL"] = mode
             elbo, se, best = eng.elbo_batch(N, seeds)
-            pts = sorted({1, min(3, eng.P - 1), eng.P // 2, eng.P - 1})
+            pts = sorted({1, min(3, eng.P - 1), eng.P // 2, eng.P - 1, max(eng.P - 7, 1), max(eng.P - 20, 1)})
             out[mode] = (elbo, se, best, [eng.elbo_logs(p, N) for p in pts])
     finally:
         if old is None:
