@@ -484,9 +484,9 @@ void pfo_logp_funnel(int d, long N, const double *X, double *out) {
 
 /* ------------------------------------------------------------------------------------------ */
 /* Counter-based RNG (this repo's replacement for Random.randn!, src/mvnormal.jl:30).          */
-/* Philox4x32-10 (Salmon et al. 2011), key = 64-bit per-fit seed.  Normal number for           */
-/* (row i, draw n): counter = (n, i/4, stream, 0) -> 4 x u32 -> u = (x + 0.5) 2^-32 ->          */
-/* Box-Muller pairs (x0,x1) -> rows 4g, 4g+1 ; (x2,x3) -> rows 4g+2, 4g+3.                     */
+/* Philox4x32 (Salmon et al. 2011), key = 64-bit per-fit seed.  Normal number for              */
+/* (row i, draw n): counter = (n, i/4, stream, 0) -> 4 x u32 -> one normal per word (rows       */
+/* 4g .. 4g+3) through the tabulated inverse normal CDF below (round 1: Box-Muller pairs).      */
 /* ------------------------------------------------------------------------------------------ */
 static inline void philox_round(uint32_t c[4], const uint32_t k[2]) {
     uint64_t p0 = (uint64_t)0xD2511F53u * c[0];

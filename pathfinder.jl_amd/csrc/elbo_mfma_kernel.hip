@@ -13,7 +13,7 @@
 //   (LDS)   tv = T (sum over waves of W)                      (Q = I - Vh T Vh', compact WY)
 //   pass 2  x~[row][c] = z[row][c] - sum_j Vh[row][j] tv[j][c] A = Vh (KC/4 MFMAs / block), B = -tv, C = z
 //   target  t[j'][c]  += sum_rows Wd[row][j'] e[row][c]        A = Wd^T (4 MFMAs / block), B = e = x - mean
-// The VALU only generates the normals (Philox + Box-Muller) and does the elementwise epilogue; MFMA is used
+// The VALU only generates the normals (Philox + table inverse CDF) and does the elementwise epilogue; MFMA is used
 // only for these true contractions over the d x 2m history block (BASELINE.json north_star).  Nothing but the
 // per-draw logp/logq (and the draws of a winning fit, when asked) is written to HBM.
 //
@@ -236,8 +236,8 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
 #pragma unroll
         for (int I = 0; I < (TR > 0 ? TR : 1); ++I) acc3[I] = 0.0;
         double *X = (WX && valid) ? (A.x + (size_t)slot * A.x_stride + (size_t)nl * d) : nullptr;
-        // Block body.  Three INDEPENDENT dependency chains are advanced side by side in each of 11 phases -- the two
-        // Box-Muller pairs of (next group, this block) and the Philox call of the following pair -- and one MFMA is
+        // Block body.  Independent dependency chains are advanced side by side in each of 11 phases -- the table look-ups of
+        // (next group, this block: issued in P0, finished in P6) and the Philox call of the following block -- and one MFMA is
         // issued per phase (3 pass-2, 4 pass-1 of the previous block, 4 target), with a scheduling barrier after each
         // phase: the wave keeps the matrix pipe (64 cycles per f64 MFMA) and the VALU busy at once, and the VALU
         // always has an independent instruction to issue while a dependent fp64 result is in flight.

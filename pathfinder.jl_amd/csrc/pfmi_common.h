@@ -220,10 +220,10 @@ __device__ __forceinline__ void pf_philox_normals(uint32_t c0, uint32_t c1, uint
 
 // ---- the standard-normal generator ------------------------------------------------------------------------------
 // One 32-bit Philox word -> one normal through the piecewise-cubic inverse normal CDF of pfmi_icdftab.h (generated by
-// tools/gen_icdf_table.py, which documents the construction): exponent / top-5 mantissa bits of p = (mag + 1/2) 2^-32 select a
-// table entry, z = +-(c0 + dp (c1 + dp (c2 + dp c3))), dp = p - p_base (evaluated in the scaled variable P = 2^32 p = mag + 1/2).  Only exactly rounded IEEE operations (cvt, fma, sub)
-// => bit-identical to the CPU checker (pfo_randn4).  13 VALU instructions + two 16-byte LDS reads per normal (round 1's
-// Box-Muller: ~27 + Philox).  Words with mag < 2^PF_ICDF_TAILBITS (probability 2^-19) are refined with a second Philox word
+// tools/gen_icdf_table.py, which documents the construction): p = (mag + 1/2) 2^-32; exponent / top-5 mantissa bits of v = (double) mag
+// select a table entry, z = +-(c0 + v (c1 + v (c2 + v c3))) -- the cubic of every interval in GLOBAL monomial form in v (the 1/2 folded
+// into the coefficients).  Only exactly rounded IEEE operations (cvt, fma) => bit-identical to the CPU checker (pfo_randn4).
+// 8 VALU instructions + two 16-byte LDS reads per normal in the scan's form (pf_icdf_issue_adj), round 1's Box-Muller: ~27 + Philox.  Words with mag < 2^PF_ICDF_TAILBITS (probability 2^-19) are refined with a second Philox word
 // (counter word 3 = 1) so that the tails reach |z| = 9.1 with >= 12 bits of resolution.
 static __device__ const double PF_ICDF_TAB_DEV[PF_ICDF_ENTRIES][4] = { PF_ICDF_TABLE_ROWS };
 
