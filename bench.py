@@ -70,8 +70,8 @@ def _launch_only(world, rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--npaths", type=int, default=64)
     ap.add_argument("--dim", type=int, default=1000)
     ap.add_argument("--ndraws-elbo", type=int, default=1000)
