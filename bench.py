@@ -13,7 +13,10 @@ value = ELBO draws per second of the whole job = (sum over fits of ndraws_elbo) 
 includes fit, PSIS and resampling, i.e. it is also the hot-path part of the multipathfinder wall-clock).
 
 Run:  python bench.py [--gpus N --steps K --warmup W]
-N > 1: one rank per GPU.  Either the caller launches the ranks (python -m torch.distributed.run ... bench.py --gpus N:
+A step is ENQUEUED as one pipeline (round 3): fit -> scan -> reduce / argmax -> winners picked on the device -> pool -> [all-gather] ->
+PSIS -> index selection -> owner gather [-> all-reduce] with ONE host synchronisation at the end (pfmi_*_enqueue,
+pfmi_pool_build_best, pfmi_comm_psis_resample); the results every step downloads: elbo / se / best_iter, k-hat, indices, draws.
+N > 1: one rank per GPU (or --single-process: ONE process drives all N GPUs through pfmi_comm_init_all).  Either the caller launches the ranks (python -m torch.distributed.run ... bench.py --gpus N:
 WORLD_SIZE is then set and must equal N), or bench.py launches them itself: `python bench.py --gpus N` without
 WORLD_SIZE in the environment re-executes itself under torch.distributed.run on 127.0.0.1.
 """
@@ -84,12 +87,18 @@ def main():
                     help="take the multi-GPU code path (RCCL all-gather / all-reduce) even in a single-rank world")
     ap.add_argument("--target", default="lowrank", choices=["lowrank", "diag", "iso", "funnel"],
                     help="synthetic target of SURVEY 8(d); the headline config uses lowrank (r = 8)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="--gpus N driven by ONE host process (N contexts, pfmi_comm_init_all) instead of one rank per GPU")
+    ap.add_argument("--minimal", action="store_true", help="timed steps only (the rocprofv3 counter passes re-run bench.py this way)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not re-run a step under rocprofv3 --pmc for roofline.traffic")
     ap.add_argument("--maxiters", type=int, default=1000)
     ap.add_argument("--init-scale", type=float, default=2.0)
     args = ap.parse_args()
 
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
+    if args.single_process:
+        return main_single_process(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(_self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -145,6 +154,8 @@ def main():
     draws_local = nfits_local * N_e
 
     comm = None
+    if not use_dist:
+        comm = pfmi.Comm.init_all([eng])                            # a world of one context: same entry points, no RCCL involved
     if use_dist:
         # the data-path collectives go through the C ABI (pfmi_comm_*: ncclAllGather / ncclAllReduce on the engine's stream,
         # csrc/comm_rccl.hip); torch.distributed only ships the 128-byte RCCL id, the barrier and the timing reduction
@@ -181,13 +192,14 @@ def main():
     state = {}
 
     def step():
+        # everything up to the last line of the `comm` branch only ENQUEUES work on the engine's stream
         eng.fit_batch(J)
-        elbo, se, best = eng.elbo_batch(N_e, seeds)
-        pts = [int(eng.offsets[k]) + int(best[k]) for k in range(Kl)]
-        eng.pool_build(N_r, pts, seeds[pts])
-        if use_dist and comm is not None:
-            res = comm.pool_psis()                                  # ONE RCCL all-gather of the log-ratio shards + replicated PSIS
-            idx, state["draws"] = comm.resample(ndraws, seed=master)   # replicated indices, owner gather, sum all-reduce, D2H
+        eng.elbo_batch_enqueue(N_e, seeds)
+        eng.pool_build_best(N_r)                                    # winners (fit_iteration per path) picked on the device
+        if comm is not None:
+            # [ONE RCCL all-gather of the log-ratio shards] + replicated PSIS + replicated indices + owner gather [+ sum all-reduce],
+            # one synchronisation, D2H of k-hat / indices / draws
+            res, idx, state["draws"] = comm.psis_resample(ndraws, seed=master)
         elif use_dist:                                              # fallback: the same orchestration through torch.distributed
             import torch
             from pfmi.distributed import pooled_psis_resample
@@ -200,11 +212,7 @@ def main():
                 gather_fn=lambda ix, o: eng.pool_gather_dev(ix, k0 * N_r, o.data_ptr()),
                 sync_fn=torch.cuda.synchronize, min_world=1)
             state["draws"] = out_dev
-        else:
-            ptr, cnt = eng.pool_log_ratios_dev()                    # syncs the engine stream
-            res = eng.psis_dev(ptr, cnt, want_weights=False)
-            idx = eng.resample_indices(K * N_r, ndraws, seed=master)
-            state["draws"] = eng.pool_gather(idx)
+        elbo, se, best = eng.elbo_batch_wait()                      # already complete: plain downloads
         state.update(elbo=elbo, best=best, pareto_k=res["pareto_shape"], idx=idx)
 
     def barrier():

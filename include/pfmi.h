@@ -54,9 +54,15 @@ typedef struct pfmi_ctx pfmi_ctx;
 #define PFMI_TARGET_GAUSS 0          /* offset - 1/2 [ sum a_i e_i^2 - || G Wd' e ||^2 ], e = x - mean  */
 #define PFMI_TARGET_FUNNEL 1         /* docs/src/examples/quickstart.md:229-234                         */
 #define PFMI_TARGET_HOST_CALLBACK 2  /* arbitrary host closure, evaluated on a host copy of the draws    */
+#define PFMI_TARGET_DEVICE_CALLBACK 3 /* arbitrary DEVICE closure: the draws never leave HBM               */
 
 /* host callback: X is d x n column-major, out[n] receives logp of every column (src/elbo.jl:15) */
 typedef void (*pfmi_logp_fn)(const double *X, int32_t d, int64_t n, double *out, void *user);
+/* device callback (the reference's general `logp` closure, src/elbo.jl:15, src/resample.jl:90-92, kept on the GPU): X_dev is a
+ * DEVICE pointer to d x n column-major draws in HBM, out_dev a DEVICE pointer to n doubles.  The function is called on the host and
+ * must ENQUEUE its kernel(s) on `stream` (a hipStream_t, the ctx's own) and return without synchronising -- e.g. an AMDGPU.jl kernel
+ * launch or a HIP launcher; the library orders its own work behind it on the same stream.  No PCIe traffic. */
+typedef void (*pfmi_logp_dev_fn)(const double *X_dev, int32_t d, int64_t n, double *out_dev, void *stream, void *user);
 
 typedef struct {
     int32_t kind;        /* PFMI_TARGET_*                                      */
@@ -69,7 +75,8 @@ typedef struct {
     const double *G;     /* GAUSS: r x r column-major, lower triangular        */
     double offset;       /* GAUSS: additive constant                           */
     pfmi_logp_fn fn;     /* HOST_CALLBACK                                      */
-    void *user;          /* HOST_CALLBACK                                      */
+    void *user;          /* HOST_CALLBACK / DEVICE_CALLBACK                    */
+    pfmi_logp_dev_fn dev_fn; /* DEVICE_CALLBACK                                */
 } pfmi_target;
 
 /* ---- library / context ----------------------------------------------------------------------- */
@@ -107,6 +114,12 @@ int32_t pfmi_set_traces(pfmi_ctx *ctx, int32_t K, const int64_t *npoints, int32_
  * npoints[k] = L_k + 1 out.  Callback targets -> PFMI_ERR_UNSUPPORTED (optimise on the host, pfmi_set_traces). */
 int32_t pfmi_optimize_batch(pfmi_ctx *ctx, int32_t K, const double *x0, int32_t history_length, int32_t maxiters,
                             double g_tol, int64_t *npoints);
+/* The same in two halves, for ONE host thread that drives several contexts (one per GPU, src/multipath.jl:190-208 fans the runs
+ * out over tasks): _enqueue uploads x0 and launches the optimisations without waiting, _wait blocks until this ctx's paths are done,
+ * packs the traces and returns npoints[K].  pfmi_optimize_batch == _enqueue + _wait. */
+int32_t pfmi_optimize_batch_enqueue(pfmi_ctx *ctx, int32_t K, const double *x0, int32_t history_length, int32_t maxiters,
+                                    double g_tol);
+int32_t pfmi_optimize_batch_wait(pfmi_ctx *ctx, int64_t *npoints);
 /* OptimizationTrace of path k (src/optimize.jl:94-100): theta/grad (L_k+1) x d point-major, logp L_k+1; any may be
  * NULL.  logp is only available for traces made by pfmi_optimize_batch. */
 int32_t pfmi_get_trace(pfmi_ctx *ctx, int32_t k, double *theta, double *logp, double *grad);
@@ -141,10 +154,20 @@ int32_t pfmi_get_fit(pfmi_ctx *ctx, int64_t point, double *alpha, double *B, dou
 int32_t pfmi_elbo_batch(pfmi_ctx *ctx, int64_t N, const uint64_t *seeds, const double *u_host,
                         double *elbo, double *se, int64_t *best_iter);
 
+/* The same in two halves (one host thread, several GPUs; or a host that wants to overlap its own work with the scan):
+ * _enqueue uploads the seeds and launches the scan, the reduction and the per-path argmax without waiting (HOST_CALLBACK targets
+ * evaluate on the calling thread, so for them _enqueue does the whole job); _wait blocks and downloads.  elbo / se / best_iter may
+ * be NULL.  pfmi_elbo_batch == _enqueue + _wait. */
+int32_t pfmi_elbo_batch_enqueue(pfmi_ctx *ctx, int64_t N, const uint64_t *seeds, const double *u_host);
+int32_t pfmi_elbo_batch_wait(pfmi_ctx *ctx, double *elbo, double *se, int64_t *best_iter);
+
 /* HOST_CALLBACK targets only: wall time spent inside the user's callback and bytes of draws handed to it (device -> pinned host)
  * during the last pfmi_elbo_batch.  The draws of a block of fits are generated and downloaded while the host evaluates the
  * previous block, so elbo_batch time ~ max(callback time, generation + PCIe time). */
 int32_t pfmi_callback_stats(pfmi_ctx *ctx, double *callback_seconds, double *bytes_to_host);
+/* DEVICE_CALLBACK targets: bytes of draws materialised in HBM for the callback during the last pfmi_elbo_batch (written once by the
+ * draw kernel, read once by the user's kernel: 16 d bytes per draw physically move) */
+int32_t pfmi_callback_stats_dev(pfmi_ctx *ctx, double *bytes_in_hbm);
 
 /* per-draw log densities of one fit from the last pfmi_elbo_batch: logp[N], logq[N] */
 int32_t pfmi_get_elbo_logs(pfmi_ctx *ctx, int64_t point, double *logp, double *logq);
@@ -178,6 +201,14 @@ int32_t pfmi_woodbury_diag(pfmi_ctx *ctx, int64_t point, double *diag);
  * `points[k]` with seed seeds[k] into the device-resident pool (d, N_r, K) and
  * log_ratios[k*N_r + n] = logp - logq (src/resample.jl:81-95; n fastest, k slowest). */
 int32_t pfmi_pool_build(pfmi_ctx *ctx, int64_t N_r, const int64_t *points, const uint64_t *seeds);
+/* The same with the winners picked ON THE DEVICE from the last pfmi_elbo_batch[_enqueue] -- no host round trip between the scan and
+ * the pool: for path k the fit is fit_distributions[fit_iteration + 1] (src/singlepath.jl:224) = point off[k] + best_iter[k]; a
+ * successful path (L > 0, ELBO finite and != -Inf, src/singlepath.jl:309-314) reuses its ELBO draws, i.e. the seed of the winning
+ * fit (src/singlepath.jl:226-230, N_r > N_e continues the same counter); a failed path draws afresh with fail_seeds[k]
+ * (rand(rng, fit_distribution, ndraws), src/singlepath.jl:231-233; fail_seeds NULL: the seed of the fit is used there too).
+ * Only enqueues.  pfmi_pool_winners reads back what was used (blocks): points[K], seeds[K], success[K]; any may be NULL. */
+int32_t pfmi_pool_build_best(pfmi_ctx *ctx, int64_t N_r, const uint64_t *fail_seeds);
+int32_t pfmi_pool_winners(pfmi_ctx *ctx, int64_t *points, uint64_t *seeds, int32_t *success);
 int32_t pfmi_pool_get(pfmi_ctx *ctx, double *draws, double *log_ratios);
 /* device pointer to the local log-ratio shard (K_local * N_r doubles) for the RCCL all-gather */
 int32_t pfmi_pool_log_ratios_dev(pfmi_ctx *ctx, void **dev_ptr, int64_t *count);
@@ -188,6 +219,9 @@ int32_t pfmi_psis_dev(pfmi_ctx *ctx, const void *log_ratios_dev, int64_t S, doub
                       double *log_weights, double *pareto_k, int64_t *tail_len);
 int32_t pfmi_psis(pfmi_ctx *ctx, const double *log_ratios, int64_t S, double *weights,
                   double *log_weights, double *pareto_k, int64_t *tail_len);
+/* the ctx's current PSIS result (PSISResult.weights / .log_weights, S doubles each; either may be NULL) -- for hosts that leave
+ * the vectors on the device until somebody looks at them */
+int32_t pfmi_psis_weights(pfmi_ctx *ctx, int64_t S, double *weights, double *log_weights);
 
 /* _resample index selection (src/resample.jl:58-66): ndraws indices into 0..S-1.
  * importance != 0: weighted by the ctx's current PSIS weights; == 0: uniform (psis_result === nothing).
@@ -236,6 +270,15 @@ int32_t pfmi_comm_pool_psis(pfmi_comm *comm, double *pareto_k, int64_t *tail_len
  * one sum all-reduce assembles draws[d * ndraws].  idx: global 0-based pool columns (component id = idx / N_r). */
 int32_t pfmi_comm_resample(pfmi_comm *comm, int64_t ndraws, int32_t importance, int32_t replace, uint64_t seed,
                            const double *uniforms, int64_t *idx, double *draws);
+/* Both stages in one call with ONE synchronisation at the end: [all-gather + PSIS when importance != 0] -> index selection -> owner
+ * gather -> sum all-reduce are enqueued on every local context before the first wait, so a single host thread keeps all its GPUs
+ * busy (src/multipath.jl:221-225).  A world of one context needs no RCCL at all (the single-GPU hot path takes this route too).
+ * pareto_k / tail_len are NaN / 0 when importance == 0.
+ * One process per GPU (pfmi_comm_init_rank): every rank must make the same sequence of pfmi_comm_* calls; a PFMI_ERR_* from any of
+ * them is fatal for the whole group -- the ranks first agree on their shard size and local status, so a local precondition failure
+ * or a size mismatch is reported on EVERY rank instead of leaving the others blocked in a collective. */
+int32_t pfmi_comm_psis_resample(pfmi_comm *comm, int64_t ndraws, int32_t importance, int32_t replace, uint64_t seed,
+                                const double *uniforms, double *pareto_k, int64_t *tail_len, int64_t *idx, double *draws);
 
 /* ---- host utility --------------------------------------------------------------------------------------------------- */
 /* The counter-based generator the Python / C host mirrors use for the reference's seed hierarchy (run_seeds =

@@ -262,6 +262,13 @@ def randn_fill(seed, d, N, n0=0):
     return U
 
 
+def icdf_words(x, x2):
+    """the normals of literal Philox words x (uint32 array; x2 = the refinement words) -- pfo_icdf_normal"""
+    f = lib().pfo_icdf_normal
+    f.restype = C.c_double
+    return np.array([f(C.c_uint32(int(a)), C.c_uint32(int(b))) for a, b in zip(x, x2)])
+
+
 def rand_u64(seed, t, stream):
     return int(lib().pfo_rand_u64(C.c_uint64(int(seed)), C.c_uint64(int(t)), C.c_uint32(stream)))
 

@@ -12,12 +12,23 @@
 //   pfmi_comm_init_all   one host process drives G contexts, one per GPU (ncclCommInitAll) -- what a single Julia process needs;
 //   pfmi_comm_init_rank  one process per GPU (ncclCommInitRank with a 128-byte id made by pfmi_comm_unique_id and shipped by
 //                        the host's own launcher), e.g. under torch.distributed.run.
-// librccl is opened with dlopen at the first pfmi_comm_* call, so libpfmi.so itself has no link-time dependency on it and a
-// process that already carries an RCCL (PyTorch bundles one under the same SONAME) keeps a single copy.
+// librccl is opened with dlopen at the first pfmi_comm_* call that needs it, so libpfmi.so itself has no link-time dependency on
+// it and a process that already carries an RCCL (PyTorch bundles one under the same SONAME) keeps a single copy.  A world of ONE
+// context needs no collective at all and does not touch RCCL (PFMI_COMM_FORCE_RCCL=1 makes it, for tests of the real library on a
+// 1-GPU box).
+//
+// Every stage is ENQUEUED on all local contexts before the first host wait (round 3): one host thread driving G GPUs keeps all of
+// them busy, and the fused pfmi_comm_psis_resample synchronises exactly once.
+//
+// Test hooks (tests/rccl_standin): PFMI_RCCL_LIB=<path> loads that library instead of librccl (an in-process stand-in that
+// implements the 11 entry points below among contexts of one process), PFMI_COMM_ALLOW_SHARED_GPU=1 lets several ranks sit on the
+// same GPU -- together they execute the G > 1 data path (rank offsets, G-way gather, zero fill, reduce) on a 1-GPU box.
 #include "pfmi_common.h"
 
 #include <dlfcn.h>
+#include <math.h>
 #include <rccl/rccl.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -40,13 +51,19 @@ RcclApi g_rccl;
 
 int32_t rccl_load() {
     if (g_rccl.handle) return PFMI_OK;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *h = nullptr;
-    for (const char *n : names) {
-        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (h) break;
+    const char *over = getenv("PFMI_RCCL_LIB");
+    if (over && over[0]) {
+        h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+        PF_CHECK(h != nullptr, PFMI_ERR_UNSUPPORTED, "PFMI_RCCL_LIB=%s could not be loaded: %s", over, dlerror());
+    } else {
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+        PF_CHECK(h != nullptr, PFMI_ERR_UNSUPPORTED, "RCCL not found (librccl.so.1): %s", dlerror());
     }
-    PF_CHECK(h != nullptr, PFMI_ERR_UNSUPPORTED, "RCCL not found (librccl.so.1): %s", dlerror());
 #define PF_SYM(field, name)                                                                      \
     do {                                                                                         \
         g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name));                 \
@@ -77,18 +94,242 @@ int32_t rccl_load() {
         }                                                                                                 \
     } while (0)
 
+bool env_on(const char *name) {
+    const char *e = getenv(name);
+    return e && e[0] && e[0] != '0';
+}
+
+// out[i] = NaN: a rank whose local stage failed still enters the all-reduce (so nobody blocks) with a poisoned contribution
+__global__ void pf_poison_kernel(double *out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = NAN;
+}
+
 }  // namespace
 
 // one communicator = the local ranks this process drives (all G under init_all, exactly one under init_rank)
 struct pfmi_comm {
-    int world = 0;                       // ranks in the RCCL world
+    int world = 0;                       // ranks in the world
+    bool rccl = false;                   // collectives go through RCCL (false: a world of one context, nothing to exchange)
     std::vector<pfmi_ctx *> ctx;         // local contexts
     std::vector<ncclComm_t> comm;        // their communicators
     std::vector<int> rank;               // their world ranks
     std::vector<DevBuf> lr_all;          // [world * shard] gathered log ratios, one per local ctx
     std::vector<DevBuf> out;             // [d * ndraws] owner-filled result, one per local ctx
-    int64_t shard = 0;                   // K_local * N_r of the last all-gather
+    std::vector<DevBuf> hs;              // [4] handshake block, one per local ctx
+    int64_t shard = 0;                   // K_local * N_r agreed by the last pooled stage
+    bool psis_pending = false;
+    int64_t rs_ndraws = 0;               // draws of the enqueued resample stage
+    bool rs_local_error = false;
 };
+
+namespace {
+
+int32_t group_all_gather(pfmi_comm *c) {
+    const size_t nl = c->ctx.size();
+    PF_NCCL(g_rccl.GroupStart());
+    for (size_t i = 0; i < nl; ++i) {
+        pfmi_ctx *x = c->ctx[i];
+        ncclResult_t r = g_rccl.AllGather(x->pool_lr.p, c->lr_all[i].p, (size_t)c->shard, ncclDouble, c->comm[i], x->stream);
+        if (r != ncclSuccess) {
+            (void)g_rccl.GroupEnd();
+            pf_set_error("ncclAllGather failed on rank %d: %s", c->rank[i], g_rccl.GetErrorString(r));
+            return PFMI_ERR_COMM;
+        }
+    }
+    PF_NCCL(g_rccl.GroupEnd());
+    return PFMI_OK;
+}
+
+int32_t group_all_reduce(pfmi_comm *c, std::vector<DevBuf> &buf, size_t count, ncclRedOp_t op) {
+    const size_t nl = c->ctx.size();
+    PF_NCCL(g_rccl.GroupStart());
+    for (size_t i = 0; i < nl; ++i) {
+        pfmi_ctx *x = c->ctx[i];
+        ncclResult_t r = g_rccl.AllReduce(buf[i].p, buf[i].p, count, ncclDouble, op, c->comm[i], x->stream);
+        if (r != ncclSuccess) {
+            (void)g_rccl.GroupEnd();
+            pf_set_error("ncclAllReduce failed on rank %d: %s", c->rank[i], g_rccl.GetErrorString(r));
+            return PFMI_ERR_COMM;
+        }
+    }
+    PF_NCCL(g_rccl.GroupEnd());
+    return PFMI_OK;
+}
+
+// Agree on the shard size and on everybody's local status BEFORE a collective whose element count depends on them.  Under
+// pfmi_comm_init_all this process sees every rank and the check is local; under pfmi_comm_init_rank the ranks exchange
+// max{shard, -shard, error} (one 4-double all-reduce): a rank without a pool or with a different K_local * N_r makes EVERY rank return
+// the same error instead of leaving the others blocked in (or corrupting) the all-gather.  `local_err` != 0: this process already
+// knows it cannot take part.
+int32_t agree_on_shard(pfmi_comm *c, int64_t *shard_out) {
+    const size_t nl = c->ctx.size();
+    int64_t shard = -1;
+    int local_err = 0;
+    char why[256] = "";
+    for (size_t i = 0; i < nl; ++i) {
+        pfmi_ctx *x = c->ctx[i];
+        if (!x->pooled) {
+            local_err = 1;
+            snprintf(why, sizeof(why), "rank %d has no pool (call pfmi_pool_build)", c->rank[i]);
+            continue;
+        }
+        const int64_t s = (int64_t)x->K * x->N_r;
+        if (shard >= 0 && s != shard) {
+            local_err = 1;
+            snprintf(why, sizeof(why), "log-ratio shards differ in size (%lld vs %lld)", (long long)s, (long long)shard);
+        }
+        shard = s;
+    }
+    if ((int)nl < c->world) {                                   // one process per GPU: the other ranks are somewhere else
+        double h[4] = {(double)shard, -(double)shard, (double)local_err, 0.0}, r[4] = {0, 0, 0, 0};
+        for (size_t i = 0; i < nl; ++i) {
+            PF_HIP(hipSetDevice(c->ctx[i]->device));
+            PF_TRY(c->hs[i].ensure(sizeof(h)));
+            PF_TRY(pf_upload(c->ctx[i], c->hs[i].p, h, sizeof(h)));
+        }
+        PF_TRY(group_all_reduce(c, c->hs, 4, ncclMax));
+        PF_HIP(hipSetDevice(c->ctx[0]->device));
+        PF_HIP(hipMemcpyAsync(r, c->hs[0].p, sizeof(r), hipMemcpyDeviceToHost, c->ctx[0]->stream));
+        PF_HIP(hipStreamSynchronize(c->ctx[0]->stream));
+        pf_arena_reset(c->ctx[0]);
+        PF_CHECK(r[2] == 0.0, PFMI_ERR_STATE, "comm: a rank of the group cannot take part in the pooled stage%s%s", local_err ? ": " : "",
+                 local_err ? why : " (see that rank's error)");
+        PF_CHECK(r[0] == -r[1], PFMI_ERR_ARG,
+                 "comm: log-ratio shards differ in size across ranks (%lld .. %lld): equal paths per GPU keep the result independent of G",
+                 (long long)-r[1], (long long)r[0]);
+    } else {
+        PF_CHECK(!local_err, strstr(why, "differ") ? PFMI_ERR_ARG : PFMI_ERR_STATE, "comm_pool_psis: %s%s", why,
+                 strstr(why, "differ") ? ": equal paths per GPU keep the result independent of G" : "");
+    }
+    *shard_out = shard;
+    return PFMI_OK;
+}
+
+// all-gather + replicated PSIS, enqueued on every local context
+int32_t enqueue_pool_psis(pfmi_comm *c) {
+    const size_t nl = c->ctx.size();
+    int64_t shard = 0;
+    PF_TRY(agree_on_shard(c, &shard));
+    c->shard = shard;
+    const int64_t S = shard * c->world;
+    if (c->rccl) {
+        for (size_t i = 0; i < nl; ++i) {
+            PF_HIP(hipSetDevice(c->ctx[i]->device));
+            PF_TRY(c->lr_all[i].ensure(sizeof(double) * (size_t)S));
+        }
+        PF_TRY(group_all_gather(c));
+    }
+    for (size_t i = 0; i < nl; ++i) {                       // replicated PSIS: same code, same input, fixed reduction order
+        pfmi_ctx *x = c->ctx[i];
+        PF_HIP(hipSetDevice(x->device));
+        PF_TRY(pf_launch_psis(x, c->rccl ? c->lr_all[i].as<double>() : x->pool_lr.as<double>(), S));
+    }
+    c->psis_pending = true;
+    return PFMI_OK;
+}
+
+int32_t finish_pool_psis(pfmi_comm *c, double *pareto_k, int64_t *tail_len) {
+    const size_t nl = c->ctx.size();
+    std::vector<double> out(4 * nl);
+    for (size_t i = 0; i < nl; ++i) {
+        pfmi_ctx *x = c->ctx[i];
+        PF_HIP(hipSetDevice(x->device));
+        PF_HIP(hipMemcpyAsync(&out[4 * i], x->psis_out.p, 4 * sizeof(double), hipMemcpyDeviceToHost, x->stream));
+    }
+    for (size_t i = 0; i < nl; ++i) {
+        PF_HIP(hipSetDevice(c->ctx[i]->device));
+        PF_HIP(hipStreamSynchronize(c->ctx[i]->stream));
+        pf_arena_reset(c->ctx[i]);
+    }
+    c->psis_pending = false;
+    const double k0 = out[0];
+    const int64_t m0 = (int64_t)out[1];
+    for (size_t i = 1; i < nl; ++i) {
+        const double k = out[4 * i];
+        PF_CHECK((int64_t)out[4 * i + 1] == m0 && (k == k0 || (k != k && k0 != k0)), PFMI_ERR_NUMERIC, "comm_pool_psis: replicas disagree (rank %d)",
+                 c->rank[i]);
+    }
+    if (pareto_k) *pareto_k = k0;
+    if (tail_len) *tail_len = m0;
+    return PFMI_OK;
+}
+
+// replicated index selection -> owner gather (zeros elsewhere) -> sum all-reduce, enqueued on every local context
+int32_t enqueue_resample(pfmi_comm *c, int64_t ndraws, int32_t importance, int32_t replace, uint64_t seed, const double *uniforms) {
+    const size_t nl = c->ctx.size();
+    const int64_t S = c->shard * c->world;
+    const int d = c->ctx[0]->d;
+    c->rs_ndraws = ndraws;
+    c->rs_local_error = false;
+    int32_t rc_local = PFMI_OK;
+    for (size_t i = 0; i < nl; ++i) {
+        pfmi_ctx *x = c->ctx[i];
+        PF_HIP(hipSetDevice(x->device));
+        PF_TRY(c->out[i].ensure(sizeof(double) * (size_t)d * ndraws));
+        int32_t rc = PFMI_OK;
+        if (x->d != d) { pf_set_error("comm_resample: dimension differs between ranks"); rc = PFMI_ERR_ARG; }
+        if (rc == PFMI_OK && importance && x->S_w != S) {
+            pf_set_error("comm_resample: importance weights for S=%lld not available on rank %d (run the pooled PSIS first)", (long long)S, c->rank[i]);
+            rc = PFMI_ERR_STATE;
+        }
+        const double *d_uni = nullptr;
+        if (rc == PFMI_OK && uniforms) {
+            rc = x->tailbuf.ensure(sizeof(double) * ndraws);
+            if (rc == PFMI_OK) rc = pf_upload(x, x->tailbuf.p, uniforms, sizeof(double) * ndraws);
+            d_uni = x->tailbuf.as<double>();
+        }
+        if (rc == PFMI_OK) rc = pf_enqueue_resample(x, S, ndraws, importance, replace, seed, d_uni);
+        if (rc == PFMI_OK) rc = pf_launch_gather(x, ndraws, x->idx.as<int64_t>(), (int64_t)c->rank[i] * c->shard, c->out[i].as<double>());
+        if (rc != PFMI_OK) {                                    // still take part in the all-reduce: NaN reaches every rank
+            rc_local = rc;
+            c->rs_local_error = true;
+            const long long n = (long long)d * ndraws;
+            hipLaunchKernelGGL(pf_poison_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, x->stream, c->out[i].as<double>(), n);
+        }
+    }
+    if (c->rccl) PF_TRY(group_all_reduce(c, c->out, (size_t)d * ndraws, ncclSum));
+    return rc_local;
+}
+
+int32_t finish_resample(pfmi_comm *c, int64_t *idx, double *draws) {
+    const size_t nl = c->ctx.size();
+    const int64_t ndraws = c->rs_ndraws;
+    const int d = c->ctx[0]->d;
+    std::vector<int64_t> h_idx((size_t)ndraws * nl);
+    std::vector<int> h_err(nl, 0);
+    double probe = 0.0;
+    for (size_t i = 0; i < nl; ++i) {
+        pfmi_ctx *x = c->ctx[i];
+        PF_HIP(hipSetDevice(x->device));
+        if (x->idx.cap >= sizeof(int64_t) * (size_t)ndraws)
+            PF_HIP(hipMemcpyAsync(&h_idx[(size_t)ndraws * i], x->idx.p, sizeof(int64_t) * ndraws, hipMemcpyDeviceToHost, x->stream));
+        if (x->rs_err.p) PF_HIP(hipMemcpyAsync(&h_err[i], x->rs_err.p, sizeof(int), hipMemcpyDeviceToHost, x->stream));
+    }
+    {
+        pfmi_ctx *x = c->ctx[0];
+        PF_HIP(hipSetDevice(x->device));
+        if (draws) PF_HIP(hipMemcpyAsync(draws, c->out[0].p, sizeof(double) * (size_t)d * ndraws, hipMemcpyDeviceToHost, x->stream));
+        else PF_HIP(hipMemcpyAsync(&probe, c->out[0].p, sizeof(double), hipMemcpyDeviceToHost, x->stream));
+    }
+    for (size_t i = 0; i < nl; ++i) {
+        PF_HIP(hipSetDevice(c->ctx[i]->device));
+        PF_HIP(hipStreamSynchronize(c->ctx[i]->stream));
+        pf_arena_reset(c->ctx[i]);
+    }
+    for (size_t i = 0; i < nl; ++i)
+        PF_CHECK(h_err[i] == 0, PFMI_ERR_NUMERIC, "resample: weights are all zero / not enough positive weights (rank %d)", c->rank[i]);
+    // a rank whose local stage failed poisoned its contribution: element 0 of the reduced result is NaN on every rank
+    const double first = draws ? draws[0] : probe;
+    PF_CHECK(first == first, PFMI_ERR_COMM, "comm_resample: a rank of the group failed its local stage (poisoned all-reduce)");
+    for (size_t i = 1; i < nl; ++i)
+        PF_CHECK(memcmp(&h_idx[(size_t)ndraws * i], h_idx.data(), sizeof(int64_t) * ndraws) == 0, PFMI_ERR_NUMERIC,
+                 "comm_resample: replicated index selection disagrees on rank %d", c->rank[i]);
+    if (idx) memcpy(idx, h_idx.data(), sizeof(int64_t) * (size_t)ndraws);
+    return PFMI_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -106,28 +347,36 @@ int32_t pfmi_comm_init_all(int32_t G, pfmi_ctx *const *ctxs, pfmi_comm **out) {
     PF_CHECK(out != nullptr, PFMI_ERR_ARG, "comm_init_all: null out");
     *out = nullptr;
     PF_CHECK(G >= 1 && ctxs != nullptr, PFMI_ERR_ARG, "comm_init_all: bad arguments");
-    PF_TRY(rccl_load());
+    const bool use_rccl = G > 1 || env_on("PFMI_COMM_FORCE_RCCL");
+    if (use_rccl) PF_TRY(rccl_load());
     std::vector<int> devs((size_t)G);
+    const bool shared_ok = env_on("PFMI_COMM_ALLOW_SHARED_GPU");       // test hook, see the header comment
     for (int r = 0; r < G; ++r) {
         PF_CHECK(ctxs[r] != nullptr, PFMI_ERR_ARG, "comm_init_all: null context %d", r);
         devs[(size_t)r] = ctxs[r]->device;
-        for (int q = 0; q < r; ++q)
-            PF_CHECK(devs[(size_t)q] != devs[(size_t)r], PFMI_ERR_ARG, "comm_init_all: contexts %d and %d share GPU %d (one rank per GPU)", q, r,
-                     devs[(size_t)r]);
+        for (int q = 0; q < r; ++q) {
+            PF_CHECK(ctxs[q] != ctxs[r], PFMI_ERR_ARG, "comm_init_all: context %d passed twice", r);
+            PF_CHECK(shared_ok || devs[(size_t)q] != devs[(size_t)r], PFMI_ERR_ARG,
+                     "comm_init_all: contexts %d and %d share GPU %d (one rank per GPU)", q, r, devs[(size_t)r]);
+        }
     }
     pfmi_comm *c = new pfmi_comm();
     c->world = G;
+    c->rccl = use_rccl;
     c->ctx.assign(ctxs, ctxs + G);
     c->comm.assign((size_t)G, nullptr);
     c->rank.resize((size_t)G);
     for (int r = 0; r < G; ++r) c->rank[(size_t)r] = r;
     c->lr_all.resize((size_t)G);
     c->out.resize((size_t)G);
-    ncclResult_t rc = g_rccl.CommInitAll(c->comm.data(), G, devs.data());
-    if (rc != ncclSuccess) {
-        pf_set_error("ncclCommInitAll(%d GPUs) failed: %s", G, g_rccl.GetErrorString(rc));
-        delete c;
-        return PFMI_ERR_COMM;
+    c->hs.resize((size_t)G);
+    if (use_rccl) {
+        ncclResult_t rc = g_rccl.CommInitAll(c->comm.data(), G, devs.data());
+        if (rc != ncclSuccess) {
+            pf_set_error("ncclCommInitAll(%d GPUs) failed: %s", G, g_rccl.GetErrorString(rc));
+            delete c;
+            return PFMI_ERR_COMM;
+        }
     }
     *out = c;
     return PFMI_OK;
@@ -143,11 +392,13 @@ int32_t pfmi_comm_init_rank(pfmi_ctx *ctx, int32_t world, int32_t rank, const ui
     memcpy(&id, id128, 128);
     pfmi_comm *c = new pfmi_comm();
     c->world = world;
+    c->rccl = true;
     c->ctx.assign(1, ctx);
     c->comm.assign(1, nullptr);
     c->rank.assign(1, rank);
     c->lr_all.resize(1);
     c->out.resize(1);
+    c->hs.resize(1);
     ncclResult_t rc = g_rccl.CommInitRank(&c->comm[0], world, id, rank);
     if (rc != ncclSuccess) {
         pf_set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, world, g_rccl.GetErrorString(rc));
@@ -166,6 +417,7 @@ int32_t pfmi_comm_destroy(pfmi_comm *c) {
         if (c->comm[i]) (void)g_rccl.CommDestroy(c->comm[i]);
         c->lr_all[i].release();
         c->out[i].release();
+        c->hs[i].release();
     }
     delete c;
     return PFMI_OK;
@@ -174,14 +426,14 @@ int32_t pfmi_comm_destroy(pfmi_comm *c) {
 int32_t pfmi_comm_info(pfmi_comm *c, int32_t *world, int32_t *nlocal, int32_t *rccl_version) {
     PF_CHECK(c != nullptr, PFMI_ERR_ARG, "null pfmi_comm");
     if (world) {
-        int n = 0;
-        PF_NCCL(g_rccl.CommCount(c->comm[0], &n));         // what RCCL itself says, not what the caller claimed
+        int n = c->world;
+        if (c->rccl) PF_NCCL(g_rccl.CommCount(c->comm[0], &n));       // what RCCL itself says, not what the caller claimed
         *world = n;
     }
     if (nlocal) *nlocal = (int32_t)c->ctx.size();
     if (rccl_version) {
-        int v = 0;
-        PF_NCCL(g_rccl.GetVersion(&v));
+        int v = 0;                                                      // 0: a world of one context, RCCL not involved
+        if (c->rccl) PF_NCCL(g_rccl.GetVersion(&v));
         *rccl_version = v;
     }
     return PFMI_OK;
@@ -190,46 +442,8 @@ int32_t pfmi_comm_info(pfmi_comm *c, int32_t *world, int32_t *nlocal, int32_t *r
 // _compute_psis_result over the pooled runs (src/multipath.jl:221): all-gather the log-ratio shards, then PSIS on every GPU.
 int32_t pfmi_comm_pool_psis(pfmi_comm *c, double *pareto_k, int64_t *tail_len) {
     PF_CHECK(c != nullptr, PFMI_ERR_ARG, "null pfmi_comm");
-    const size_t nl = c->ctx.size();
-    int64_t shard = -1;
-    for (size_t i = 0; i < nl; ++i) {
-        pfmi_ctx *x = c->ctx[i];
-        PF_CHECK(x->pooled, PFMI_ERR_STATE, "comm_pool_psis: rank %d has no pool (call pfmi_pool_build)", c->rank[i]);
-        const int64_t s = (int64_t)x->K * x->N_r;
-        PF_CHECK(shard < 0 || s == shard, PFMI_ERR_ARG,
-                 "comm_pool_psis: log-ratio shards differ in size (%lld vs %lld): equal paths per GPU keep the result independent of G",
-                 (long long)s, (long long)shard);
-        shard = s;
-    }
-    c->shard = shard;
-    const int64_t S = shard * c->world;
-    for (size_t i = 0; i < nl; ++i) {
-        PF_HIP(hipSetDevice(c->ctx[i]->device));
-        PF_TRY(c->lr_all[i].ensure(sizeof(double) * (size_t)S));
-    }
-    PF_NCCL(g_rccl.GroupStart());
-    for (size_t i = 0; i < nl; ++i) {
-        pfmi_ctx *x = c->ctx[i];
-        ncclResult_t r = g_rccl.AllGather(x->pool_lr.p, c->lr_all[i].p, (size_t)shard, ncclDouble, c->comm[i], x->stream);
-        if (r != ncclSuccess) {
-            (void)g_rccl.GroupEnd();
-            pf_set_error("ncclAllGather failed on rank %d: %s", c->rank[i], g_rccl.GetErrorString(r));
-            return PFMI_ERR_COMM;
-        }
-    }
-    PF_NCCL(g_rccl.GroupEnd());
-    double k0 = 0.0;
-    int64_t m0 = 0;
-    for (size_t i = 0; i < nl; ++i) {                       // replicated PSIS: same code, same input, fixed reduction order
-        double k;
-        int64_t m;
-        PF_TRY(pfmi_psis_dev(c->ctx[i], c->lr_all[i].p, S, nullptr, nullptr, &k, &m));
-        if (i == 0) { k0 = k; m0 = m; }
-        else PF_CHECK(m == m0 && (k == k0 || (k != k && k0 != k0)), PFMI_ERR_NUMERIC, "comm_pool_psis: replicas disagree (rank %d)", c->rank[i]);
-    }
-    if (pareto_k) *pareto_k = k0;
-    if (tail_len) *tail_len = m0;
-    return PFMI_OK;
+    PF_TRY(enqueue_pool_psis(c));
+    return finish_pool_psis(c, pareto_k, tail_len);
 }
 
 // _resample over the pooled runs (src/multipath.jl:225, src/resample.jl:58-72): replicated index selection, owner gather,
@@ -239,42 +453,31 @@ int32_t pfmi_comm_resample(pfmi_comm *c, int64_t ndraws, int32_t importance, int
     PF_CHECK(c != nullptr, PFMI_ERR_ARG, "null pfmi_comm");
     PF_CHECK(ndraws >= 1, PFMI_ERR_ARG, "comm_resample: ndraws must be positive");
     PF_CHECK(c->shard > 0, PFMI_ERR_STATE, "comm_resample: call pfmi_comm_pool_psis first");
-    const size_t nl = c->ctx.size();
-    const int64_t S = c->shard * c->world;
-    const int d = c->ctx[0]->d;
-    std::vector<int64_t> h_idx((size_t)ndraws), h_idx0;
-    for (size_t i = 0; i < nl; ++i) {
-        pfmi_ctx *x = c->ctx[i];
-        PF_CHECK(x->d == d, PFMI_ERR_ARG, "comm_resample: dimension differs between ranks");
-        PF_TRY(pfmi_resample_indices(x, S, ndraws, importance, replace, seed, uniforms, h_idx.data()));
-        if (i == 0) h_idx0 = h_idx;
-        else PF_CHECK(h_idx == h_idx0, PFMI_ERR_NUMERIC, "comm_resample: replicated index selection disagrees on rank %d", c->rank[i]);
-        PF_TRY(c->out[i].ensure(sizeof(double) * (size_t)d * ndraws));
-        PF_TRY(pfmi_pool_gather_dev(x, ndraws, h_idx0.data(), (int64_t)c->rank[i] * c->shard, c->out[i].p));   // zeros where not owned
+    const int32_t rc = enqueue_resample(c, ndraws, importance, replace, seed, uniforms);
+    const int32_t rf = finish_resample(c, idx, draws);
+    return rc != PFMI_OK ? rc : rf;
+}
+
+// both stages, one synchronisation (src/multipath.jl:221-225)
+int32_t pfmi_comm_psis_resample(pfmi_comm *c, int64_t ndraws, int32_t importance, int32_t replace, uint64_t seed, const double *uniforms,
+                                double *pareto_k, int64_t *tail_len, int64_t *idx, double *draws) {
+    PF_CHECK(c != nullptr, PFMI_ERR_ARG, "null pfmi_comm");
+    PF_CHECK(ndraws >= 1, PFMI_ERR_ARG, "comm_psis_resample: ndraws must be positive");
+    if (importance) PF_TRY(enqueue_pool_psis(c));
+    else {
+        int64_t shard = 0;
+        PF_TRY(agree_on_shard(c, &shard));
+        c->shard = shard;
     }
-    PF_NCCL(g_rccl.GroupStart());
-    for (size_t i = 0; i < nl; ++i) {
-        pfmi_ctx *x = c->ctx[i];
-        ncclResult_t r = g_rccl.AllReduce(c->out[i].p, c->out[i].p, (size_t)d * ndraws, ncclDouble, ncclSum, c->comm[i], x->stream);
-        if (r != ncclSuccess) {
-            (void)g_rccl.GroupEnd();
-            pf_set_error("ncclAllReduce failed on rank %d: %s", c->rank[i], g_rccl.GetErrorString(r));
-            return PFMI_ERR_COMM;
-        }
-    }
-    PF_NCCL(g_rccl.GroupEnd());
-    for (size_t i = 0; i < nl; ++i) {
-        PF_HIP(hipSetDevice(c->ctx[i]->device));
-        PF_HIP(hipStreamSynchronize(c->ctx[i]->stream));
-    }
-    if (idx) memcpy(idx, h_idx0.data(), sizeof(int64_t) * (size_t)ndraws);
-    if (draws) {
-        pfmi_ctx *x = c->ctx[0];
-        PF_HIP(hipSetDevice(x->device));
-        PF_HIP(hipMemcpyAsync(draws, c->out[0].p, sizeof(double) * (size_t)d * ndraws, hipMemcpyDeviceToHost, x->stream));
-        PF_HIP(hipStreamSynchronize(x->stream));
-    }
-    return PFMI_OK;
+    const int32_t rc = enqueue_resample(c, ndraws, importance, replace, seed, uniforms);
+    double k = NAN;
+    int64_t m = 0;
+    int32_t rp = PFMI_OK;
+    if (importance) rp = finish_pool_psis(c, &k, &m);                   // first wait: everything above is already in flight
+    const int32_t rf = finish_resample(c, idx, draws);
+    if (pareto_k) *pareto_k = k;
+    if (tail_len) *tail_len = m;
+    return rc != PFMI_OK ? rc : (rp != PFMI_OK ? rp : rf);
 }
 
 }  // extern "C"

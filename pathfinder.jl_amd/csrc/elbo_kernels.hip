@@ -260,12 +260,40 @@ __global__ void pf_logratio_kernel(int64_t n, const double *__restrict__ lp, con
 
 // dst[points[s] * N + n] = src[s * N + n]: the callback path's per-fit log densities into the point-indexed table (one launch
 // instead of one device-to-device copy per fit)
-__global__ void pf_scatter_rows_kernel(int64_t ns, int64_t N, const int32_t *__restrict__ points, const double *__restrict__ src,
-                                       double *__restrict__ dst) {
+// (a failed fit has no draws: its closure values are computed on stale memory and replaced by NaN, like an exception in the reference)
+__global__ void pf_scatter_rows_kernel(int64_t ns, int64_t N, const int32_t *__restrict__ points, const int32_t *__restrict__ status,
+                                       const double *__restrict__ src, double *__restrict__ dst) {
     const int64_t s = blockIdx.y;
     if (s >= ns) return;
+    const int p = points[s];
+    const bool ok = status[p] == PFMI_FIT_OK;
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x)
-        dst[(size_t)points[s] * N + n] = src[(size_t)s * N + n];
+        dst[(size_t)p * N + n] = ok ? src[(size_t)s * N + n] : NAN;
+}
+__global__ void pf_nan_failed_kernel(int64_t ns, int64_t N, const int32_t *__restrict__ points, const int32_t *__restrict__ status,
+                                     double *__restrict__ lp) {
+    const int64_t s = blockIdx.y;
+    if (s >= ns || status[points[s]] == PFMI_FIT_OK) return;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x)
+        lp[(size_t)s * N + n] = NAN;
+}
+
+// Winners of the ELBO scan picked on the device (pfmi_pool_build_best): fit_distributions[fit_iteration + 1] (src/singlepath.jl:224),
+// success = L > 0 && ELBO finite and != -Inf (src/singlepath.jl:299, 309-314); a successful path reuses the seed of its winning
+// fit (src/singlepath.jl:226-230), a failed one takes fail_seeds[k] (rand(rng, fit_distribution, ndraws), :231-233).
+__global__ void pf_pool_pick_kernel(int K, const int64_t *__restrict__ off, const int64_t *__restrict__ best_iter,
+                                    const double *__restrict__ elbo, const uint64_t *__restrict__ seeds,
+                                    const uint64_t *__restrict__ fail_seeds, int32_t *__restrict__ points, uint64_t *__restrict__ pseeds,
+                                    int32_t *__restrict__ ok) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const int64_t p0 = off[k], L = off[k + 1] - p0 - 1, b = best_iter[k];
+    const int64_t p = p0 + b;
+    const double v = (b > 0) ? elbo[p] : NAN;
+    const int good = (L > 0 && b > 0 && !isnan(v) && v != -INFINITY) ? 1 : 0;
+    points[k] = (int32_t)p;
+    pseeds[k] = (good || fail_seeds == nullptr) ? seeds[p] : fail_seeds[k];
+    ok[k] = good;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -431,7 +459,29 @@ int32_t pf_launch_elbo_reduce(pfmi_ctx *c) {
 int32_t pf_launch_scatter_rows(pfmi_ctx *c, int64_t ns, int64_t N, const int32_t *d_points, const double *d_src, double *d_dst) {
     if (ns <= 0 || N <= 0) return PFMI_OK;
     const unsigned gx = (unsigned)((N + 255) / 256 < 64 ? (N + 255) / 256 : 64);
-    hipLaunchKernelGGL(pf_scatter_rows_kernel, dim3(gx, (unsigned)ns), dim3(256), 0, c->stream, ns, N, d_points, d_src, d_dst);
+    hipLaunchKernelGGL(pf_scatter_rows_kernel, dim3(gx, (unsigned)ns), dim3(256), 0, c->stream, ns, N, d_points, c->status.as<int32_t>(),
+                       d_src, d_dst);
+    PF_HIP(hipGetLastError());
+    return PFMI_OK;
+}
+
+int32_t pf_launch_nan_failed(pfmi_ctx *c, int64_t ns, int64_t N, const int32_t *d_points, double *d_lp) {
+    if (ns <= 0 || N <= 0) return PFMI_OK;
+    const unsigned gx = (unsigned)((N + 255) / 256 < 64 ? (N + 255) / 256 : 64);
+    for (int64_t s0 = 0; s0 < ns; s0 += 32768) {
+        const int64_t n1 = ns - s0 < 32768 ? ns - s0 : 32768;
+        hipLaunchKernelGGL(pf_nan_failed_kernel, dim3(gx, (unsigned)n1), dim3(256), 0, c->stream, n1, N, d_points + s0,
+                           c->status.as<int32_t>(), d_lp + (size_t)s0 * N);
+    }
+    PF_HIP(hipGetLastError());
+    return PFMI_OK;
+}
+
+int32_t pf_launch_pool_pick(pfmi_ctx *c, int have_fail_seeds) {
+    hipLaunchKernelGGL(pf_pool_pick_kernel, dim3((unsigned)((c->K + 63) / 64)), dim3(64), 0, c->stream, c->K, c->d_off.as<int64_t>(),
+                       c->best_iter.as<int64_t>(), c->elbo.as<double>(), c->seeds.as<uint64_t>(),
+                       have_fail_seeds ? c->fail_seeds.as<uint64_t>() : (const uint64_t *)nullptr, c->pool_points.as<int32_t>(),
+                       c->pool_seeds.as<uint64_t>(), c->pool_ok.as<int32_t>());
     PF_HIP(hipGetLastError());
     return PFMI_OK;
 }

@@ -22,6 +22,7 @@
 //   * per 16-row block a wave issues 4 k-steps x (2 KC/4 + RPAD/4) quarter-size MFMAs (16 cycles each) -- the same
 //     matrix work as the two-pass kernel -- plus the RNG.
 #include <type_traits>
+#include <stdlib.h>
 #include "pfmi_common.h"
 #include "pfmi_fastmath.h"
 #include "elbo_args.h"
@@ -38,6 +39,13 @@
 #endif
 #define QF_MIN_FRONT 1024             // doubles in front of the inverse-CDF table (>= (32 - 19) * 32 * 2 = 832)
 #define QF_CHB 16                      // blocks (of 16 rows) per streamed chunk
+
+// Results must not depend on the launch geometry (which fits fall into the tail launch, how a fit's groups are cut into pieces,
+// which of a wave's groups a draw lands in): the block body exists in several inlined instances (first batch / steady state,
+// group 0 / group 1), and with the default -ffp-contract=fast LLVM decides PER INSTANCE whether `a * b + c` becomes an fma -- round 3
+// found ELBOs differing in the last bit between a 64-path and a 16-path launch of the same fits.  Every fused operation in this file is
+// an explicit fma(); nothing else may be contracted.
+#pragma clang fp contract(off)
 
 typedef double qf_d4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ qf_d4 qf_mfma16(double a, double b, qf_d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
@@ -545,7 +553,8 @@ static int32_t launch_qf_ng(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
     // (each piece recomputes the per-fit constants in its pseudo-group slot) whenever that finishes sooner.
     int64_t tail = 0;
     int gpw_t = gpw, gx_t = gx;
-    if (split == 1 && TGT != 0) {
+    const char *no_tail = getenv("PFMI_QF_NO_TAIL");            // test hook: one launch for every fit (geometry-invariance tests)
+    if (split == 1 && TGT != 0 && !(no_tail && no_tail[0] == '1')) {
         int ncu = 0;
         PF_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device));
         const int slots = QF_WAVES * NG, nb_full = (ngroups + NPG + slots - 1) / slots;

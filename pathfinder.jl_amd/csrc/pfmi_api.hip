@@ -30,17 +30,51 @@ void pf_kernel_end(pfmi_ctx *c, const char *name) {
     s.launches += 1;
 }
 
-static int32_t h2d(pfmi_ctx *c, void *dst, const void *src, size_t bytes) {
+// ---- host <-> device copies ---------------------------------------------------------------------------------------
+// Uploads up to PF_ARENA_MAX bytes are staged in the ctx's pinned arena and copied asynchronously: the caller's buffer is free on
+// return and the stream is NOT synchronised, so a chain of entry points (fit -> scan -> pool -> PSIS -> resample) is enqueued
+// without a single host round trip.  Larger blocks (traces, parity-mode normals) take the plain synchronous path.
+#define PF_ARENA_BYTES (16u << 20)
+#define PF_ARENA_MAX (4u << 20)
+void pf_arena_reset(pfmi_ctx *c) { c->arena.off = 0; }
+int32_t pf_upload(pfmi_ctx *c, void *dst, const void *src, size_t bytes) {
     if (bytes == 0) return PFMI_OK;
-    PF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    if (bytes > PF_ARENA_MAX) {
+        PF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+        PF_HIP(hipStreamSynchronize(c->stream));
+        pf_arena_reset(c);
+        return PFMI_OK;
+    }
+    PinArena &a = c->arena;
+    if (!a.base) {
+        void *pp = nullptr;
+        PF_HIP(hipHostMalloc(&pp, PF_ARENA_BYTES, hipHostMallocDefault));
+        a.base = reinterpret_cast<char *>(pp); a.cap = PF_ARENA_BYTES; a.off = 0;
+    }
+    if (a.off + bytes > a.cap) {                 // full: everything staged so far must have been consumed before the rewind
+        PF_HIP(hipStreamSynchronize(c->stream));
+        a.off = 0;
+    }
+    memcpy(a.base + a.off, src, bytes);
+    PF_HIP(hipMemcpyAsync(dst, a.base + a.off, bytes, hipMemcpyHostToDevice, c->stream));
+    a.off += (bytes + 255) & ~(size_t)255;
+    return PFMI_OK;
+}
+static int32_t h2d(pfmi_ctx *c, void *dst, const void *src, size_t bytes) { return pf_upload(c, dst, src, bytes); }
+static int32_t d2h_async(pfmi_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return PFMI_OK;
+    PF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    return PFMI_OK;
+}
+static int32_t stream_sync(pfmi_ctx *c) {
     PF_HIP(hipStreamSynchronize(c->stream));
+    pf_arena_reset(c);
     return PFMI_OK;
 }
 static int32_t d2h(pfmi_ctx *c, void *dst, const void *src, size_t bytes) {
     if (bytes == 0) return PFMI_OK;
-    PF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
-    PF_HIP(hipStreamSynchronize(c->stream));
-    return PFMI_OK;
+    PF_TRY(d2h_async(c, dst, src, bytes));
+    return stream_sync(c);
 }
 // pinned host staging of the callback path (grown on demand, freed in pfmi_destroy)
 static int32_t ensure_pinned(pfmi_ctx *c, size_t x_bytes, size_t lp_bytes) {
@@ -95,6 +129,7 @@ int32_t pfmi_create(int32_t device, pfmi_ctx **out) {
     PF_HIP(hipSetDevice(device));
     pfmi_ctx *c = new pfmi_ctx();
     c->device = device;
+    c->ncu = prop.multiProcessorCount;
     PF_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     PF_HIP(hipEventCreate(&c->ev0));
     PF_HIP(hipEventCreate(&c->ev1));
@@ -114,7 +149,8 @@ int32_t pfmi_destroy(pfmi_ctx *c) {
                       &c->elbo, &c->se, &c->best_iter, &c->fit_list, &c->ubuf, &c->xbuf, &c->scratch, &c->fit_scratch, &c->pool,
                       &c->pool_lr, &c->pool_lp, &c->pool_lq, &c->pool_points, &c->pool_seeds, &c->lw, &c->w,
                       &c->psis_out, &c->psis_aux, &c->tailbuf, &c->cdf, &c->idx, &c->gbuf, &c->trace_lp, &c->st_theta, &c->st_grad,
-                      &c->st_lp, &c->st_npts, &c->lb_hs, &c->lb_hy, &c->lb_x0, &c->sortk, &c->sorti};
+                      &c->st_lp, &c->st_npts, &c->lb_hs, &c->lb_hy, &c->lb_x0, &c->sortk, &c->sorti,
+                      &c->pool_ok, &c->fail_seeds, &c->rs_err};
     for (DevBuf *b : bufs) b->release();
     for (int b = 0; b < 2; ++b) {
         c->cb_x[b].release(); c->cb_lp[b].release();
@@ -122,6 +158,7 @@ int32_t pfmi_destroy(pfmi_ctx *c) {
         if (c->pin_lp[b]) (void)hipHostFree(c->pin_lp[b]);
         if (c->cb_ev[b]) (void)hipEventDestroy(c->cb_ev[b]);
     }
+    if (c->arena.base) (void)hipHostFree(c->arena.base);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     (void)hipEventDestroy(c->kev0); (void)hipEventDestroy(c->kev1);
     (void)hipStreamDestroy(c->stream);
@@ -131,8 +168,7 @@ int32_t pfmi_destroy(pfmi_ctx *c) {
 
 int32_t pfmi_sync(pfmi_ctx *c) {
     PF_CTX(c);
-    PF_HIP(hipStreamSynchronize(c->stream));
-    return PFMI_OK;
+    return stream_sync(c);
 }
 
 int32_t pfmi_timer_start(pfmi_ctx *c) {
@@ -170,7 +206,7 @@ int32_t pfmi_set_target(pfmi_ctx *c, const pfmi_target *t) {
     PF_CHECK(t != nullptr, PFMI_ERR_ARG, "null target");
     PF_CHECK(t->d > 0, PFMI_ERR_ARG, "target dimension must be positive");
     TargetDev &T = c->target;
-    T.kind = t->kind; T.d = t->d; T.r = 0; T.rpad = 0; T.offset = 0.0; T.fn = nullptr; T.user = nullptr;
+    T.kind = t->kind; T.d = t->d; T.r = 0; T.rpad = 0; T.offset = 0.0; T.fn = nullptr; T.dev_fn = nullptr; T.user = nullptr;
     if (t->kind == PFMI_TARGET_GAUSS) {
         PF_CHECK(t->mean && t->a, PFMI_ERR_ARG, "GAUSS target needs mean and a");
         PF_CHECK(t->r >= 0 && t->r <= 16, PFMI_ERR_UNSUPPORTED, "GAUSS target rank %d > 16 unsupported", t->r);
@@ -203,6 +239,9 @@ int32_t pfmi_set_target(pfmi_ctx *c, const pfmi_target *t) {
     } else if (t->kind == PFMI_TARGET_HOST_CALLBACK) {
         PF_CHECK(t->fn != nullptr, PFMI_ERR_ARG, "HOST_CALLBACK target needs fn");
         T.fn = t->fn; T.user = t->user;
+    } else if (t->kind == PFMI_TARGET_DEVICE_CALLBACK) {
+        PF_CHECK(t->dev_fn != nullptr, PFMI_ERR_ARG, "DEVICE_CALLBACK target needs dev_fn");
+        T.dev_fn = t->dev_fn; T.user = t->user;
     } else {
         T.kind = -1;
         PF_CHECK(false, PFMI_ERR_ARG, "unknown target kind %d", t->kind);
@@ -239,13 +278,12 @@ int32_t pfmi_set_traces(pfmi_ctx *c, int32_t K, const int64_t *npoints, int32_t 
 }
 
 // ---- device trajectory generation ------------------------------------------------------------------------
-int32_t pfmi_optimize_batch(pfmi_ctx *c, int32_t K, const double *x0, int32_t J, int32_t maxiters, double g_tol,
-                            int64_t *npoints) {
+int32_t pfmi_optimize_batch_enqueue(pfmi_ctx *c, int32_t K, const double *x0, int32_t J, int32_t maxiters, double g_tol) {
     PF_CTX(c);
     const TargetDev &T = c->target;
     PF_CHECK(T.kind == PFMI_TARGET_GAUSS || T.kind == PFMI_TARGET_FUNNEL, PFMI_ERR_UNSUPPORTED,
              "optimize_batch: needs a built-in target (optimise callback targets on the host, then pfmi_set_traces)");
-    PF_CHECK(K > 0 && x0 && npoints && maxiters >= 0, PFMI_ERR_ARG, "optimize_batch: bad arguments");
+    PF_CHECK(K > 0 && x0 && maxiters >= 0, PFMI_ERR_ARG, "optimize_batch: bad arguments");
     PF_CHECK(J >= 1 && J <= 16, PFMI_ERR_UNSUPPORTED, "optimize_batch: history_length %d outside 1..16", J);
     const int d = T.d;
     const size_t cap = (size_t)maxiters + 1;
@@ -258,6 +296,18 @@ int32_t pfmi_optimize_batch(pfmi_ctx *c, int32_t K, const double *x0, int32_t J,
     pf_kernel_begin(c);
     PF_TRY(pf_launch_lbfgs(c, K, J, maxiters, g_tol, c->lb_x0.as<double>()));
     pf_kernel_end(c, "optimize");
+    c->opt_pending = true; c->opt_K = K; c->opt_cap = (int32_t)cap;
+    c->fitted = false; c->elbo_done = false; c->pooled = false; c->have_trace_lp = false; c->P = 0;
+    return PFMI_OK;
+}
+
+int32_t pfmi_optimize_batch_wait(pfmi_ctx *c, int64_t *npoints) {
+    PF_CTX(c);
+    PF_CHECK(c->opt_pending, PFMI_ERR_STATE, "optimize_batch_wait: no pfmi_optimize_batch_enqueue outstanding");
+    PF_CHECK(npoints != nullptr, PFMI_ERR_ARG, "optimize_batch_wait: null npoints");
+    c->opt_pending = false;
+    const int K = c->opt_K, d = c->target.d;
+    const size_t cap = (size_t)c->opt_cap;
     std::vector<int32_t> np32((size_t)K);
     PF_TRY(d2h(c, np32.data(), c->st_npts.p, sizeof(int32_t) * K));
     c->off.assign((size_t)K + 1, 0);
@@ -273,7 +323,6 @@ int32_t pfmi_optimize_batch(pfmi_ctx *c, int32_t K, const double *x0, int32_t J,
     for (int k = 0; k < K; ++k)
         for (int64_t p = c->off[k]; p < c->off[k + 1]; ++p) c->path_of[(size_t)p] = k;
     c->K = K; c->d = d; c->P = P;
-    c->fitted = false; c->elbo_done = false; c->pooled = false;
     const size_t bytes = sizeof(double) * (size_t)P * d;
     PF_TRY(c->theta.ensure(bytes));
     PF_TRY(c->grad.ensure(bytes));
@@ -287,6 +336,13 @@ int32_t pfmi_optimize_batch(pfmi_ctx *c, int32_t K, const double *x0, int32_t J,
     pf_kernel_end(c, "trace_pack");
     c->have_trace_lp = true;
     return PFMI_OK;
+}
+
+int32_t pfmi_optimize_batch(pfmi_ctx *c, int32_t K, const double *x0, int32_t J, int32_t maxiters, double g_tol,
+                            int64_t *npoints) {
+    PF_CHECK(npoints != nullptr, PFMI_ERR_ARG, "optimize_batch: bad arguments");
+    PF_TRY(pfmi_optimize_batch_enqueue(c, K, x0, J, maxiters, g_tol));
+    return pfmi_optimize_batch_wait(c, npoints);
 }
 
 int32_t pfmi_get_trace(pfmi_ctx *c, int32_t k, double *theta, double *logp, double *grad) {
@@ -339,14 +395,14 @@ int32_t pfmi_fit_batch(pfmi_ctx *c, int32_t J, double eps) {
 int32_t pfmi_get_fit_status(pfmi_ctx *c, int32_t *status, int32_t *j_eff, double *logdet, int64_t *n_rejected) {
     PF_CTX(c);
     PF_CHECK(c->fitted, PFMI_ERR_STATE, "get_fit_status: call pfmi_fit_batch first");
-    if (status) PF_TRY(d2h(c, status, c->status.p, sizeof(int32_t) * c->P));
-    if (j_eff) PF_TRY(d2h(c, j_eff, c->hist_len.p, sizeof(int32_t) * c->P));
-    if (logdet) PF_TRY(d2h(c, logdet, c->logdet.p, sizeof(double) * c->P));
-    if (n_rejected) {
-        std::vector<int32_t> r((size_t)c->K);
-        PF_TRY(d2h(c, r.data(), c->n_rej.p, sizeof(int32_t) * c->K));
+    std::vector<int32_t> r((size_t)c->K);
+    if (status) PF_TRY(d2h_async(c, status, c->status.p, sizeof(int32_t) * c->P));
+    if (j_eff) PF_TRY(d2h_async(c, j_eff, c->hist_len.p, sizeof(int32_t) * c->P));
+    if (logdet) PF_TRY(d2h_async(c, logdet, c->logdet.p, sizeof(double) * c->P));
+    if (n_rejected) PF_TRY(d2h_async(c, r.data(), c->n_rej.p, sizeof(int32_t) * c->K));
+    PF_TRY(stream_sync(c));
+    if (n_rejected)
         for (int k = 0; k < c->K; ++k) n_rejected[k] = r[(size_t)k];
-    }
     return PFMI_OK;
 }
 
@@ -432,8 +488,28 @@ static int32_t callback_logp(pfmi_ctx *c, const double *d_x, int64_t n, double *
     return PFMI_OK;
 }
 
-int32_t pfmi_elbo_batch(pfmi_ctx *c, int64_t N, const uint64_t *seeds, const double *u_host, double *elbo,
-                        double *se, int64_t *best_iter) {
+// chunk of fits whose draws are materialised in HBM at a time for a DEVICE_CALLBACK target (PFMI_DEVCB_CHUNK_MB, default 2048 MB)
+static int64_t devcb_chunk_fits(int64_t per_fit_doubles, int64_t nf) {
+    double mb = 2048.0;
+    if (const char *e = getenv("PFMI_DEVCB_CHUNK_MB")) { const double v = atof(e); if (v > 0) mb = v; }
+    int64_t chunk = (int64_t)(mb * 1048576.0 / (sizeof(double) * (double)per_fit_doubles));
+    if (chunk < 1) chunk = 1;
+    if (chunk > nf) chunk = nf > 0 ? nf : 1;
+    return chunk;
+}
+
+// DEVICE_CALLBACK: the user's kernel on `n` columns at d_x -> d_lp, on the ctx stream.  Failed fits leave their draws unwritten (the
+// closure then sees stale memory); their log densities are NaN, like an exception in the reference: `npts` slots of `N` values each
+// are patched by status afterwards.
+static int32_t devcb_logp(pfmi_ctx *c, const double *d_x, int64_t n, double *d_lp, const int32_t *d_points, int64_t npts, int64_t N) {
+    pf_kernel_begin(c);
+    c->target.dev_fn(d_x, c->d, n, d_lp, (void *)c->stream, c->target.user);
+    pf_kernel_end(c, "device_callback");
+    PF_HIP(hipGetLastError());
+    return pf_launch_nan_failed(c, npts, N, d_points, d_lp);
+}
+
+int32_t pfmi_elbo_batch_enqueue(pfmi_ctx *c, int64_t N, const uint64_t *seeds, const double *u_host) {
     PF_CTX(c);
     PF_CHECK(c->fitted, PFMI_ERR_STATE, "elbo_batch: call pfmi_fit_batch first");
     PF_CHECK(c->target.kind >= 0, PFMI_ERR_STATE, "elbo_batch: call pfmi_set_target first");
@@ -468,7 +544,26 @@ int32_t pfmi_elbo_batch(pfmi_ctx *c, int64_t N, const uint64_t *seeds, const dou
         d_u = c->ubuf.as<double>();
     }
     const int64_t ustride = (int64_t)d * N;
-    if (c->target.kind != PFMI_TARGET_HOST_CALLBACK) {
+    if (c->target.kind == PFMI_TARGET_DEVICE_CALLBACK) {
+        // device closure (the reference's general logp kept on the GPU): the draws of a block of fits are materialised in HBM
+        // (8 d bytes written per draw), the user's kernel reads them on the same stream (8 d bytes read per draw) and its log
+        // densities are scattered into the point-indexed table.  Nothing crosses PCIe, nothing synchronises.
+        const int64_t per = (int64_t)d * N;
+        const int64_t chunk = devcb_chunk_fits(per, nf);
+        PF_TRY(c->cb_x[0].ensure(sizeof(double) * (size_t)chunk * per));
+        PF_TRY(c->cb_lp[0].ensure(sizeof(double) * (size_t)chunk * N));
+        c->cb_bytes_dev = 0.0;
+        for (int64_t s0 = 0; s0 < nf; s0 += chunk) {
+            const int64_t ns = (nf - s0 < chunk) ? nf - s0 : chunk;
+            PF_TRY(pf_launch_elbo_draws(c, d_list + s0, d_lseeds + s0, ns, 0, N, d_u, ustride, c->cb_x[0].as<double>(), per,
+                                        c->logp.as<double>(), c->logq.as<double>(), N, false, true));
+            pf_kernel_begin(c);
+            c->target.dev_fn(c->cb_x[0].as<double>(), d, ns * N, c->cb_lp[0].as<double>(), (void *)c->stream, c->target.user);
+            pf_kernel_end(c, "device_callback");
+            PF_TRY(pf_launch_scatter_rows(c, ns, N, d_list + s0, c->cb_lp[0].as<double>(), c->logp.as<double>()));
+            c->cb_bytes_dev += (double)sizeof(double) * (double)ns * (double)per;
+        }
+    } else if (c->target.kind != PFMI_TARGET_HOST_CALLBACK) {
         PF_TRY(pf_launch_elbo_draws(c, d_list, d_lseeds, nf, 0, N, d_u, ustride, nullptr, 0, c->logp.as<double>(),
                                     c->logq.as<double>(), N, true, true));
     } else {
@@ -509,17 +604,36 @@ int32_t pfmi_elbo_batch(pfmi_ctx *c, int64_t N, const uint64_t *seeds, const dou
     }
     PF_TRY(pf_launch_elbo_reduce(c));
     c->elbo_done = true;
-    if (elbo) PF_TRY(d2h(c, elbo, c->elbo.p, sizeof(double) * P));
-    if (se) PF_TRY(d2h(c, se, c->se.p, sizeof(double) * P));
-    if (best_iter) PF_TRY(d2h(c, best_iter, c->best_iter.p, sizeof(int64_t) * c->K));
-    PF_HIP(hipStreamSynchronize(c->stream));
+    c->elbo_pending = true;
     return PFMI_OK;
+}
+
+int32_t pfmi_elbo_batch_wait(pfmi_ctx *c, double *elbo, double *se, int64_t *best_iter) {
+    PF_CTX(c);
+    PF_CHECK(c->elbo_done, PFMI_ERR_STATE, "elbo_batch_wait: call pfmi_elbo_batch_enqueue first");
+    c->elbo_pending = false;
+    if (elbo) PF_TRY(d2h_async(c, elbo, c->elbo.p, sizeof(double) * c->P));
+    if (se) PF_TRY(d2h_async(c, se, c->se.p, sizeof(double) * c->P));
+    if (best_iter) PF_TRY(d2h_async(c, best_iter, c->best_iter.p, sizeof(int64_t) * c->K));
+    return stream_sync(c);
+}
+
+int32_t pfmi_elbo_batch(pfmi_ctx *c, int64_t N, const uint64_t *seeds, const double *u_host, double *elbo,
+                        double *se, int64_t *best_iter) {
+    PF_TRY(pfmi_elbo_batch_enqueue(c, N, seeds, u_host));
+    return pfmi_elbo_batch_wait(c, elbo, se, best_iter);
 }
 
 int32_t pfmi_callback_stats(pfmi_ctx *c, double *callback_seconds, double *bytes_to_host) {
     PF_CTX(c);
     if (callback_seconds) *callback_seconds = c->cb_seconds;
     if (bytes_to_host) *bytes_to_host = c->cb_bytes_d2h;
+    return PFMI_OK;
+}
+
+int32_t pfmi_callback_stats_dev(pfmi_ctx *c, double *bytes_in_hbm) {
+    PF_CTX(c);
+    if (bytes_in_hbm) *bytes_in_hbm = c->cb_bytes_dev;
     return PFMI_OK;
 }
 
@@ -554,9 +668,11 @@ int32_t pfmi_draws(pfmi_ctx *c, int64_t p, uint64_t seed, int64_t n0, int64_t N,
         d_u = c->ubuf.as<double>();
     }
     const bool cb = have_t && c->target.kind == PFMI_TARGET_HOST_CALLBACK;
+    const bool dcb = have_t && c->target.kind == PFMI_TARGET_DEVICE_CALLBACK;
     PF_TRY(pf_launch_elbo_draws(c, d_pt, d_sd, 1, n0, N, d_u, 0, c->xbuf.as<double>(), 0, d_lp, d_lq, N,
-                                have_t && !cb, false));
+                                have_t && !cb && !dcb, false));
     if (cb) PF_TRY(callback_logp(c, c->xbuf.as<double>(), N, d_lp));
+    if (dcb) PF_TRY(devcb_logp(c, c->xbuf.as<double>(), N, d_lp, d_pt, 1, N));
     if (X) PF_TRY(d2h(c, X, c->xbuf.p, sizeof(double) * (size_t)d * N));
     if (logp) PF_TRY(d2h(c, logp, d_lp, sizeof(double) * N));
     if (logq) PF_TRY(d2h(c, logq, d_lq, sizeof(double) * N));
@@ -623,18 +739,9 @@ int32_t pfmi_woodbury_diag(pfmi_ctx *c, int64_t p, double *diag) {
 }
 
 // ---- pool / PSIS / resample ---------------------------------------------------------------------------
-int32_t pfmi_pool_build(pfmi_ctx *c, int64_t N_r, const int64_t *points, const uint64_t *seeds) {
-    PF_CTX(c);
-    PF_CHECK(c->fitted, PFMI_ERR_STATE, "pool_build: call pfmi_fit_batch first");
-    PF_CHECK(c->target.kind >= 0, PFMI_ERR_STATE, "pool_build: call pfmi_set_target first");
-    PF_CHECK(N_r >= 1 && points && seeds, PFMI_ERR_ARG, "pool_build: bad arguments");
+static int32_t pool_fill(pfmi_ctx *c);
+static int32_t pool_alloc(pfmi_ctx *c, int64_t N_r) {
     const int K = c->K, d = c->d;
-    std::vector<int32_t> pts((size_t)K);
-    for (int k = 0; k < K; ++k) {
-        PF_CHECK(points[k] >= c->off[k] && points[k] < c->off[k + 1], PFMI_ERR_ARG,
-                 "pool_build: point %lld does not belong to path %d", (long long)points[k], k);
-        pts[(size_t)k] = (int32_t)points[k];
-    }
     c->N_r = N_r;
     const size_t S = (size_t)K * N_r;
     PF_TRY(c->pool.ensure(sizeof(double) * S * d));
@@ -643,15 +750,72 @@ int32_t pfmi_pool_build(pfmi_ctx *c, int64_t N_r, const int64_t *points, const u
     PF_TRY(c->pool_lq.ensure(sizeof(double) * S));
     PF_TRY(c->pool_points.ensure(sizeof(int32_t) * K));
     PF_TRY(c->pool_seeds.ensure(sizeof(uint64_t) * K));
+    return PFMI_OK;
+}
+
+int32_t pfmi_pool_build(pfmi_ctx *c, int64_t N_r, const int64_t *points, const uint64_t *seeds) {
+    PF_CTX(c);
+    PF_CHECK(c->fitted, PFMI_ERR_STATE, "pool_build: call pfmi_fit_batch first");
+    PF_CHECK(c->target.kind >= 0, PFMI_ERR_STATE, "pool_build: call pfmi_set_target first");
+    PF_CHECK(N_r >= 1 && points && seeds, PFMI_ERR_ARG, "pool_build: bad arguments");
+    const int K = c->K;
+    std::vector<int32_t> pts((size_t)K);
+    for (int k = 0; k < K; ++k) {
+        PF_CHECK(points[k] >= c->off[k] && points[k] < c->off[k + 1], PFMI_ERR_ARG,
+                 "pool_build: point %lld does not belong to path %d", (long long)points[k], k);
+        pts[(size_t)k] = (int32_t)points[k];
+    }
+    PF_TRY(pool_alloc(c, N_r));
     PF_TRY(h2d(c, c->pool_points.p, pts.data(), sizeof(int32_t) * K));
     PF_TRY(h2d(c, c->pool_seeds.p, seeds, sizeof(uint64_t) * K));
-    const bool cb = c->target.kind == PFMI_TARGET_HOST_CALLBACK;
+    c->pool_from_best = false;
+    return pool_fill(c);
+}
+
+// draws of the K fits in pool_points / pool_seeds (device) -> pool, log ratios
+static int32_t pool_fill(pfmi_ctx *c) {
+    const int K = c->K, d = c->d;
+    const int64_t N_r = c->N_r;
+    const size_t S = (size_t)K * N_r;
+    const bool cb = c->target.kind == PFMI_TARGET_HOST_CALLBACK, dcb = c->target.kind == PFMI_TARGET_DEVICE_CALLBACK;
     PF_TRY(pf_launch_elbo_draws(c, c->pool_points.as<int32_t>(), c->pool_seeds.as<uint64_t>(), K, 0, N_r, nullptr, 0,
                                 c->pool.as<double>(), (int64_t)N_r * d, c->pool_lp.as<double>(),
-                                c->pool_lq.as<double>(), N_r, !cb, false));
+                                c->pool_lq.as<double>(), N_r, !cb && !dcb, false));
     if (cb) PF_TRY(callback_logp(c, c->pool.as<double>(), (int64_t)S, c->pool_lp.as<double>()));
+    if (dcb) PF_TRY(devcb_logp(c, c->pool.as<double>(), (int64_t)S, c->pool_lp.as<double>(), c->pool_points.as<int32_t>(), K, N_r));
     PF_TRY(pf_launch_logratio(c, (int64_t)S));
     c->pooled = true;
+    return PFMI_OK;
+}
+
+int32_t pfmi_pool_build_best(pfmi_ctx *c, int64_t N_r, const uint64_t *fail_seeds) {
+    PF_CTX(c);
+    PF_CHECK(c->elbo_done, PFMI_ERR_STATE, "pool_build_best: call pfmi_elbo_batch[_enqueue] first");
+    PF_CHECK(N_r >= 1, PFMI_ERR_ARG, "pool_build_best: bad arguments");
+    PF_TRY(pool_alloc(c, N_r));
+    PF_TRY(c->pool_ok.ensure(sizeof(int32_t) * c->K));
+    if (fail_seeds) {
+        PF_TRY(c->fail_seeds.ensure(sizeof(uint64_t) * c->K));
+        PF_TRY(h2d(c, c->fail_seeds.p, fail_seeds, sizeof(uint64_t) * c->K));
+    }
+    PF_TRY(pf_launch_pool_pick(c, fail_seeds != nullptr));
+    c->pool_from_best = true;
+    return pool_fill(c);
+}
+
+int32_t pfmi_pool_winners(pfmi_ctx *c, int64_t *points, uint64_t *seeds, int32_t *success) {
+    PF_CTX(c);
+    PF_CHECK(c->pooled, PFMI_ERR_STATE, "pool_winners: call pfmi_pool_build[_best] first");
+    std::vector<int32_t> pts((size_t)c->K);
+    if (points) PF_TRY(d2h_async(c, pts.data(), c->pool_points.p, sizeof(int32_t) * c->K));
+    if (seeds) PF_TRY(d2h_async(c, seeds, c->pool_seeds.p, sizeof(uint64_t) * c->K));
+    if (success) {
+        PF_CHECK(c->pool_from_best, PFMI_ERR_STATE, "pool_winners: success flags exist only after pfmi_pool_build_best");
+        PF_TRY(d2h_async(c, success, c->pool_ok.p, sizeof(int32_t) * c->K));
+    }
+    PF_TRY(stream_sync(c));
+    if (points)
+        for (int k = 0; k < c->K; ++k) points[k] = pts[(size_t)k];
     return PFMI_OK;
 }
 
@@ -685,6 +849,14 @@ int32_t pfmi_psis_dev(pfmi_ctx *c, const void *lr_dev, int64_t S, double *weight
     if (weights) PF_TRY(d2h(c, weights, c->w.p, sizeof(double) * S));
     if (log_weights) PF_TRY(d2h(c, log_weights, c->lw.p, sizeof(double) * S));
     return PFMI_OK;
+}
+
+int32_t pfmi_psis_weights(pfmi_ctx *c, int64_t S, double *weights, double *log_weights) {
+    PF_CTX(c);
+    PF_CHECK(S > 0 && c->S_w == S, PFMI_ERR_STATE, "psis_weights: no PSIS result for S=%lld on this ctx", (long long)S);
+    if (weights) PF_TRY(d2h_async(c, weights, c->w.p, sizeof(double) * S));
+    if (log_weights) PF_TRY(d2h_async(c, log_weights, c->lw.p, sizeof(double) * S));
+    return stream_sync(c);
 }
 
 int32_t pfmi_psis(pfmi_ctx *c, const double *lr, int64_t S, double *weights, double *log_weights, double *pareto_k,

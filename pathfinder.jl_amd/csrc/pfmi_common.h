@@ -53,6 +53,11 @@ struct DevBuf {
 
 struct KernelStat { double ms = 0.0; int64_t launches = 0; };
 
+// pinned host arena of a ctx: small host -> device uploads are staged here and copied asynchronously on the ctx stream, so that an
+// upload never forces a stream synchronisation in the middle of an enqueued pipeline (pf_upload in pfmi_api.hip).  Bump allocated;
+// rewound whenever the stream is known to be idle (pf_arena_reset after a full synchronisation).
+struct PinArena { char *base = nullptr; size_t cap = 0, off = 0; };
+
 // device-resident target description (Gaussian family rows are stored row-major for scalar loads)
 struct TargetDev {
     int32_t kind = -1, d = 0, r = 0, rpad = 0;
@@ -60,6 +65,7 @@ struct TargetDev {
     DevBuf mean, a, wd /* [d][rpad] row-major */, g /* [rpad][rpad] row-major, lower */;
     DevBuf wd16;   // [ceil(d/16)*16][16] row-major, zero padded: MFMA A-operand source of the low-rank target part
     pfmi_logp_fn fn = nullptr;
+    pfmi_logp_dev_fn dev_fn = nullptr;   // DEVICE_CALLBACK: launches the user's kernel(s) on the ctx stream
     void *user = nullptr;
 };
 
@@ -70,6 +76,8 @@ struct pfmi_ctx {
     bool profile = false;
     std::map<std::string, KernelStat> kstats;
     std::set<const void *> lds_attr_done;   // kernels whose dynamic-LDS limit was raised on THIS ctx's device (see pf_raise_lds_limit)
+    PinArena arena;                         // staging of small uploads (pf_upload)
+    int ncu = 0;                            // compute units of the device
 
     // traces
     int32_t K = 0, d = 0;
@@ -140,7 +148,21 @@ struct pfmi_ctx {
     hipEvent_t cb_ev[2] = {nullptr, nullptr};
     double cb_seconds = 0.0;      // wall time spent inside the user's callback during the last elbo_batch
     double cb_bytes_d2h = 0.0;    // bytes of draws handed to the callback
+    double cb_bytes_dev = 0.0;    // DEVICE_CALLBACK: bytes of draws materialised in HBM for the callback
+    // enqueue / wait split of the blocking entry points
+    bool opt_pending = false;     // pfmi_optimize_batch_enqueue issued, _wait not yet called
+    int32_t opt_K = 0, opt_cap = 0;
+    bool elbo_pending = false;    // pfmi_elbo_batch_enqueue issued
+    bool pool_from_best = false;  // the pool was filled by pfmi_pool_build_best (pool_ok is valid)
+    DevBuf pool_ok;               // int32 [K]: 1 = the path's winning fit was a success (pfmi_pool_build_best)
+    DevBuf fail_seeds;            // u64 [K]
+    DevBuf rs_err;                // int32: error flag of the last enqueued index selection
 };
+
+// small host -> device upload on the ctx stream WITHOUT synchronising it (pinned arena); large blocks take the synchronous path
+int32_t pf_upload(pfmi_ctx *c, void *dst, const void *src, size_t bytes);
+// the stream is idle: the arena may be reused from its start
+void pf_arena_reset(pfmi_ctx *c);
 
 // ---- launch helpers (implemented in the .hip files) ----------------------------------------------
 int32_t pf_launch_history(pfmi_ctx *c, double eps);
@@ -154,6 +176,13 @@ int32_t pf_launch_logpdf(pfmi_ctx *c, int64_t point, int64_t N, const double *d_
 int32_t pf_launch_psis(pfmi_ctx *c, const double *d_lr, int64_t S);
 int32_t pf_launch_resample(pfmi_ctx *c, int64_t S, int64_t ndraws, int importance, int replace,
                            uint64_t seed, const double *d_uniforms);
+// the same without the final synchronisation: the error flag stays in c->rs_err until pf_resample_check reads it
+int32_t pf_enqueue_resample(pfmi_ctx *c, int64_t S, int64_t ndraws, int importance, int replace,
+                            uint64_t seed, const double *d_uniforms);
+int32_t pf_resample_check(pfmi_ctx *c);
+int32_t pf_launch_pool_pick(pfmi_ctx *c, int have_fail_seeds);
+// d_lp[s * N + n] = NaN for every slot s whose fit d_points[s] failed
+int32_t pf_launch_nan_failed(pfmi_ctx *c, int64_t npts, int64_t N, const int32_t *d_points, double *d_lp);
 int32_t pf_launch_resample_direct(pfmi_ctx *c, int64_t S, int64_t ndraws, const double *d_uniforms);
 int32_t pf_launch_gather(pfmi_ctx *c, int64_t ndraws, const int64_t *d_idx, int64_t col_offset, double *d_out);
 int32_t pf_launch_logratio(pfmi_ctx *c, int64_t n);

@@ -683,11 +683,12 @@ int32_t pf_launch_psis(pfmi_ctx *c, const double *d_lr, int64_t S) {
     return PFMI_OK;
 }
 
-int32_t pf_launch_resample(pfmi_ctx *c, int64_t S, int64_t ndraws, int importance, int replace, uint64_t seed,
-                           const double *d_uniforms) {
+int32_t pf_enqueue_resample(pfmi_ctx *c, int64_t S, int64_t ndraws, int importance, int replace, uint64_t seed,
+                            const double *d_uniforms) {
     PF_TRY(c->idx.ensure(sizeof(int64_t) * (ndraws > 0 ? ndraws : 1)));
     PF_TRY(c->scratch.ensure(sizeof(double) * (S > 0 ? S : 1) + 64));
-    int *d_err = reinterpret_cast<int *>(c->scratch.as<char>() + sizeof(double) * (S > 0 ? S : 1));
+    PF_TRY(c->rs_err.ensure(sizeof(int)));
+    int *d_err = c->rs_err.as<int>();
     PF_HIP(hipMemsetAsync(d_err, 0, sizeof(int), c->stream));
     pf_kernel_begin(c);
     if (replace) {
@@ -725,11 +726,23 @@ int32_t pf_launch_resample(pfmi_ctx *c, int64_t S, int64_t ndraws, int importanc
     }
     pf_kernel_end(c, "resample");
     PF_HIP(hipGetLastError());
+    return PFMI_OK;
+}
+
+// blocks: reads the error flag of the last pf_enqueue_resample
+int32_t pf_resample_check(pfmi_ctx *c) {
     int err = 0;
-    PF_HIP(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PF_HIP(hipMemcpyAsync(&err, c->rs_err.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     PF_HIP(hipStreamSynchronize(c->stream));
+    pf_arena_reset(c);
     PF_CHECK(err == 0, PFMI_ERR_NUMERIC, "resample: weights are all zero / not enough positive weights");
     return PFMI_OK;
+}
+
+int32_t pf_launch_resample(pfmi_ctx *c, int64_t S, int64_t ndraws, int importance, int replace, uint64_t seed,
+                           const double *d_uniforms) {
+    PF_TRY(pf_enqueue_resample(c, S, ndraws, importance, replace, seed, d_uniforms));
+    return pf_resample_check(c);
 }
 
 int32_t pf_launch_resample_direct(pfmi_ctx *c, int64_t S, int64_t ndraws, const double *d_uniforms) {

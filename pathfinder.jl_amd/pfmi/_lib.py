@@ -19,10 +19,12 @@ class pfmi_target(C.Structure):
     _fields_ = [("kind", C.c_int32), ("d", C.c_int32), ("r", C.c_int32), ("reserved", C.c_int32),
                 ("mean", C.POINTER(C.c_double)), ("a", C.POINTER(C.c_double)),
                 ("Wd", C.POINTER(C.c_double)), ("G", C.POINTER(C.c_double)), ("offset", C.c_double),
-                ("fn", C.c_void_p), ("user", C.c_void_p)]
+                ("fn", C.c_void_p), ("user", C.c_void_p), ("dev_fn", C.c_void_p)]
 
 
 LOGP_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int32, C.c_int64, C.POINTER(C.c_double), C.c_void_p)
+# device callback: (X_dev, d, n, out_dev, stream, user) -- raw device addresses, see include/pfmi.h
+LOGP_DEV_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p)
 
 # every symbol include/pfmi.h declares (tests/test_abi.py checks the built library exports them all)
 SYMBOLS = [
@@ -34,6 +36,8 @@ SYMBOLS = [
     "pfmi_pool_gather_dev", "pfmi_malloc_dev", "pfmi_free_dev", "pfmi_memcpy_h2d", "pfmi_memcpy_d2h",
     "pfmi_comm_unique_id", "pfmi_comm_init_all", "pfmi_comm_init_rank", "pfmi_comm_destroy", "pfmi_comm_info",
     "pfmi_comm_pool_psis", "pfmi_comm_resample", "pfmi_host_rand_u64",
+    "pfmi_optimize_batch_enqueue", "pfmi_optimize_batch_wait", "pfmi_elbo_batch_enqueue", "pfmi_elbo_batch_wait",
+    "pfmi_callback_stats_dev", "pfmi_pool_build_best", "pfmi_pool_winners", "pfmi_psis_weights", "pfmi_comm_psis_resample",
 ]
 
 

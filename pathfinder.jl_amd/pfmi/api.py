@@ -257,6 +257,7 @@ class MultiPathfinderResult:        # src/multipath.jl:31-44
     psis_result: Optional[PSISResult]
     engine: Any = field(repr=False, default=None)
     ndraws_per_run: int = 0
+    engines: Any = field(repr=False, default=None)      # the engines the runs are sharded over (contiguous blocks)
 
     @property
     def fit_distribution_transformed(self): return self.fit_distribution
@@ -376,16 +377,45 @@ def _use_device_optimizer(target, optimizer):
 
 
 # ---- batched driver shared by pathfinder / multipathfinder ------------------------------------------------
-def _run_paths(eng, target, inits, run_rngs, *, dim, history_length, ndraws_elbo, ntries, init_sampler,
-               optimizer_kwargs, materialise, optimizer="auto", strict=True):
-    """Runs every path to success (or ntries), batching the GPU work.  Returns per-path dicts.
-    The K optimisations run on the device for built-in targets (pfmi_optimize_batch, all paths in one launch) and
-    through the host driver for callback targets (the reference's general case, src/optimize.jl:35-59)."""
+def _comm_for(engs):
+    """the pfmi_comm joining `engs` (cached on the first engine; a single engine forms a world of one without RCCL)"""
+    from .core import Comm
+    key = tuple(id(e) for e in engs)
+    cache = engs[0].__dict__.setdefault("_comm_cache", {})
+    if key not in cache or cache[key].h is None:
+        cache[key] = Comm.init_all(engs)
+    return cache[key]
+
+
+def _blocks(K, G):
+    """contiguous blocks of paths, one per engine (pool order stays k-major, src/resample.jl:93)"""
+    if K % G != 0:
+        raise ValueError(f"nruns={K} must be divisible by the number of engines {G} "
+                         "(equal log-ratio shards keep the result independent of the GPU count)")
+    per = K // G
+    return [(g * per, (g + 1) * per) for g in range(G)]
+
+
+def _run_paths(engs, target, inits, run_rngs, *, dim, history_length, ndraws_elbo, ntries, init_sampler,
+               optimizer_kwargs, materialise, optimizer="auto", strict=True, pool=None):
+    """Runs every path to success (or ntries), batching the GPU work over the engines (contiguous blocks of paths, one engine per
+    GPU, driven by THIS host thread: every stage is enqueued on all engines before the first wait).  Returns per-path dicts.
+    The K optimisations run on the device for built-in targets (pfmi_optimize_batch, all paths of an engine in one launch) and
+    through the host driver for callback targets (the reference's general case, src/optimize.jl:35-59).
+    pool = dict(N_r, ndraws, importance, replace, seed): the pooled stage (winners picked on the device, pool, PSIS, index selection,
+    gather) is enqueued right behind the ELBO scan -- no host round trip in between; its result is valid when no path needed a retry
+    and is recomputed with the retry otherwise."""
     K = len(inits)
+    G = len(engs)
+    blocks = _blocks(K, G)
     state = [dict(itry=0, done=False) for _ in range(K)]
+    for g, (k0, k1) in enumerate(blocks):
+        for k in range(k0, k1):
+            state[k].update(eng=engs[g], g=g, kl=k - k0)
     pending = list(range(K))
     on_device = _use_device_optimizer(target, optimizer)
     okw = {k: v for k, v in optimizer_kwargs.items() if k in ("maxiters", "g_tol")}
+    pooled = None
     while pending:
         need = []
         for k in pending:
@@ -402,57 +432,78 @@ def _run_paths(eng, target, inits, run_rngs, *, dim, history_length, ndraws_elbo
         else:
             for k in need:
                 state[k]["x0"] = init_sampler(run_rngs[k], np.empty(dim))
-        if not on_device:
+        if on_device:     # every path in one launch per engine; finished paths are recomputed identically from their x0
+            for eng, (k0, k1) in zip(engs, blocks):
+                eng.optimize_batch_enqueue(np.stack([s["x0"] for s in state[k0:k1]]), history_length, **okw)
+            for eng, (k0, k1) in zip(engs, blocks):
+                npts = eng.optimize_batch_wait()
+                for k in range(k0, k1):
+                    state[k]["trace"] = DeviceOptimizationTrace(eng, k - k0, int(npts[k - k0]))
+                    if materialise:
+                        state[k]["trace"].materialise()
+        else:
             for k in pending:
                 state[k]["trace"] = optimize_with_trace(target, state[k]["x0"], history_length=history_length, **optimizer_kwargs)
-        if on_device:     # every path in one launch; finished paths are recomputed identically from their x0
-            npts = eng.optimize_batch(np.stack([s["x0"] for s in state]), history_length, **okw)
-            for k in range(K):
-                state[k]["trace"] = DeviceOptimizationTrace(eng, k, int(npts[k]))
-                if materialise:
-                    state[k]["trace"].materialise()
-        else:
-            eng.set_traces([s["trace"].points for s in state], [s["trace"].gradients for s in state])
+            for eng, (k0, k1) in zip(engs, blocks):
+                eng.set_traces([s["trace"].points for s in state[k0:k1]], [s["trace"].gradients for s in state[k0:k1]])
         # one batched fit + ELBO over every path (finished paths are recomputed identically from their seeds).  fit_batch only
         # ENQUEUES the history walk and the fits; the per-fit seeds are drawn on the host while they run
-        eng.fit_batch(history_length)
+        for eng in engs:
+            eng.fit_batch(history_length)
         fresh = rand_u64_multi([run_rngs[k] for k in pending], [len(state[k]["trace"]) - 1 for k in pending])
         for k, sd in zip(pending, fresh):                           # seeds = rand!(rng_k, UInt64[L_k])  (src/elbo.jl:2)
             state[k]["seeds"] = np.concatenate([[np.uint64(0)], sd]).astype(np.uint64)
-        status, jeff, logdet, nrej = eng.fit_status()
-        bad = np.flatnonzero(status)
-        if len(bad) and strict:
-            # WoodburyPDMat's constructor throws inside fit_mvnormals (src/woodbury.jl:202,205) and nothing in
-            # _pathfinder / the retry loop catches it (src/singlepath.jl:259-314): the reference's call fails as a whole
-            p = int(bad[0])
-            k = int(np.searchsorted(eng.offsets, p, side="right") - 1)
-            raise PosDefException(f"run {k + 1}, fit {p - int(eng.offsets[k]) + 1}: {_STATUS_MSG.get(int(status[p]), 'failed')} "
-                                  f"({len(bad)} of {len(status)} fits failed; strict=False keeps them as NaN ELBOs instead)")
-        seeds = np.concatenate([s["seeds"] for s in state])
-        elbo, se, best = eng.elbo_batch(ndraws_elbo, seeds)
+            # what rand(rng_k, fit_distribution, ndraws) would use if this try ends in failure (src/singlepath.jl:231-233): peeked from a
+            # copy, the run's rng only advances when the path really fails (_assemble_path)
+            state[k]["fail_seed"] = np.uint64(run_rngs[k].copy().rand_u64(1)[0])
+        for eng, (k0, k1) in zip(engs, blocks):
+            eng.elbo_batch_enqueue(ndraws_elbo, np.concatenate([s["seeds"] for s in state[k0:k1]]))
+        if pool is not None:                                        # optimistic: right behind the scan, no host round trip
+            for eng, (k0, k1) in zip(engs, blocks):
+                eng.pool_build_best(pool["N_r"], np.array([s["fail_seed"] for s in state[k0:k1]], dtype=np.uint64))
+            comm = _comm_for(engs)
+            res, idx, draws = comm.psis_resample(pool["ndraws"], importance=pool["importance"], replace=pool.get("replace", True),
+                                                 seed=pool["seed"])
+            pooled = dict(psis=res, idx=idx, draws=draws, comm=comm)
+        # ---- first wait of this try: everything above is in flight on every engine
         new_pending = []
-        for k in range(K):
-            st = state[k]
-            p0, p1 = int(eng.offsets[k]), int(eng.offsets[k + 1])
-            L = p1 - p0 - 1
-            fit_it = int(best[k])
-            ok = L > 0                                           # src/singlepath.jl:299
-            if fit_it > 0:
-                v = elbo[p0 + fit_it]
-                ok = ok and (not np.isnan(v)) and v != -np.inf   # :309-314
-            else:
-                ok = False
-            st.update(p0=p0, L=L, fit_iteration=fit_it, success=ok, status=status[p0:p1], jeff=jeff[p0:p1],
-                      elbo=elbo[p0:p1], se=se[p0:p1], nrej=int(nrej[k]))
-            if not ok and st["itry"] < ntries and not st["done"]:
-                new_pending.append(k)
-            else:
-                st["done"] = True
+        all_status, all_jeff = [], []
+        for eng, (k0, k1) in zip(engs, blocks):
+            status, jeff, logdet, nrej = eng.fit_status()
+            all_status.append(status); all_jeff.append(jeff)
+            bad = np.flatnonzero(status)
+            if len(bad) and strict:
+                # WoodburyPDMat's constructor throws inside fit_mvnormals (src/woodbury.jl:202,205) and nothing in
+                # _pathfinder / the retry loop catches it (src/singlepath.jl:259-314): the reference's call fails as a whole
+                p = int(bad[0])
+                kl = int(np.searchsorted(eng.offsets, p, side="right") - 1)
+                raise PosDefException(f"run {k0 + kl + 1}, fit {p - int(eng.offsets[kl]) + 1}: {_STATUS_MSG.get(int(status[p]), 'failed')} "
+                                      f"({len(bad)} of {len(status)} fits failed; strict=False keeps them as NaN ELBOs instead)")
+            elbo, se, best = eng.elbo_batch_wait()
+            for k in range(k0, k1):
+                st = state[k]
+                kl = k - k0
+                p0, p1 = int(eng.offsets[kl]), int(eng.offsets[kl + 1])
+                L = p1 - p0 - 1
+                fit_it = int(best[kl])
+                ok = L > 0                                           # src/singlepath.jl:299
+                if fit_it > 0:
+                    v = elbo[p0 + fit_it]
+                    ok = ok and (not np.isnan(v)) and v != -np.inf   # :309-314
+                else:
+                    ok = False
+                st.update(p0=p0, L=L, fit_iteration=fit_it, success=ok, status=status[p0:p1], jeff=jeff[p0:p1],
+                          elbo=elbo[p0:p1], se=se[p0:p1], nrej=int(nrej[kl]), status_all=status, jeff_all=jeff)
+                if not ok and st["itry"] < ntries and not st["done"]:
+                    new_pending.append(k)
+                else:
+                    st["done"] = True
         pending = new_pending
-    return state, status, jeff
+    return state, pooled
 
 
-def _assemble_path(eng, target, st, rng, ndraws, ndraws_elbo, input_, status, jeff, materialise, warn=True):
+def _assemble_path(st, rng, ndraws_elbo, materialise, warn=True):
+    eng = st["eng"]
     p0, L = st["p0"], st["L"]
     if not st["success"] and warn:
         warnings.warn(f"Pathfinder failed after {st['itry']} tries. Increase `ntries`, inspect the model for "
@@ -461,7 +512,7 @@ def _assemble_path(eng, target, st, rng, ndraws, ndraws_elbo, input_, status, je
         perc = round(st["nrej"] * 100 / (L + 1), 1)
         warnings.warn(f"{st['nrej']} ({perc}%) updates to the inverse Hessian estimate were rejected to keep it "
                       "positive definite.")
-    dists = _make_dists(eng, p0, L + 1, status, jeff, materialise)
+    dists = _make_dists(eng, p0, L + 1, st["status_all"], st["jeff_all"], materialise)
     tok = eng.fit_token()
 
     def _est(i, st=st):
@@ -476,6 +527,7 @@ def _assemble_path(eng, target, st, rng, ndraws, ndraws_elbo, input_, status, je
         draw_seed = int(st["seeds"][fit_it])                      # reuse the ELBO draws, top up if needed
     else:
         draw_seed = int(rng.rand_u64(1)[0])                       # rand(rng, fit_distribution, ndraws)
+        assert draw_seed == int(st["fail_seed"])                  # what pfmi_pool_build_best was given for this path
     return dict(dists=dists, ests=ests, fit_point=fit_point, draw_seed=draw_seed)
 
 
@@ -497,11 +549,11 @@ def pathfinder(target, *, rng=None, init=None, dim=-1, init_scale=2, init_sample
         dim = len(init)
     eng = engine or Engine()
     eng.set_target(target)
-    state, status, jeff = _run_paths(eng, target, [init], [rng], dim=dim, history_length=history_length,
-                                     ndraws_elbo=ndraws_elbo, ntries=ntries, init_sampler=init_sampler,
-                                     optimizer_kwargs=optimizer_kwargs, materialise=materialise, optimizer=optimizer, strict=strict)
+    state, _ = _run_paths([eng], target, [init], [rng], dim=dim, history_length=history_length,
+                          ndraws_elbo=ndraws_elbo, ntries=ntries, init_sampler=init_sampler,
+                          optimizer_kwargs=optimizer_kwargs, materialise=materialise, optimizer=optimizer, strict=strict)
     st = state[0]
-    a = _assemble_path(eng, target, st, rng, ndraws, ndraws_elbo, input, status, jeff, materialise)
+    a = _assemble_path(st, rng, ndraws_elbo, materialise)
     X = eng.draws(a["fit_point"], a["draw_seed"], ndraws)[0]     # src/singlepath.jl:226-233
     return PathfinderResult(input if input is not None else target, rng, target.logp,
                             a["dists"][st["fit_iteration"]], X, st["fit_iteration"], st["itry"], st["trace"],
@@ -510,9 +562,12 @@ def pathfinder(target, *, rng=None, init=None, dim=-1, init_scale=2, init_sample
 
 def multipathfinder(target, ndraws, *, init=None, nruns=-1, ndraws_elbo=DEFAULT_NDRAWS_ELBO, ndraws_per_run=None,
                     rng=None, history_length=DEFAULT_HISTORY_LENGTH, importance=True, dim=-1, init_scale=2,
-                    init_sampler=None, ntries=1000, ntasks=1, ntasks_per_run=1, input=None, engine=None,
+                    init_sampler=None, ntries=1000, ntasks=1, ntasks_per_run=1, input=None, engine=None, engines=None,
                     materialise=False, optimizer="auto", strict=True, **optimizer_kwargs):
-    """Multi-path Pathfinder (reference src/multipath.jl:118-245).  optimizer, strict: see pathfinder()."""
+    """Multi-path Pathfinder (reference src/multipath.jl:118-245).  optimizer, strict: see pathfinder().
+    engines=[Engine(0), Engine(1), ...]: the runs are sharded in contiguous blocks over several GPUs driven by this one host thread
+    (the reference fans them out over tasks, src/multipath.jl:190-208); the pooled stage (:215-225) goes through the RCCL group of
+    the engines.  The result does not depend on the number of engines (test/multipath.jl:107-140 extended to GPUs)."""
     if init is None:
         if nruns <= 0:
             raise ValueError("A positive `nruns` must be set or `init` must be provided.")     # :148-150
@@ -530,27 +585,28 @@ def multipathfinder(target, ndraws, *, init=None, nruns=-1, ndraws_elbo=DEFAULT_
         dim = getattr(target, "d", -1) if inits[0] is None else len(inits[0])
     run_seeds = rng.rand_u64(nruns)                                                             # :162
     run_rngs = [rng.copy().seed_(int(s)) for s in run_seeds]                                    # :189-193
-    eng = engine or Engine()
-    eng.set_target(target)
-    state, status, jeff = _run_paths(eng, target, inits, run_rngs, dim=dim, history_length=history_length,
-                                     ndraws_elbo=ndraws_elbo, ntries=ntries, init_sampler=init_sampler,
-                                     optimizer_kwargs=optimizer_kwargs, materialise=materialise, optimizer=optimizer, strict=strict)
-    parts = [_assemble_path(eng, target, st, r, ndraws_per_run, ndraws_elbo, input, status, jeff, materialise)
-             for st, r in zip(state, run_rngs)]
-    # draws_per_component = stack(draws)   (:217) -- device resident
-    eng.pool_build(ndraws_per_run, [a["fit_point"] for a in parts], [a["draw_seed"] for a in parts])
+    engs = list(engines) if engines else [engine or Engine()]
+    for e in engs:
+        e.set_target(target)
+    resample_seed = int(rng.rand_u64(1)[0])                                                     # _resample's draw from the top-level rng (:225)
+    # draws_per_component = stack(draws) (:217), _compute_psis_result (:221), _resample (:225): enqueued behind the ELBO scan
+    state, pooled = _run_paths(engs, target, inits, run_rngs, dim=dim, history_length=history_length,
+                               ndraws_elbo=ndraws_elbo, ntries=ntries, init_sampler=init_sampler,
+                               optimizer_kwargs=optimizer_kwargs, materialise=materialise, optimizer=optimizer, strict=strict,
+                               pool=dict(N_r=ndraws_per_run, ndraws=ndraws, importance=importance, seed=resample_seed))
+    parts = [_assemble_path(st, r, ndraws_elbo, materialise) for st, r in zip(state, run_rngs)]
     # the per-run draws (d, N_r, K) stay on the device.  A run's block is a pure function of (fit, draw_seed, N_r): when it is
     # looked at it is REGENERATED from the seed (bit-identical to the pool block, tests: pool == eng.draws), so the handle
     # does not depend on what a later resample() put into the pool; it does depend on the fits, hence the token.
     results = []
-    tok = eng.fit_token()
 
-    def _run_draws(fit_point, seed):
+    def _run_draws(eng, tok, fit_point, seed):
         eng.check_token(tok, "PathfinderResult.draws")
         return eng.draws(fit_point, seed, ndraws_per_run)[0]
 
     for k, (st, a) in enumerate(zip(state, parts)):
-        thunk = (lambda a=a: _run_draws(a["fit_point"], a["draw_seed"]))
+        eng = st["eng"]
+        thunk = (lambda eng=eng, tok=eng.fit_token(), a=a: _run_draws(eng, tok, a["fit_point"], a["draw_seed"]))
         results.append(PathfinderResult(input if input is not None else target, run_rngs[k], target.logp,
                                         a["dists"][st["fit_iteration"]], thunk, st["fit_iteration"],
                                         st["itry"], st["trace"], a["dists"], a["ests"], st["nrej"], st["success"],
@@ -560,43 +616,46 @@ def multipathfinder(target, ndraws, *, init=None, nruns=-1, ndraws_elbo=DEFAULT_
     S = nruns * ndraws_per_run
     psis_result = None
     if importance:                                                                               # :220-224
-        ptr, cnt = eng.pool_log_ratios_dev()
-        psis_result = PSISResult(**eng.psis_dev(ptr, cnt))
-    draws, ids = _resample(rng, eng, S, ndraws_per_run, psis_result, ndraws)                     # :225
+        w, lw = engs[0].psis_weights(S)
+        psis_result = PSISResult(w, lw, pooled["psis"]["pareto_shape"], pooled["psis"]["tail_length"])
+    ids = pooled["idx"] // ndraws_per_run + 1                                                   # cld.(inds, N) with 1-based inds
     return MultiPathfinderResult(input if input is not None else target, rng, target.logp,
-                                 [r.fit_distribution for r in results], draws, ids, results, psis_result, eng,
-                                 ndraws_per_run)
+                                 [r.fit_distribution for r in results], pooled["draws"], ids, results, psis_result, engs[0],
+                                 ndraws_per_run, engs)
 
 
-def _resample(rng, eng, S, ndraws_per_component, psis_result, ndraws, replace=True):
-    """_resample (reference src/resample.jl:58-72): indices on the device, gather, component ids."""
+def _resample(rng, comm, psis, ndraws_per_component, ndraws, replace=True):
+    """_compute_psis_result + _resample (reference src/resample.jl:58-79) over the engines of `comm`: pooled PSIS, indices on the
+    device, owner gather, component ids -- one synchronisation."""
     seed = int(rng.rand_u64(1)[0])
-    idx = eng.resample_indices(S, ndraws, importance=psis_result is not None, replace=replace, seed=seed)
-    draws = eng.pool_gather(idx)
+    res, idx, draws = comm.psis_resample(ndraws, importance=psis, replace=replace, seed=seed)
     ids = idx // ndraws_per_component + 1                          # cld.(inds, N) with 1-based inds
-    return draws, ids
+    return res, draws, ids
 
 
 def resample(result, ndraws, *, rng=None, replace=True, importance=True, ndraws_per_run=None, ntasks=1):
     """resample(result::MultiPathfinderResult, ndraws; ...)  (reference src/resample.jl:20-46)"""
     rng = rng if rng is not None else result.rng
-    eng = result.engine
-    K = len(result.pathfinder_results)
-    for r in result.pathfinder_results:
+    engs = result.engines or [result.engine]
+    runs = result.pathfinder_results
+    K = len(runs)
+    blocks = _blocks(K, len(engs))
+    for r in runs:
         r.fit_distribution._live()                                  # the fits must still be the engine's current ones
     if ndraws_per_run is not None:                                  # fresh candidates (:102-109)
         seeds = rng.rand_u64(K)
-        eng.pool_build(ndraws_per_run, [r.fit_distribution.point for r in result.pathfinder_results], seeds)
         npr = ndraws_per_run
     else:                                                           # reuse stored draws (:97-101): the candidates are
-        npr = result.pathfinder_results[0].ndraws_per_run           # pathfinder_results[k].draws, whatever an earlier
-        eng.pool_build(npr, [r.fit_distribution.point for r in result.pathfinder_results],   # resample() drew fresh
-                       [r.draw_seed for r in result.pathfinder_results])
+        npr = runs[0].ndraws_per_run                                # pathfinder_results[k].draws, whatever an earlier
+        seeds = [r.draw_seed for r in runs]                         # resample() drew fresh
+    for eng, (k0, k1) in zip(engs, blocks):
+        eng.pool_build(npr, [r.fit_distribution.point for r in runs[k0:k1]], seeds[k0:k1])
     S = K * npr
-    if importance:                                                  # PSIS of the (re)built pool: for stored draws this
-        psis_result = PSISResult(**eng.psis_dev(*eng.pool_log_ratios_dev()))   # reproduces result.psis_result bit for bit
-    else:
-        psis_result = None
-    draws, ids = _resample(rng, eng, S, npr, psis_result, ndraws, replace=replace)
+    # PSIS of the (re)built pool: for stored draws this reproduces result.psis_result bit for bit
+    res, draws, ids = _resample(rng, _comm_for(engs), importance, npr, ndraws, replace=replace)
+    psis_result = None
+    if importance:
+        w, lw = engs[0].psis_weights(S)
+        psis_result = PSISResult(w, lw, res["pareto_shape"], res["tail_length"])
     return MultiPathfinderResult(result.input, result.rng, result.logp, result.fit_distribution, draws, ids,
-                                 result.pathfinder_results, psis_result, eng, npr)
+                                 runs, psis_result, engs[0], npr, engs)

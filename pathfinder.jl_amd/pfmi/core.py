@@ -35,6 +35,12 @@ class Engine:
         self.J = 0
 
     def close(self):
+        for cm in list(getattr(self, "_comm_cache", {}).values()):      # groups formed by the API layer with this engine first
+            try:
+                cm.close()
+            except Exception:
+                pass
+        self.__dict__.pop("_comm_cache", None)
         if getattr(self, "ctx", None) is not None and self.ctx:
             self.L.pfmi_destroy(self.ctx)
             self.ctx = None
@@ -110,6 +116,23 @@ class Engine:
         self.offsets = np.concatenate([[0], np.cumsum(npts)]).astype(np.int64)
         return npts
 
+    def optimize_batch_enqueue(self, x0, history_length=6, maxiters=1000, g_tol=1e-8):
+        """first half of optimize_batch: uploads x0 and launches the K optimisations, does not wait"""
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        K, d = x0.shape
+        assert self.target is not None and d == self.target.d
+        self.gen_traces += 1
+        self._opt_K, self.K, self.P, self.d, self.offsets = K, K, 0, d, None
+        check(self.L.pfmi_optimize_batch_enqueue(self.ctx, C.c_int32(K), _d(x0), C.c_int32(history_length), C.c_int32(maxiters),
+                                                 C.c_double(g_tol)))
+
+    def optimize_batch_wait(self):
+        npts = np.empty(self._opt_K, dtype=np.int64)
+        check(self.L.pfmi_optimize_batch_wait(self.ctx, npts.ctypes.data_as(_i64p)))
+        self.P = int(npts.sum())
+        self.offsets = np.concatenate([[0], np.cumsum(npts)]).astype(np.int64)
+        return npts
+
     def get_trace(self, k, logp=True):
         n = int(self.offsets[k + 1] - self.offsets[k])
         theta, grad = np.empty((n, self.d)), np.empty((n, self.d))
@@ -157,6 +180,26 @@ class Engine:
         check(self.L.pfmi_elbo_batch(self.ctx, C.c_int64(N), seeds.ctypes.data_as(_u64p), _d(u), _d(elbo), _d(se),
                                      best.ctypes.data_as(_i64p)))
         return elbo, se, best
+
+    def elbo_batch_enqueue(self, N, seeds, u=None):
+        """first half of elbo_batch: uploads the seeds, launches scan + reduction + per-path argmax, does not wait"""
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        assert len(seeds) == self.P
+        if u is not None:
+            u = np.ascontiguousarray(u, dtype=np.float64)
+            assert u.size == self.P * self.d * N
+        check(self.L.pfmi_elbo_batch_enqueue(self.ctx, C.c_int64(N), seeds.ctypes.data_as(_u64p), _d(u)))
+
+    def elbo_batch_wait(self):
+        elbo, se = np.empty(self.P), np.empty(self.P)
+        best = np.empty(self.K, dtype=np.int64)
+        check(self.L.pfmi_elbo_batch_wait(self.ctx, _d(elbo), _d(se), best.ctypes.data_as(_i64p)))
+        return elbo, se, best
+
+    def callback_stats_dev(self):
+        nb = C.c_double()
+        check(self.L.pfmi_callback_stats_dev(self.ctx, C.byref(nb)))
+        return dict(bytes_in_hbm=nb.value)
 
     def callback_stats(self):
         sec, nb = C.c_double(), C.c_double()
@@ -214,6 +257,28 @@ class Engine:
         self.gen_pool += 1
         check(self.L.pfmi_pool_build(self.ctx, C.c_int64(N_r), points.ctypes.data_as(_i64p),
                                      seeds.ctypes.data_as(_u64p)))
+
+    def pool_build_best(self, N_r, fail_seeds=None):
+        """pool of the winners picked on the device from the last elbo_batch[_enqueue]; only enqueues"""
+        if fail_seeds is not None:
+            fail_seeds = np.ascontiguousarray(fail_seeds, dtype=np.uint64)
+            assert len(fail_seeds) == self.K
+        self.N_r = N_r
+        self.gen_pool += 1
+        check(self.L.pfmi_pool_build_best(self.ctx, C.c_int64(N_r),
+                                          fail_seeds.ctypes.data_as(_u64p) if fail_seeds is not None else None))
+
+    def pool_winners(self):
+        pts = np.empty(self.K, dtype=np.int64)
+        seeds = np.empty(self.K, dtype=np.uint64)
+        ok = np.empty(self.K, dtype=np.int32)
+        check(self.L.pfmi_pool_winners(self.ctx, pts.ctypes.data_as(_i64p), seeds.ctypes.data_as(_u64p), ok.ctypes.data_as(_i32p)))
+        return pts, seeds, ok.astype(bool)
+
+    def psis_weights(self, S):
+        w, lw = np.empty(S), np.empty(S)
+        check(self.L.pfmi_psis_weights(self.ctx, C.c_int64(S), _d(w), _d(lw)))
+        return w, lw
 
     def pool_get(self, draws=True):
         S = self.K * self.N_r
@@ -338,6 +403,19 @@ class Comm:
         check(self.L.pfmi_comm_resample(self.h, C.c_int64(ndraws), C.c_int32(int(importance)), C.c_int32(int(replace)),
                                         C.c_uint64(int(seed)), _d(uniforms), idx.ctypes.data_as(_i64p), _d(out)))
         return idx, out
+
+    def psis_resample(self, ndraws, importance=True, replace=True, seed=0, uniforms=None, want_draws=True):
+        """pooled PSIS + index selection + owner gather + all-reduce, enqueued on every local context, ONE synchronisation"""
+        d = self.engines[0].d
+        idx = np.empty(ndraws, dtype=np.int64)
+        out = np.empty((d, ndraws), order="F") if want_draws else None
+        if uniforms is not None:
+            uniforms = np.ascontiguousarray(uniforms, dtype=np.float64)
+        k, M = C.c_double(), C.c_int64()
+        check(self.L.pfmi_comm_psis_resample(self.h, C.c_int64(ndraws), C.c_int32(int(importance)), C.c_int32(int(replace)),
+                                             C.c_uint64(int(seed)), _d(uniforms), C.byref(k), C.byref(M),
+                                             idx.ctypes.data_as(_i64p), _d(out)))
+        return dict(pareto_shape=k.value, tail_length=M.value), idx, out
 
     def close(self):
         if self.h:

@@ -12,7 +12,7 @@ import numpy as np
 from . import _lib
 from .hostrng import HostRNG
 
-KIND_GAUSS, KIND_FUNNEL, KIND_CALLBACK = 0, 1, 2
+KIND_GAUSS, KIND_FUNNEL, KIND_CALLBACK, KIND_DEVICE_CALLBACK = 0, 1, 2, 3
 
 
 class GaussTarget:
@@ -149,6 +149,62 @@ class CallbackTarget:
         t.kind, t.d = KIND_CALLBACK, self.d
         t.fn = C.cast(self._cfn, C.c_void_p)
         return t
+
+
+class DeviceCallbackTarget:
+    """Arbitrary DEVICE closure (PFMI_TARGET_DEVICE_CALLBACK): the draws stay in HBM, `dev_fn` launches the user's kernel on the
+    engine's stream.  dev_fn: a C function pointer (int address or ctypes function) with the pfmi_logp_dev_fn signature
+    (X_dev, d, n, out_dev, stream, user) -- e.g. from a HIP library, or an AMDGPU.jl launcher on the Julia side; `user` is passed
+    through.  `host` (optional): an object with logp / grad / logp_and_grad for the host optimiser and for host-side checks (the
+    reference evaluates the same closure in the optimiser and in the ELBO; a device closure needs its host twin for the former)."""
+    kind = KIND_DEVICE_CALLBACK
+
+    def __init__(self, d, dev_fn, user=None, host=None, keepalive=None):
+        self.d = d
+        self._fn = dev_fn
+        self._user = user
+        self.host = host
+        self._keep = keepalive
+
+    def _h(self):
+        if self.host is None:
+            raise ValueError("this DeviceCallbackTarget has no host twin (logp / grad on the host)")
+        return self.host
+
+    def logp(self, x): return self._h().logp(x)
+    def grad(self, x): return self._h().grad(x)
+    def logp_and_grad(self, x): return self._h().logp_and_grad(x)
+
+    def descriptor(self):
+        t = _lib.pfmi_target()
+        t.kind, t.d = KIND_DEVICE_CALLBACK, self.d
+        fn = self._fn
+        t.dev_fn = fn if isinstance(fn, int) else C.cast(fn, C.c_void_p)
+        t.user = self._user
+        return t
+
+
+class TorchDeviceTarget(DeviceCallbackTarget):
+    """Device closure written with torch ops: fn(X) -> (n,) tensor for X of shape (n, d) (rows = draws; a zero-copy view of the
+    draws in HBM), evaluated on the engine's own stream.  The Python host's answer to the reference's arbitrary `logp` closure
+    (src/elbo.jl:15) without the PCIe round trip of CallbackTarget.  `host`: see DeviceCallbackTarget."""
+
+    def __init__(self, d, fn, host=None, device=0):
+        import torch
+
+        class _View:
+            def __init__(self, ptr, shape):
+                self.__cuda_array_interface__ = {"shape": shape, "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+        def _cb(xp, d_, n, outp, stream, _user):
+            dev = torch.device("cuda", device)
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=dev)):
+                X = torch.as_tensor(_View(xp, (n, d_)), device=dev)
+                out = torch.as_tensor(_View(outp, (n,)), device=dev)
+                out.copy_(fn(X).to(torch.float64).reshape(n))
+
+        self._cfn = _lib.LOGP_DEV_FN(_cb)
+        super().__init__(d, self._cfn, None, host)
 
 
 # ---- the synthetic targets of SURVEY.md 8(d) ------------------------------------------------------------

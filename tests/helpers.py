@@ -24,3 +24,28 @@ def make_traces(target, K, seed, scale=2.0, history_length=6, maxiters=1000):
 def fit_seeds(P, seed):
     import pfmi
     return pfmi.hostrng.rand_u64(seed, np.arange(P, dtype=np.uint64), 9)
+
+
+ROOT = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+STANDIN_LIB = __import__("os").path.join(ROOT, "tests", "rccl_standin", "librccl_standin.so")
+DEMO_LIB = __import__("os").path.join(ROOT, "examples", "device_logp", "liblogp_demo.so")
+
+
+def demo_device_target(tg):
+    """The user-side HIP closure of examples/device_logp for a built-in target `tg` (same parameters): a
+    PFMI_TARGET_DEVICE_CALLBACK target whose kernel reads the materialised draws from HBM."""
+    import ctypes as C
+    import pfmi
+    pfmi.lib()                                            # one HIP runtime per process: libpfmi (and torch) first
+    L = C.CDLL(DEMO_LIB)
+    dp = C.POINTER(C.c_double)
+    if tg.kind == 1:
+        fn = C.cast(L.pfx_funnel_logp, C.c_void_p).value
+        return pfmi.DeviceCallbackTarget(tg.d, fn, None, host=tg, keepalive=L)
+    L.pfx_gauss_create.restype = C.c_void_p
+    L.pfx_gauss_create.argtypes = [C.c_int32, C.c_int32, dp, dp, dp, dp, C.c_double]
+    h = L.pfx_gauss_create(tg.d, tg.r, tg.mean.ctypes.data_as(dp), tg.a.ctypes.data_as(dp),
+                           tg.Wd.ctypes.data_as(dp) if tg.r else None, tg.G.ctypes.data_as(dp) if tg.r else None, tg.offset)
+    assert h, "pfx_gauss_create failed"
+    fn = C.cast(L.pfx_gauss_logp, C.c_void_p).value
+    return pfmi.DeviceCallbackTarget(tg.d, fn, C.c_void_p(h), host=tg, keepalive=(L, h))
