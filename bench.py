@@ -70,6 +70,132 @@ def _launch_only(world, rank):
         print(json.dumps({"launch_only": True, "n_gpus": world, "ranks_in_collective": int(t[0]), "world_size": n}), flush=True)
 
 
+def _demo_device_target(pfmi, tg):
+    """`tg` as a PFMI_TARGET_DEVICE_CALLBACK closure: the user-side HIP kernel of examples/device_logp reads the draws the library
+    materialises in HBM (the route an arbitrary device-resident `logp` takes; the built-in targets never form x)."""
+    import ctypes as C
+    pfmi.lib()
+    L = C.CDLL(os.path.join(ROOT, "examples", "device_logp", "liblogp_demo.so"))
+    dp = C.POINTER(C.c_double)
+    if tg.kind == 1:
+        return pfmi.DeviceCallbackTarget(tg.d, C.cast(L.pfx_funnel_logp, C.c_void_p).value, None, host=tg, keepalive=L)
+    L.pfx_gauss_create.restype = C.c_void_p
+    L.pfx_gauss_create.argtypes = [C.c_int32, C.c_int32, dp, dp, dp, dp, C.c_double]
+    h = L.pfx_gauss_create(tg.d, tg.r, tg.mean.ctypes.data_as(dp), tg.a.ctypes.data_as(dp),
+                           tg.Wd.ctypes.data_as(dp) if tg.r else None, tg.G.ctypes.data_as(dp) if tg.r else None, tg.offset)
+    if not h:
+        raise RuntimeError("pfx_gauss_create failed")
+    return pfmi.DeviceCallbackTarget(tg.d, C.cast(L.pfx_gauss_logp, C.c_void_p).value, C.c_void_p(h), host=tg, keepalive=(L, h))
+
+
+def _pmc_traffic(argv_tail, kernel_like):
+    """HBM bytes per launch of the dominant kernel, measured IN THIS RUN: one step of this very command re-run twice under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `... WRITE_SIZE` (separate passes: the TCC block cannot hold both counters), units and
+    the gfx950 correction as /opt/skills/guides/MI355X_MICROARCH.md prescribes (KiB; FETCH_SIZE reports half of a wide coalesced read)."""
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="pfmi_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            dd = os.path.join(tmp, ctr)
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "-d", dd, "-o", "p", "--", sys.executable, os.path.abspath(__file__)] + argv_tail + \
+                  ["--steps", "1", "--warmup", "0", "--minimal", "--no-cpu-baseline", "--no-pmc"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            dbs = glob.glob(os.path.join(dd, "**", "*_results.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode}): {r.stderr[-300:]}"
+            con = sqlite3.connect(dbs[0])
+            rows = list(con.execute(
+                "select grid_size, sum(value), count(distinct dispatch_id), avg(duration) from counters_collection "
+                "where kernel_name like ? and counter_name = ? group by grid_size order by grid_size desc", (kernel_like, ctr)))
+            con.close()
+            if not rows:
+                return None, f"no {ctr} rows for {kernel_like}"
+            g, v, n, dur = rows[0]                                  # the main launch (largest grid)
+            out[ctr] = (v / n * 1024.0, int(n), dur / 1e6)
+    except Exception as ex:
+        return None, repr(ex)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch, write = 2.0 * out["FETCH_SIZE"][0], out["WRITE_SIZE"][0]
+    return {"traffic_bytes_per_launch": fetch + write, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
+            "fetch_correction": 2.0, "launches_profiled": out["FETCH_SIZE"][1], "avg_duration_ms_under_pmc": round(out["FETCH_SIZE"][2], 3),
+            "source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, two separate passes of one step"}, None
+
+
+def main_single_process(args):
+    """--gpus N --single-process: ONE host process (thread) drives N contexts, one per GPU -- what a single Julia caller of
+    multipathfinder does (north star).  pfmi_comm_init_all; every stage is enqueued on all GPUs before the first wait."""
+    import pfmi
+    from pfmi.hostrng import rand_u64
+    K, d, N_e, J, ndraws, G = args.npaths, args.dim, args.ndraws_elbo, args.history, args.ndraws, args.gpus
+    assert K % G == 0, "npaths must be divisible by the number of GPUs"
+    Kl = K // G
+    N_r = max(N_e, -(-ndraws // K))
+    master = 20260928
+    tg = {"lowrank": lambda: pfmi.t_lowrank(d, r=8, seed=2), "diag": lambda: pfmi.t_diag(d, seed=1), "iso": lambda: pfmi.t_iso(d),
+          "funnel": lambda: pfmi.t_funnel(d)}[args.target]()
+    run_seeds = rand_u64(master, np.arange(K, dtype=np.uint64), 9)
+    sc = args.init_scale
+    x0 = np.stack([pfmi.HostRNG(int(s)).rand(d) * 2 * sc - sc for s in run_seeds])
+    import ctypes as C
+    ndev = C.c_int32()
+    pfmi.lib().pfmi_device_count(C.byref(ndev))
+    engs = [pfmi.Engine(g % max(ndev.value, 1)) for g in range(G)]     # fewer GPUs than ranks: test hook (PFMI_COMM_ALLOW_SHARED_GPU)
+    for e in engs:
+        e.set_target(tg)
+    for g, e in enumerate(engs):
+        e.optimize_batch_enqueue(x0[g * Kl:(g + 1) * Kl], J, args.maxiters)
+    seeds = []
+    for g, e in enumerate(engs):
+        npts = e.optimize_batch_wait()
+        seeds.append(np.concatenate([rand_u64(int(run_seeds[g * Kl + i]), np.arange(n, dtype=np.uint64), 10) for i, n in enumerate(npts)]))
+    comm = pfmi.Comm.init_all(engs)
+    info = comm.info()
+    total_draws = float(sum((e.P - Kl) * N_e for e in engs))
+    state = {}
+
+    def step():
+        for e, sd in zip(engs, seeds):
+            e.fit_batch(J)
+            e.elbo_batch_enqueue(N_e, sd)
+            e.pool_build_best(N_r)
+        res, idx, state["draws"] = comm.psis_resample(ndraws, seed=master)
+        state["best"] = [e.elbo_batch_wait()[2] for e in engs]
+        state.update(pareto_k=res["pareto_shape"], idx=idx)
+
+    for _ in range(args.warmup):
+        step()
+    for e in engs:
+        e.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    for e in engs:
+        e.sync()
+    ms_per_step = (time.perf_counter() - t0) / args.steps * 1e3
+    line = {"metric": "ELBO draws/sec (multipathfinder hot path: fit + ELBO + pool + PSIS + resample)",
+            "value": round(total_draws / (ms_per_step * 1e-3), 1), "unit": "ELBO draws/s", "n_gpus": G, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"multipathfinder npaths={K} d={d} target={args.target}, history_length={J}, ndraws_elbo={N_e}, ndraws={ndraws}",
+                       "npaths": K, "paths_per_gpu": Kl, "fits_total": int(total_draws // N_e), "elbo_draws_per_step": int(total_draws),
+                       "parallelism": f"paths sharded x{G}, ONE host process / thread (pfmi_comm_init_all)",
+                       "ranks_in_collective": info["world"], "rccl_version": info["rccl_version"]},
+            "pareto_k": state.get("pareto_k"), "roofline": None, "cpu_baseline": None}
+    comm.close()
+    for e in engs:
+        e.close()
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -248,7 +374,7 @@ def main():
 
     # ---- metric (ii): end-to-end wall-clock incl. trajectory generation (x0 on the host -> resampled draws on the host)
     wall_e2e = None
-    if not args.host_traces:
+    if not args.host_traces and not args.minimal:
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -260,7 +386,7 @@ def main():
     # ---- the same job through the public host API (pfmi.multipathfinder: x0 sampling, device L-BFGS, fit, ELBO, pool, PSIS,
     #      resample, result objects), single GPU only
     api_wall = None
-    if G == 1 and not use_dist and not args.host_traces:
+    if G == 1 and not use_dist and not args.host_traces and not args.minimal:
         ts = []
         for rep in range(4):
             t0 = time.perf_counter()
@@ -274,7 +400,7 @@ def main():
     #      to cross PCIe, so this is a separate, much lower line.  Bounded sample: the first 2 paths of this run, a vectorised
     #      NumPy closure (-|x|^2 / 2); the draws of block i + 1 are generated / downloaded while the host evaluates block i.
     callback_line = None
-    if G == 1 and not use_dist and not args.host_traces and not args.no_cpu_baseline:
+    if G == 1 and not use_dist and not args.host_traces and not args.no_cpu_baseline and not args.minimal:
         try:
             Kc = min(2, Kl)
             trs = [eng.get_trace(k, logp=False) for k in range(Kc)]
@@ -298,17 +424,60 @@ def main():
         except Exception as ex:  # pragma: no cover
             callback_line = {"error": repr(ex)}
 
+    # ---- DEVICE-callback targets (round 3): the same arbitrary-closure contract, but the closure is a kernel -- the draws are
+    #      materialised in HBM (8 d bytes written per draw) and read there by the user's kernel (8 d bytes read): the path on which
+    #      SURVEY 8(d)'s 16 d bytes per draw PHYSICALLY move, so its HBM fraction is a real utilisation.  Bounded sample: 8 paths.
+    devcb_line = None
+    if G == 1 and not use_dist and not args.host_traces and not args.minimal:
+        try:
+            Kd = min(8, Kl)
+            trs = [eng.get_trace(k, logp=False) for k in range(Kd)]
+            e3 = pfmi.Engine(local_rank)
+            e3.set_target(_demo_device_target(pfmi, tg))
+            e3.set_traces([t[0] for t in trs], [t[2] for t in trs])
+            e3.fit_batch(J)
+            sd = seeds[:e3.P]
+            e3.elbo_batch(N_e, sd)                                      # warm-up: the block buffers are allocated here
+            reps = 3
+            e3.sync()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                e3.elbo_batch_enqueue(N_e, sd)
+            elbo_d = e3.elbo_batch_wait()[0]
+            dtd = (time.perf_counter() - t0) / reps
+            ndr = (e3.P - Kd) * N_e
+            e3.profile(True)
+            e3.elbo_batch(N_e, sd)
+            tw, nw = e3.kernel_time("elbo_draws_x")
+            tr_, nr = e3.kernel_time("device_callback")
+            e3.profile(False)
+            moved = 16.0 * d * ndr
+            ref_el = state["elbo"][:e3.P]
+            fin = np.isfinite(ref_el)
+            devcb_line = {"draws_per_s": round(ndr / dtd, 1), "wall_s": round(dtd, 5),
+                          "hbm_GBps": round(moved / dtd / 1e9, 1), "frac_of_8TBps_spec": round(moved / dtd / 8e12, 4),
+                          "frac_of_6.29TBps_measured_copy": round(moved / dtd / 6.29e12, 4),
+                          "bytes_per_draw_moved": 16.0 * d,
+                          "writer_kernel": {"ms": round(tw, 3), "launches": int(nw), "GBps_written": round(8.0 * d * ndr / max(tw, 1e-9) / 1e6, 1)},
+                          "reader_kernel": {"ms": round(tr_, 3), "launches": int(nr), "GBps_read": round(8.0 * d * ndr / max(tr_, 1e-9) / 1e6, 1)},
+                          "max_rel_elbo_diff_vs_builtin_target": float(np.max(np.abs(elbo_d[fin] - ref_el[fin]) / (1 + np.abs(ref_el[fin])))),
+                          "sample": f"first {Kd} paths, {e3.P - Kd} fits x {N_e} draws, d={d}; closure = examples/device_logp (HIP, same target)",
+                          "note": "draws written to HBM by the library's draw kernel, read by the user's kernel on the same stream; no PCIe"}
+            e3.close()
+        except Exception as ex:  # pragma: no cover
+            devcb_line = {"error": repr(ex)}
+
     # ---- roofline of the dominant kernel (pf_elbo_draws_kernel), hipEvents on the engine's stream ---------
     roofline = None
     stages = {}
-    if rank == 0:
+    if rank == 0 and not args.minimal:
         eng.profile(True)
-    if not args.host_traces:
+    if not args.host_traces and not args.minimal:
         eng.optimize_batch(x0s, J, args.maxiters)
-    for _ in range(3):          # every rank takes part (collectives); only rank 0 records kernel events; 3 steps: launch averages
+    for _ in range(0 if args.minimal else 3):   # every rank takes part (collectives); only rank 0 records kernel events; 3 steps: launch averages
         step()
     barrier()
-    if rank == 0:
+    if rank == 0 and not args.minimal:
         for name in ("optimize", "trace_pack", "history", "fit", "elbo_draws", "elbo_draws_x", "elbo_reduce", "psis", "resample"):
             ms, n = eng.kernel_time(name)
             stages[name] = {"ms": round(ms / max(n, 1), 4), "launches": int(n)}      # average per launch
@@ -318,38 +487,49 @@ def main():
         bytes_per_draw = 16.0 * d + 8.0 * d * (m + 2) / N_e           # algorithmic bytes per ELBO draw
         alg_bytes = bytes_per_draw * draws_local                       # one launch = every ELBO draw of this rank
         achieved = alg_bytes / (ms / max(n, 1) * 1e-3) / 1e9 if ms > 0 else 0.0
-        traffic = None
-        try:                                                           # HBM bytes per launch from the committed PMC passes
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-                pmc = json.load(fh)
-            if (K, d, N_e, J, G) == (64, 1000, 1000, 6, 1):             # only valid for the profiled workload
-                traffic = pmc["traffic_bytes_per_launch"]
-        except Exception:
-            pass
-        # the kernel's real bound is instruction issue (f64 MFMA shares the fp64 lanes with the VALU on gfx950): report
-        # the matrix rate beside the contract's figure.  Per 16 rows x 16 draws a group issues 4 x (2 KC/4 + RPAD/4) MFMA 4x4x4 (512 flop)
+        # ---- what bounds the kernel: fp64 ISSUE.  On gfx950 the f64 MFMA executes on the SIMD's fp64 lanes: nothing co-issues with it
+        # (profiles/r02_coissue_microbench.txt, re-tested in round 3), so the floor of the kernel is the SUM of its issue streams.
+        # Per 16 rows x 16 draws a group issues 4 x (2 KC/4 + RPAD/4) MFMA 4x4x4 (512 flop each).
         kc = next(o for o in (4, 8, 12, 16, 20, 32) if m <= o)
         rpad = (8 if getattr(tg, "r", 0) <= 8 else 16) if getattr(tg, "r", 0) > 0 else 0
         ncols = 2 * kc + rpad          # w = Vh'z, A3 = Vh'(a s^2 z), A4 = Wd'(s z)
         nblk = -(-d // 16)
+        t_launch = ms / max(n, 1) * 1e-3
         mfma_flops = draws_local / 16.0 * nblk * 4 * (ncols // 4) * 512.0
-        mfma_tf = mfma_flops / (ms / max(n, 1) * 1e-3) / 1e12 if ms > 0 else 0.0
-        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                    "label": "equivalent materialised-draw bandwidth: algorithmic bytes of SURVEY 8(d) / measured launch time "
-                             "(the fused kernel moves < 3 % of them; HBM is idle, so the fraction can pass 1.0 -- the real bound is instruction issue, see mfma_f64)",
-                    "mfma_f64": {"achieved": round(mfma_tf, 2), "peak": 78.6, "unit": "TFLOP/s", "frac": round(mfma_tf / 78.6, 4),
-                                 "note": "f64 MFMA flops of the scan / launch time; the kernel's floor is the SUM of its MFMA and VALU "
-                                         "issue streams (no co-issue on gfx950, profiles/r02_coissue_microbench.txt): ~84 % of that floor, DESIGN.md 4.1"},
+        mfma_tf = mfma_flops / t_launch / 1e12 if ms > 0 else 0.0
+        # summed-issue floor from the unit times of the co-issue microbenchmark (2 waves per SIMD; they embed the sustained clock):
+        # MFMA 4x4x4 7.44 ns, Philox round 10.5 ns, other VALU ~2.0 ns; per wave and block of 16 rows x 32 draws (two groups per wave)
+        issue = None
+        if kc <= 12 and N_e >= 768:
+            n_mfma, n_phx, n_valu = 2 * 4 * (ncols // 4), 2 * 7, 111
+            per_block_us = (n_mfma * 7.44 + n_phx * 10.5 + n_valu * 2.0) * 1e-3
+            batches = -(-(-(-N_e // 16) + 1) // 16)                     # 16 group slots per workgroup pass (8 waves x 2), one pseudo group
+            wave_blocks_per_simd = nfits_local * batches * nblk * 8 / (4.0 * 256)
+            floor_ms = per_block_us * wave_blocks_per_simd * 1e-3
+            issue = {"floor_ms": round(floor_ms, 3), "measured_over_floor": round(t_launch * 1e3 / floor_ms, 4) if floor_ms > 0 else None,
+                     "frac_of_floor": round(floor_ms / (t_launch * 1e3), 4) if ms > 0 else None,
+                     "model": f"per wave and 16x32 block: {n_mfma} MFMA4 x 7.44 ns + {n_phx} Philox rounds x 10.5 ns + {n_valu} VALU x 2.0 ns, "
+                              "2 waves per SIMD, no MFMA/VALU co-issue (profiles/r02_coissue_microbench.txt, profiles/r03_*)"}
+        traffic, traffic_meta = None, None
+        if not args.no_pmc and not args.minimal and G == 1 and not use_dist:
+            pmc, why = _pmc_traffic([a for a in sys.argv[1:] if a not in ("--no-cpu-baseline",)], "%pf_elbo_qf_kernel%")
+            if pmc is not None:
+                traffic, traffic_meta = pmc["traffic_bytes_per_launch"], pmc
+            else:
+                traffic_meta = {"source": f"unavailable in this run ({why})"}
+        roofline = {"bound": "mfma", "achieved": round(mfma_tf, 2), "peak": 78.6, "unit": "TFLOP/s", "frac": round(mfma_tf / 78.6, 4),
+                    "traffic": traffic, "traffic_detail": traffic_meta,
                     "kernel": "pf_elbo_qf_kernel (single-pass ELBO scan; one scan = the main launch + a short tail launch for the fits beyond "
-                              "the last full round of CUs, timed together: profiles/r02_bench_kernel_stats.md lists both grids)",
+                              "the last full round of CUs, timed together with hipEvents on the engine's stream)",
                     "launches": int(n), "avg_launch_ms": round(ms / max(n, 1), 4),
-                    "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_draw": bytes_per_draw,
-                    "note": "achieved = algorithmic bytes (16*d + factor bytes per draw, SURVEY 8d) / measured launch time. The "
-                            "kernel is fused: normals are generated in registers and draws of non-winning fits are never "
-                            "written, so measured HBM traffic (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, two separate --pmc passes, "
-                            "profiles/pmc_traffic.json) is <3% of the algorithmic bytes; the real bound is the fp64 VALU / f64 MFMA "
-                            "issue rate (see mfma_f64)."}
+                    "label": "f64 matrix flops of the scan / launch time against the 78.6 TF f64 MFMA peak.  The kernel is fp64-ISSUE bound: "
+                             "its floor is the SUM of the MFMA and VALU issue streams (see issue_floor), not the matrix peak alone",
+                    "issue_floor": issue,
+                    "hbm_equivalent": {"achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
+                                       "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_draw": bytes_per_draw,
+                                       "label": "SECONDARY: SURVEY 8(d)'s yardstick (16 d + factor bytes per draw) / launch time.  The fused scan "
+                                                "never forms x, so these bytes are NOT moved (see traffic: a few % of them) and this is not a "
+                                                "utilisation; the path where they do move is device_callback_target"}}
 
     # ---- CPU baseline: the oracle (a port of the reference algorithm) on this box's host cores ------------
     cpu = None
@@ -420,6 +600,7 @@ def main():
             "pareto_k": state.get("pareto_k"),
             "stages_ms": stages,
             "callback_target": callback_line,
+            "device_callback_target": devcb_line,
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
@@ -428,6 +609,8 @@ def main():
         if comm is not None:
             comm.close()
         dist.destroy_process_group()
+    elif comm is not None:
+        comm.close()
     eng.close()
     if rank == 0:
         # RCCL writes a version banner through C stdio that would otherwise be flushed at exit, AFTER this line:

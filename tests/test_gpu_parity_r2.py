@@ -482,7 +482,7 @@ def test_statsbase_direct_index_mode_and_large_norep(pfmi_mod, eng):
 
 
 # ---- collectives behind the C ABI -------------------------------------------------------------------------------
-@pytest.mark.parametrize("mode", ["init_all", "init_rank"])
+@pytest.mark.parametrize("mode", ["init_all", "init_all_local", "init_rank"])
 def test_comm_rccl_world1_equals_local_path(pfmi_mod, eng, mode):
     """pfmi_comm_* (csrc/comm_rccl.hip: ncclAllGather of the log-ratio shards, replicated PSIS / index selection, owner gather,
     ncclAllReduce) in the only RCCL world a 1-GPU box allows.  Both ways of forming the group -- ncclCommInitAll (one process,
@@ -501,13 +501,24 @@ def test_comm_rccl_world1_equals_local_path(pfmi_mod, eng, mode):
     ref = eng.psis(lr)
     ref_idx = eng.resample_indices(len(lr), 40, seed=9)
     ref_norep = eng.resample_indices(len(lr), 40, replace=False, seed=9)
-    if mode == "init_all":
+    if mode == "init_all":                                           # the REAL librccl in the only world a 1-GPU box allows
+        os.environ["PFMI_COMM_FORCE_RCCL"] = "1"
+        try:
+            comm = pfmi_mod.Comm.init_all([eng])
+        finally:
+            os.environ.pop("PFMI_COMM_FORCE_RCCL", None)
+    elif mode == "init_all_local":                                   # round 3: a world of one context does not touch RCCL at all
         comm = pfmi_mod.Comm.init_all([eng])
     else:
         comm = pfmi_mod.Comm.init_rank(eng, 1, 0, pfmi_mod.Comm.unique_id())
     try:
         info = comm.info()
-        assert info["world"] == 1 and info["nlocal"] == 1 and info["rccl_version"] > 20000
+        assert info["world"] == 1 and info["nlocal"] == 1
+        assert (info["rccl_version"] == 0) if mode == "init_all_local" else (info["rccl_version"] > 20000)
+        r_f, idx_f, draws_f = comm.psis_resample(40, seed=9)         # the fused entry (one synchronisation)
+        assert r_f["pareto_shape"] == ref["pareto_shape"] and r_f["tail_length"] == ref["tail_length"]
+        np.testing.assert_array_equal(idx_f, ref_idx)
+        np.testing.assert_array_equal(draws_f, pool.reshape(tg.d, -1, order="F")[:, ref_idx])
         res = comm.pool_psis()
         assert res["pareto_shape"] == ref["pareto_shape"] and res["tail_length"] == ref["tail_length"]
         idx, draws = comm.resample(40, seed=9)
