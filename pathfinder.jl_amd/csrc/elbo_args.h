@@ -26,3 +26,5 @@ struct ElboArgs {
 int32_t pf_launch_elbo_mfma(struct pfmi_ctx *c, const ElboArgs &a, int64_t nfits, int tgt, int rpad, bool *handled);
 // implemented in elbo_qf_kernel.hip: single-pass quadratic-form scan (in-kernel RNG, no draws written), any d
 int32_t pf_launch_elbo_qf(struct pfmi_ctx *c, const ElboArgs &a, int64_t nfits, int tgt, int rpad, bool *handled);
+// implemented in elbo_xw_kernel.hip: the draw writer (x materialised in HBM, in-kernel RNG, logq; no target), any d
+int32_t pf_launch_elbo_xw(struct pfmi_ctx *c, const ElboArgs &a, int64_t nfits, bool *handled);

@@ -409,6 +409,22 @@ int32_t pf_launch_elbo_draws(pfmi_ctx *c, const int32_t *d_points, const uint64_
         const bool mf_shape = a.d <= 1024 && c->kpad <= 16;
         const bool want_qf = (force && force[0] == 'q') || (!(force && force[0] == 'm') && (N >= 64 || (!mf_shape && N >= 16)));
         if (want_qf && !d_x) rc = pf_launch_elbo_qf(c, a, nfits, tgt, rpad, &handled);
+        // launches that WRITE draws (pool, pfmi_draws, device-closure scans): the streaming writer (any d), then -- for a built-in
+        // target -- the scan on the same (fit, seed, n0, N) for logp: a draw's logp through the expanded form, its logq the same bits
+        // from both kernels.  PFMI_ELBO_KERNEL = xw forces it, = mfma | lane keep round 2's writers (tests cross-check them).
+        // (a built-in target whose factor fits the two-pass kernel -- d <= 1024, J <= 8 -- keeps that kernel: it evaluates logp in the same
+        // launch, 0.26 ms for the pool of config 3 against 0.49 ms for writer + scan)
+        const bool want_xw = d_x && ((force && force[0] == 'x') || (!(force && force[0] == 'm') && N >= 16 && !(tgt != 0 && mf_shape)));
+        if (want_xw) {
+            rc = pf_launch_elbo_xw(c, a, nfits, &handled);
+            if (handled && rc == PFMI_OK && tgt != 0) {
+                ElboArgs b = a;
+                b.x = nullptr; b.x_stride = 0;
+                bool h2 = false;
+                rc = pf_launch_elbo_qf(c, b, nfits, tgt, rpad, &h2);
+                if (rc == PFMI_OK && !h2) { pf_set_error("elbo_draws: scan kernel unavailable for kpad %d", c->kpad); rc = PFMI_ERR_UNSUPPORTED; }
+            }
+        }
         if (!handled) rc = pf_launch_elbo_mfma(c, a, nfits, tgt, rpad, &handled);
         if (handled) {
             pf_kernel_end(c, d_x ? "elbo_draws_x" : "elbo_draws");

@@ -38,7 +38,9 @@
 #define QF_ABLATE 0
 #endif
 #define QF_MIN_FRONT 1024             // doubles in front of the inverse-CDF table (>= (32 - 19) * 32 * 2 = 832)
-#define QF_CHB 16                      // blocks (of 16 rows) per streamed chunk
+// blocks (of 16 rows) per streamed chunk; KC = 32 halves it: two staging buffers of 16 blocks x 32 columns would not fit 160 KB of LDS
+// (round 3: history_length 11..16 with d > ~1000 used to fail with "LDS too large")
+template <int KC> struct qf_chb { static constexpr int v = (KC > 20) ? 8 : 16; };
 
 // Results must not depend on the launch geometry (which fits fall into the tail launch, how a fit's groups are cut into pieces,
 // which of a wave's groups a draw lands in): the block body exists in several inlined instances (first batch / steady state,
@@ -76,6 +78,7 @@ template <int KC, int TGT, int RPAD, int NG>
 __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int ch_blocks, int nchunks, int groups_per_wg, int ngroups) {
     extern __shared__ double lds[];
     constexpr int NT = KC / 4, TR = RPAD / 4, NC = qf_nconst(KC, RPAD);
+    constexpr int QF_CHB = qf_chb<KC>::v;
     constexpr int PRE = (QF_CHB * 16 * KC + QF_THREADS - 1) / QF_THREADS;      // prefetch registers per thread (streaming)
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, q = lane >> 4, c = lane & 15, l3 = lane & 3;
     const int d = A.d, nblk = (d + 15) >> 4;
@@ -523,6 +526,7 @@ template <int KC, int TGT, int RPAD, int NG>
 static int32_t launch_qf_ng(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
     const int nblk = (a.d + 15) / 16;
     int ch_blocks = nblk, nchunks = 1;
+    constexpr int QF_CHB = qf_chb<KC>::v;
     if (qf_lds_bytes(nblk, 1, KC, RPAD) > 156 * 1024) { ch_blocks = QF_CHB; nchunks = (nblk + QF_CHB - 1) / QF_CHB; }
     const size_t lds_bytes = qf_lds_bytes(ch_blocks, nchunks, KC, RPAD);
     PF_CHECK(lds_bytes <= 160 * 1024, PFMI_ERR_UNSUPPORTED, "qf kernel LDS %zu too large", lds_bytes);

@@ -1,0 +1,432 @@
+// elbo_xw_kernel.hip -- the draw WRITER: rand_and_logpdf (reference src/mvnormal.jl:24-39, unwhiten! src/woodbury.jl:401-406,
+// 136-143) for launches that MATERIALISE x = mu + U'(z - Vh T Vh'z) in HBM: the pool of the winning fits (src/multipath.jl:217),
+// pfmi_draws, and every fit of an ELBO scan whose target is a device-resident closure (PFMI_TARGET_DEVICE_CALLBACK: the closure reads
+// the draws where this kernel wrote them).  Any d, any history length; in-kernel generator only.
+//
+// Mapping (that of the single-pass scan, elbo_qf_kernel.hip): a WAVE owns 16 draws end to end -- lane (q, c) generates rows
+// 16 blk + 4q + {0..3} of draw c with one Philox4x32-7 call per block -- the 8 waves of a workgroup own 8 different groups, Vh is
+// only read (LDS, in MFMA operand order, resident or streamed in 256-row chunks): no cross-wave reduction, no barrier in the
+// steady state.  The compact-WY form needs w = Vh'z BEFORE the first row of x can be formed, so the rows are walked twice:
+//   pass 1   normals, |u|^2, head transform z_head = V'u_head, w += Vh'z           (NT quarter-size MFMAs per k-step)
+//            tv = T w on v_mfma_f64_16x16x4 (lane (q, c) holds entries 4 s + q of draw c = B operand and result layout at once)
+//   pass 2   the SAME normals again (counter-based generator: nothing was kept), x~ = z - Vh tv as 16x16x4 MFMAs with z as the
+//            C operand, x = mu + sqrt(alpha) x~
+// The two-pass kernel of round 1 (elbo_mfma_kernel.hip) keeps z in registers instead and pays for it with the rows of ONE group
+// split over the 8 waves: two barriers and an LDS reduction per 16 draws, 16 draws in flight per CU, 8-byte stores scattered over
+// 16 columns.  Here the second Philox + table pass buys 128 draws in flight per CU and no synchronisation.
+//
+// Stores: a draw is a column of d contiguous doubles.  Lane (q, c) ends up with 4 consecutive rows of column c; written directly
+// that is 16 columns x four 8-byte pieces per instruction.  Instead a block (16 rows x 16 draws; XW_SB = 2: two blocks) goes through a
+// wave-private, XOR-swizzled LDS tile and leaves as 4 instructions of 4 x 128 contiguous bytes -- whole 128-byte lines.
+// logq is accumulated exactly as the scan does (same lane ownership, same order), so it is bit-identical to the scan's.
+#include <type_traits>
+#include "pfmi_common.h"
+#include "elbo_args.h"
+
+#ifndef XW_WAVES
+#define XW_WAVES 16                    // waves per workgroup (4 per SIMD: measured 5.5 ms against 6.0 with 8 on the config-3 sample)
+#endif
+#define XW_THREADS (XW_WAVES * 64)
+#ifndef XW_SB
+#define XW_SB 1                        // blocks (of 16 rows) per store burst: 2 -> 256 contiguous bytes per column and instruction
+#endif
+#ifndef XW_NG
+#define XW_NG 1                        // 16-draw groups per wave (2 share the operand fetches but measured slower: 6.4 ms with 8 waves)
+#endif
+#ifndef XW_SM_LDS
+#define XW_SM_LDS 0                    // 1: sqrt(alpha) / mu of a chunk staged in LDS (measured slower: 5.85 vs 5.47 ms, LDS is the scarcer resource)
+#endif
+#ifndef XW_ABLATE
+#define XW_ABLATE 0                    // timing experiments only: 1 = no global stores, 2 = pass 2 without generator, 3 = no pass 1
+#endif
+#define XW_SR (16 * XW_SB)
+#define XW_LD XW_SR                    // leading dimension of the 16 x XW_SR transposition tile (no padding: rows are XOR-swizzled)
+// binades of the inverse-CDF table kept in LDS: all 19 with 8 waves; 12 (12 KB) with 16 waves, whose tiles need the room at d = 1000
+// (words below 2^19, probability 2^-12 per normal, then take the global-table path -- same values)
+#ifndef XW_NB
+#define XW_NB ((XW_SM_LDS && XW_WAVES * XW_NG > 8) ? 12 : PF_ICDF_NB_LDS)
+#endif
+// row `row` (0 .. XW_SR-1) of column `col` inside a tile: the XOR spreads both the (q, c)-ordered writes and the row-ordered reads over
+// all 32 bank pairs (two passes per 64-lane access, the minimum for 8-byte words)
+__device__ __forceinline__ int xw_tile_pos(int col, int row) { return col * XW_LD + (row ^ ((col >> 1) & 7)); }
+// blocks per streamed chunk (a multiple of XW_SB: a store burst never straddles chunks); KC = 32 halves it to stay inside 160 KB of LDS
+template <int KC> struct xw_chb { static constexpr int v = (KC > 20) ? 8 : 16; };
+
+// fused operations are explicit fma(); nothing else may be contracted (results must not depend on the launch geometry)
+#pragma clang fp contract(off)
+
+typedef double xw_d4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ xw_d4 xw_mfma16(double a, double b, xw_d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ double xw_mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+
+// LDS layout of one staged chunk: [(bl*4 + r)*NT + T][q*4 + i] = Vh[row 16 bl + 4 q + r][4 T + i]   (16 contiguous doubles = one
+// A operand of the quarter-size MFMA; the same layout as the scan's)
+template <int KC>
+__device__ __forceinline__ int xw_vh_pos(int lrow, int col) {
+    const int bl = lrow >> 4, rr = lrow & 15, q = rr >> 2, r = rr & 3, T = col >> 2, i = col & 3;
+    return (((bl * 4 + r) * (KC / 4) + T) << 4) + q * 4 + i;
+}
+
+template <int KC>
+__global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int ch_blocks, int nchunks, int groups_per_wg, int ngroups) {
+    extern __shared__ double lds[];
+    constexpr int NT = KC / 4, NG = XW_NG;
+    constexpr int XW_CHB = xw_chb<KC>::v;
+    constexpr int PRE = (XW_CHB * 16 * KC + XW_THREADS - 1) / XW_THREADS;      // prefetch registers per thread (streaming)
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, q = lane >> 4, c = lane & 15, l3 = lane & 3;
+    const int d = A.d, nblk = (d + 15) >> 4;
+    const int slot = blockIdx.y;
+    const int p = A.points[slot];
+    const size_t blkidx = A.by_point ? (size_t)p : (size_t)slot;
+    double *out_lp = A.logp + blkidx * A.log_stride, *out_lq = A.logq + blkidx * A.log_stride;
+    const int g_begin = blockIdx.x * groups_per_wg;
+    const int g_end = (g_begin + groups_per_wg < ngroups) ? g_begin + groups_per_wg : ngroups;
+    const int nlb = (g_end - g_begin + XW_WAVES * NG - 1) / (XW_WAVES * NG);    // batches of XW_WAVES * NG groups
+    if (A.status[p] != PFMI_FIT_OK) {          // failed fit: no draws (x stays unwritten), NaN log densities
+        for (int64_t n = (int64_t)g_begin * 16 + tid; n < (int64_t)g_end * 16 && n < A.N; n += XW_THREADS) {
+            out_lp[n] = NAN; out_lq[n] = NAN;
+        }
+        return;
+    }
+    // ---- LDS carve-up (offsets in doubles)
+    // a staged chunk = the Householder block (MFMA operand order) [+ per block of 16 rows: sqrt(alpha)[16], mu[16] when XW_SM_LDS]
+    const int vh_sz = ch_blocks * 16 * KC, sm_sz = XW_SM_LDS ? ch_blocks * 32 : 0;
+    const int buf_stride = (nchunks > 1) ? vh_sz + sm_sz : 0;
+    const int stage_sz = (nchunks > 1 ? 2 : 1) * (vh_sz + sm_sz);
+    double *t_s = lds + stage_sz;                  // [KC][KC]
+    double2 *icdf = reinterpret_cast<double2 *>(t_s + KC * KC);                 // [2 * 32 XW_NB]
+    double *xt0 = reinterpret_cast<double *>(icdf + 2 * (XW_NB << PF_ICDF_B)) + wv * (NG * 16 * XW_LD);   // this wave's 16 x XW_SR tiles
+
+    const double *Vh = A.vh + (size_t)p * d * KC, *mu = A.mu + (size_t)p * d, *sqa = A.sqrt_alpha + (size_t)p * d;
+    {
+        const double *T = A.tmat + (size_t)p * KC * KC;
+        for (int i = tid; i < KC * KC; i += XW_THREADS) t_s[i] = T[i];
+        pf_icdf_load<XW_NB>(icdf);
+        for (int idx = tid; idx < ch_blocks * 16 * KC; idx += XW_THREADS) {   // chunk 0 (the whole block when resident)
+            const int lrow = idx / KC, col = idx - lrow * KC;
+            lds[xw_vh_pos<KC>(lrow, col)] = (lrow < d) ? Vh[(size_t)lrow * KC + col] : 0.0;
+        }
+        for (int lrow = tid; XW_SM_LDS && lrow < ch_blocks * 16; lrow += XW_THREADS) {
+            double *o = lds + vh_sz + (lrow >> 4) * 32 + (lrow & 15);
+            o[0] = (lrow < d) ? sqa[lrow] : 0.0; o[16] = (lrow < d) ? mu[lrow] : 0.0;
+        }
+    }
+    // head transform z_head = V'u_head on 16x16x4 MFMAs: lane (q, c) supplies A_r[i' = c][k = q] = H[rho(c)][4 q + r], H = V'
+    // identity padded (rho: the row permutation that makes result register r of lane (q, c) row 4 q + r); block 1 when KC > 16
+    const int rho = 4 * (c & 3) + (c >> 2);
+    double a_h00[4], a_h10[4], a_h11[4];
+    {
+        const double *Vc = A.vchol + (size_t)p * KC * KC;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = 4 * q + r;
+            double v = (rho == b) ? 1.0 : 0.0;
+            if (rho < KC && b < KC) v = Vc[b * KC + rho];
+            a_h00[r] = v;
+            if (KC > 16) {
+                const int i1 = 16 + rho, b1 = 16 + b;
+                a_h10[r] = (i1 < KC) ? Vc[b * KC + i1] : 0.0;
+                double v1 = (i1 == b1) ? 1.0 : 0.0;
+                if (i1 < KC && b1 < KC) v1 = Vc[b1 * KC + i1];
+                a_h11[r] = v1;
+            } else { a_h10[r] = 0.0; a_h11[r] = 0.0; }
+        }
+    }
+    const uint64_t seed = A.seeds[slot];
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const double logdet = A.logdet[p];
+    __syncthreads();
+
+    int cur = 0;
+    for (int lb = 0; lb < nlb; ++lb) {
+        // a wave owns NG 16-draw groups of the batch: they share every operand fetch of a block and give the scheduler NG independent
+        // generator / MFMA chains to interleave (one wave's Philox -> table -> cubic -> MFMA chain alone leaves the SIMD half idle)
+        int64_t nl0[NG];
+        uint32_t n[NG];
+        bool act[NG], fullc[NG];
+        double *xg[NG];
+        double accw[NG][NT], ntv[NG][NT], u0[NG][4], usq[NG];
+        int nact = 0;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int grp = g_begin + (lb * XW_WAVES + wv) * NG + g;           // wave-uniform
+            act[g] = grp < g_end;
+            nact += act[g] ? 1 : 0;
+            nl0[g] = (int64_t)grp * 16;
+            n[g] = (uint32_t)(A.n0 + nl0[g] + c);
+            fullc[g] = nl0[g] + 16 <= A.N;
+            xg[g] = act[g] ? A.x + (size_t)slot * A.x_stride + (size_t)nl0[g] * d : A.x;   // draw nl0 + col starts at xg + col * d
+            usq[g] = 0.0;
+#pragma unroll
+            for (int T = 0; T < NT; ++T) { accw[g][T] = 0.0; ntv[g][T] = 0.0; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u0[g][r] = 0.0;
+        }
+        // normals of rows 16 blk + 4q + {0..3} of the draws of group g, head transform included.  FIRST: accumulate |u|^2 (pass 1).
+        // SPECIAL: the first / second / last block of the walk (head transform, rows >= d); interior blocks are straight-line code
+        auto normals = [&](const int g, const int blk, double (&z)[4], auto first_tag, auto special_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value, SPECIAL = decltype(special_tag)::value;
+            uint32_t x[4];
+            pf_philox_normals(n[g], (uint32_t)(blk * 4 + q), 0u, 0u, k0, k1, x);
+            pf_icdf4<XW_NB>(x, n[g], (uint32_t)(blk * 4 + q), 0u, k0, k1, icdf, z);
+            if (SPECIAL && blk == nblk - 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z[r] = (blk * 16 + 4 * q + r < d) ? z[r] : 0.0;
+            }
+            if (FIRST) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) usq[g] = fma(z[r], z[r], usq[g]);  // |u|^2 before the transform (src/mvnormal.jl:31)
+            }
+            if (SPECIAL) {
+                if (blk == 0) {                                                // z[1:k] = V'u[1:k] (src/woodbury.jl:139)
+                    xw_d4 h = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { u0[g][r] = z[r]; h = xw_mfma16(a_h00[r], z[r], h); }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) z[r] = h[r];
+                } else if (KC > 16 && blk == 1) {
+                    xw_d4 h = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h = xw_mfma16(a_h10[r], u0[g][r], h);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h = xw_mfma16(a_h11[r], z[r], h);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) z[r] = h[r];
+                }
+            }
+        };
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int ck = 0; ck < nchunks; ++ck) {
+                // ---- streaming: fetch the next chunk of the walk (pass 1 -> pass 2 -> next batch) into registers while this one is used
+                double pre[PRE], pr_s = 0.0, pr_m = 0.0;
+                const int nck = (ck + 1 < nchunks) ? ck + 1 : 0;
+                const bool do_pre = (nchunks > 1) && (ck + 1 < nchunks || pass == 0 || lb + 1 < nlb);
+                if (do_pre) {
+                    const int row0 = nck * XW_CHB * 16;
+#pragma unroll
+                    for (int e = 0; e < PRE; ++e) {
+                        const int idx = tid + e * XW_THREADS;
+                        const int lrow = idx / KC, row = row0 + lrow;
+                        pre[e] = (idx < XW_CHB * 16 * KC && row < d) ? Vh[(size_t)row0 * KC + idx] : 0.0;
+                    }
+                    if (XW_SM_LDS && tid < XW_CHB * 16 && row0 + tid < d) { pr_s = sqa[row0 + tid]; pr_m = mu[row0 + tid]; }
+                }
+                if (nact > 0) {
+                    const double *vs = lds + cur * buf_stride;
+                    const int blk0 = ck * ch_blocks;
+                    const int nb = (nblk - blk0 < ch_blocks) ? nblk - blk0 : ch_blocks;
+                    if (pass == 0) {
+                        // ---- pass 1: w += Vh'z   (NGA = groups of this wave that exist: the last batch may have fewer)
+                        auto body1 = [&](const int bl, auto special_tag, auto nga_tag) {
+                            constexpr int NGA = decltype(nga_tag)::value;
+                            double av[4][NT];
+                            const double *ap = vs + ((bl * 4) * NT << 4) + q * 4 + l3;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                                for (int T = 0; T < NT; ++T) av[r][T] = ap[(r * NT + T) << 4];
+                            double z[NGA][4];
+#pragma unroll
+                            for (int g = 0; g < NGA; ++g) normals(g, blk0 + bl, z[g], std::true_type{}, special_tag);
+#pragma unroll
+                            for (int g = 0; g < NGA; ++g)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                                    for (int T = 0; T < NT; ++T) accw[g][T] = xw_mfma4(av[r][T], z[g][r], accw[g][T]);
+                        };
+                        for (int bl = 0; bl < (XW_ABLATE == 3 ? 1 : nb); ++bl) {
+                            const int blk = blk0 + bl;
+                            const bool special = (blk == 0) | (blk == nblk - 1) | (KC > 16 && blk == 1);
+                            if (NG == 2 && nact == 2) {
+                                if (__builtin_expect(special, 0)) body1(bl, std::true_type{}, std::integral_constant<int, NG>{});
+                                else body1(bl, std::false_type{}, std::integral_constant<int, NG>{});
+                            } else {
+                                if (__builtin_expect(special, 0)) body1(bl, std::true_type{}, std::integral_constant<int, 1>{});
+                                else body1(bl, std::false_type{}, std::integral_constant<int, 1>{});
+                            }
+                        }
+                    } else {
+                        // ---- pass 2: the same normals again, x~ = z - Vh tv, x = mu + sqrt(alpha) x~, full-line stores
+                        auto body2 = [&](const int bl, auto special_tag, auto nga_tag) {
+                            constexpr bool SPECIAL = decltype(special_tag)::value;
+                            constexpr int NGA = decltype(nga_tag)::value;
+                            const int blk = blk0 + bl;
+                            // A[i' = c][k = q] = Vh[16 blk + rho(c)][4 s + q]
+                            const double *a2p = vs + ((bl * 4 + (c >> 2)) * NT << 4) + (c & 3) * 4 + q;
+                            double a2v[NT], s4[4], m4[4];
+#pragma unroll
+                            for (int s = 0; s < NT; ++s) a2v[s] = a2p[s << 4];
+                            if (XW_SM_LDS) {
+                                const double *smp = vs + vh_sz + bl * 32 + 4 * q;        // rows >= d hold zeros: x = 0 there, never stored
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { s4[r] = smp[r]; m4[r] = smp[16 + r]; }
+                            } else if (SPECIAL && blk == nblk - 1) {                     // rows >= d exist only in the last block
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int row = (blk * 16 + 4 * q + r < d) ? blk * 16 + 4 * q + r : d - 1;
+                                    s4[r] = sqa[row]; m4[r] = mu[row];
+                                }
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { s4[r] = sqa[blk * 16 + 4 * q + r]; m4[r] = mu[blk * 16 + 4 * q + r]; }
+                            }
+                            double z[NGA][4];
+#pragma unroll
+                            for (int g = 0; g < NGA; ++g) {
+#if XW_ABLATE == 2
+                                z[g][0] = s4[0]; z[g][1] = s4[1]; z[g][2] = m4[2]; z[g][3] = m4[3];
+#else
+                                normals(g, blk, z[g], std::false_type{}, special_tag);
+#endif
+                            }
+                            const int sb = blk % XW_SB;                                  // position inside the store burst
+#pragma unroll
+                            for (int g = 0; g < NGA; ++g) {
+                                xw_d4 xa = {z[g][0], z[g][1], z[g][2], z[g][3]};
+#pragma unroll
+                                for (int s = 0; s < NT; ++s) xa = xw_mfma16(a2v[s], ntv[g][s], xa);
+                                double *tp = xt0 + g * (16 * XW_LD);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) tp[xw_tile_pos(c, sb * 16 + 4 * q + r)] = fma(s4[r], xa[r], m4[r]);  // x = mu + sqrt(alpha) x~
+                            }
+                            if (sb == XW_SB - 1 || (SPECIAL && blk == nblk - 1)) {       // XW_SR rows x 16 draws staged: store them
+                                __builtin_amdgcn_wave_barrier();
+                                constexpr int CPI = 64 / XW_SR;                          // columns per store instruction
+                                const int r0 = (blk - sb) * 16, lr = lane % XW_SR;
+#pragma unroll
+                                for (int g = 0; g < NGA; ++g) {
+                                    const double *tr = xt0 + g * (16 * XW_LD);
+                                    double *xo = xg[g] + (lane / XW_SR) * d + r0 + lr;
+                                    if (!SPECIAL && fullc[g] && XW_ABLATE != 1) {        // whole burst, whole group: no predicates
+#pragma unroll
+                                        for (int it = 0; it < 16 / CPI; ++it) xo[it * CPI * d] = tr[xw_tile_pos(CPI * it + lane / XW_SR, lr)];
+                                    } else {
+#pragma unroll
+                                        for (int it = 0; it < 16 / CPI; ++it) {
+                                            const int col = CPI * it + lane / XW_SR;
+                                            const double v = tr[xw_tile_pos(col, lr)];
+                                            if (r0 + lr < d && lr < 16 * (sb + 1) && nl0[g] + col < A.N && (XW_ABLATE != 1 || v == 1.2345e301))
+                                                xo[it * CPI * d] = v;
+                                        }
+                                    }
+                                }
+                                __builtin_amdgcn_wave_barrier();
+                            }
+                        };
+                        for (int bl = 0; bl < nb; ++bl) {
+                            const int blk = blk0 + bl;
+                            const bool special = (blk == 0) | (blk >= nblk - XW_SB) | (KC > 16 && blk == 1);
+                            if (NG == 2 && nact == 2) {
+                                if (__builtin_expect(special, 0)) body2(bl, std::true_type{}, std::integral_constant<int, NG>{});
+                                else body2(bl, std::false_type{}, std::integral_constant<int, NG>{});
+                            } else {
+                                if (__builtin_expect(special, 0)) body2(bl, std::true_type{}, std::integral_constant<int, 1>{});
+                                else body2(bl, std::false_type{}, std::integral_constant<int, 1>{});
+                            }
+                        }
+                    }
+                }
+                if (nchunks > 1) {
+                    if (do_pre) {
+                        double *vs = lds + (cur ^ 1) * buf_stride;
+#pragma unroll
+                        for (int e = 0; e < PRE; ++e) {
+                            const int idx = tid + e * XW_THREADS;
+                            if (idx < XW_CHB * 16 * KC) { const int lrow = idx / KC; vs[xw_vh_pos<KC>(lrow, idx - lrow * KC)] = pre[e]; }
+                        }
+                        if (XW_SM_LDS && tid < XW_CHB * 16) {
+                            double *o = vs + vh_sz + (tid >> 4) * 32 + (tid & 15);
+                            o[0] = pr_s; o[16] = pr_m;
+                        }
+                    }
+                    __syncthreads();
+                    cur ^= 1;
+                }
+            }
+            if (pass == 0) {
+                // tv = T w on v_mfma_f64_16x16x4: lane (q, c) holds entries 4 s + q of draw c -- B operand (k = q, column = draw) and
+                // result (rows q + 4 reg) layout at once; A = T[row 16 rt + c][4 s + q] from LDS
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (!act[g]) continue;
+#pragma unroll
+                    for (int rt = 0; rt < (NT + 3) / 4; ++rt) {
+                        xw_d4 acc = {0.0, 0.0, 0.0, 0.0};
+                        const int row = 16 * rt + c;
+#pragma unroll
+                        for (int st = 0; st < NT; ++st) {
+                            const int col = 4 * st + q;
+                            const double av = (row < KC) ? t_s[row * KC + col] : 0.0;
+                            acc = xw_mfma16(av, accw[g][st], acc);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (4 * rt + r < NT) ntv[g][4 * rt + r] = -acc[r];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (!act[g]) continue;
+            const double us = pf_sum_q(usq[g]);
+            const int64_t nl = nl0[g] + c;
+            if (q == 0 && nl < A.N) {
+                out_lq[nl] = ((double)d * PF_LOG2PI + logdet + us) / -2.0;      // src/mvnormal.jl:36
+                out_lp[nl] = NAN;                                                // the target is evaluated by the caller's next launch
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+static size_t xw_lds_bytes(int ch_blocks, int nchunks, int kc) {
+    const size_t stage = ((size_t)ch_blocks * 16 * kc + (XW_SM_LDS ? (size_t)ch_blocks * 32 : 0)) * (nchunks > 1 ? 2 : 1);
+    return sizeof(double) * (stage + (size_t)kc * kc + 4 * (XW_NB << PF_ICDF_B) + (size_t)XW_WAVES * XW_NG * 16 * XW_LD);
+}
+
+template <int KC>
+static int32_t launch_xw(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
+    const int nblk = (a.d + 15) / 16;
+    int ch_blocks = nblk, nchunks = 1;
+    constexpr int XW_CHB = xw_chb<KC>::v;
+    if (xw_lds_bytes(nblk, 1, KC) > 160 * 1024) { ch_blocks = XW_CHB; nchunks = (nblk + XW_CHB - 1) / XW_CHB; }
+    const size_t lds_bytes = xw_lds_bytes(ch_blocks, nchunks, KC);
+    PF_CHECK(lds_bytes <= 160 * 1024, PFMI_ERR_UNSUPPORTED, "xw kernel LDS %zu too large", lds_bytes);
+    auto kern = pf_elbo_xw_kernel<KC>;
+    PF_TRY(pf_raise_lds_limit(c, reinterpret_cast<const void *>(kern), 160 * 1024));
+    const int ngroups = (int)((a.N + 15) / 16);
+    // one workgroup per fit; a fit's groups are cut into several workgroups (whole batches of 8 groups) while there are fewer
+    // workgroups than CUs can hold
+    int split = 1;
+    constexpr int SLOTS = XW_WAVES * XW_NG;
+    while ((int64_t)split * nfits < 2 * (c->ncu > 0 ? c->ncu : 256) && ngroups / (split * 2) >= SLOTS) split *= 2;
+    int gpw = (ngroups + split - 1) / split;
+    gpw = (gpw + SLOTS - 1) / SLOTS * SLOTS;
+    const int gx = (ngroups + gpw - 1) / gpw;
+    for (int64_t s0 = 0; s0 < nfits; s0 += 32768) {
+        const int64_t ns = (nfits - s0 < 32768) ? (nfits - s0) : 32768;
+        ElboArgs b = a;
+        b.points = a.points + s0; b.seeds = a.seeds + s0;
+        b.x = a.x + s0 * a.x_stride;
+        if (!a.by_point) { b.logp += s0 * a.log_stride; b.logq += s0 * a.log_stride; }
+        hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)ns), dim3(XW_THREADS), lds_bytes, c->stream, b, ch_blocks, nchunks, gpw, ngroups);
+    }
+    return PFMI_OK;
+}
+
+// draws written, in-kernel generator, no target; kpad in {4, 8, 12, 16, 20, 32}
+int32_t pf_launch_elbo_xw(pfmi_ctx *c, const ElboArgs &a, int64_t nfits, bool *handled) {
+    *handled = false;
+    if (a.u != nullptr || a.x == nullptr) return PFMI_OK;
+    *handled = true;
+    switch (c->kpad) {
+        case 4: return launch_xw<4>(c, a, nfits);
+        case 8: return launch_xw<8>(c, a, nfits);
+        case 12: return launch_xw<12>(c, a, nfits);
+        case 16: return launch_xw<16>(c, a, nfits);
+        case 20: return launch_xw<20>(c, a, nfits);
+        case 32: return launch_xw<32>(c, a, nfits);
+        default: *handled = false; return PFMI_OK;
+    }
+}

@@ -15,6 +15,6 @@ for pat in sys.argv[2:]:
                            "from counters_collection group by kernel_name, counter_name order by sum(duration) desc").fetchall()
         for name, ctr, val, n, dur in rows:
             short = name.split("(")[0][:70]
-            if not any(k in short for k in ("pf_elbo_qf", "pf_fit", "pf_history", "pf_psis", "pf_elbo_mfma")):
+            if not any(k in short for k in ("pf_elbo_qf", "pf_elbo_xw", "pfx_", "pf_fit", "pf_history", "pf_psis", "pf_elbo_mfma")):
                 continue
             print(f"| `{short}` | {ctr} | {val:.4g} | {n} | {val / n:.4g} | {dur / 1e6:.3f} |")

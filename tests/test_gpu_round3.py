@@ -391,3 +391,79 @@ def test_scan_is_bitwise_independent_of_launch_geometry(pfmi_mod, eng, N):
         np.testing.assert_array_equal(best_c, best_a[:2])
     finally:
         e2.close()
+
+
+# ---- the streaming draw writer (elbo_xw_kernel.hip) ---------------------------------------------------------------------------
+def _with_kernel(mode, fn):
+    old = os.environ.get("PFMI_ELBO_KERNEL")
+    os.environ["PFMI_ELBO_KERNEL"] = mode
+    try:
+        return fn()
+    finally:
+        os.environ.pop("PFMI_ELBO_KERNEL", None)
+        if old is not None:
+            os.environ["PFMI_ELBO_KERNEL"] = old
+
+
+@pytest.mark.parametrize("tname,d,J,N,scale,maxit", [
+    ("lr", 1000, 6, 1000, 2.0, 25),        # config 3's shape: Vh resident in LDS
+    ("lr", 130, 6, 200, 2.0, 25),          # ragged last block (130 = 8 x 16 + 2) and last group (200 = 12 x 16 + 8)
+    ("diag", 10, 6, 64, 2.0, 25),          # 2 j > d: the head transform covers every row
+    ("diag", 33, 3, 17, 2.0, 12),          # KC = 8, a single ragged group
+    ("funnel", 500, 10, 300, 3.0, 30),     # KC = 20: head transform spills into block 1
+    ("lr", 3000, 10, 272, 2.0, 20),        # streamed Vh (12 chunks), KC = 20
+    ("diag", 2500, 16, 100, 2.0, 24),      # KC = 32, streamed
+    ("funnel", 10000, 10, 160, 10.0, 12),  # config 5's shape
+])
+def test_draw_writer_matches_lane_kernel_and_oracle_normals(pfmi_mod, eng, tname, d, J, N, scale, maxit):
+    """The streaming writer (two passes with regenerated normals, MFMA compact-WY apply, LDS-transposed full-line stores) against
+    the lane-per-draw kernel on the same (fit, seed): draws <= 1e-10 per column, logq <= 1e-12, logp (built-in target: the scan's
+    expanded form on the same draws) <= 1e-10; n0 > 0 continues the same counter (top-up draws, src/singlepath.jl:229-230);
+    pool_build takes the same route."""
+    tg = {"diag": lambda d: pfmi_mod.t_diag(d, 1), "lr": lambda d: pfmi_mod.t_lowrank(d, 8, 2), "funnel": pfmi_mod.t_funnel}[tname](d)
+    K = 2
+    eng.set_target(tg)
+    x0 = pfmi_mod.HostRNG(3).rand(K * d).reshape(K, d) * 2 * scale - scale
+    eng.optimize_batch(x0, J, maxit)
+    eng.fit_batch(J)
+    status, jeff, _, _ = eng.fit_status()
+    pts = sorted({1, eng.P - 1, int(eng.offsets[1]) + 1, eng.P // 2})
+    assert jeff.max() == min(J, maxit)
+    for p in pts:
+        if status[p] != 0:
+            continue
+        seed = 1000 + p
+        Xw, lpw, lqw = _with_kernel("xw", lambda: eng.draws(p, seed, N))
+        Xl, lpl, lql = _with_kernel("lane", lambda: eng.draws(p, seed, N))
+        scale_x = 1 + np.abs(Xl).max(axis=0)
+        assert np.max(np.abs(Xw - Xl) / scale_x) <= 1e-10, (p, np.max(np.abs(Xw - Xl) / scale_x))
+        assert np.max(np.abs(lqw - lql) / (1 + np.abs(lql))) <= 1e-12
+        assert np.max(np.abs(lpw - lpl) / (1 + np.abs(lpl))) <= 1e-10
+        # default route == forced route; a later window of the same stream
+        Xd, lpd, lqd = eng.draws(p, seed, N)
+        np.testing.assert_array_equal(Xd, Xw)
+        n0 = 16 * 3 + 5
+        X2, lp2, lq2 = eng.draws(p, seed, 40, n0=n0)
+        if N >= n0 + 40:
+            np.testing.assert_array_equal(X2, Xw[:, n0:n0 + 40])
+            np.testing.assert_array_equal(lq2, lqw[n0:n0 + 40])
+    best = [1, 1]
+    pp = [int(eng.offsets[k]) + best[k] for k in range(K)]
+    sd = np.array([77, 78], dtype=np.uint64)
+    eng.pool_build(N, pp, sd)
+    pool, lr = eng.pool_get()
+    for k in range(K):
+        X, lp, lq = eng.draws(pp[k], int(sd[k]), N)
+        np.testing.assert_array_equal(pool[:, :, k], X)
+        np.testing.assert_array_equal(lr[k * N:(k + 1) * N], lp - lq)
+
+
+def test_draw_writer_normals_bit_identical_to_oracle(pfmi_mod, eng):
+    """theta = grad = 0: the first fit is N(0, I), so x = u -- the writer's normals ARE the oracle's, bit for bit (incl. refined words)"""
+    d, N = 50, 300_000
+    eng.set_target(pfmi_mod.t_iso(d))
+    eng.set_traces([np.zeros((2, d))], [np.zeros((2, d))])
+    eng.fit_batch(6)
+    X, lp, lq = _with_kernel("xw", lambda: eng.draws(0, 0xC0FFEE123456789, N))
+    U = po.randn_fill(0xC0FFEE123456789, d, N)
+    np.testing.assert_array_equal(X, U)
