@@ -5,8 +5,15 @@
  * the executed stand-in for the wrapper (tests/test_gpu_parity_r2.py::test_julia_call_sequence_in_c builds and runs it on the
  * GPU box).  Each block names the Julia function whose ccalls it replays.
  *
- *   gcc -O2 -Iinclude examples/julia_sequence.c -o julia_sequence -Lpathfinder.jl_amd/lib -lpfmi -Wl,-rpath,... -lm
+ *   gcc -O2 -Iinclude examples/julia_sequence.c -o julia_sequence -Lpathfinder.jl_amd/lib -lpfmi -Wl,-rpath,... -lm -ldl
+ *
+ * Round 3 (second half of main): `multipathfinder(engines::Vector{Engine}, target::DeviceTarget, ...)` -- built-in targets through
+ * CTarget kinds 0 / 1, the enqueue / wait entry points, winners picked on the device, the fused pooled stage; `julia_sequence G`
+ * shards the runs over G engines (G > 1 on a 1-GPU box: PFMI_RCCL_LIB = the in-process stand-in, PFMI_COMM_ALLOW_SHARED_GPU = 1) and
+ * demands the single-engine result bit for bit; with PFMI_DEMO_LIB = examples/device_logp/liblogp_demo.so also a
+ * `DeviceClosureTarget` (kind 3: the closure is a kernel launcher, draws never leave HBM).
  */
+#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -69,8 +76,9 @@ static void host_trace(uint64_t *rng, double *theta, double *grad) {
     }
 }
 
-int main(void) {
+int main(int argc, char **argv) {
     uint64_t rng = 20260928ull;
+    const int G = argc > 1 ? atoi(argv[1]) : 1;
     for (int i = 0; i < D; ++i) { g_a[i] = exp(-1.0 + 2.0 * unif(&rng)); g_m[i] = 2.0 * unif(&rng) - 1.0; }
 
     /* ---- Engine(device) ------------------------------------------------------------------------------------------------- */
@@ -280,7 +288,144 @@ int main(void) {
         }
     }
 
+    /* ================= round 3: multipathfinder(engines, target::DeviceTarget, ndraws) =================================================== */
+    {
+#define K3 8
+#define MAXIT 60
+        REQUIRE(G >= 1 && K3 % G == 0, "G = %d must divide %d runs", G, K3);
+        /* set_target!(eng, GaussTarget(mean, a)): CTarget(kind = 0, d, r = 0, mean, a, ...) -- the library copies the parameters */
+        pfmi_target gt;
+        memset(&gt, 0, sizeof(gt));
+        gt.kind = PFMI_TARGET_GAUSS; gt.d = D; gt.r = 0; gt.mean = g_m; gt.a = g_a; gt.offset = 0.0;
+        uint64_t rng3 = 777ull, run3[K3], fail3[K3];
+        static double x0[K3 * D];
+        for (int k = 0; k < K3; ++k) run3[k] = splitmix(&rng3);
+        for (int k = 0; k < K3; ++k)
+            for (int i = 0; i < D; ++i) x0[k * D + i] = 4.0 * unif(&run3[k]) - 2.0;              /* init_sampler(rngs[k], ...) */
+        const uint64_t rs3 = splitmix(&rng3);                                                   /* rand(rng, UInt64) of _resample */
+        /* ---- reference: ONE engine, the blocking entry points, winners chosen by the host */
+        pfmi_ctx *e1 = NULL;
+        CHECK(pfmi_create(0, &e1));
+        CHECK(pfmi_set_target(e1, &gt));
+        int64_t np1[K3], off1[K3 + 1];
+        CHECK(pfmi_optimize_batch(e1, K3, x0, 6, MAXIT, 1e-8, np1));
+        off1[0] = 0;
+        for (int k = 0; k < K3; ++k) off1[k + 1] = off1[k] + np1[k];
+        const int64_t P1 = off1[K3];
+        uint64_t *sd1 = calloc((size_t)P1, sizeof(uint64_t));
+        uint64_t r3[K3];
+        memcpy(r3, run3, sizeof(r3));
+        for (int k = 0; k < K3; ++k) {
+            for (int64_t l = 1; l < np1[k]; ++l) sd1[off1[k] + l] = splitmix(&r3[k]);            /* rand!(rng_k, UInt64[L_k]) */
+            uint64_t peek = r3[k];
+            fail3[k] = splitmix(&peek);                                                         /* rand(copy(rng_k), UInt64) */
+        }
+        CHECK(pfmi_fit_batch(e1, 6, 1e-12));
+        double *el1 = malloc(sizeof(double) * P1), *se1 = malloc(sizeof(double) * P1);
+        int64_t best1[K3], fp1[K3];
+        uint64_t ds1[K3];
+        CHECK(pfmi_elbo_batch(e1, N_ELBO, sd1, NULL, el1, se1, best1));
+        for (int k = 0; k < K3; ++k) {
+            REQUIRE(best1[k] >= 1 && isfinite(el1[off1[k] + best1[k]]), "run %d of the built-in target failed", k);
+            fp1[k] = off1[k] + best1[k]; ds1[k] = sd1[fp1[k]];
+        }
+        CHECK(pfmi_pool_build(e1, N_R, fp1, ds1));
+        void *lrd = NULL;
+        int64_t c1 = 0;
+        CHECK(pfmi_pool_log_ratios_dev(e1, &lrd, &c1));
+        static double w1[K3 * N_R];
+        double k1 = NAN;
+        int64_t M1 = 0, idx1[NDRAWS];
+        static double dr1[D * NDRAWS];
+        CHECK(pfmi_psis_dev(e1, lrd, c1, w1, NULL, &k1, &M1));
+        CHECK(pfmi_resample_indices(e1, c1, NDRAWS, 1, 1, rs3, NULL, idx1));
+        CHECK(pfmi_pool_gather(e1, NDRAWS, idx1, 0, dr1));
+
+        /* ---- the Julia sequence: G engines, every stage enqueued on all of them before the first wait */
+        pfmi_ctx *eg[K3];
+        int ndev = 0;
+        CHECK(pfmi_device_count(&ndev));
+        const int Kl = K3 / G;
+        for (int g = 0; g < G; ++g) {
+            CHECK(pfmi_create(g % ndev, &eg[g]));
+            CHECK(pfmi_set_target(eg[g], &gt));
+        }
+        for (int g = 0; g < G; ++g) CHECK(pfmi_optimize_batch_enqueue(eg[g], Kl, x0 + (size_t)g * Kl * D, 6, MAXIT, 1e-8));
+        int64_t npg[K3];
+        for (int g = 0; g < G; ++g) CHECK(pfmi_optimize_batch_wait(eg[g], npg + g * Kl));
+        for (int k = 0; k < K3; ++k) REQUIRE(npg[k] == np1[k], "trace length of run %d depends on the sharding", k);
+        for (int g = 0; g < G; ++g) CHECK(pfmi_fit_batch(eg[g], 6, 1e-12));
+        for (int g = 0; g < G; ++g) {                       /* seeds of the block = the corresponding slice of the single-engine table */
+            CHECK(pfmi_elbo_batch_enqueue(eg[g], N_ELBO, sd1 + off1[g * Kl], NULL));
+            CHECK(pfmi_pool_build_best(eg[g], N_R, fail3 + g * Kl));
+        }
+        pfmi_comm *cm = NULL;
+        CHECK(pfmi_comm_init_all(G, eg, &cm));
+        int32_t world = 0, nlocal = 0, ver = -1;
+        CHECK(pfmi_comm_info(cm, &world, &nlocal, &ver));
+        REQUIRE(world == G && nlocal == G, "comm of %d engines reports world %d", G, world);
+        double kg = NAN;
+        int64_t Mg = 0, idxg[NDRAWS];
+        static double drg[D * NDRAWS];
+        CHECK(pfmi_comm_psis_resample(cm, NDRAWS, 1, 1, rs3, NULL, &kg, &Mg, idxg, drg));           /* ONE synchronisation */
+        REQUIRE(kg == k1 && Mg == M1, "pooled PSIS depends on the sharding: k %.17g vs %.17g", kg, k1);
+        REQUIRE(memcmp(idxg, idx1, sizeof(idx1)) == 0 && memcmp(drg, dr1, sizeof(dr1)) == 0, "resampled draws depend on the sharding (G = %d)", G);
+        for (int g = 0; g < G; ++g) {                       /* the downloads come last */
+            const int64_t Pg = off1[(g + 1) * Kl] - off1[g * Kl];
+            double *elg = malloc(sizeof(double) * Pg);
+            int64_t bg[K3], pg[K3];
+            uint64_t sg[K3];
+            int32_t okg[K3], *stg = malloc(sizeof(int32_t) * Pg);
+            CHECK(pfmi_get_fit_status(eg[g], stg, NULL, NULL, NULL));
+            CHECK(pfmi_elbo_batch_wait(eg[g], elg, NULL, bg));
+            CHECK(pfmi_pool_winners(eg[g], pg, sg, okg));
+            for (int j = 0; j < Kl; ++j) {
+                const int k = g * Kl + j;
+                REQUIRE(bg[j] == best1[k] && okg[j] == 1 && sg[j] == ds1[k], "winner of run %d", k);
+                REQUIRE(pg[j] + off1[g * Kl] == fp1[k], "fit point of run %d", k);
+            }
+            REQUIRE(memcmp(elg + 1, el1 + off1[g * Kl] + 1, sizeof(double) * (np1[g * Kl] - 1)) == 0, "ELBO table of engine %d", g);
+            free(elg); free(stg);
+        }
+        static double wg[K3 * N_R];
+        CHECK(pfmi_psis_weights(eg[0], (int64_t)K3 * N_R, wg, NULL));                             /* DevicePSISResult.weights */
+        REQUIRE(memcmp(wg, w1, sizeof(w1)) == 0, "PSIS weights depend on the sharding");
+        CHECK(pfmi_comm_destroy(cm));
+
+        /* ---- DeviceClosureTarget (kind 3): the closure is a kernel launcher from a user library; same draws, logp evaluated in HBM */
+        const char *demo = getenv("PFMI_DEMO_LIB");
+        if (demo && demo[0]) {
+            void *h = dlopen(demo, RTLD_NOW | RTLD_LOCAL);
+            REQUIRE(h != NULL, "dlopen %s: %s", demo, dlerror());
+            void *(*create)(int32_t, int32_t, const double *, const double *, const double *, const double *, double) =
+                (void *(*)(int32_t, int32_t, const double *, const double *, const double *, const double *, double))dlsym(h, "pfx_gauss_create");
+            pfmi_logp_dev_fn fn = (pfmi_logp_dev_fn)dlsym(h, "pfx_gauss_logp");
+            REQUIRE(create && fn, "demo library symbols");
+            void *user = create(D, 0, g_m, g_a, NULL, NULL, 0.0);
+            REQUIRE(user != NULL, "pfx_gauss_create");
+            pfmi_target dt;
+            memset(&dt, 0, sizeof(dt));
+            dt.kind = PFMI_TARGET_DEVICE_CALLBACK; dt.d = D; dt.dev_fn = fn; dt.user = user;
+            CHECK(pfmi_set_target(e1, &dt));               /* same engine, same fits: only logp's route changes */
+            double *el3 = malloc(sizeof(double) * P1);
+            int64_t b3[K3];
+            CHECK(pfmi_elbo_batch(e1, N_ELBO, sd1, NULL, el3, NULL, b3));
+            double hb = 0.0;
+            CHECK(pfmi_callback_stats_dev(e1, &hb));
+            REQUIRE(hb == 8.0 * D * N_ELBO * (double)(P1 - K3), "bytes materialised for the closure: %g", hb);
+            for (int64_t p = 0; p < P1; ++p)
+                REQUIRE((isnan(el3[p]) && isnan(el1[p])) || fabs(el3[p] - el1[p]) <= 1e-9 * (1 + fabs(el1[p])), "closure ELBO of fit %lld", (long long)p);
+            for (int k = 0; k < K3; ++k) REQUIRE(b3[k] == best1[k], "closure argmax of run %d", k);
+            free(el3);
+            printf("device closure ok (%s)\n", demo);
+        }
+        for (int g = 0; g < G; ++g) CHECK(pfmi_destroy(eg[g]));
+        CHECK(pfmi_destroy(e1));
+        free(sd1); free(el1); free(se1);
+        printf("round-3 sequence ok: G=%d engines, rccl_version=%d\n", G, ver);
+    }
+
     CHECK(pfmi_destroy(ctx));
-    printf("OK julia_sequence: K=%d d=%d pareto_k=%.4f callback calls=%ld columns=%ld\n", K, D, khat, g_calls, g_cols);
+    printf("OK julia_sequence: K=%d d=%d pareto_k=%.4f callback calls=%ld columns=%ld G=%d\n", K, D, khat, g_calls, g_cols, G);
     return 0;
 }

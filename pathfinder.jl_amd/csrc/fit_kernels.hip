@@ -94,7 +94,11 @@ __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
             for (int e = 0; e < EPT; ++e) {
                 const double sa = sv[e] * ial[e];
                 const double x = a * ial[e] + yv[e] * yv[e] - aoc * sa * sa;
-                al[e] = b / x;                                                  // the reference's formula, bit for bit
+                // the reference's formula (alpha' = b / (a/alpha + y^2 - (a/c)(s/alpha)^2)) with 1/alpha CARRIED as x * (1/b) instead of
+                // recomputed by a division: a / alpha -> a * ial and s / alpha -> s * ial differ from the reference's quotients in the last
+                // bit or two per accepted step.  The oracle divides like the reference; tests bound the drift over full-length
+                // traces (alpha and everything downstream <= 1e-10, status / j_eff array-equal: test_config3_whole_trace_...)
+                al[e] = b / x;
                 ial[e] = x * rb;                                                // 1 / alpha for the next step without a second division
             }
             n_acc += 1;

@@ -12,6 +12,14 @@
 # calls it makes is replayed and checked on the GPU by `examples/julia_sequence.c` (tests/test_gpu_parity_r2.py::
 # test_julia_call_sequence_in_c).  Everything numerical sits behind the C ABI and is tested from Python / C.
 #
+# Round 3.  (i) Targets: besides the host closure (`set_target!(eng, logp, dim)`, kind 2) the built-in device targets are
+# reachable -- `GaussTarget(mean, a, Wd, G)` / `FunnelTarget(d)` (kinds 0 / 1: the single-pass scan that never forms x, and the
+# device L-BFGS) -- and `DeviceClosureTarget(d, fptr, user)` (kind 3): a `logp` that is itself a GPU kernel launcher (e.g. an
+# AMDGPU.jl kernel wrapped in `@cfunction`), evaluated on draws that never leave HBM.  (ii) One Julia process drives several
+# GPUs: `multipathfinder(engines::Vector{Engine}, ...)` shards the runs in contiguous blocks; every stage is ENQUEUED on all
+# engines before the first wait (`pfmi_*_enqueue`, `pfmi_pool_build_best`, `pfmi_comm_psis_resample`), so one thread keeps all
+# GPUs busy, and the pooled stage goes through the RCCL group (`Comm`).
+#
 # Results.  `multipathfinder(eng, ...)` returns the reference's own `Pathfinder.MultiPathfinderResult` (its fields are
 # untyped); per-run results are `DevicePathfinderResult`s -- the reference's `PathfinderResult` requires
 # `fit_distributions::Vector{FD}` and an eager `elbo_estimates`, i.e. O(L d N) host memory (89 GB at the headline
@@ -51,12 +59,27 @@ end
 struct StaleHandleError <: Exception end
 _live(eng::Engine, gen::Int) = eng.generation == gen || throw(StaleHandleError())
 
+# ---- multi-GPU: one Julia process, G engines (pfmi_comm_init_all = ncclCommInitAll), paths in contiguous blocks -------------------------
+mutable struct Comm
+    ptr::Ptr{Cvoid}
+    engines::Vector{Engine}
+    function Comm(engines::Vector{Engine})
+        ref = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:pfmi_comm_init_all, libpfmi), Int32, (Int32, Ptr{Ptr{Cvoid}}, Ref{Ptr{Cvoid}}),
+                    length(engines), [e.ptr for e in engines], ref))
+        c = new(ref[], engines)
+        finalizer(x -> ccall((:pfmi_comm_destroy, libpfmi), Int32, (Ptr{Cvoid},), x.ptr), c)
+        return c
+    end
+end
+
 # ---- target: arbitrary Julia closure through @cfunction (the reference's general logp, src/elbo.jl:15) --------------------
 struct CTarget
     kind::Int32; d::Int32; r::Int32; reserved::Int32
     mean::Ptr{Float64}; a::Ptr{Float64}; Wd::Ptr{Float64}; G::Ptr{Float64}
     offset::Float64
     fn::Ptr{Cvoid}; user::Ptr{Cvoid}
+    dev_fn::Ptr{Cvoid}                                    # kind 3 (pfmi_logp_dev_fn); appended in round 3 -- same layout as pfmi_target
 end
 # logp is called one column at a time, exactly like `logp.(eachcol(phi))` (src/elbo.jl:15, src/resample.jl:90-92)
 function _logp_trampoline(X::Ptr{Float64}, d::Int32, n::Int64, out::Ptr{Float64}, user::Ptr{Cvoid})::Cvoid
@@ -72,10 +95,76 @@ function set_target!(eng::Engine, logp, dim::Integer)
     box = Ref{Any}(logp)
     eng.keepalive = box                                   # alive as long as the engine may call back
     cfn = @cfunction(_logp_trampoline, Cvoid, (Ptr{Float64}, Int32, Int64, Ptr{Float64}, Ptr{Cvoid}))
-    t = Ref(CTarget(2, dim, 0, 0, C_NULL, C_NULL, C_NULL, C_NULL, 0.0, cfn, pointer_from_objref(box)))
+    t = Ref(CTarget(2, dim, 0, 0, C_NULL, C_NULL, C_NULL, C_NULL, 0.0, cfn, pointer_from_objref(box), C_NULL))
     check(ccall((:pfmi_set_target, libpfmi), Int32, (Ptr{Cvoid}, Ref{CTarget}), eng.ptr, t))
     return nothing
 end
+
+# ---- device-resident targets (round 3) ---------------------------------------------------------------------------------------
+abstract type DeviceTarget end
+"""
+    GaussTarget(mean, a[, Wd, G]; offset = 0)      logp(x) = offset - (e'diag(a)e - |G Wd'e|^2) / 2,  e = x - mean
+
+PFMI_TARGET_GAUSS: `a` the diagonal precision part, `Wd = diag(a) W` (d x r, r <= 16) and `G` (r x r lower triangular,
+`G'G = inv(I + W'diag(a)W)`) the low-rank correction of `Sigma* = diag(1 ./ a) + W W'`.  Evaluated by the single-pass ELBO scan
+without ever forming the draws; also what the device L-BFGS (`optimize_batch!`) differentiates.
+"""
+struct GaussTarget <: DeviceTarget
+    mean::Vector{Float64}; a::Vector{Float64}; Wd::Matrix{Float64}; G::Matrix{Float64}; offset::Float64
+end
+GaussTarget(mean, a; offset=0.0) = GaussTarget(collect(Float64, mean), collect(Float64, a), zeros(length(mean), 0), zeros(0, 0), offset)
+GaussTarget(mean, a, Wd, G; offset=0.0) = GaussTarget(collect(Float64, mean), collect(Float64, a), Matrix{Float64}(Wd), Matrix{Float64}(G), offset)
+"`GaussTarget` of `N(mean, diag(sigma2) + W W')` (the parameterisation of SURVEY.md 8d's T_lr)"
+function GaussTarget(mean, sigma2, W::AbstractMatrix; offset=0.0)
+    a = 1.0 ./ collect(Float64, sigma2)
+    Wd = a .* W
+    G = inv(cholesky(Symmetric(I + W' * Wd)).L)
+    return GaussTarget(collect(Float64, mean), a, Matrix{Float64}(Wd), Matrix{Float64}(G), offset)
+end
+"PFMI_TARGET_FUNNEL (reference docs/src/examples/quickstart.md:229-234)"
+struct FunnelTarget <: DeviceTarget
+    d::Int
+end
+"""
+    DeviceClosureTarget(d, fptr, user = C_NULL)
+
+PFMI_TARGET_DEVICE_CALLBACK: `fptr` is a C function pointer `(X_dev::Ptr{Float64}, d::Int32, n::Int64, out_dev::Ptr{Float64},
+stream::Ptr{Cvoid}, user::Ptr{Cvoid}) -> Cvoid` that ENQUEUES the caller's kernel on `stream` (the engine's hipStream_t) and
+returns: e.g. `@cfunction` of a function that wraps the two device pointers in `AMDGPU.unsafe_wrap(ROCArray, ...)` and launches
+an AMDGPU.jl kernel on `HIPStream(stream)`.  The reference's arbitrary `logp` (src/elbo.jl:15) without the PCIe round trip.
+"""
+struct DeviceClosureTarget <: DeviceTarget
+    d::Int; fptr::Ptr{Cvoid}; user::Ptr{Cvoid}
+end
+DeviceClosureTarget(d::Integer, fptr::Ptr{Cvoid}) = DeviceClosureTarget(d, fptr, C_NULL)
+dimension(t::GaussTarget) = length(t.mean)
+dimension(t::Union{FunnelTarget,DeviceClosureTarget}) = t.d
+function set_target!(eng::Engine, t::GaussTarget)
+    r = size(t.Wd, 2)
+    eng.keepalive = t
+    GC.@preserve t begin
+        ct = Ref(CTarget(0, length(t.mean), r, 0, pointer(t.mean), pointer(t.a), r > 0 ? pointer(t.Wd) : C_NULL,
+                         r > 0 ? pointer(t.G) : C_NULL, t.offset, C_NULL, C_NULL, C_NULL))
+        check(ccall((:pfmi_set_target, libpfmi), Int32, (Ptr{Cvoid}, Ref{CTarget}), eng.ptr, ct))   # the library copies the parameters
+    end
+    return nothing
+end
+function set_target!(eng::Engine, t::FunnelTarget)
+    ct = Ref(CTarget(1, t.d, 0, 0, C_NULL, C_NULL, C_NULL, C_NULL, 0.0, C_NULL, C_NULL, C_NULL))
+    check(ccall((:pfmi_set_target, libpfmi), Int32, (Ptr{Cvoid}, Ref{CTarget}), eng.ptr, ct))
+end
+function set_target!(eng::Engine, t::DeviceClosureTarget)
+    ct = Ref(CTarget(3, t.d, 0, 0, C_NULL, C_NULL, C_NULL, C_NULL, 0.0, C_NULL, t.user, t.fptr))
+    check(ccall((:pfmi_set_target, libpfmi), Int32, (Ptr{Cvoid}, Ref{CTarget}), eng.ptr, ct))
+end
+"host twin of a built-in target (the optimiser's `logp`, result objects): the same formula in Julia"
+function logdensity(t::GaussTarget, x)
+    e = x .- t.mean
+    q = sum(t.a .* e .* e)
+    size(t.Wd, 2) > 0 && (q -= sum(abs2, t.G * (t.Wd' * e)))
+    return t.offset - q / 2
+end
+logdensity(t::FunnelTarget, x) = ((x[1] / 3)^2 + (t.d - 1) * x[1] + exp(-x[1]) * sum(abs2, @view x[2:end])) / -2
 
 # ---- per-batch state --------------------------------------------------------------------------------------------------------
 struct Batch
@@ -267,8 +356,12 @@ Index selection + gather (src/resample.jl:58-72).  `statsbase` chooses who draws
 * `:host`: EXACTLY the reference -- `StatsBase.sample(rng, 1:S, ProbabilityWeights(w, 1), ndraws; replace)` runs in Julia on
   the downloaded PSIS weights (whatever algorithm the installed StatsBase picks: direct, alias, Efraimidis-Spirakis) and only
   the gather of the selected columns happens on the device;
-* `true` (weighted, with replacement): the indices ARE `StatsBase.direct_sample!(rng, 1:S, ProbabilityWeights(w, 1), x)` --
-  Julia draws the uniforms, the device does the scan (no weight download).
+* `true` (weighted, with replacement): the indices are those of `StatsBase.direct_sample!(rng, 1:S, ProbabilityWeights(w, 1), x)`
+  -- Julia draws the uniforms ONE SCALAR `rand(rng)` PER DRAW, as that loop does (a bulk `rand(rng, n)` fills from a different
+  stream position for Xoshiro / MersenneTwister), the device does the scan (no weight download).  Note that
+  `StatsBase.sample` itself only takes `direct_sample!` for small requests (pool < 40 or ndraws < 32 / 64); at real pool sizes it
+  switches to `alias_sample!` (version dependent), which nothing here restates: ONLY `:host` reproduces `StatsBase.sample` bit for
+  bit at every size.
 """
 function _resample(b::Batch, rng::Random.AbstractRNG, psis_result, N_r::Int, K::Int, ndraws::Int; replace::Bool=true,
                    statsbase::Union{Bool,Symbol}=false)
@@ -283,7 +376,7 @@ function _resample(b::Batch, rng::Random.AbstractRNG, psis_result, N_r::Int, K::
         end
         idx .= inds .- 1
     elseif statsbase === true && psis_result !== nothing && replace
-        u = rand(rng, ndraws)                                       # what direct_sample! consumes, one rand(rng) per draw
+        u = Float64[rand(rng) for _ in 1:ndraws]                    # what direct_sample! consumes: one scalar rand(rng) per draw
         check(ccall((:pfmi_resample_indices_direct, libpfmi), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Ptr{Int64}),
                     b.eng.ptr, S, ndraws, u, idx))
     else
@@ -386,6 +479,190 @@ function pathfinder(eng::Engine, optim_fun::SciMLBase.OptimizationFunction; init
     return res.pathfinder_results[1]
 end
 
+# ---- round 3: device-resident targets, several GPUs driven by ONE Julia thread -------------------------------------------------------
+# Every stage is enqueued on every engine before the first wait: pfmi_optimize_batch_enqueue / _wait, pfmi_fit_batch (never blocks),
+# pfmi_elbo_batch_enqueue, pfmi_pool_build_best (the winners are picked on the device: no host round trip between the scan and the
+# pool), pfmi_comm_psis_resample (all-gather + PSIS + index selection + owner gather + all-reduce, ONE synchronisation); the
+# per-engine downloads (status, ELBO table, winners) come last, when everything is already in flight.
+"contiguous blocks of runs, one per engine (pool order stays k-major, src/resample.jl:93)"
+function _blocks(K::Int, G::Int)
+    K % G == 0 || throw(ArgumentError("nruns = $K must be divisible by the number of engines $G (equal log-ratio shards keep the result independent of the GPU count)"))
+    per = K ÷ G
+    return [((g - 1) * per + 1):(g * per) for g in 1:G]
+end
+
+function _fit_enqueue!(eng::Engine, history_length::Int, ϵ::Float64)
+    check(ccall((:pfmi_fit_batch, libpfmi), Int32, (Ptr{Cvoid}, Int32, Float64), eng.ptr, history_length, ϵ))
+end
+function _fit_finish(eng::Engine, npts::Vector{Int64}, d::Int)
+    K = length(npts); P = sum(npts)
+    status = Vector{Int32}(undef, P); jeff = Vector{Int32}(undef, P); nrej = Vector{Int64}(undef, K)
+    check(ccall((:pfmi_get_fit_status, libpfmi), Int32, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ptr{Int64}),
+                eng.ptr, status, jeff, C_NULL, nrej))
+    return Batch(eng, eng.generation, d, vcat(0, cumsum(npts)), status, jeff, nrej)
+end
+function _elbo_enqueue!(eng::Engine, seeds::Vector{UInt64}, ndraws::Int)
+    check(ccall((:pfmi_elbo_batch_enqueue, libpfmi), Int32, (Ptr{Cvoid}, Int64, Ptr{UInt64}, Ptr{Float64}), eng.ptr, ndraws, seeds, C_NULL))
+end
+function _elbo_wait(b::Batch, seeds::Vector{UInt64}, ndraws::Int)
+    P = b.offsets[end]; K = npaths(b)
+    elbo = Vector{Float64}(undef, P); se = similar(elbo); best = Vector{Int64}(undef, K)
+    check(ccall((:pfmi_elbo_batch_wait, libpfmi), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}), b.eng.ptr, elbo, se, best))
+    return ElboBatch(b, ndraws, seeds, elbo, se, best)
+end
+"pool of the winners picked on the device (src/singlepath.jl:224-233): a failed run draws afresh with `fail_seeds[k]`"
+function _pool_build_best!(eng::Engine, N_r::Int, fail_seeds::Vector{UInt64})
+    check(ccall((:pfmi_pool_build_best, libpfmi), Int32, (Ptr{Cvoid}, Int64, Ptr{UInt64}), eng.ptr, N_r, fail_seeds))
+end
+function _pool_winners(eng::Engine, K::Int)
+    pts = Vector{Int64}(undef, K); sd = Vector{UInt64}(undef, K); ok = Vector{Int32}(undef, K)
+    check(ccall((:pfmi_pool_winners, libpfmi), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{UInt64}, Ptr{Int32}), eng.ptr, pts, sd, ok))
+    return pts, sd, ok .!= 0
+end
+
+"""
+    multipathfinder(engines::Vector{Engine}, target::DeviceTarget, ndraws; nruns | init, optim_fun = nothing, kwargs...)
+
+The reference's `multipathfinder` (src/multipath.jl:118-245) for a device-resident target on one or several GPUs driven by this
+Julia thread.  Built-in targets (`GaussTarget`, `FunnelTarget`) are optimised on the device (`pfmi_optimize_batch`, this
+repository's own L-BFGS: trajectory parity with Optim.jl is not claimed -- the trace is the hot path's INPUT); a
+`DeviceClosureTarget` needs its host twin `optim_fun::SciMLBase.OptimizationFunction` for `Pathfinder.optimize_with_trace`.
+The result does not depend on `length(engines)` (test/multipath.jl:107-140 extended to the GPU count).
+"""
+function multipathfinder(engines::Vector{Engine}, target::DeviceTarget, ndraws::Int;
+                         init=nothing, input=target, nruns::Int=init === nothing ? -1 : length(init),
+                         ndraws_elbo::Int=Pathfinder.DEFAULT_NDRAWS_ELBO,
+                         ndraws_per_run::Int=max(ndraws_elbo, cld(ndraws, max(nruns, 1))),
+                         rng::Random.AbstractRNG=Random.default_rng(),
+                         history_length::Int=Pathfinder.DEFAULT_HISTORY_LENGTH, importance::Bool=true, ntries::Int=1_000,
+                         init_scale=2, init_sampler=Pathfinder.UniformSampler(init_scale), optim_fun=nothing,
+                         optimizer=Pathfinder.default_optimizer(history_length), maxiters::Int=1_000, g_tol::Float64=1e-8,
+                         comm::Union{Nothing,Comm}=nothing, kwargs...)
+    d = dimension(target)
+    _init = if init === nothing
+        nruns > 0 || throw(ArgumentError("A positive `nruns` must be set or `init` must be provided."))      # :148-150
+        [init_sampler(rng, Vector{Float64}(undef, d)) for _ in 1:nruns]                                     # src/singlepath.jl:167-168
+    else
+        collect(init)
+    end
+    nruns = length(_init)
+    G = length(engines); blocks = _blocks(nruns, G)
+    if ndraws > ndraws_per_run * nruns
+        @warn "More draws requested than total number of draws across replicas. Draws will not be unique."
+    end
+    on_device = !(target isa DeviceClosureTarget)
+    on_device || optim_fun !== nothing || throw(ArgumentError("a DeviceClosureTarget needs `optim_fun` (its host twin) for the optimiser"))
+    logp = on_device ? (x -> logdensity(target, x)) : (x -> -optim_fun.f(x, nothing))                     # :159
+    foreach(e -> set_target!(e, target), engines)
+    run_seeds = rand!(rng, Vector{UInt64}(undef, nruns))                                                    # :162
+    rngs = [Random.seed!(copy(rng), s) for s in run_seeds]                                                  # :189-193
+    resample_seed = nothing
+    x0 = [copy(x) for x in _init]
+    itry = ones(Int, nruns); pending = collect(1:nruns); success = falses(nruns)
+    fit_seeds = [UInt64[] for _ in 1:nruns]; fail_seeds = zeros(UInt64, nruns)
+    traces = Vector{Any}(undef, nruns); sols = Vector{Any}(undef, nruns)
+    batches = Vector{Batch}(undef, G); elbos = Vector{ElboBatch}(undef, G)
+    cm = comm === nothing ? Comm(engines) : comm
+    local k̂::Float64, M::Int, idx::Vector{Int64}, draws_::Matrix{Float64}
+    rs_seed = rand(rng, UInt64)                                       # _resample's draw from the top-level rng (:225)
+    while true                                                        # the retry loop of src/singlepath.jl:259-283, batched
+        npts = Vector{Vector{Int64}}(undef, G)
+        if on_device                                                  # every run of an engine in one launch; nothing waits yet
+            for (g, eng) in enumerate(engines)
+                X0 = reduce(hcat, x0[blocks[g]])                      # d x K_g column-major == K_g x d point-major
+                eng.generation += 1
+                check(ccall((:pfmi_optimize_batch_enqueue, libpfmi), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Int32, Int32, Float64),
+                            eng.ptr, length(blocks[g]), X0, history_length, maxiters, g_tol))
+            end
+            for (g, eng) in enumerate(engines)
+                npts[g] = Vector{Int64}(undef, length(blocks[g]))
+                check(ccall((:pfmi_optimize_batch_wait, libpfmi), Int32, (Ptr{Cvoid}, Ptr{Int64}), eng.ptr, npts[g]))
+            end
+        else
+            for k in pending
+                prob = SciMLBase.OptimizationProblem(optim_fun, x0[k], nothing)
+                sols[k], traces[k] = Pathfinder.optimize_with_trace(prob, deepcopy(optimizer); kwargs...)   # host, src/optimize.jl:35-59
+            end
+            for (g, eng) in enumerate(engines)
+                tr = traces[blocks[g]]
+                npts[g] = Int64[length(t.points) for t in tr]
+                theta = reduce(hcat, reduce(vcat, [t.points for t in tr])); grad = reduce(hcat, reduce(vcat, [t.gradients for t in tr]))
+                eng.generation += 1
+                check(ccall((:pfmi_set_traces, libpfmi), Int32, (Ptr{Cvoid}, Int32, Ptr{Int64}, Int32, Ptr{Float64}, Ptr{Float64}),
+                            eng.ptr, length(tr), npts[g], d, theta, grad))
+            end
+        end
+        foreach(e -> _fit_enqueue!(e, history_length, 1e-12), engines)
+        seeds = Vector{Vector{UInt64}}(undef, G)
+        for (g, eng) in enumerate(engines)
+            sd = UInt64[]
+            for (j, k) in enumerate(blocks[g])
+                L = Int(npts[g][j]) - 1
+                if k in pending
+                    fit_seeds[k] = rand!(rngs[k], Vector{UInt64}(undef, L))                                 # src/elbo.jl:2
+                    fail_seeds[k] = rand(copy(rngs[k]), UInt64)       # what rand(rng_k, fit_distribution, n) would consume after a failure
+                end
+                push!(sd, UInt64(0)); append!(sd, fit_seeds[k])
+            end
+            seeds[g] = sd
+            _elbo_enqueue!(eng, sd, ndraws_elbo)
+            _pool_build_best!(eng, ndraws_per_run, fail_seeds[blocks[g]])
+        end
+        # draws_per_component = stack(draws) (:217), _compute_psis_result (:221), _resample (:225) -- enqueued behind the scans
+        k̂, M, idx, draws_ = psis_resample(cm, d, ndraws; importance, seed=rs_seed)
+        for (g, eng) in enumerate(engines)                            # first waits: everything above is in flight on every GPU
+            batches[g] = _fit_finish(eng, npts[g], d)
+            any(!=(0), batches[g].status) && throw(LinearAlgebra.PosDefException(Int(first(filter(!=(0), batches[g].status)))))
+            elbos[g] = _elbo_wait(batches[g], seeds[g], ndraws_elbo)
+        end
+        for k in pending
+            g = findfirst(r -> k in r, blocks); j = k - first(blocks[g]) + 1
+            b, e = batches[g], elbos[g]
+            L = b.offsets[j + 1] - b.offsets[j] - 1
+            it = e.iteration_opt[j]
+            v = it > 0 ? e.value[b.offsets[j] + it + 1] : NaN
+            success[k] = L > 0 && it > 0 && !isnan(v) && v != -Inf     # src/singlepath.jl:299, 309-314
+        end
+        pending = [k for k in pending if !success[k] && itry[k] < ntries]
+        isempty(pending) && break
+        for k in pending
+            itry[k] += 1
+            x0[k] = init_sampler(rngs[k], copy(x0[k]))                                                     # :277
+        end
+    end
+    results = Vector{DevicePathfinderResult}(undef, nruns)
+    components = Vector{Any}(undef, nruns)
+    for (g, eng) in enumerate(engines)
+        b, e = batches[g], elbos[g]
+        for (j, k) in enumerate(blocks[g])
+            it = Int(e.iteration_opt[j])
+            success[k] || @warn "Pathfinder failed after $(itry[k]) tries. Increase `ntries`, inspect the model for numerical instability, or provide a more suitable `init_sampler`."
+            if b.nrej[j] > 0
+                perc = round(b.nrej[j] * (100 // (b.offsets[j + 1] - b.offsets[j])); digits=1)
+                @warn "$(b.nrej[j]) ($(perc)%) updates to the inverse Hessian estimate were rejected to keep it positive definite."
+            end
+            p = b.offsets[j] + it
+            seed = success[k] ? e.seeds[p + 1] : rand(rngs[k], UInt64)                                     # == fail_seeds[k]
+            tr = on_device ? nothing : traces[k]                        # device traces: get_trace(eng, j - 1, npoints, d) on demand
+            results[k] = DevicePathfinderResult(input, optimizer, rngs[k], nothing, logp, it, itry[k], on_device ? nothing : sols[k], tr,
+                                                LazyFitDistributions(b, j, Dict{Int,Any}()), LazyELBOEstimates(e, j, Dict{Int,Any}()),
+                                                Int(b.nrej[j]), success[k], seed, ndraws_per_run, nothing)
+            components[k] = fit_distribution(b, p)
+        end
+    end
+    psis_result = nothing
+    if importance
+        S = nruns * ndraws_per_run
+        w = Vector{Float64}(undef, S); lw = similar(w)
+        check(ccall((:pfmi_psis_weights, libpfmi), Int32, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}), engines[1].ptr, S, w, lw))
+        psis_result = DevicePSISResult(w, lw, k̂, M)
+    end
+    fit_dist = Distributions.MixtureModel(components)                                                      # :215-216
+    return Pathfinder.MultiPathfinderResult(input, optimizer, rng, optim_fun, logp, fit_dist, draws_, cld.(idx .+ 1, ndraws_per_run),
+                                            fit_dist, draws_, results, psis_result)
+end
+multipathfinder(eng::Engine, target::DeviceTarget, ndraws::Int; kwargs...) = multipathfinder([eng], target, ndraws; kwargs...)
+
 """
     resample(eng, result::Pathfinder.MultiPathfinderResult, ndraws; rng, replace, importance, ndraws_per_run)
 
@@ -409,18 +686,21 @@ function resample(result::Pathfinder.MultiPathfinderResult, ndraws::Int; rng::Ra
                                             result.fit_distribution, draws_, ids, result.fit_distribution, draws_, runs, psis_result)
 end
 
-# ---- multi-GPU: one Julia process, G engines (pfmi_comm_init_all = ncclCommInitAll), paths in contiguous blocks -------------------------
-mutable struct Comm
-    ptr::Ptr{Cvoid}
-    engines::Vector{Engine}
-    function Comm(engines::Vector{Engine})
-        ref = Ref{Ptr{Cvoid}}(C_NULL)
-        check(ccall((:pfmi_comm_init_all, libpfmi), Int32, (Int32, Ptr{Ptr{Cvoid}}, Ref{Ptr{Cvoid}}),
-                    length(engines), [e.ptr for e in engines], ref))
-        c = new(ref[], engines)
-        finalizer(x -> ccall((:pfmi_comm_destroy, libpfmi), Int32, (Ptr{Cvoid},), x.ptr), c)
-        return c
-    end
+# ---- multi-GPU collectives (the `Comm` type itself is defined next to `Engine`) ---------------------------------------------------------
+"""
+    psis_resample(c, dim, ndraws; importance, replace, seed) -> (pareto_shape, tail_length, idx0, draws)
+
+`_compute_psis_result` + `_resample` over every engine's runs (src/multipath.jl:221-225) in ONE call with one synchronisation:
+all-gather of the log-ratio shards, PSIS and index selection replicated, owner gather, sum all-reduce.  A `Comm` of one engine
+needs no RCCL.  `idx0` is 0-based (global pool columns).
+"""
+function psis_resample(c::Comm, dim::Int, ndraws::Int; importance::Bool=true, replace::Bool=true, seed::UInt64)
+    idx = Vector{Int64}(undef, ndraws); X = Matrix{Float64}(undef, dim, ndraws)
+    k̂ = Ref{Float64}(NaN); M = Ref{Int64}(0)
+    check(ccall((:pfmi_comm_psis_resample, libpfmi), Int32,
+                (Ptr{Cvoid}, Int64, Int32, Int32, UInt64, Ptr{Float64}, Ref{Float64}, Ref{Int64}, Ptr{Int64}, Ptr{Float64}),
+                c.ptr, ndraws, importance, replace, seed, C_NULL, k̂, M, idx, X))
+    return k̂[], Int(M[]), idx, X
 end
 "pooled PSIS over every GPU's runs: one RCCL all-gather of the log-ratio shards, PSIS replicated (src/multipath.jl:221)"
 function pool_psis(c::Comm)

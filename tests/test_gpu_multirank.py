@@ -60,3 +60,22 @@ def test_shard_mismatch_and_missing_pool_fail_on_every_rank():
 def test_multipathfinder_over_several_engines_one_host_thread():
     """pfmi.multipathfinder(engines=[...]) / resample() on a sharded result == the single-engine calls, bit for bit."""
     assert "api ok" in _run("api", 850)
+
+
+@pytest.mark.timeout(600)
+def test_bench_single_process_drives_several_contexts():
+    """`bench.py --gpus G --single-process`: ONE host process / thread drives G contexts through pfmi_comm_init_all (what a single
+    Julia caller of multipathfinder does); here G = 2 contexts on GPU 0 through the stand-in.  The line reports the ranks the
+    library itself counted and the same k-hat as the one-context run of the same workload."""
+    import json
+    env = dict(os.environ, PFMI_RCCL_LIB=STANDIN_LIB, PFMI_COMM_ALLOW_SHARED_GPU="1")
+    out = {}
+    for G in (1, 2):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(G), "--single-process", "--steps", "2", "--warmup", "1",
+                            "--npaths", "8", "--dim", "200", "--ndraws-elbo", "256", "--ndraws", "256"], env=env, capture_output=True,
+                           text=True, timeout=500)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        out[G] = json.loads(r.stdout.strip().splitlines()[-1])
+        assert out[G]["n_gpus"] == G and out[G]["config"]["ranks_in_collective"] == G
+    assert out[2]["config"]["rccl_version"] == 99999 and out[1]["config"]["rccl_version"] == 0
+    assert out[1]["pareto_k"] == out[2]["pareto_k"] and out[1]["config"]["elbo_draws_per_step"] == out[2]["config"]["elbo_draws_per_step"]

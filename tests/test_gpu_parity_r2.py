@@ -553,10 +553,19 @@ def test_julia_call_sequence_in_c(tmp_path):
     exe = str(tmp_path / "julia_sequence")
     libdir = os.path.join(root, "pathfinder.jl_amd", "lib")
     subprocess.check_call(["gcc", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "julia_sequence.c"), "-o", exe,
-                           "-L", libdir, "-lpfmi", f"-Wl,-rpath,{libdir}", "-lm"])
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+                           "-L", libdir, "-lpfmi", f"-Wl,-rpath,{libdir}", "-lm", "-ldl"])
+    from helpers import DEMO_LIB, STANDIN_LIB
+    env = dict(os.environ, PFMI_DEMO_LIB=DEMO_LIB)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert r.stdout.strip().splitlines()[-1].startswith("OK julia_sequence")
+    assert r.stdout.strip().splitlines()[-1].startswith("OK julia_sequence") and "device closure ok" in r.stdout
+    # round 3: multipathfinder(engines::Vector{Engine}, ...) -- the same program with the runs sharded over G engines (all on GPU 0,
+    # the in-process RCCL stand-in of tests/rccl_standin) must reproduce the single-engine result bit for bit
+    for G in (2, 4):
+        envg = dict(env, PFMI_RCCL_LIB=STANDIN_LIB, PFMI_COMM_ALLOW_SHARED_GPU="1")
+        r = subprocess.run([exe, str(G)], capture_output=True, text=True, timeout=300, env=envg)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        assert f"round-3 sequence ok: G={G} engines, rccl_version=99999" in r.stdout
 
 
 # ---- bench.py contract on the GPU box ---------------------------------------------------------------------------

@@ -142,3 +142,50 @@ def test_tail_refinement_occurs_in_the_stream():
         if found >= 2:
             break
     assert found >= 1
+
+
+def test_seven_round_stream_has_no_serial_or_cross_stream_correlation():
+    """every GPU-vs-oracle parity test shares the 7-round generator, so a statistical defect of the stream would be
+    invisible to them.  The counter layout of the kernels is (draw n, row / 4, stream, refinement): neighbouring draws differ in
+    counter word 0 only, neighbouring row groups in word 1 only, the four rows of a group are the four output words of ONE call,
+    and different fits differ in the key.  Each of these adjacencies is tested for correlation of the NORMALS (lag-1 along n, along
+    the row group, between output words, between consecutive seeds), for correlation of the squares (the ELBO's logq sums u^2), and
+    the low-order bits of adjacent words for independence -- with the 10-round generator as the control on the same statistics."""
+    d, N = 256, 20000                                            # 5.1e6 normals per seed
+    seeds = [20260928, 20260929, 0x1234567890ABCDEF]
+    U = [po.randn_fill(s, d, N) for s in seeds]
+    n_eff = d * (N - 1)
+    tol = 5.0 / np.sqrt(n_eff)                                   # 5 sigma of a sample correlation of independent normals
+
+    def corr(a, b):
+        a = a - a.mean(); b = b - b.mean()
+        return float((a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum()))
+
+    for u in U:
+        assert abs(corr(u[:, :-1].ravel(), u[:, 1:].ravel())) < tol                  # adjacent draws (counter word 0)
+        assert abs(corr(u[:-4, :].ravel(), u[4:, :].ravel())) < tol                  # adjacent row groups (counter word 1), same word
+        for a in range(4):                                                           # the four words of one Philox call
+            for b in range(a + 1, 4):
+                assert abs(corr(u[a::4, :].ravel(), u[b::4, :].ravel())) < 5.0 / np.sqrt(d * N / 4)
+        s2 = u * u
+        assert abs(corr(s2[:, :-1].ravel(), s2[:, 1:].ravel())) < tol                # squares: what logq / the quadratic forms sum
+        assert abs(corr(s2[:-4, :].ravel(), s2[4:, :].ravel())) < tol
+        assert abs(corr(u[:, :-1].ravel(), s2[:, 1:].ravel())) < tol
+    assert abs(corr(U[0].ravel(), U[1].ravel())) < 5.0 / np.sqrt(d * N)              # seeds k and k + 1 (key differs in one bit)
+    assert abs(corr(U[0].ravel(), U[2].ravel())) < 5.0 / np.sqrt(d * N)
+    # column sums of squares must be chi-square(d): mean d, variance 2 d -- a defect correlated across rows would inflate the variance
+    for u in U:
+        q = (u * u).sum(axis=0)
+        assert abs(q.mean() - d) < 5 * np.sqrt(2 * d / N)
+        assert abs(q.var() / (2 * d) - 1) < 5 * np.sqrt(2.0 / N) * 1.5
+    # bit level: XOR of the words of adjacent counters is uniform (each of the 32 bit positions set with frequency 1/2), 7 vs 10 rounds
+    key = np.array([0x9ABCDEF0, 0x12345678], dtype=np.uint32)
+    for rounds in (7, 10):
+        cnt = np.zeros(32)
+        m = 6000
+        for n in range(m):
+            a = po.philox4x32(np.array([n, 5, 0, 0], dtype=np.uint32), key, rounds)
+            b = po.philox4x32(np.array([n + 1, 5, 0, 0], dtype=np.uint32), key, rounds)
+            x = np.uint32(a[0]) ^ np.uint32(b[0])
+            cnt += [(int(x) >> t) & 1 for t in range(32)]
+        assert np.all(np.abs(cnt / m - 0.5) < 5 * 0.5 / np.sqrt(m)), (rounds, cnt / m)
