@@ -414,7 +414,8 @@ int32_t pf_launch_elbo_draws(pfmi_ctx *c, const int32_t *d_points, const uint64_
         // from both kernels.  PFMI_ELBO_KERNEL = xw forces it, = mfma | lane keep round 2's writers (tests cross-check them).
         // (a built-in target whose factor fits the two-pass kernel -- d <= 1024, J <= 8 -- keeps that kernel: it evaluates logp in the same
         // launch, 0.26 ms for the pool of config 3 against 0.49 ms for writer + scan)
-        const bool want_xw = d_x && ((force && force[0] == 'x') || (!(force && force[0] == 'm') && N >= 16 && !(tgt != 0 && mf_shape)));
+        const bool want_xw = d_x && ((force && force[0] == 'x') || (!(force && force[0] == 'm') && !(tgt != 0 && mf_shape)));   // by shape, never by N:
+        // a draw is the same bits whether it is made alone (top-up, pfmi_draws) or as part of a pool
         if (want_xw) {
             rc = pf_launch_elbo_xw(c, a, nfits, &handled);
             if (handled && rc == PFMI_OK && tgt != 0) {

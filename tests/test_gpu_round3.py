@@ -222,8 +222,12 @@ def test_device_callback_matches_builtin_target_and_oracle(pfmi_mod, eng, shape)
             assert np.max(np.abs(lp1 - logs0[k][0]) / (1 + np.abs(logs0[k][0]))) <= 1e-9
         e2.pool_build(N, pts, seeds[pts])
         pool1, lr1 = e2.pool_get()
-        np.testing.assert_array_equal(pool1, pool0)
+        # same normals, same factor; the built-in route may use another writer (two-pass kernel for d <= 1024): roundoff apart
+        assert np.max(np.abs(pool1 - pool0) / (1 + np.abs(pool0).max(axis=0))) <= 1e-10
         assert np.max(np.abs(lr1 - lr0) / (1 + np.abs(lr0))) <= 1e-9
+        for k in range(K):                                        # within ONE target a draw is the same bits alone or in the pool
+            Xk, _, _ = e2.draws(pts[k], seeds[pts[k]], 3, n0=7)
+            np.testing.assert_array_equal(Xk, pool1[:, 7:10, k])
         # against the closure evaluated on the host copy of the same draws, and pfmi_draws through the closure
         X, lpd, lqd = e2.draws(pts[0], seeds[pts[0]], 50)
         assert np.max(np.abs(lpd - tg.logp(X)) / (1 + np.abs(lpd))) <= 1e-11
@@ -439,14 +443,18 @@ def test_draw_writer_matches_lane_kernel_and_oracle_normals(pfmi_mod, eng, tname
         assert np.max(np.abs(Xw - Xl) / scale_x) <= 1e-10, (p, np.max(np.abs(Xw - Xl) / scale_x))
         assert np.max(np.abs(lqw - lql) / (1 + np.abs(lql))) <= 1e-12
         assert np.max(np.abs(lpw - lpl) / (1 + np.abs(lpl))) <= 1e-10
-        # default route == forced route; a later window of the same stream
+        # the default route (the two-pass kernel when d <= 1024, J <= 8 and the target is built in; the writer otherwise) and a later
+        # window of the same stream: the same bits whether a draw is made alone or in a block
         Xd, lpd, lqd = eng.draws(p, seed, N)
-        np.testing.assert_array_equal(Xd, Xw)
+        assert np.max(np.abs(Xd - Xw) / scale_x) <= 1e-10
         n0 = 16 * 3 + 5
-        X2, lp2, lq2 = eng.draws(p, seed, 40, n0=n0)
         if N >= n0 + 40:
-            np.testing.assert_array_equal(X2, Xw[:, n0:n0 + 40])
-            np.testing.assert_array_equal(lq2, lqw[n0:n0 + 40])
+            X2, lp2, lq2 = eng.draws(p, seed, 40, n0=n0)
+            np.testing.assert_array_equal(X2, Xd[:, n0:n0 + 40])
+            np.testing.assert_array_equal(lq2, lqd[n0:n0 + 40])
+            X3, _, lq3 = _with_kernel("xw", lambda: eng.draws(p, seed, 40, n0=n0))
+            np.testing.assert_array_equal(X3, Xw[:, n0:n0 + 40])
+            np.testing.assert_array_equal(lq3, lqw[n0:n0 + 40])
     best = [1, 1]
     pp = [int(eng.offsets[k]) + best[k] for k in range(K)]
     sd = np.array([77, 78], dtype=np.uint64)
