@@ -37,6 +37,12 @@
 #ifndef QF_ABLATE
 #define QF_ABLATE 0
 #endif
+#ifndef QF_NG2_MAXKC
+#define QF_NG2_MAXKC 20                // two groups per wave up to this KC (round 2: 12; KC = 16, 20 take the register-lean block body)
+#endif
+#ifndef QF_SETPRIO
+#define QF_SETPRIO 0                   // s_setprio level during a group's MFMA burst (0 = off; A/B in profiles/r03_scan_experiments.md)
+#endif
 #define QF_MIN_FRONT 1024             // doubles in front of the inverse-CDF table (>= (32 - 19) * 32 * 2 = 832)
 // blocks (of 16 rows) per streamed chunk; KC = 32 halves it: two staging buffers of 16 blocks x 32 columns would not fit 160 KB of LDS
 // (round 3: history_length 11..16 with d > ~1000 used to fail with "LDS too large")
@@ -139,24 +145,32 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
     // head transform z_head = V'u_head as 16x16x4 MFMAs (same operand trick as the two-pass kernel): lane (q, c) supplies
     // A_r[i' = c][k = q] = H[rho(c)][4 q + r], H = V' identity padded; block 1 needs H10, H11 when KC > 16
     const int rho = 4 * (c & 3) + (c >> 2);
-    double a_h00[4], a_h10[4], a_h11[4];
-    {
-        const double *Vc = A.vchol + (size_t)p * KC * KC;
+    // (two groups per wave at KC >= 16 need the registers: there the operands are fetched when a special block comes up -- L2, twice per
+    // 16-draw group -- instead of living in 48 VGPRs for the whole kernel)
+    constexpr bool HREG = !(NG == 2 && KC >= 16);
+    const double *Vc = A.vchol + (size_t)p * KC * KC;
+    auto head_op = [&](const int which, const int r) -> double {          // which: 0 = H00, 1 = H10, 2 = H11
+        const int b = 4 * q + r;
+        if (which == 0) { double v = (rho == b) ? 1.0 : 0.0; if (rho < KC && b < KC) v = Vc[b * KC + rho]; return v; }
+        const int i1 = 16 + rho, b1 = 16 + b;
+        if (which == 1) return (i1 < KC) ? Vc[b * KC + i1] : 0.0;
+        double v1 = (i1 == b1) ? 1.0 : 0.0;
+        if (i1 < KC && b1 < KC) v1 = Vc[b1 * KC + i1];
+        return v1;
+    };
+    double a_h00[HREG ? 4 : 1], a_h10[HREG ? 4 : 1], a_h11[HREG ? 4 : 1];
+    if (HREG) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int b = 4 * q + r;
-            double v = (rho == b) ? 1.0 : 0.0;
-            if (rho < KC && b < KC) v = Vc[b * KC + rho];
-            a_h00[r] = v;
-            if (KC > 16) {
-                const int i1 = 16 + rho, b1 = 16 + b;
-                a_h10[r] = (i1 < KC) ? Vc[b * KC + i1] : 0.0;
-                double v1 = (i1 == b1) ? 1.0 : 0.0;
-                if (i1 < KC && b1 < KC) v1 = Vc[b1 * KC + i1];
-                a_h11[r] = v1;
-            } else { a_h10[r] = 0.0; a_h11[r] = 0.0; }
+            a_h00[HREG ? r : 0] = head_op(0, r);
+            a_h10[HREG ? r : 0] = (KC > 16) ? head_op(1, r) : 0.0;
+            a_h11[HREG ? r : 0] = (KC > 16) ? head_op(2, r) : 0.0;
         }
     }
+    auto hop = [&](const int which, const int r) -> double {
+        if (HREG) return which == 0 ? a_h00[HREG ? r : 0] : (which == 1 ? a_h10[HREG ? r : 0] : a_h11[HREG ? r : 0]);
+        return head_op(which, r);
+    };
     const uint64_t seed = A.seeds[slot];
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     const double logdet = A.logdet[p];
@@ -258,6 +272,9 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
                 };
                 // the contractions of one group: w = Vh'z, A3 = Vh'(a s^2 z), A4 = Wd'(s z), and the two scalars
                 auto contract = [&](const int g, const double (&z)[4], const Ops &o, const bool with_w) {
+#if QF_SETPRIO                         // experiment (round 3): raise the wave's priority for its MFMA burst
+                    __builtin_amdgcn_s_setprio(QF_SETPRIO);
+#endif
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const double zr = z[r];
@@ -277,6 +294,9 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
                             for (int T = 0; T < TR; ++T) acc4[g][T] = qf_mfma4(o.wd[r][T], bs, acc4[g][T]);
                         }
                     }
+#if QF_SETPRIO
+                    __builtin_amdgcn_s_setprio(0);
+#endif
                 };
                 // normals of rows 16 blk + 4q + {0..3} of draw n[g], head transform included
                 auto normals = [&](const int g, const int blk, double (&z)[4]) {
@@ -292,16 +312,16 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
                     if (blk == 0) {                                                    // z[1:k] = V'u[1:k] (src/woodbury.jl:139)
                         qf_d4 h = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { u0[g][r] = z[r]; h = qf_mfma16(a_h00[r], z[r], h); }
+                        for (int r = 0; r < 4; ++r) { u0[g][r] = z[r]; h = qf_mfma16(hop(0, r), z[r], h); }
 #pragma unroll
                         for (int r = 0; r < 4; ++r) z[r] = h[r];
                         z00[g] = z[0];
                     } else if (KC > 16 && blk == 1) {
                         qf_d4 h = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) h = qf_mfma16(a_h10[r], u0[g][r], h);
+                        for (int r = 0; r < 4; ++r) h = qf_mfma16(hop(1, r), u0[g][r], h);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) h = qf_mfma16(a_h11[r], z[r], h);
+                        for (int r = 0; r < 4; ++r) h = qf_mfma16(hop(2, r), z[r], h);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) z[r] = h[r];
                     }
@@ -323,16 +343,16 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
                         if (blk == 0) {                                          // z[1:k] = V'u[1:k] (src/woodbury.jl:139)
                             qf_d4 h = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) { u0[g][r] = z[r]; h = qf_mfma16(a_h00[r], z[r], h); }
+                            for (int r = 0; r < 4; ++r) { u0[g][r] = z[r]; h = qf_mfma16(hop(0, r), z[r], h); }
 #pragma unroll
                             for (int r = 0; r < 4; ++r) z[r] = h[r];
                             z00[g] = z[0];
                         } else if (KC > 16 && blk == 1) {
                             qf_d4 h = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) h = qf_mfma16(a_h10[r], u0[g][r], h);
+                            for (int r = 0; r < 4; ++r) h = qf_mfma16(hop(1, r), u0[g][r], h);
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) h = qf_mfma16(a_h11[r], z[r], h);
+                            for (int r = 0; r < 4; ++r) h = qf_mfma16(hop(2, r), z[r], h);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) z[r] = h[r];
                         }
@@ -372,7 +392,57 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
                 } else {
                     // one block of both groups; the body exists twice: interior blocks (no row masking, no head transform) and the
                     // first / second / last block, selected by ONE wave-uniform branch per block
+                    // KC >= 16 with two groups (round 3): the block is MFMA dominated (2 x 4 x 2 NT quarter-size MFMAs), registers are the
+                    // scarce resource -- one set of pending look-ups at a time, and the A tiles of ONE k-step (4 rows) live at a time,
+                    // shared by both groups' MFMAs (the r loop is outermost)
+                    auto block_body_seq = [&](const int bl, auto special_tag) {
+                        const int blk = blk0 + bl;
+                        double z[NG][4];
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) {
+                            Pend pp;
+                            gen_issue(g, blk, pp);
+                            finish(g, blk, pp, z[g], special_tag);
+                        }
+                        const double *rp = rs + bl * 48 + 4 * q;
+                        const double *ap = vs + ((bl * 4) * NT << 4) + q * 4 + l3;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            double av[NT];
+#pragma unroll
+                            for (int T = 0; T < NT; ++T) av[T] = ap[(r * NT + T) << 4];
+                            const double r0 = rp[r], r1 = rp[16 + r];
+#pragma unroll
+                            for (int g = 0; g < NG; ++g) {
+                                const double zr = z[g][r];
+                                double bp = 0.0;
+                                if (TGT != 0) {
+                                    bp = r0 * zr;
+                                    q12[g] = fma(bp + r1, zr, q12[g]);
+                                }
+#pragma unroll
+                                for (int T = 0; T < NT; ++T) {
+                                    accw[g][T] = qf_mfma4(av[T], zr, accw[g][T]);
+                                    if (TGT != 0) acc3[g][T] = qf_mfma4(av[T], bp, acc3[g][T]);
+                                }
+                            }
+                            if (TGT == 1 && RPAD > 0) {
+                                const double *wp = A.t_wd16 + ((size_t)(blk0 + bl) * 16 + 4 * q + r) * 16 + l3;
+                                double wd[TR > 0 ? TR : 1];
+#pragma unroll
+                                for (int T = 0; T < TR; ++T) wd[T] = wp[4 * T];
+                                const double r2 = rp[32 + r];
+#pragma unroll
+                                for (int g = 0; g < NG; ++g) {
+                                    const double bs = r2 * z[g][r];
+#pragma unroll
+                                    for (int T = 0; T < TR; ++T) acc4[g][T] = qf_mfma4(wd[T], bs, acc4[g][T]);
+                                }
+                            }
+                        }
+                    };
                     auto block_body = [&](const int bl, auto special_tag) {
+                        if constexpr (NG == 2 && KC >= 16) { block_body_seq(bl, special_tag); return; }
                         const int blk = blk0 + bl;
                         Ops oa;
                         load_ops(bl, oa);                        // operands first: the generator below hides their latency
@@ -576,8 +646,9 @@ static int32_t launch_qf_ng(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
 // short scans keep one group per wave so that more waves are busy); KC >= 16 would spill with two groups
 template <int KC, int TGT, int RPAD>
 static int32_t launch_qf(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
-    if constexpr (KC <= 12 && QF_NG == 2) {
-        if (a.N >= 768) return launch_qf_ng<KC, TGT, RPAD, 2>(c, a, nfits);
+    if constexpr (KC <= QF_NG2_MAXKC && QF_NG == 2) {
+        // (KC >= 16: only when there are fits enough to fill the CUs -- a pool of a few fits wants more, smaller pieces)
+        if (a.N >= 768 && (KC <= 12 || nfits >= 128)) return launch_qf_ng<KC, TGT, RPAD, 2>(c, a, nfits);
     }
     return launch_qf_ng<KC, TGT, RPAD, 1>(c, a, nfits);
 }

@@ -400,9 +400,12 @@ static int32_t launch_xw(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
     // workgroups than CUs can hold
     int split = 1;
     constexpr int SLOTS = XW_WAVES * XW_NG;
-    while ((int64_t)split * nfits < 2 * (c->ncu > 0 ? c->ncu : 256) && ngroups / (split * 2) >= SLOTS) split *= 2;
+    // (a streamed Vh is re-read per batch whatever the cut, so pieces may shrink to a few groups; a resident one is staged once per
+    // piece: whole batches only)
+    const int min_piece = nchunks > 1 ? 4 : SLOTS;
+    while ((int64_t)split * nfits < 2 * (c->ncu > 0 ? c->ncu : 256) && ngroups / (split * 2) >= min_piece) split *= 2;
     int gpw = (ngroups + split - 1) / split;
-    gpw = (gpw + SLOTS - 1) / SLOTS * SLOTS;
+    if (nchunks == 1) gpw = (gpw + SLOTS - 1) / SLOTS * SLOTS;
     const int gx = (ngroups + gpw - 1) / gpw;
     for (int64_t s0 = 0; s0 < nfits; s0 += 32768) {
         const int64_t ns = (nfits - s0 < 32768) ? (nfits - s0) : 32768;

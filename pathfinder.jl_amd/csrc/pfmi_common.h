@@ -299,6 +299,9 @@ __device__ __forceinline__ void pf_icdf_issue(uint32_t x, const double2 *lds_tab
 // (hi32(P) >> 15) = 0 would have (loop-invariant, kept opaque so that the compiler does not split the constant off again -- it
 // emitted three v_add_u32 per normal), the second coefficient pair sits NENT entries further (immediate ds_read offset).  Only for
 // callers that guarantee readable LDS below the table (CLAMP = false above).
+#ifndef PF_ICDF_CLAMP_ADJ
+#define PF_ICDF_CLAMP_ADJ 1
+#endif
 typedef double pf_v2d __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(3))) pf_v2d *pf_lds_d2;
 template <int NB = PF_ICDF_NB_LDS>
@@ -315,6 +318,9 @@ __device__ __forceinline__ void pf_icdf_issue_adj(uint32_t x, uint32_t adj, doub
     v = (double)(x & 0x7FFFFFFFu);
     const unsigned hi = (unsigned)__double2hiint(v);
     unsigned idx = hi >> (20 - PF_ICDF_B);
+#if PF_ICDF_CLAMP_ADJ                  // never form an LDS address in front of the caller's guard region (mag = 0: idx = 0)
+    idx = max(idx, (unsigned)(PF_ICDF_IDX0 - ((32 << PF_ICDF_B) - 1)));
+#endif
     asm("" : "+v"(idx));                                            // keeps (idx << 4) + adj one v_lshl_add_u32 (else: shift, mask, add)
     const pf_lds_d2 e = (pf_lds_d2)(uintptr_t)(adj + (idx << 4));
     const pf_v2d a = e[0], b = e[NENT];

@@ -432,9 +432,15 @@ def _run_paths(engs, target, inits, run_rngs, *, dim, history_length, ndraws_elb
         else:
             for k in need:
                 state[k]["x0"] = init_sampler(run_rngs[k], np.empty(dim))
+        predrawn = None
         if on_device:     # every path in one launch per engine; finished paths are recomputed identically from their x0
             for eng, (k0, k1) in zip(engs, blocks):
                 eng.optimize_batch_enqueue(np.stack([s["x0"] for s in state[k0:k1]]), history_length, **okw)
+            # while the optimisations run: the per-fit seeds of every pending run for the LONGEST possible trace, drawn from copies of
+            # the runs' rngs (counter-based: the real rng is advanced by L_k once L_k is known, so the stream consumption is the
+            # reference's: rand!(rng_k, UInt64[L_k]), src/elbo.jl:2)
+            cap = int(okw.get("maxiters", 1000)) + 1
+            predrawn = dict(zip(pending, rand_u64_multi([run_rngs[k].copy() for k in pending], [cap] * len(pending))))
             for eng, (k0, k1) in zip(engs, blocks):
                 npts = eng.optimize_batch_wait()
                 for k in range(k0, k1):
@@ -450,12 +456,19 @@ def _run_paths(engs, target, inits, run_rngs, *, dim, history_length, ndraws_elb
         # ENQUEUES the history walk and the fits; the per-fit seeds are drawn on the host while they run
         for eng in engs:
             eng.fit_batch(history_length)
-        fresh = rand_u64_multi([run_rngs[k] for k in pending], [len(state[k]["trace"]) - 1 for k in pending])
-        for k, sd in zip(pending, fresh):                           # seeds = rand!(rng_k, UInt64[L_k])  (src/elbo.jl:2)
-            state[k]["seeds"] = np.concatenate([[np.uint64(0)], sd]).astype(np.uint64)
-            # what rand(rng_k, fit_distribution, ndraws) would use if this try ends in failure (src/singlepath.jl:231-233): peeked from a
-            # copy, the run's rng only advances when the path really fails (_assemble_path)
-            state[k]["fail_seed"] = np.uint64(run_rngs[k].copy().rand_u64(1)[0])
+        if predrawn is not None:
+            for k in pending:
+                L = len(state[k]["trace"]) - 1
+                state[k]["seeds"] = np.concatenate([[np.uint64(0)], predrawn[k][:L]]).astype(np.uint64)
+                state[k]["fail_seed"] = np.uint64(predrawn[k][L])     # the value the rng would produce next (see below)
+                run_rngs[k].counter += L
+        else:
+            fresh = rand_u64_multi([run_rngs[k] for k in pending], [len(state[k]["trace"]) - 1 for k in pending])
+            for k, sd in zip(pending, fresh):                       # seeds = rand!(rng_k, UInt64[L_k])  (src/elbo.jl:2)
+                state[k]["seeds"] = np.concatenate([[np.uint64(0)], sd]).astype(np.uint64)
+                # what rand(rng_k, fit_distribution, ndraws) would use if this try ends in failure (src/singlepath.jl:231-233): peeked
+                # from a copy, the run's rng only advances when the path really fails (_assemble_path)
+                state[k]["fail_seed"] = np.uint64(run_rngs[k].copy().rand_u64(1)[0])
         for eng, (k0, k1) in zip(engs, blocks):
             eng.elbo_batch_enqueue(ndraws_elbo, np.concatenate([s["seeds"] for s in state[k0:k1]]))
         if pool is not None:                                        # optimistic: right behind the scan, no host round trip

@@ -774,7 +774,10 @@ def test_multipathfinder_device_and_host_optimizers_agree(pfmi_mod):
     ("iso", 10, 2, 6, 100, 2, 1000), ("diag", 30, 2, 6, 200, 2, 1000), ("lr", 50, 2, 6, 200, 2, 1000), ("lr", 300, 2, 6, 500, 2, 1000),
     ("funnel", 12, 2, 6, 100, 10, 40), ("diag", 30, 2, 10, 200, 2, 1000), ("lr", 50, 2, 16, 200, 2, 1000),
     ("diag", 3000, 2, 6, 200, 2, 30), ("funnel", 2500, 2, 10, 300, 10, 30), ("lr", 1100, 2, 8, 130, 2, 40),
-    ("lr", 64, 8, 6, 1000, 2, 45), ("diag", 48, 7, 4, 500, 2, 50)])
+    ("lr", 64, 8, 6, 1000, 2, 45), ("diag", 48, 7, 4, 500, 2, 50),
+    # round 3: two groups per wave at KC = 16 / 20 (N >= 768), resident and streamed, every target family, ragged tails
+    ("funnel", 2000, 2, 10, 800, 10, 24), ("lr", 600, 2, 8, 1000, 2, 30), ("diag", 100, 2, 10, 784, 2, 40), ("lr", 1500, 2, 10, 770, 2, 24),
+    ("lr", 3000, 2, 16, 200, 2, 20)])
 def test_single_pass_scan_matches_lane_kernel(pfmi_mod, eng, tname, d, K, J, N, scale, maxit):
     """the single-pass quadratic-form scan (elbo_qf_kernel.hip: logp from per-draw contractions, x never formed; Vh resident or
     streamed through LDS; KC up to 32) against the lane-per-draw kernel that evaluates logp(x) on the materialised draw, same
