@@ -88,10 +88,11 @@ def _demo_device_target(pfmi, tg):
     return pfmi.DeviceCallbackTarget(tg.d, C.cast(L.pfx_gauss_logp, C.c_void_p).value, C.c_void_p(h), host=tg, keepalive=(L, h))
 
 
-def _pmc_traffic(argv_tail, kernel_like):
-    """HBM bytes per launch of the dominant kernel, measured IN THIS RUN: one step of this very command re-run twice under
-    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `... WRITE_SIZE` (separate passes: the TCC block cannot hold both counters), units and
-    the gfx950 correction as /opt/skills/guides/MI355X_MICROARCH.md prescribes (KiB; FETCH_SIZE reports half of a wide coalesced read)."""
+def _pmc_traffic(argv_tail, kernels):
+    """HBM bytes per launch of the kernels in `kernels` ({label: SQL LIKE pattern}), measured IN THIS RUN: one step of this very command
+    (+ one device-closure scan) re-run twice under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `... WRITE_SIZE` (separate passes: the
+    TCC block cannot hold both counters), units and the gfx950 correction as /opt/skills/guides/MI355X_MICROARCH.md prescribes (KiB;
+    FETCH_SIZE reports half of a wide coalesced read).  Returns ({label: {...}}, None) or (None, reason)."""
     import glob
     import shutil
     import sqlite3
@@ -99,35 +100,42 @@ def _pmc_traffic(argv_tail, kernel_like):
     exe = shutil.which("rocprofv3")
     if not exe:
         return None, "rocprofv3 not on PATH"
-    out = {}
+    raw = {}
     tmp = tempfile.mkdtemp(prefix="pfmi_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             dd = os.path.join(tmp, ctr)
             cmd = [exe, "--kernel-trace", "--pmc", ctr, "-d", dd, "-o", "p", "--", sys.executable, os.path.abspath(__file__)] + argv_tail + \
-                  ["--steps", "1", "--warmup", "0", "--minimal", "--no-cpu-baseline", "--no-pmc"]
+                  ["--steps", "1", "--warmup", "0", "--minimal", "--with-devcb", "--no-cpu-baseline", "--no-pmc"]
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
             dbs = glob.glob(os.path.join(dd, "**", "*_results.db"), recursive=True)
             if r.returncode != 0 or not dbs:
                 return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode}): {r.stderr[-300:]}"
             con = sqlite3.connect(dbs[0])
-            rows = list(con.execute(
-                "select grid_size, sum(value), count(distinct dispatch_id), avg(duration) from counters_collection "
-                "where kernel_name like ? and counter_name = ? group by grid_size order by grid_size desc", (kernel_like, ctr)))
+            for label, like in kernels.items():
+                rows = list(con.execute(
+                    "select grid_size, sum(value), count(distinct dispatch_id), avg(duration) from counters_collection "
+                    "where kernel_name like ? and counter_name = ? group by grid_size order by sum(value) desc", (like, ctr)))
+                if rows:
+                    g, v, n, dur = rows[0]                          # the launch shape that moves the most bytes (the main launch)
+                    raw.setdefault(label, {})[ctr] = (v / n * 1024.0, int(n), dur / 1e6)
             con.close()
-            if not rows:
-                return None, f"no {ctr} rows for {kernel_like}"
-            g, v, n, dur = rows[0]                                  # the main launch (largest grid)
-            out[ctr] = (v / n * 1024.0, int(n), dur / 1e6)
     except Exception as ex:
         return None, repr(ex)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    fetch, write = 2.0 * out["FETCH_SIZE"][0], out["WRITE_SIZE"][0]
-    return {"traffic_bytes_per_launch": fetch + write, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
-            "fetch_correction": 2.0, "launches_profiled": out["FETCH_SIZE"][1], "avg_duration_ms_under_pmc": round(out["FETCH_SIZE"][2], 3),
-            "source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, two separate passes of one step"}, None
+    out = {}
+    for label, rr in raw.items():
+        if "FETCH_SIZE" not in rr or "WRITE_SIZE" not in rr:
+            continue
+        fetch, write = 2.0 * rr["FETCH_SIZE"][0], rr["WRITE_SIZE"][0]
+        out[label] = {"traffic_bytes_per_launch": fetch + write, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
+                      "fetch_correction": 2.0, "launches_profiled": rr["FETCH_SIZE"][1], "avg_duration_ms_under_pmc": round(rr["FETCH_SIZE"][2], 3),
+                      "source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, two separate passes of one step"}
+    if not out:
+        return None, "no counter rows for the requested kernels"
+    return out, None
 
 
 def main_single_process(args):
@@ -216,6 +224,7 @@ def main():
     ap.add_argument("--single-process", action="store_true",
                     help="--gpus N driven by ONE host process (N contexts, pfmi_comm_init_all) instead of one rank per GPU")
     ap.add_argument("--minimal", action="store_true", help="timed steps only (the rocprofv3 counter passes re-run bench.py this way)")
+    ap.add_argument("--with-devcb", action="store_true", help="with --minimal: also one device-closure scan (counter passes)")
     ap.add_argument("--no-pmc", action="store_true", help="do not re-run a step under rocprofv3 --pmc for roofline.traffic")
     ap.add_argument("--maxiters", type=int, default=1000)
     ap.add_argument("--init-scale", type=float, default=2.0)
@@ -428,7 +437,7 @@ def main():
     #      materialised in HBM (8 d bytes written per draw) and read there by the user's kernel (8 d bytes read): the path on which
     #      SURVEY 8(d)'s 16 d bytes per draw PHYSICALLY move, so its HBM fraction is a real utilisation.  Bounded sample: 8 paths.
     devcb_line = None
-    if G == 1 and not use_dist and not args.host_traces and not args.minimal:
+    if G == 1 and not use_dist and not args.host_traces and (not args.minimal or args.with_devcb):
         try:
             Kd = min(8, Kl)
             trs = [eng.get_trace(k, logp=False) for k in range(Kd)]
@@ -438,7 +447,7 @@ def main():
             e3.fit_batch(J)
             sd = seeds[:e3.P]
             e3.elbo_batch(N_e, sd)                                      # warm-up: the block buffers are allocated here
-            reps = 3
+            reps = 1 if args.minimal else 3
             e3.sync()
             t0 = time.perf_counter()
             for _ in range(reps):
@@ -466,6 +475,42 @@ def main():
             e3.close()
         except Exception as ex:  # pragma: no cover
             devcb_line = {"error": repr(ex)}
+
+    # ---- the same workload on a target Pathfinder can actually fit: at the headline definition (W_ij ~ N(0, 1): 8
+    #      directions with variance ~ d) the pooled weights are degenerate (Pareto k ~ 3.8), so the timed work is real but its resampled
+    #      output is statistically meaningless.  Same d, K, J, N with W scaled by 2 / sqrt(d): same kernels, same shapes -- the step time
+    #      and the Pareto k of a run whose answer is usable.
+    fitted_line = None
+    if G == 1 and not use_dist and not args.host_traces and not args.minimal and args.target == "lowrank":
+        try:
+            tg2 = pfmi.t_lowrank(d, r=8, seed=2, wscale=2.0 / np.sqrt(d))
+            e4 = pfmi.Engine(local_rank)
+            e4.set_target(tg2)
+            npts2 = e4.optimize_batch(x0s, J, args.maxiters)
+            sd2 = np.concatenate([rand_u64(int(run_seeds[k0 + i]), np.arange(n, dtype=np.uint64), 10) for i, n in enumerate(npts2)])
+            c4 = pfmi.Comm.init_all([e4])
+
+            def step2():
+                e4.fit_batch(J)
+                e4.elbo_batch_enqueue(N_e, sd2)
+                e4.pool_build_best(N_r)
+                r4 = c4.psis_resample(ndraws, seed=master)
+                e4.elbo_batch_wait()
+                return r4
+
+            step2()
+            e4.sync()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                r4 = step2()
+            dt4 = (time.perf_counter() - t0) / 5
+            nd4 = (e4.P - Kl) * N_e
+            fitted_line = {"pareto_k": r4[0]["pareto_shape"], "ms_per_step": round(dt4 * 1e3, 3), "elbo_draws_per_s": round(nd4 / dt4, 1),
+                           "fits": int(e4.P - Kl), "target": f"T_lr(d={d}, r=8) with W_ij ~ N(0, 4/d): Sigma* = diag + low rank of comparable scale"}
+            c4.close()
+            e4.close()
+        except Exception as ex:  # pragma: no cover
+            fitted_line = {"error": repr(ex)}
 
     # ---- roofline of the dominant kernel (pf_elbo_draws_kernel), hipEvents on the engine's stream ---------
     roofline = None
@@ -512,11 +557,20 @@ def main():
                               "2 waves per SIMD, no MFMA/VALU co-issue (profiles/r02_coissue_microbench.txt, profiles/r03_*)"}
         traffic, traffic_meta = None, None
         if not args.no_pmc and not args.minimal and G == 1 and not use_dist:
-            pmc, why = _pmc_traffic([a for a in sys.argv[1:] if a not in ("--no-cpu-baseline",)], "%pf_elbo_qf_kernel%")
-            if pmc is not None:
-                traffic, traffic_meta = pmc["traffic_bytes_per_launch"], pmc
+            pmc, why = _pmc_traffic([a for a in sys.argv[1:] if a not in ("--no-cpu-baseline",)],
+                                    {"scan": "%pf_elbo_qf_kernel%", "writer": "%pf_elbo_xw_kernel%", "reader": "%pfx_%"})
+            if pmc is not None and "scan" in pmc:
+                traffic, traffic_meta = pmc["scan"]["traffic_bytes_per_launch"], pmc["scan"]
             else:
                 traffic_meta = {"source": f"unavailable in this run ({why})"}
+            if pmc is not None and isinstance(devcb_line, dict) and "writer" in pmc and "reader" in pmc and "error" not in devcb_line:
+                # the device-closure path per launch (one block of fits): measured bytes against the bytes that must move (8 d per draw
+                # written by the writer, 8 d per draw read by the closure)
+                devcb_line["measured_hbm_bytes_per_launch"] = {
+                    "writer": {k: pmc["writer"][k] for k in ("fetch_bytes_per_launch", "write_bytes_per_launch", "launches_profiled")},
+                    "reader": {k: pmc["reader"][k] for k in ("fetch_bytes_per_launch", "write_bytes_per_launch", "launches_profiled")},
+                    "note": "per launch = one block of fits (PFMI_DEVCB_CHUNK_MB); the writer must write and the reader must read "
+                            "8 d bytes per draw of the block; FETCH_SIZE x 2 (gfx950), WRITE_SIZE as reported"}
         roofline = {"bound": "mfma", "achieved": round(mfma_tf, 2), "peak": 78.6, "unit": "TFLOP/s", "frac": round(mfma_tf / 78.6, 4),
                     "traffic": traffic, "traffic_detail": traffic_meta,
                     "kernel": "pf_elbo_qf_kernel (single-pass ELBO scan; one scan = the main launch + a short tail launch for the fits beyond "
@@ -601,6 +655,7 @@ def main():
             "stages_ms": stages,
             "callback_target": callback_line,
             "device_callback_target": devcb_line,
+            "fitted_variant": fitted_line,
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

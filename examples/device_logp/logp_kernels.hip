@@ -53,17 +53,25 @@ __global__ __launch_bounds__(PFX_THREADS) void pfx_gauss_kernel(Gauss P, const d
 #pragma unroll
         for (int c = 0; c < 16; ++c) q[c] = 0.0;
         d4 acc = {0.0, 0.0, 0.0, 0.0};
-        for (int t = wv; t < ntiles; t += PFX_WAVES) {
+        // software pipeline: the 16 loads of tile t + 4 are in flight while tile t is consumed (a wave then has 2 x 8 KB outstanding)
+        double xn[16];
+        auto fetch = [&](const int t, double (&x)[16]) {
             const int row = t * 64 + lane;
-            const bool rv = row < d;
-            const double m = P.mean[row], av = P.a[row];
-            double e[16];
+            const bool rv = t < ntiles && row < d;
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 const long long cc = c0 + c;
-                const double x = (rv && cc < n) ? X[(size_t)cc * d + row] : m;
-                e[c] = x - m;
+                x[c] = (rv && cc < n) ? __builtin_nontemporal_load(&X[(size_t)cc * d + row]) : 0.0;
             }
+        };
+        fetch(wv, xn);
+        for (int t = wv; t < ntiles; t += PFX_WAVES) {
+            const int row = t * 64 + lane;
+            const double m = P.mean[row], av = P.a[row];
+            double e[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) e[c] = (row < d && c0 + c < n) ? xn[c] - m : 0.0;       // (a NaN draw stays NaN)
+            fetch(t + PFX_WAVES, xn);
 #pragma unroll
             for (int c = 0; c < 16; ++c) q[c] = fma(av * e[c], e[c], q[c]);
             if (LOWRANK) {

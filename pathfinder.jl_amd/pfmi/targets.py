@@ -220,10 +220,14 @@ def t_diag(d, seed=1):
     return GaussTarget(m, np.exp(2 * logsig))
 
 
-def t_lowrank(d, r=8, seed=2):
+def t_lowrank(d, r=8, seed=2, wscale=1.0):
+    """T_lr of SURVEY.md 8(d): Sigma* = diag(sigma^2) + W W', W_ij ~ N(0, wscale^2).  wscale = 1 is the headline definition: the r
+    low-rank directions then carry variance ~ d (1000 x the diagonal's), more than an L-BFGS history of 6 pairs can represent, and the
+    pooled importance weights are degenerate (Pareto k ~ 3.8).  wscale ~ 2 / sqrt(d) gives the same structure at a scale Pathfinder
+    fits (bench.py's `fitted_variant` line)."""
     rng = HostRNG(seed)
     logsig = -0.5 + 1.0 * rng.rand(d)
-    W = rng.randn(d * r).reshape(d, r)
+    W = rng.randn(d * r).reshape(d, r) * wscale
     m = rng.randn(d)
     return GaussTarget(m, np.exp(2 * logsig), W)
 
