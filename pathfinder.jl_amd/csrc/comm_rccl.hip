@@ -27,6 +27,7 @@
 
 #include <dlfcn.h>
 #include <math.h>
+#include <mutex>
 #include <rccl/rccl.h>
 #include <stdlib.h>
 #include <string.h>
@@ -48,8 +49,10 @@ struct RcclApi {
     decltype(&ncclGetVersion) GetVersion = nullptr;
 };
 RcclApi g_rccl;
+std::mutex g_rccl_mu;                    // ranks may be host threads (one context each): the first ones race to load the library
 
 int32_t rccl_load() {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
     if (g_rccl.handle) return PFMI_OK;
     void *h = nullptr;
     const char *over = getenv("PFMI_RCCL_LIB");

@@ -1,6 +1,7 @@
 """Engine: thin Python handle over a pfmi_ctx (one GPU, one stream).  All numerics run in
 libpfmi.so on the MI355X; this file only marshals arrays across the C ABI."""
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -15,6 +16,9 @@ _u64p = C.POINTER(C.c_uint64)
 
 def _d(a):
     return a.ctypes.data_as(_dp) if a is not None else None
+
+
+_LIVE_COMMS = weakref.WeakSet()          # a pfmi_comm holds raw pointers to its contexts: it must go before any of them does
 
 
 class StaleHandleError(RuntimeError):
@@ -35,11 +39,12 @@ class Engine:
         self.J = 0
 
     def close(self):
-        for cm in list(getattr(self, "_comm_cache", {}).values()):      # groups formed by the API layer with this engine first
-            try:
-                cm.close()
-            except Exception:
-                pass
+        for cm in list(_LIVE_COMMS):                                    # every group this engine is a member of goes first
+            if any(e is self for e in cm.engines):
+                try:
+                    cm.close()
+                except Exception:
+                    pass
         self.__dict__.pop("_comm_cache", None)
         if getattr(self, "ctx", None) is not None and self.ctx:
             self.L.pfmi_destroy(self.ctx)
@@ -363,6 +368,7 @@ class Comm:
 
     def __init__(self, handle, engines):
         self.h, self.engines, self.L = handle, list(engines), _lib.lib()
+        _LIVE_COMMS.add(self)
 
     @staticmethod
     def unique_id():

@@ -70,3 +70,34 @@ def test_findmax_mirror_and_api_errors():
         pfmi.multipathfinder(pfmi.t_iso(3), 10)                  # ArgumentError, reference src/multipath.jl:148-150
     assert pfmi.maximize_elbo(pfmi.HostRNG(0), pfmi.t_iso(3), [], 10) == (0, [])   # reference src/elbo.jl:7
     assert pfmi.DEFAULT_HISTORY_LENGTH == 6 and pfmi.DEFAULT_NDRAWS_ELBO == 5
+
+
+def test_predrawn_fit_seeds_equal_the_sequential_draws():
+    """api._run_paths draws the per-fit seeds of a run for the LONGEST possible trace while the device still optimises, from a copy of the
+    run's rng, and advances the real rng by L_k afterwards: the seeds, the value a failed run would draw next
+    (rand(rng, fit_distribution, n), src/singlepath.jl:231-233) and the rng's final state must be those of the reference's order of
+    operations -- rand!(rng_k, UInt64[L_k]) (src/elbo.jl:2) after the optimisation."""
+    import numpy as np
+    from pfmi.hostrng import HostRNG, rand_u64_multi
+    rngs = [HostRNG(s) for s in (3, 4, 5)]
+    for r in rngs:
+        r.rand(7)                                                  # the init sampler already consumed something
+    ref = [r.copy() for r in rngs]
+    Ls = [5, 0, 12]
+    cap = 21
+    pre = rand_u64_multi([r.copy() for r in rngs], [cap] * 3)
+    for r, L, p, q in zip(rngs, Ls, pre, ref):
+        seeds = p[:L]
+        fail = p[L]
+        r.counter += L
+        np.testing.assert_array_equal(seeds, q.rand_u64(L))
+        assert fail == q.copy().rand_u64(1)[0]
+        assert r.counter == q.counter and r.rand_u64(1)[0] == q.rand_u64(1)[0]
+
+
+def test_contiguous_blocks_of_runs_per_engine():
+    import pytest
+    from pfmi.api import _blocks
+    assert _blocks(64, 8) == [(8 * g, 8 * g + 8) for g in range(8)] and _blocks(5, 1) == [(0, 5)]
+    with pytest.raises(ValueError, match="divisible"):
+        _blocks(10, 4)
