@@ -39,6 +39,7 @@
 #ifndef XW_ABLATE
 #define XW_ABLATE 0                    // timing experiments only: 1 = no global stores, 2 = pass 2 without generator, 3 = no pass 1
 #endif
+#define XW_MIN_FRONT 1024              // doubles in front of the inverse-CDF table (>= (32 - 19) * 32 * 2 = 832)
 #define XW_SR (16 * XW_SB)
 #define XW_LD XW_SR                    // leading dimension of the 16 x XW_SR transposition tile (no padding: rows are XOR-swizzled)
 // binades of the inverse-CDF table kept in LDS: all 19 with 8 waves; 12 (12 KB) with 16 waves, whose tiles need the room at d = 1000
@@ -93,7 +94,9 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
     const int vh_sz = ch_blocks * 16 * KC, sm_sz = XW_SM_LDS ? ch_blocks * 32 : 0;
     const int buf_stride = (nchunks > 1) ? vh_sz + sm_sz : 0;
     const int stage_sz = (nchunks > 1 ? 2 : 1) * (vh_sz + sm_sz);
-    double *t_s = lds + stage_sz;                  // [KC][KC]
+    // the index-clamped fast look-up (pf_icdf_issue_adj) may read up to (32 - XW_NB) binades x 32 x 16 B = 6.5 KB in FRONT of the table:
+    // keep at least that much staged data before it (only matters for d < 64)
+    double *t_s = lds + (stage_sz > XW_MIN_FRONT ? stage_sz : XW_MIN_FRONT);   // [KC][KC]
     double2 *icdf = reinterpret_cast<double2 *>(t_s + KC * KC);                 // [2 * 32 XW_NB]
     double *xt0 = reinterpret_cast<double *>(icdf + 2 * (XW_NB << PF_ICDF_B)) + wv * (NG * 16 * XW_LD);   // this wave's 16 x XW_SR tiles
 
@@ -135,6 +138,7 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
     const uint64_t seed = A.seeds[slot];
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     const double logdet = A.logdet[p];
+    const uint32_t icdf_adj = pf_icdf_adj<XW_NB>(icdf);
     __syncthreads();
 
     int cur = 0;
@@ -146,6 +150,7 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
         bool act[NG], fullc[NG];
         double *xg[NG];
         double accw[NG][NT], ntv[NG][NT], u0[NG][4], usq[NG];
+        uint32_t xnext[NG][4];                                 // Philox words of the next block (software pipeline, see `normals`)
         int nact = 0;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -166,9 +171,23 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
         // SPECIAL: the first / second / last block of the walk (head transform, rows >= d); interior blocks are straight-line code
         auto normals = [&](const int g, const int blk, double (&z)[4], auto first_tag, auto special_tag) {
             constexpr bool FIRST = decltype(first_tag)::value, SPECIAL = decltype(special_tag)::value;
+            // software pipeline over the blocks of a walk: the Philox words of THIS block were computed during the previous block
+            // (xnext), its table reads are issued first, and the Philox call of the NEXT block (7 dependent rounds of pure VALU work)
+            // runs while they are in flight -- a wave's chain Philox -> table -> cubic -> MFMA otherwise pays every latency in turn
             uint32_t x[4];
-            pf_philox_normals(n[g], (uint32_t)(blk * 4 + q), 0u, 0u, k0, k1, x);
-            pf_icdf4<XW_NB>(x, n[g], (uint32_t)(blk * 4 + q), 0u, k0, k1, icdf, z);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = xnext[g][r];
+            {   // the scan's 9-instruction look-up: all four table reads in flight before the first cubic is evaluated
+                double dp[4];
+                double2 c01[4], c23[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pf_icdf_issue_adj<XW_NB>(x[r], icdf_adj, dp[r], c01[r], c23[r]);
+                pf_philox_normals(n[g], (uint32_t)((blk + 1) * 4 + q), 0u, 0u, k0, k1, xnext[g]);   // (one call past the last block: discarded)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z[r] = pf_icdf_finish(x[r], dp[r], c01[r], c23[r]);
+                if (__builtin_expect(__any(pf_icdf_miss4<XW_NB>(x)), 0))         // probability 2^-XW_NB per normal
+                    pf_icdf4_fix<XW_NB>(x, n[g], (uint32_t)(blk * 4 + q), 0u, k0, k1, z);
+            }
             if (SPECIAL && blk == nblk - 1) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) z[r] = (blk * 16 + 4 * q + r < d) ? z[r] : 0.0;
@@ -196,6 +215,8 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
             }
         };
         for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) pf_philox_normals(n[g], (uint32_t)q, 0u, 0u, k0, k1, xnext[g]);      // block 0 of this walk
             for (int ck = 0; ck < nchunks; ++ck) {
                 // ---- streaming: fetch the next chunk of the walk (pass 1 -> pass 2 -> next batch) into registers while this one is used
                 double pre[PRE], pr_s = 0.0, pr_m = 0.0;
@@ -381,7 +402,8 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
 
 // ---------------------------------------------------------------------------------------------------
 static size_t xw_lds_bytes(int ch_blocks, int nchunks, int kc) {
-    const size_t stage = ((size_t)ch_blocks * 16 * kc + (XW_SM_LDS ? (size_t)ch_blocks * 32 : 0)) * (nchunks > 1 ? 2 : 1);
+    size_t stage = ((size_t)ch_blocks * 16 * kc + (XW_SM_LDS ? (size_t)ch_blocks * 32 : 0)) * (nchunks > 1 ? 2 : 1);
+    if (stage < XW_MIN_FRONT) stage = XW_MIN_FRONT;
     return sizeof(double) * (stage + (size_t)kc * kc + 4 * (XW_NB << PF_ICDF_B) + (size_t)XW_WAVES * XW_NG * 16 * XW_LD);
 }
 
