@@ -3,16 +3,34 @@
 // Plays the role of reference src/optimize.jl:35-121 (optimize_with_trace + OptimizationCallback): it PRODUCES the hot
 // path's input, the trace (theta_l, logp_l, grad logp_l), directly in HBM so that fit_batch can consume it without a
 // host round trip.  The reference delegates the optimisation itself to Optim.LBFGS + HagerZhang (third party); this is
-// this repo's own driver -- two-loop recursion with gamma = s'y / y'y, strong-Wolfe bracketing + bisection zoom,
-// maxiters as src/optimize.jl:40, stop at |g|_inf <= g_tol -- the same algorithm as pfmi/optimize.py (host, for
+// this repo's own driver -- L-BFGS direction with gamma = s'y / y'y, strong-Wolfe bracketing + bisection zoom,
+// maxiters as src/optimize.jl:40, stop at |g|_inf <= g_tol -- the same iteration as pfmi/optimize.py (host, for
 // callback targets); tests check it against the scalar C restatement under oracle/.  Built-in targets only
 // (analytic gradients).
 //
 // One persistent workgroup per path (paths are independent, src/multipath.jl:190-208); every vector lives in
-// registers (thread t owns elements t, t+NT, ...), the (s, y) ring lives in LDS when J*d*16 B fits and in an
-// L2-resident scratch otherwise (element i of every history vector is only ever touched by its owner thread, so the
-// ring needs no barriers).  All scalars that steer control flow come out of fixed-order block reductions and are
-// bit-identical in every thread, so the whole workgroup walks the same line-search branches.
+// registers (thread t owns elements t, t+NT, ...), the (s, y) ring lives in LDS when it fits and in an L2-resident
+// scratch otherwise (element i of every history vector is only ever touched by its owner thread, so the ring needs no
+// barriers).  All scalars that steer control flow come out of fixed-order block reductions and are bit-identical in
+// every thread, so the whole workgroup walks the same line-search branches.
+//
+// One path = one workgroup = one chain of dependent steps with a single wave per SIMD: the kernel is bound by LATENCY, so the
+// iteration is arranged around few, wide steps (round 3; round 2 ran the textbook two-loop recursion: 2 h + 5 block reductions
+// and 2 h one-slot-at-a-time sweeps of the ring through flat loads per iteration):
+//   * H g is applied in the compact form of Byrd, Nocedal & Schnabel (1994): H = gamma I + [S gamma Y] M [S'; gamma Y'] with M built from
+//     R = triu(S'Y), D = diag(R) and Y'Y.  Mathematically the two-loop recursion; all it needs are inner products.
+//   * ONE fused reduction when a step is accepted gathers everything the next direction needs: for every pair c of the ring
+//     (s_c'y_new, y_c'y_new, s_c'g_new, y_c'g_new) -- the new column of R and Y'Y and the vectors S'g, Y'g -- plus the curvature test, the
+//     convergence test (count of |g_i| > g_tol), g'g and the "moved / finite" flags: 4 CH + 8 values per CH pairs of the ring.
+//   * the (h x h) triangular solves run in every thread redundantly on a wave-private LDS copy of the Gram data (uniform
+//     addresses = broadcast reads; no barrier, no cross-lane traffic, bit-identical everywhere).
+//   * a function evaluation is ONE reduction: the directional derivative g(x + a p)'p is accumulated in the same sweep
+//     (Gaussian: sum a_i e_i p_i - h'(W~'p); funnel: g_0 p_0 + e^-tau sum x_i p_i) instead of a second dot product.
+//   * the ring is addressed as LDS (ds_read) or as global memory by a template flag, never through a pointer that could be
+//     either, and its rows are padded to EPT * NT so that every sweep is a batch of unconditional loads.
+//   * block reductions: wave butterfly, one barrier, then lane l of every wave sums the waves' partials of value l (instead of every
+//     thread reading all NV x nwaves partials); the few totals a thread needs as scalars are broadcast with v_readlane.
+// 2 + (line-search evaluations) reductions per iteration instead of 2 h + 5.
 #include "pfmi_common.h"
 
 struct LbfgsArgs {
@@ -20,76 +38,170 @@ struct LbfgsArgs {
     double g_tol, offset;
     const double *x0;                       // [K][d]
     const double *mean, *a, *wd, *gm;       // target (TargetDev layout)
-    double *hs, *hy;                        // [K][J][d] scratch ring (used when !hist_in_lds)
+    double *hs, *hy;                        // [K][J][EPT * NT] scratch ring (used when !hist_in_lds)
     double *tr_theta, *tr_grad, *tr_lp;     // staging trace [K][maxiters+1][d], [K][maxiters+1]
     int32_t *npts;                          // [K]
 };
 
+// XGM (the 1024-thread variants, 128 registers per thread): the gradient g of the current point and the target's mean / diagonal are
+// not held in registers but re-read where they are used -- g from the trace row the kernel has just written (record() stores -g of
+// every accepted point; an L2 hit, needed once per iteration), so that x, p, xn, gn (4 EPT doubles) are the vectors a thread carries.
 template <int EPT, int NT, int RPAD>
 struct LbfgsState {
-    double x[EPT], g[EPT], p[EPT], xn[EPT], gn[EPT], mean[EPT], av[EPT];
+    static constexpr bool XGM = NT > 256;
+    static constexpr int NS = XGM ? 1 : EPT;
+    double x[EPT], g[NS], p[EPT], gn[EPT], mean[NS], av[NS];
+    double a_last;                               // the trial point of the last evaluation is XN(e) = fma(a_last, p, x): recomputed, never stored
+    __device__ __forceinline__ double XN(int e) const { return fma(a_last, p[e], x[e]); }
+    const double *grow, *tmean, *ta;             // XGM: trace row of the current point's gradient, the target's vectors
+    __device__ __forceinline__ double G(int e, int i, int d) const { if constexpr (XGM) return i < d ? -grow[i] : 0.0; else return g[e]; }
+    __device__ __forceinline__ double M(int e, int i, int d) const { if constexpr (XGM) return (tmean && i < d) ? tmean[i] : 0.0; else return mean[e]; }
+    __device__ __forceinline__ double AV(int e, int i, int d) const { if constexpr (XGM) return (ta && i < d) ? ta[i] : 0.0; else return av[e]; }
     // this thread's rows of the low-rank target factor, when they fit in registers (256-thread workgroups run one wave per SIMD: 512
     // registers each): both sweeps of every function evaluation used to re-load them from L2 inside the line search's critical path
     static constexpr bool WD_REG = (RPAD > 0) && (EPT * RPAD <= 64);
     double wdr[WD_REG ? EPT : 1][WD_REG ? RPAD : 1];
     const double *gm;                        // r x r factor (LDS copy)
     double fn;
+#ifdef LB_PROF
+    long long ec[4] = {0, 0, 0, 0}, et;
+    int nev = 0;
+#endif
+};
+#ifdef LB_PROF
+#define LB_E0(S) (S).et = clock64()
+#define LB_E(S, i) do { const long long now_ = clock64(); (S).ec[i] += now_ - (S).et; (S).et = now_; } while (0)
+#else
+#define LB_E0(S)
+#define LB_E(S, i)
+#endif
+
+template <int RPAD> struct LbNv {
+    static constexpr int EVAL = (2 * RPAD + 2 + 3) / 4 * 4 < 4 ? 4 : (2 * RPAD + 2 + 3) / 4 * 4;      // values of one function evaluation
+};
+template <int NT> struct LbCh { static constexpr int CH = NT <= 256 ? 6 : 2, LB = NT <= 256 ? 3 : 1; };       // ring pairs per fused reduction / per batch of loads                  // ring pairs per fused reduction
+template <int NT, int RPAD> struct LbRed {
+    static constexpr int G = 4 * LbCh<NT>::CH + 8;
+    static constexpr int NVMAX = LbNv<RPAD>::EVAL > G ? LbNv<RPAD>::EVAL : G;
 };
 
-// f = -logp at xn = x + a p, gn = grad f(xn), dphi = gn . p
+__device__ __forceinline__ double lb_rl(double v, int lane) {          // value of a (uniform) lane, in every lane
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// Block-wide sums of NV values per thread (NV % 4 == 0, NV <= 64), one barrier (ping-pong scratch of 2 * (NT / 64) * NVMAX doubles, as
+// pf_block_sum_mv).  Returns, in lane l of EVERY wave, the total of value l % NVP (NVP = NV rounded up to a power of two; garbage-free
+// zero for l % NVP >= NV): wave stage = pf_block_sum_mv's butterfly; then lane l adds the partials of its value over the waves
+// {g, g + G, ...} (g = l / NVP, G = 64 / NVP) in increasing order and the G groups are combined by xor butterflies (fp addition is
+// commutative: all lanes of a value, in all waves, end with the same bits).
+template <int NV, int NVMAX, int NT>
+__device__ __forceinline__ double lb_block_sum(double (&v)[NV], double *red, int &flip) {
+    static_assert(NV % 4 == 0 && NV <= 64, "lb_block_sum: NV must be a multiple of 4, at most 64");
+    constexpr int NW = NT / 64, NVP = NV <= 4 ? 4 : NV <= 8 ? 8 : NV <= 16 ? 16 : NV <= 32 ? 32 : 64, G = 64 / NVP;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *buf = red + flip * (NW * NVMAX);
+    flip ^= 1;
+    double r[NV / 2], q[NV / 4];
+#pragma unroll
+    for (int j = 0; j < NV / 2; ++j) r[j] = pf_swap32_add(v[j], v[j + NV / 2]);
+#pragma unroll
+    for (int j = 0; j < NV / 4; ++j) q[j] = pf_swap16_add(r[j], r[j + NV / 4]);
+#pragma unroll
+    for (int j = 0; j < NV / 4; ++j) {
+        q[j] = pf_dpp_add<0x111, 0xf>(q[j]);   // row_shr:1
+        q[j] = pf_dpp_add<0x112, 0xf>(q[j]);   // row_shr:2
+        q[j] = pf_dpp_add<0x114, 0xf>(q[j]);   // row_shr:4
+        q[j] = pf_dpp_add<0x118, 0xf>(q[j]);   // row_shr:8  -> lane 15 of each row
+    }
+    if ((lane & 15) == 15) {
+#pragma unroll
+        for (int j = 0; j < NV / 4; ++j) buf[wave * NV + (lane >> 4) * (NV / 4) + j] = q[j];
+    }
+    __syncthreads();
+    const int i = lane & (NVP - 1), g = lane / NVP;
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < (NW + G - 1) / G; ++w) {
+        const int ww = g + w * G;
+        const double part = buf[(ww < NW ? ww : 0) * NV + (i < NV ? i : 0)];
+        s += (ww < NW && i < NV) ? part : 0.0;
+    }
+    if (G >= 2) s = pf_add_xor32(s);
+    if (G >= 4) s = pf_add_xor16(s);
+    if (G >= 8) s += __shfl_xor(s, 8, 64);
+    if (G >= 16) s += __shfl_xor(s, 4, 64);
+    return s;
+}
+
+// f = -logp at xn = x + a p, gn = grad f(xn), dphi = gn . p  -- one block reduction
 template <int EPT, int NT, int RPAD>
 __device__ __forceinline__ void lb_eval(const LbfgsArgs &A, LbfgsState<EPT, NT, RPAD> &S, double a, double *red, int &flip, double &f,
                                         double &dphi) {
     const int tid = threadIdx.x, d = A.d;
-    constexpr int NVP = (RPAD + 2 + 3) / 4 * 4;            // padded to a multiple of 4: multi-value butterfly reduction
+    constexpr int NVP = LbNv<RPAD>::EVAL, NVMAX = LbRed<NT, RPAD>::NVMAX;
     double v[NVP];
+    S.a_last = a;
+#ifdef LB_PROF
+    ++S.nev;
+#endif
 #pragma unroll
     for (int j = 0; j < NVP; ++j) v[j] = 0.0;
     if (A.kind == PFMI_TARGET_FUNNEL) {
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             const int i = tid + e * NT;
-            S.xn[e] = S.x[e] + a * S.p[e];
-            if (i == 0) v[1] = S.xn[e];
-            else if (i < d) v[0] += S.xn[e] * S.xn[e];
+            const double xn = S.XN(e);
+            if (i == 0) { v[1] = xn; v[3] = S.p[e]; }
+            else if (i < d) { v[0] += xn * xn; v[2] += xn * S.p[e]; }
         }
-        pf_block_sum_pp<NVP, RPAD + 4, (NT <= 256 ? NT / 64 : 0)>(v, red, flip);
-        const double tau = v[1], ss = v[0], ee = exp(-tau), dm1 = (double)(d - 1);
+        const double tot = lb_block_sum<NVP, NVMAX, NT>(v, red, flip);
+        const double ss = lb_rl(tot, 0), tau = lb_rl(tot, 1), xp = lb_rl(tot, 2), p0 = lb_rl(tot, 3);
+        const double ee = exp(-tau), dm1 = (double)(d - 1);
         f = 0.5 * ((tau / 3.0) * (tau / 3.0) + dm1 * tau + ee * ss);
+        const double g0v = 0.5 * (2.0 * tau / 9.0 + dm1 - ee * ss);
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             const int i = tid + e * NT;
-            S.gn[e] = (i == 0) ? 0.5 * (2.0 * tau / 9.0 + dm1 - ee * ss) : (i < d ? ee * S.xn[e] : 0.0);
+            S.gn[e] = (i == 0) ? g0v : (i < d ? ee * S.XN(e) : 0.0);
         }
+        dphi = g0v * p0 + ee * xp;
     } else {
         double ev[EPT];
+        LB_E0(S);
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             const int i = tid + e * NT;
-            S.xn[e] = S.x[e] + a * S.p[e];
-            ev[e] = S.xn[e] - S.mean[e];
-            v[0] += S.av[e] * ev[e] * ev[e];
+            ev[e] = S.XN(e) - S.M(e, i, d);
+            const double ae = S.AV(e, i, d) * ev[e];
+            v[0] += ae * ev[e];
+            v[1] += ae * S.p[e];
             if (RPAD > 0 && i < d) {
                 if constexpr (LbfgsState<EPT, NT, RPAD>::WD_REG) {
 #pragma unroll
-                    for (int j = 0; j < RPAD; ++j) v[2 + j] += S.wdr[e][j] * ev[e];
+                    for (int j = 0; j < RPAD; ++j) { v[2 + j] += S.wdr[e][j] * ev[e]; v[2 + RPAD + j] += S.wdr[e][j] * S.p[e]; }
                 } else {
                     const double *row = A.wd + (size_t)i * RPAD;
 #pragma unroll
-                    for (int j = 0; j < RPAD; ++j) v[2 + j] += row[j] * ev[e];
+                    for (int j = 0; j < RPAD; ++j) { const double wj = row[j]; v[2 + j] += wj * ev[e]; v[2 + RPAD + j] += wj * S.p[e]; }
                 }
             }
         }
-        pf_block_sum_pp<NVP, RPAD + 4, (NT <= 256 ? NT / 64 : 0)>(v, red, flip);
-        double corr = 0.0;
+        LB_E(S, 0);
+        const double tot = lb_block_sum<NVP, NVMAX, NT>(v, red, flip);
+        const double qa = lb_rl(tot, 0), qp = lb_rl(tot, 1);
+        LB_E(S, 1);
+        double corr = 0.0, hp = 0.0;
         double hh[RPAD > 0 ? RPAD : 1];
         if (RPAD > 0) {
-            double gg[RPAD > 0 ? RPAD : 1];
+            double we[RPAD > 0 ? RPAD : 1], gg[RPAD > 0 ? RPAD : 1];
+#pragma unroll
+            for (int j = 0; j < RPAD; ++j) we[j] = lb_rl(tot, 2 + j);
 #pragma unroll
             for (int j = 0; j < RPAD; ++j) {
                 double s = 0.0;
 #pragma unroll
-                for (int l = 0; l <= j; ++l) s += S.gm[j * RPAD + l] * v[2 + l];
+                for (int l = 0; l <= j; ++l) s += S.gm[j * RPAD + l] * we[l];
                 gg[j] = s;
                 corr += s * s;
             }
@@ -99,13 +211,16 @@ __device__ __forceinline__ void lb_eval(const LbfgsArgs &A, LbfgsState<EPT, NT, 
 #pragma unroll
                 for (int j = l; j < RPAD; ++j) s += S.gm[j * RPAD + l] * gg[j];
                 hh[l] = s;
+                hp += s * lb_rl(tot, 2 + RPAD + l);
             }
         }
-        f = 0.5 * (v[0] - corr) - A.offset;
+        f = 0.5 * (qa - corr) - A.offset;
+        dphi = qp - hp;                                     // (a e - W~ h)'p
+        LB_E(S, 2);
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             const int i = tid + e * NT;
-            double gv = S.av[e] * ev[e];
+            double gv = S.AV(e, i, d) * ev[e];
             if (RPAD > 0 && i < d) {
                 if constexpr (LbfgsState<EPT, NT, RPAD>::WD_REG) {
 #pragma unroll
@@ -118,74 +233,86 @@ __device__ __forceinline__ void lb_eval(const LbfgsArgs &A, LbfgsState<EPT, NT, 
             }
             S.gn[e] = gv;
         }
+        LB_E(S, 3);
     }
-    double dp = 0.0;
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) dp += S.gn[e] * S.p[e];
-    dphi = pf_block_sum1_pp<RPAD + 4, (NT <= 256 ? NT / 64 : 0)>(dp, red, flip);
     S.fn = f;
 }
 
-template <int EPT, int NT, int RPAD>
-__device__ __forceinline__ void lb_zoom(const LbfgsArgs &A, LbfgsState<EPT, NT, RPAD> &S, double *red, int &flip, double lo, double hi,
-                                        double f_lo, double f0, double g0) {
-    const double c1 = 1e-4, c2 = 0.9;
-    for (int it = 0; it < 30; ++it) {
-        const double a = 0.5 * (lo + hi);
-        double f, g;
-        lb_eval<EPT, NT, RPAD>(A, S, a, red, flip, f, g);
-        if ((f > f0 + c1 * a * g0) || (f >= f_lo)) {
-            hi = a;
-        } else {
-            if (fabs(g) <= -c2 * g0) return;
-            if (g * (hi - lo) >= 0) hi = lo;
-            lo = a; f_lo = f;
-        }
-    }
-}
-
+// Strong-Wolfe line search: bracketing (step doubling) then bisection zoom, as pfmi/optimize.py.  ONE call site of lb_eval (a state
+// machine instead of nested loops): the function evaluation is the bulk of the iteration's code, and this kernel runs a single wave
+// per SIMD straight through its loop body -- three inlined copies pushed the loop past the 64 KB instruction cache.
 template <int EPT, int NT, int RPAD>
 __device__ __forceinline__ void lb_search(const LbfgsArgs &A, LbfgsState<EPT, NT, RPAD> &S, double *red, int &flip, double f0, double g0,
                                           double a_init) {
     const double c1 = 1e-4, c2 = 0.9, amax = 1e10;
-    double a_prev = 0.0, f_prev = f0, a = a_init;
-    for (int it = 0; it < 25; ++it) {
+    double a_prev = 0.0, f_prev = f0, a = a_init, lo = 0.0, hi = 0.0, f_lo = 0.0;
+    int it = 0, zit = 0;
+    bool zoom = false;
+    for (;;) {
         double f, g;
         lb_eval<EPT, NT, RPAD>(A, S, a, red, flip, f, g);
-        if (!isfinite(f)) { a = 0.5 * (a_prev + a); continue; }
-        if ((f > f0 + c1 * a * g0) || (it > 0 && f >= f_prev)) { lb_zoom<EPT, NT, RPAD>(A, S, red, flip, a_prev, a, f_prev, f0, g0); return; }
-        if (fabs(g) <= -c2 * g0) return;
-        if (g >= 0) { lb_zoom<EPT, NT, RPAD>(A, S, red, flip, a, a_prev, f, f0, g0); return; }
-        a_prev = a; f_prev = f;
-        a = fmin(2 * a, amax);
+        if (!zoom) {
+            const int it0 = it++;
+            if (!isfinite(f)) { a = 0.5 * (a_prev + a); if (it >= 25) return; continue; }
+            if ((f > f0 + c1 * a * g0) || (it0 > 0 && f >= f_prev)) { zoom = true; lo = a_prev; hi = a; f_lo = f_prev; }
+            else if (fabs(g) <= -c2 * g0) return;
+            else if (g >= 0) { zoom = true; lo = a; hi = a_prev; f_lo = f; }
+            else { a_prev = a; f_prev = f; a = fmin(2 * a, amax); if (it >= 25) return; continue; }
+        } else {
+            if ((f > f0 + c1 * a * g0) || (f >= f_lo)) {
+                hi = a;
+            } else {
+                if (fabs(g) <= -c2 * g0) return;
+                if (g * (hi - lo) >= 0) hi = lo;
+                lo = a; f_lo = f;
+            }
+            if (++zit >= 30) return;
+        }
+        a = 0.5 * (lo + hi);
     }
 }
 
-template <int EPT, int NT, int RPAD>
+// HL: the (s, y) ring lives in LDS
+template <int EPT, int NT, int RPAD, bool HL>
 __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
+    constexpr int CH = LbCh<NT>::CH, LB = LbCh<NT>::LB, NVG = LbRed<NT, RPAD>::G, NVMAX = LbRed<NT, RPAD>::NVMAX, DP = EPT * NT;
     extern __shared__ double lb_dyn[];
-    __shared__ double red[2 * (NT / 64) * (RPAD + 4)];   // two halves: one barrier per block reduction (pf_block_sum_pp)
+    __shared__ double red[2 * (NT / 64) * NVMAX];        // two halves: one barrier per block reduction
     int flip = 0;
-    __shared__ double s_rho[16], s_al[16];
     __shared__ double s_gm[RPAD > 0 ? RPAD * RPAD : 1];      // the target's r x r Cholesky factor: read in every function evaluation
     if (RPAD > 0) { for (int t = threadIdx.x; t < RPAD * RPAD; t += NT) s_gm[t] = A.gm[t]; __syncthreads(); }
-    const int k = blockIdx.x, tid = threadIdx.x, d = A.d, J = A.J;
-    double *hs = A.hist_in_lds ? lb_dyn : A.hs + (size_t)k * J * d;
-    double *hy = A.hist_in_lds ? lb_dyn + (size_t)J * d : A.hy + (size_t)k * J * d;
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, d = A.d, J = A.J;
+    // wave-private copy of the Gram data: SY[J][J] (s_c'y_c', slot indexed), YY[J][J], U[J] = S'g, W[J] = Y'g, RI[J] = 1 / (s_c'y_c).
+    // Written by lanes of this wave, read by all of them: LDS operations of one wave execute in program order.
+    const int gstride = 2 * J * J + 3 * J;
+    double *GSY = lb_dyn + (size_t)(tid >> 6) * gstride, *GYY = GSY + J * J, *GU = GYY + J * J, *GW = GU + J, *GRI = GW + J;
+    double *ring = lb_dyn + (size_t)(NT / 64) * gstride;            // LDS ring: s at [slot][DP], y behind the J slots of s
+    double *const ghs = A.hs + (size_t)k * J * DP, *const ghy = A.hy + (size_t)k * J * DP;
+    auto ld_s = [&](int slot, int i) -> double { if constexpr (HL) return ring[slot * DP + i]; else return ghs[(size_t)slot * DP + i]; };
+    auto ld_y = [&](int slot, int i) -> double { if constexpr (HL) return ring[(J + slot) * DP + i]; else return ghy[(size_t)slot * DP + i]; };
+    auto st_sy = [&](int slot, int i, double sv_, double yv_) {
+        if constexpr (HL) { ring[slot * DP + i] = sv_; ring[(J + slot) * DP + i] = yv_; }
+        else { ghs[(size_t)slot * DP + i] = sv_; ghy[(size_t)slot * DP + i] = yv_; }
+    };
     const size_t tcap = (size_t)A.maxiters + 1;
     double *tr_theta = A.tr_theta + (size_t)k * tcap * d, *tr_grad = A.tr_grad + (size_t)k * tcap * d;
     double *tr_lp = A.tr_lp + (size_t)k * tcap;
 
     LbfgsState<EPT, NT, RPAD> S;
+    constexpr bool XGM = LbfgsState<EPT, NT, RPAD>::XGM;
     S.gm = s_gm;
+    S.grow = nullptr;
+    S.tmean = A.kind == PFMI_TARGET_GAUSS ? A.mean : nullptr; S.ta = A.kind == PFMI_TARGET_GAUSS ? A.a : nullptr;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int i = tid + e * NT;
         const bool act = i < d;
-        S.x[e] = act ? A.x0[(size_t)k * d + i] : 0.0;
         S.p[e] = 0.0;
-        S.mean[e] = (act && A.kind == PFMI_TARGET_GAUSS) ? A.mean[i] : 0.0;
-        S.av[e] = (act && A.kind == PFMI_TARGET_GAUSS) ? A.a[i] : 0.0;
+        S.x[e] = act ? A.x0[(size_t)k * d + i] : 0.0;
+        if constexpr (!XGM) {
+            S.mean[e] = (act && A.kind == PFMI_TARGET_GAUSS) ? A.mean[i] : 0.0;
+            S.av[e] = (act && A.kind == PFMI_TARGET_GAUSS) ? A.a[i] : 0.0;
+        }
         if constexpr (LbfgsState<EPT, NT, RPAD>::WD_REG) {
 #pragma unroll
             for (int j = 0; j < RPAD; ++j) S.wdr[e][j] = act ? A.wd[(size_t)i * RPAD + j] : 0.0;
@@ -193,115 +320,255 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
     }
     double f, dphi;
     lb_eval<EPT, NT, RPAD>(A, S, 0.0, red, flip, f, dphi);
+    if constexpr (!XGM) {
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) S.g[e] = S.gn[e];
+        for (int e = 0; e < EPT; ++e) S.g[e] = S.gn[e];
+    }
     int n = 0, h = 0, head = 0;
     double gam = 1.0;
     auto record = [&]() {
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             const int i = tid + e * NT;
-            if (i < d) { tr_theta[(size_t)n * d + i] = S.x[e]; tr_grad[(size_t)n * d + i] = -S.g[e]; }
+            if (i < d) { tr_theta[(size_t)n * d + i] = S.x[e]; tr_grad[(size_t)n * d + i] = -S.gn[e]; }      // (gn: the gradient at x, see the callers)
         }
         if (tid == 0) tr_lp[n] = -f;
+        S.grow = tr_grad + (size_t)n * d;                                      // (XGM: every thread re-reads only what it wrote)
         ++n;
     };
     record();
-    for (int it = 0; it < A.maxiters; ++it) {
-        double gm = 0.0;
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) gm = fmax(gm, isfinite(S.g[e]) ? fabs(S.g[e]) : INFINITY);
-        gm = pf_block_max1_pp<RPAD + 4, (NT <= 256 ? NT / 64 : 0)>(gm, red, flip);
-        if (!isfinite(f) || !(gm < INFINITY)) break;                   // src/optimize.jl:103-105
-        if (gm <= A.g_tol) break;
-        // ---- two-loop recursion: q = H g
-        double q[EPT];
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) q[e] = S.g[e];
-        for (int c = h - 1; c >= 0; --c) {
-            const int slot = (head + c) % J;
-            const double *s = hs + (size_t)slot * d, *y = hy + (size_t)slot * d;
-            double sq = 0.0, yv[EPT];
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) {
-                const int i = tid + e * NT;
-                yv[e] = i < d ? y[i] : 0.0;
-                sq += (i < d ? s[i] : 0.0) * q[e];
-            }
-            sq = pf_block_sum1_pp<RPAD + 4, (NT <= 256 ? NT / 64 : 0)>(sq, red, flip);
-            const double al = s_rho[slot] * sq;
-            if (tid == 0) s_al[slot] = al;
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) q[e] -= al * yv[e];
-        }
-        if (h) {
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) q[e] *= gam;
-        }
-        __syncthreads();                                               // s_al visible
-        for (int c = 0; c < h; ++c) {
-            const int slot = (head + c) % J;
-            const double *s = hs + (size_t)slot * d, *y = hy + (size_t)slot * d;
-            double yq = 0.0, sv[EPT];
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) {
-                const int i = tid + e * NT;
-                sv[e] = i < d ? s[i] : 0.0;
-                yq += (i < d ? y[i] : 0.0) * q[e];
-            }
-            yq = pf_block_sum1_pp<RPAD + 4, (NT <= 256 ? NT / 64 : 0)>(yq, red, flip);
-            const double co = s_al[slot] - s_rho[slot] * yq;
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) q[e] += co * sv[e];
-        }
-        double v2[2] = {0.0, 0.0};
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) { S.p[e] = -q[e]; v2[0] += S.g[e] * S.p[e]; v2[1] += S.g[e] * S.g[e]; }
-        pf_block_sum_pp<2, RPAD + 4, (NT <= 256 ? NT / 64 : 0)>(v2, red, flip);
-        double g0 = v2[0];
-        if (g0 >= 0) {                                                  // not a descent direction: restart
-            h = 0; head = 0;
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) S.p[e] = -S.g[e];
-            g0 = -v2[1];
-        }
-        double a0 = 1.0;
-        if (!h) a0 = fmin(1.0, 1.0 / fmax(sqrt(v2[1]), 1e-300));
-        lb_search<EPT, NT, RPAD>(A, S, red, flip, f, g0, a0);
-        // ---- accept the last evaluated point
-        double v4[4] = {0.0, 0.0, 0.0, 0.0};
-        double sv[EPT], yv[EPT];
+    // state of the current point that the fused reduction of the previous acceptance left behind: g'g, #{|g_i| > g_tol}, non-finite flag
+    double gg, nbig, nbad;
+    {
+        double v[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
-            sv[e] = S.xn[e] - S.x[e];
-            yv[e] = S.gn[e] - S.g[e];
-            v4[0] += yv[e] * sv[e];
-            v4[1] += yv[e] * yv[e];
-            v4[2] += (S.xn[e] != S.x[e]) ? 1.0 : 0.0;
-            v4[3] += isfinite(S.gn[e]) ? 0.0 : 1.0;
+            v[0] += S.gn[e] * S.gn[e];
+            v[1] += (fabs(S.gn[e]) > A.g_tol) ? 1.0 : 0.0;
+            v[2] += isfinite(S.gn[e]) ? 0.0 : 1.0;
         }
-        pf_block_sum_pp<4, RPAD + 4, (NT <= 256 ? NT / 64 : 0)>(v4, red, flip);
-        if (!isfinite(S.fn) || v4[3] > 0.0) break;
-        if (v4[0] > 1e-10 * v4[1]) {
-            if (h == J) { head = (head + 1) % J; h = J - 1; }
-            const int slot = (head + h) % J;
-            double *s = hs + (size_t)slot * d, *y = hy + (size_t)slot * d;
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) {
-                const int i = tid + e * NT;
-                if (i < d) { s[i] = sv[e]; y[i] = yv[e]; }
+        const double tot = lb_block_sum<4, NVMAX, NT>(v, red, flip);
+        gg = lb_rl(tot, 0); nbig = lb_rl(tot, 1); nbad = lb_rl(tot, 2);
+    }
+#ifdef LB_PROF
+    long long pc[7] = {0, 0, 0, 0, 0, 0, 0}, pt0 = clock64();
+#define LB_T(i) do { const long long now_ = clock64(); pc[i] += now_ - pt0; pt0 = now_; } while (0)
+#else
+#define LB_T(i)
+#endif
+    for (int it = 0; it < A.maxiters; ++it) {
+        LB_T(5);
+        if (!isfinite(f) || nbad > 0.0) break;                       // src/optimize.jl:103-105
+        if (nbig == 0.0) break;                                     // |g|_inf <= g_tol
+        // ---- direction p = -H g
+        double g0 = 0.0;
+        if (h > 0) {
+            // the two h x h triangular solves on the lanes of every wave (lane i < h = the pair of age i, 0 = oldest; run-time loops: code
+            // size matters more than instruction count here):  t = R^-1 (S'g);  a = R^-T ((D + gamma Y'Y) t - gamma Y'g);
+            // H g = gamma g + S a - gamma Y t
+            const int li = lane < h ? lane : 0;
+            const int sl = head + li - (head + li >= J ? J : 0);
+            double u = GU[sl];
+            const double w = GW[sl], ri = GRI[sl], u0 = u, dd = GSY[sl * J + sl];
+            double t = 0.0, acc = 0.0;
+            auto slot_of = [&](int j) { const int jj = j < 0 ? 0 : (j >= h ? h - 1 : j); return head + jj - (head + jj >= J ? J : 0); };
+            // (the Gram entries of step j -/+ 1 are fetched while step j computes: the recurrence is a chain of cross-lane reads and
+            //  must not wait for an LDS round trip per step as well)
+            double rij = GSY[sl * J + slot_of(h - 1)], yij = GYY[sl * J + slot_of(h - 1)];
+            for (int j = h - 1; j >= 0; --j) {
+                const int sn = slot_of(j - 1);
+                const double rnext = GSY[sl * J + sn], ynext = GYY[sl * J + sn];
+                const double tj = lb_rl(u, j) * lb_rl(ri, j);
+                if (lane == j) t = tj;
+                if (lane < j) u -= rij * tj;
+                acc += yij * tj;
+                rij = rnext; yij = ynext;
             }
-            if (tid == 0) s_rho[slot] = 1.0 / v4[0];
-            gam = v4[0] / v4[1];
-            ++h;
-            __syncthreads();                                           // s_rho visible
+            double z = dd * t + gam * (acc - w), ca = 0.0;
+            double rji = GSY[slot_of(0) * J + sl];
+            for (int j = 0; j < h; ++j) {
+                const double rnext = GSY[slot_of(j + 1) * J + sl];
+                const double aj = lb_rl(z, j) * lb_rl(ri, j);
+                if (lane == j) ca = aj;
+                if (lane > j) z -= rji * aj;
+                rji = rnext;
+            }
+            double s1 = (lane < h) ? u0 * ca - gam * (w * t) : 0.0;          // sum over the h lanes, in lane order
+            {
+                double tot1 = 0.0;
+                for (int i = 0; i < h; ++i) tot1 += lb_rl(s1, i);
+                s1 = tot1;
+            }
+            g0 = -(gam * gg + s1);                                   // g'p
+            LB_T(0);
+            double q[EPT];
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) q[e] = gam * S.G(e, tid + e * NT, d);
+            if constexpr (XGM) {                                     // register-starved variants: no staging, one pair at a time
+                for (int c = 0; c < h; ++c) {
+                    const int slot = head + c - (head + c >= J ? J : 0);
+                    const double cs = lb_rl(ca, c), cy = -gam * lb_rl(t, c);
+#pragma unroll
+                    for (int e = 0; e < EPT; ++e) q[e] += cs * ld_s(slot, tid + e * NT) + cy * ld_y(slot, tid + e * NT);
+                }
+            } else
+            for (int c0 = 0; c0 < h; c0 += LB) {                     // LB pairs per batch of loads
+                double sr[LB][EPT], yr[LB][EPT], cs[LB], cy[LB];
+#pragma unroll
+                for (int cc = 0; cc < LB; ++cc) {
+                    const bool on = c0 + cc < h;
+                    const int c = on ? c0 + cc : 0;
+                    const int slot = head + c - (head + c >= J ? J : 0);
+                    cs[cc] = on ? lb_rl(ca, c) : 0.0;
+                    cy[cc] = on ? -gam * lb_rl(t, c) : 0.0;
+#pragma unroll
+                    for (int e = 0; e < EPT; ++e) { sr[cc][e] = ld_s(slot, tid + e * NT); yr[cc][e] = ld_y(slot, tid + e * NT); }
+                }
+#pragma unroll
+                for (int cc = 0; cc < LB; ++cc)
+#pragma unroll
+                    for (int e = 0; e < EPT; ++e) q[e] += cs[cc] * sr[cc][e] + cy[cc] * yr[cc][e];
+            }
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) S.p[e] = -q[e];
+        }
+        if (h == 0 || !(g0 < 0)) {                                   // first step, or not a descent direction: restart
+            h = 0; head = 0;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) S.p[e] = -S.G(e, tid + e * NT, d);
+            g0 = -gg;
+        }
+        double a0 = 1.0;
+        if (!h) a0 = fmin(1.0, 1.0 / fmax(sqrt(gg), 1e-300));
+        LB_T(1);
+        lb_search<EPT, NT, RPAD>(A, S, red, flip, f, g0, a0);
+        LB_T(2);
+        // ---- accept the last evaluated point: one fused reduction (per CH pairs of the ring) for the curvature test, the stopping
+        //      tests and every inner product of the next direction.  Values 4 cc + {0, 1, 2, 3} = (s_c'y, y_c'y, s_c'g, y_c'g) of ring
+        //      slot c = c0 + cc against the new pair (s, y) and the new gradient g; values 4 CH + {0..7} (first batch only) =
+        //      s'y, y'y, #moved, #non-finite, g'g, #{|g_i| > g_tol}, s'g, y'g.
+        double yv[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) yv[e] = S.gn[e] - S.G(e, tid + e * NT, d);
+        const int slot_new = (h == J) ? head : head + h - (head + h >= J ? J : 0);       // h == J: the oldest pair is replaced
+        double sy = 0.0, yy = 0.0, moved = 0.0;
+        bool take = false, stop = false;
+        for (int pass = 0; pass < 2 && !stop; ++pass) {              // second pass only when the pair fails the curvature test (rare):
+            const int snew = pass == 0 ? slot_new : -1;              // S'g, Y'g of the unchanged ring
+            for (int c0 = 0; c0 < J; c0 += CH) {
+                double v[NVG];
+#pragma unroll
+                for (int j = 0; j < NVG; ++j) v[j] = 0.0;
+                if constexpr (XGM) {
+#pragma unroll
+                    for (int cc = 0; cc < CH; ++cc) {
+                        const int c = c0 + cc;
+                        const int age = c - head + (c < head ? J : 0);
+                        if (c < J && c != snew && age < h) {
+#pragma unroll
+                            for (int e = 0; e < EPT; ++e) {
+                                const double s_ = ld_s(c, tid + e * NT), y_ = ld_y(c, tid + e * NT);
+                                v[4 * cc + 0] += s_ * yv[e];
+                                v[4 * cc + 1] += y_ * yv[e];
+                                v[4 * cc + 2] += s_ * S.gn[e];
+                                v[4 * cc + 3] += y_ * S.gn[e];
+                            }
+                        }
+                    }
+                } else
+#pragma unroll
+                for (int cb = 0; cb < CH; cb += LB) {                          // LB pairs per batch of loads
+                    double sr[LB][EPT], yr[LB][EPT];
+                    bool on[LB];
+#pragma unroll
+                    for (int cc = 0; cc < LB; ++cc) {
+                        const int c = c0 + cb + cc;
+                        const int age = c - head + (c < head ? J : 0);
+                        on[cc] = c < J && c != snew && age < h;               // a live pair of the ring (uniform)
+                        if (on[cc]) {
+#pragma unroll
+                            for (int e = 0; e < EPT; ++e) { sr[cc][e] = ld_s(c, tid + e * NT); yr[cc][e] = ld_y(c, tid + e * NT); }
+                        }
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < LB; ++cc) {
+                        if (on[cc]) {
+#pragma unroll
+                            for (int e = 0; e < EPT; ++e) {
+                                v[4 * (cb + cc) + 0] += sr[cc][e] * yv[e];
+                                v[4 * (cb + cc) + 1] += yr[cc][e] * yv[e];
+                                v[4 * (cb + cc) + 2] += sr[cc][e] * S.gn[e];
+                                v[4 * (cb + cc) + 3] += yr[cc][e] * S.gn[e];
+                            }
+                        }
+                    }
+                }
+                const bool first = c0 == 0 && pass == 0;
+                if (first) {
+#pragma unroll
+                    for (int e = 0; e < EPT; ++e) {
+                        const double xe = S.x[e], xne = S.XN(e), sve = xne - xe;
+                        v[4 * CH + 0] += yv[e] * sve;
+                        v[4 * CH + 1] += yv[e] * yv[e];
+                        v[4 * CH + 2] += (xne != xe) ? 1.0 : 0.0;
+                        v[4 * CH + 3] += isfinite(S.gn[e]) ? 0.0 : 1.0;
+                        v[4 * CH + 4] += S.gn[e] * S.gn[e];
+                        v[4 * CH + 5] += (fabs(S.gn[e]) > A.g_tol) ? 1.0 : 0.0;
+                        v[4 * CH + 6] += sve * S.gn[e];
+                        v[4 * CH + 7] += yv[e] * S.gn[e];
+                    }
+                }
+                LB_T(3);
+                const double tot = lb_block_sum<NVG, NVMAX, NT>(v, red, flip);
+                LB_T(4);
+                if (first) {
+                    sy = lb_rl(tot, 4 * CH + 0); yy = lb_rl(tot, 4 * CH + 1); moved = lb_rl(tot, 4 * CH + 2); nbad = lb_rl(tot, 4 * CH + 3);
+                    gg = lb_rl(tot, 4 * CH + 4); nbig = lb_rl(tot, 4 * CH + 5);
+                    if (!isfinite(S.fn) || nbad > 0.0) { stop = true; break; }
+                    take = sy > 1e-10 * yy;
+                    if (!take) break;
+                }
+                // the lanes that own a total file it in this wave's Gram data
+                const double ri_new = 1.0 / sy;                               // (uniform: every lane has s'y)
+                if (lane < 4 * CH) {
+                    const int cc = lane >> 2, t = lane & 3, c = c0 + cc;
+                    const int age = c - head + (c < head ? J : 0);
+                    if (c < J && c != snew && age < h) {
+                        if (t == 2) GU[c] = tot;
+                        else if (t == 3) GW[c] = tot;
+                        else if (pass == 0) {
+                            if (t == 0) GSY[c * J + slot_new] = tot;
+                            else { GYY[c * J + slot_new] = tot; GYY[slot_new * J + c] = tot; }
+                        }
+                    }
+                } else if (first && lane < NVG) {
+                    const int e = lane - 4 * CH;
+                    if (e == 0) { GSY[slot_new * J + slot_new] = tot; GRI[slot_new] = ri_new; }
+                    else if (e == 1) GYY[slot_new * J + slot_new] = tot;
+                    else if (e == 6) GU[slot_new] = tot;
+                    else if (e == 7) GW[slot_new] = tot;
+                }
+            }
+            if (take) break;
+        }
+        LB_T(6);
+        if (stop) break;
+        if (take) {
+            if (h == J) head = head + 1 == J ? 0 : head + 1; else ++h;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) st_sy(slot_new, tid + e * NT, S.XN(e) - S.x[e], yv[e]);
+            gam = sy / yy;
         }
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) { S.x[e] = S.xn[e]; S.g[e] = S.gn[e]; }
+        for (int e = 0; e < EPT; ++e) { S.x[e] = S.XN(e); if constexpr (!XGM) S.g[e] = S.gn[e]; }
+        S.a_last = 0.0;                                              // XN(e) = x again (the accepted point)
         f = S.fn;
         record();
-        if (!(v4[2] > 0.0)) break;
+        if (!(moved > 0.0)) break;
     }
+#ifdef LB_PROF
+    if (tid == 0 && k == 0) printf("lbprof n=%d evals=%d cycles/iter: algebra %lld combine %lld search %lld (eval: sweep1 %lld reduce %lld small %lld sweep2 %lld) accept: sweep %lld reduce %lld writes %lld rest %lld\n", n, S.nev, pc[0] / n, pc[1] / n, pc[2] / n, S.ec[0] / n, S.ec[1] / n, S.ec[2] / n, S.ec[3] / n, pc[3] / n, pc[4] / n, pc[6] / n, pc[5] / n);
+#endif
     if (tid == 0) A.npts[k] = n;
 }
 
@@ -321,7 +588,7 @@ __global__ void pf_trace_pack_kernel(int d, int64_t cap, const int64_t *__restri
 // ---------------------------------------------------------------------------------------------------
 template <int EPT, int NT, int RPAD>
 static int32_t launch_lb(pfmi_ctx *c, const LbfgsArgs &A, int K, size_t dyn) {
-    auto kern = pf_lbfgs_kernel<EPT, NT, RPAD>;
+    auto kern = A.hist_in_lds ? pf_lbfgs_kernel<EPT, NT, RPAD, true> : pf_lbfgs_kernel<EPT, NT, RPAD, false>;
     if (dyn > 0) PF_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     hipLaunchKernelGGL(kern, dim3(K), dim3(NT), dyn, c->stream, A);
     PF_HIP(hipGetLastError());
@@ -335,8 +602,10 @@ int32_t pf_launch_lbfgs(pfmi_ctx *c, int K, int J, int maxiters, double g_tol, c
     A.d = d; A.J = J; A.maxiters = maxiters; A.kind = T.kind; A.r = T.r; A.g_tol = g_tol; A.offset = T.offset;
     A.x0 = d_x0;
     A.mean = T.mean.as<double>(); A.a = T.a.as<double>(); A.wd = T.wd.as<double>(); A.gm = T.g.as<double>();
-    const size_t hist_bytes = sizeof(double) * 2 * (size_t)J * d;
-    A.hist_in_lds = hist_bytes <= 144 * 1024;
+    const int nt = d <= 256 ? 64 : d <= 1024 ? 256 : 512, ept = d <= 1024 ? 4 : d <= 10240 ? 20 : 32;
+    const size_t hist_bytes = sizeof(double) * 2 * (size_t)J * nt * ept;          // rows padded to EPT * NT
+    const size_t gram_bytes = sizeof(double) * (size_t)(nt / 64) * (2 * J * J + 3 * J);      // wave-private Gram data
+    A.hist_in_lds = hist_bytes + gram_bytes <= 140 * 1024;
     if (!A.hist_in_lds) {
         PF_TRY(c->lb_hs.ensure(hist_bytes / 2 * K));
         PF_TRY(c->lb_hy.ensure(hist_bytes / 2 * K));
@@ -344,16 +613,16 @@ int32_t pf_launch_lbfgs(pfmi_ctx *c, int K, int J, int maxiters, double g_tol, c
     A.hs = c->lb_hs.as<double>(); A.hy = c->lb_hy.as<double>();
     A.tr_theta = c->st_theta.as<double>(); A.tr_grad = c->st_grad.as<double>(); A.tr_lp = c->st_lp.as<double>();
     A.npts = c->st_npts.as<int32_t>();
-    const size_t dyn = A.hist_in_lds ? hist_bytes : 0;
+    const size_t dyn = gram_bytes + (A.hist_in_lds ? hist_bytes : 0);
     const int rp = T.kind == PFMI_TARGET_GAUSS ? T.rpad : 0;
 #define PF_LB(EPT, NT)                                                                    \
     (rp == 0 ? launch_lb<EPT, NT, 0>(c, A, K, dyn)                                        \
              : rp == 8 ? launch_lb<EPT, NT, 8>(c, A, K, dyn) : launch_lb<EPT, NT, 16>(c, A, K, dyn))
     if (d <= 256) return PF_LB(4, 64);                       // a single wave: block reductions need no cross-wave exchange
-    if (d <= 1024) return PF_LB(4, 256);
-    if (d <= 10240) return PF_LB(10, 1024);
+    if (d <= 1024) return PF_LB(4, 256);                     // (2 x 512 threads: 8.9 instead of 6.8 us per iteration -- the reductions span twice the waves)
+    if (d <= 10240) return PF_LB(20, 512);                   // (10 x 1024 threads: 128 registers per thread, the state spills)
     PF_CHECK(d <= 16384, PFMI_ERR_UNSUPPORTED, "optimize_batch: d = %d > 16384 unsupported", d);
-    return PF_LB(16, 1024);
+    return PF_LB(32, 512);
 #undef PF_LB
 }
 

@@ -146,6 +146,9 @@ def test_config5_share_full_ring_vs_oracle(pfmi_mod, eng, tname):
             mu_gpu = eng.get_fit(p0 + l, int(jeff[p0 + l]))["mu"]
             assert np.max(np.abs(mu_gpu - mu_ref)) <= 1e-9 * (1 + np.abs(mu_ref).max()), (k, l)
             n_mu += 1
+            if not (np.isfinite(a) and np.isfinite(b)):         # logp overflows on both sides (funnel: exp(-tau) of a far draw): same value
+                assert (np.isnan(a) and np.isnan(b)) or a == b, (k, l, a, b)
+                continue
             if _wc(F):
                 n_strict += 1
                 assert abs(a - b) <= 1e-8 * (1 + abs(b)), (k, l, a, b)
