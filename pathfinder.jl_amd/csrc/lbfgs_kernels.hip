@@ -35,6 +35,7 @@
 
 struct LbfgsArgs {
     int d, J, maxiters, kind, r, hist_in_lds;
+    int reject_every;                       // test hook (PFMI_LBFGS_REJECT_EVERY): every n-th pair is treated as failing the curvature test
     double g_tol, offset;
     const double *x0;                       // [K][d]
     const double *mean, *a, *wd, *gm;       // target (TargetDev layout)
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
                     sy = lb_rl(tot, 4 * CH + 0); yy = lb_rl(tot, 4 * CH + 1); moved = lb_rl(tot, 4 * CH + 2); nbad = lb_rl(tot, 4 * CH + 3);
                     gg = lb_rl(tot, 4 * CH + 4); nbig = lb_rl(tot, 4 * CH + 5);
                     if (!isfinite(S.fn) || nbad > 0.0) { stop = true; break; }
-                    take = sy > 1e-10 * yy;
+                    take = sy > 1e-10 * yy && !(A.reject_every > 0 && (it + 1) % A.reject_every == 0);
                     if (!take) break;
                 }
                 // the lanes that own a total file it in this wave's Gram data
@@ -601,6 +602,7 @@ int32_t pf_launch_lbfgs(pfmi_ctx *c, int K, int J, int maxiters, double g_tol, c
     LbfgsArgs A;
     A.d = d; A.J = J; A.maxiters = maxiters; A.kind = T.kind; A.r = T.r; A.g_tol = g_tol; A.offset = T.offset;
     A.x0 = d_x0;
+    { const char *rj = getenv("PFMI_LBFGS_REJECT_EVERY"); A.reject_every = rj ? atoi(rj) : 0; }
     A.mean = T.mean.as<double>(); A.a = T.a.as<double>(); A.wd = T.wd.as<double>(); A.gm = T.g.as<double>();
     const int nt = d <= 256 ? 64 : d <= 1024 ? 256 : 512, ept = d <= 1024 ? 4 : d <= 10240 ? 20 : 32;
     const size_t hist_bytes = sizeof(double) * 2 * (size_t)J * nt * ept;          // rows padded to EPT * NT

@@ -65,8 +65,9 @@ def _line_search(fg, x, f0, g0vec, p, a_init, c1=1e-4, c2=0.9, amax=1e10):
     return a, pack
 
 
-def optimize_with_trace(target, x0, history_length=6, maxiters=1000, g_tol=1e-8, fail_on_nonfinite=True):
-    """Minimise f = -logp from x0.  Returns OptimizationTrace (iterate 0 included)."""
+def optimize_with_trace(target, x0, history_length=6, maxiters=1000, g_tol=1e-8, fail_on_nonfinite=True, _reject_every=0):
+    """Minimise f = -logp from x0.  Returns OptimizationTrace (iterate 0 included).  `_reject_every` (tests): every n-th (s, y) pair
+    is treated as failing the curvature test, like the device kernel under PFMI_LBFGS_REJECT_EVERY."""
     def fg(x):
         lp, g = target.logp_and_grad(x)
         return -lp, -g
@@ -106,7 +107,7 @@ def optimize_with_trace(target, x0, history_length=6, maxiters=1000, g_tol=1e-8,
         if not (np.isfinite(fn) and np.all(np.isfinite(gn))):
             break
         s, y = xn - x, gn - g
-        if y @ s > 1e-10 * (y @ y):
+        if y @ s > 1e-10 * (y @ y) and not (_reject_every and (it + 1) % _reject_every == 0):
             S.append(s)
             Y.append(y)
             if len(S) > history_length:

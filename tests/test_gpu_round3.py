@@ -478,3 +478,43 @@ def test_draw_writer_normals_bit_identical_to_oracle(pfmi_mod, eng):
     X, lp, lq = _with_kernel("xw", lambda: eng.draws(0, 0xC0FFEE123456789, N))
     U = po.randn_fill(0xC0FFEE123456789, d, N)
     np.testing.assert_array_equal(X, U)
+
+
+# ---- device L-BFGS: the pair-rejected branch (second gather of S'g, Y'g over the unchanged ring) ---------------------------------
+@pytest.mark.parametrize("name,d,J", [("lr", 200, 6), ("diag", 1500, 4), ("funnel", 40, 6)])
+def test_device_lbfgs_rejected_pairs_follow_the_host_driver(pfmi_mod, name, d, J, monkeypatch):
+    """A strong-Wolfe step always passes the curvature test, so the kernel's `pair rejected' branch (ring left as it is, inner
+    products of the OLD ring with the new gradient gathered in a second pass) never runs on its own: PFMI_LBFGS_REJECT_EVERY=3 drops
+    every third pair, pfmi/optimize.py (the host twin: two-loop recursion in NumPy) does the same, and the iterates must agree
+    -- through several rejections, a full ring and its wrap-around."""
+    from pfmi.optimize import optimize_with_trace
+    tg = {"lr": lambda: pfmi_mod.t_lowrank(d, 8, 2), "diag": lambda: pfmi_mod.t_diag(d, 1), "funnel": lambda: pfmi_mod.t_funnel(d)}[name]()
+    K = 3
+    x0 = pfmi_mod.HostRNG(11).rand(K * d).reshape(K, d) * 4 - 2
+    monkeypatch.setenv("PFMI_LBFGS_REJECT_EVERY", "3")
+    e2 = pfmi_mod.Engine(0)
+    try:
+        e2.set_target(tg)
+        npts = e2.optimize_batch(x0, J, 40)
+        for k in range(K):
+            th, lp, gr = e2.get_trace(k)
+            ref = optimize_with_trace(tg, x0[k], J, 40, _reject_every=3)
+            n = min(len(th), len(ref), 14)
+            assert n >= 10, (n, npts)
+            rt = 1e-5 if name == "funnel" else 1e-7           # (the funnel amplifies roundoff between the two recursions faster)
+            np.testing.assert_allclose(th[:n], ref.points[:n], rtol=rt, atol=rt / 10)
+            np.testing.assert_allclose(gr[:n], ref.gradients[:n], rtol=10 * rt, atol=rt * max(1.0, np.abs(ref.gradients[:n]).max()))
+            assert np.all(np.diff(lp) >= -1e-9 * np.maximum(1.0, np.abs(lp[1:])))
+    finally:
+        e2.close()
+    monkeypatch.delenv("PFMI_LBFGS_REJECT_EVERY")
+    e3 = pfmi_mod.Engine(0)
+    try:                                                     # and without the hook the host twin follows the kernel as well
+        e3.set_target(tg)
+        e3.optimize_batch(x0, J, 40)
+        th, lp, gr = e3.get_trace(0)
+        ref = optimize_with_trace(tg, x0[0], J, 40)
+        n = min(len(th), len(ref), 14)
+        np.testing.assert_allclose(th[:n], ref.points[:n], rtol=rt, atol=rt / 10)
+    finally:
+        e3.close()
