@@ -149,6 +149,7 @@ __device__ __forceinline__ void lb_eval(const LbfgsArgs &A, LbfgsState<EPT, NT, 
 #pragma unroll
     for (int j = 0; j < NVP; ++j) v[j] = 0.0;
     if (A.kind == PFMI_TARGET_FUNNEL) {
+        LB_E0(S);
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             const int i = tid + e * NT;
@@ -156,7 +157,9 @@ __device__ __forceinline__ void lb_eval(const LbfgsArgs &A, LbfgsState<EPT, NT, 
             if (i == 0) { v[1] = xn; v[3] = S.p[e]; }
             else if (i < d) { v[0] += xn * xn; v[2] += xn * S.p[e]; }
         }
+        LB_E(S, 0);
         const double tot = lb_block_sum<NVP, NVMAX, NT>(v, red, flip);
+        LB_E(S, 1);
         const double ss = lb_rl(tot, 0), tau = lb_rl(tot, 1), xp = lb_rl(tot, 2), p0 = lb_rl(tot, 3);
         const double ee = exp(-tau), dm1 = (double)(d - 1);
         f = 0.5 * ((tau / 3.0) * (tau / 3.0) + dm1 * tau + ee * ss);
@@ -167,6 +170,7 @@ __device__ __forceinline__ void lb_eval(const LbfgsArgs &A, LbfgsState<EPT, NT, 
             S.gn[e] = (i == 0) ? g0v : (i < d ? ee * S.XN(e) : 0.0);
         }
         dphi = g0v * p0 + ee * xp;
+        LB_E(S, 3);
     } else {
         double ev[EPT];
         LB_E0(S);
@@ -409,8 +413,16 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
                 for (int c = 0; c < h; ++c) {
                     const int slot = head + c - (head + c >= J ? J : 0);
                     const double cs = lb_rl(ca, c), cy = -gam * lb_rl(t, c);
+                    if constexpr (EPT <= 20) {                        // all loads of the pair in flight before the first use
+                        double sr[EPT], yr[EPT];                      // (32 rows per thread: the staging itself spills -- 167 against 134 us)
 #pragma unroll
-                    for (int e = 0; e < EPT; ++e) q[e] += cs * ld_s(slot, tid + e * NT) + cy * ld_y(slot, tid + e * NT);
+                        for (int e = 0; e < EPT; ++e) { sr[e] = ld_s(slot, tid + e * NT); yr[e] = ld_y(slot, tid + e * NT); }
+#pragma unroll
+                        for (int e = 0; e < EPT; ++e) q[e] += cs * sr[e] + cy * yr[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < EPT; ++e) q[e] += cs * ld_s(slot, tid + e * NT) + cy * ld_y(slot, tid + e * NT);
+                    }
                 }
             } else
             for (int c0 = 0; c0 < h; c0 += LB) {                     // LB pairs per batch of loads
@@ -466,13 +478,19 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
                         const int c = c0 + cc;
                         const int age = c - head + (c < head ? J : 0);
                         if (c < J && c != snew && age < h) {
+                            constexpr int EB = EPT <= 20 ? EPT : 1;               // rows whose loads are issued together
 #pragma unroll
-                            for (int e = 0; e < EPT; ++e) {
-                                const double s_ = ld_s(c, tid + e * NT), y_ = ld_y(c, tid + e * NT);
-                                v[4 * cc + 0] += s_ * yv[e];
-                                v[4 * cc + 1] += y_ * yv[e];
-                                v[4 * cc + 2] += s_ * S.gn[e];
-                                v[4 * cc + 3] += y_ * S.gn[e];
+                            for (int e0 = 0; e0 < EPT; e0 += EB) {
+                                double sr[EB], yr[EB];
+#pragma unroll
+                                for (int e = 0; e < EB; ++e) { sr[e] = ld_s(c, tid + (e0 + e) * NT); yr[e] = ld_y(c, tid + (e0 + e) * NT); }
+#pragma unroll
+                                for (int e = 0; e < EB; ++e) {
+                                    v[4 * cc + 0] += sr[e] * yv[e0 + e];
+                                    v[4 * cc + 1] += yr[e] * yv[e0 + e];
+                                    v[4 * cc + 2] += sr[e] * S.gn[e0 + e];
+                                    v[4 * cc + 3] += yr[e] * S.gn[e0 + e];
+                                }
                             }
                         }
                     }
