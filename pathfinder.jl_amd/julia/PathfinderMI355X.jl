@@ -182,11 +182,11 @@ npaths(b::Batch) = length(b.offsets) - 1
 """
     fit_mvnormals(eng, traces; history_length, ϵ) -> Batch
 
-All runs at once.  `traces[k]` is the `OptimizationTrace` of run k (`.points`, `.gradients`: vectors of vectors,
+All runs at once (`strict`: see below).  `traces[k]` is the `OptimizationTrace` of run k (`.points`, `.gradients`: vectors of vectors,
 src/optimize.jl:94-114).  Replaces `fit_mvnormals` (src/mvnormal.jl:14-21) = `lbfgs_inverse_hessians` + `WoodburyPDMat` +
 `muladd(Σ, ∇logp, θ)` for every trace point.
 """
-function fit_mvnormals(eng::Engine, traces; history_length::Int=Pathfinder.DEFAULT_HISTORY_LENGTH, ϵ::Float64=1e-12)
+function fit_mvnormals(eng::Engine, traces; history_length::Int=Pathfinder.DEFAULT_HISTORY_LENGTH, ϵ::Float64=1e-12, strict::Bool=true)
     K = length(traces)
     npts = Int64[length(t.points) for t in traces]
     d = length(first(first(traces).points))
@@ -200,6 +200,9 @@ function fit_mvnormals(eng::Engine, traces; history_length::Int=Pathfinder.DEFAU
     status = Vector{Int32}(undef, P); jeff = Vector{Int32}(undef, P); nrej = Vector{Int64}(undef, K)
     check(ccall((:pfmi_get_fit_status, libpfmi), Int32, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ptr{Int64}),
                 eng.ptr, status, jeff, C_NULL, nrej))
+    # the reference builds every WoodburyPDMat eagerly, so a non-positive-definite fit throws here (src/woodbury.jl:202,205);
+    # strict = false keeps the library's per-fit status instead (the fit's ELBO is NaN and the argmax skips it)
+    strict && any(!=(0), status) && throw(LinearAlgebra.PosDefException(Int(first(filter(!=(0), status)))))
     return Batch(eng, eng.generation, d, vcat(0, cumsum(npts)), status, jeff, nrej)
 end
 
@@ -556,7 +559,6 @@ function multipathfinder(engines::Vector{Engine}, target::DeviceTarget, ndraws::
     foreach(e -> set_target!(e, target), engines)
     run_seeds = rand!(rng, Vector{UInt64}(undef, nruns))                                                    # :162
     rngs = [Random.seed!(copy(rng), s) for s in run_seeds]                                                  # :189-193
-    resample_seed = nothing
     x0 = [copy(x) for x in _init]
     itry = ones(Int, nruns); pending = collect(1:nruns); success = falses(nruns)
     fit_seeds = [UInt64[] for _ in 1:nruns]; fail_seeds = zeros(UInt64, nruns)
