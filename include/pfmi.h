@@ -90,7 +90,10 @@ int32_t pfmi_sync(pfmi_ctx *ctx);
 /* device-time instrumentation (hipEvents on the ctx stream).  pfmi_timer_* bracket any sequence of
  * calls; pfmi_kernel_time returns accumulated time and launch count of one named kernel family
  * ("history", "fit", "elbo_draws" = ELBO scan, "elbo_draws_x" = draw launches that also write x, "elbo_reduce",
- * "psis", "resample") since pfmi_profile(ctx, 1). */
+ * "psis", "resample") since pfmi_profile(ctx, mode).  mode 1: the host waits after every stage (each stage starts on an idle
+ * GPU: its figure includes the host's launch latency); mode 2: the event pairs stay in the stream and are read by
+ * pfmi_kernel_time (which waits for them) -- the pipeline runs as it does unprofiled and a stage's figure is its kernels'
+ * time; mode 0: off. */
 int32_t pfmi_timer_start(pfmi_ctx *ctx);
 int32_t pfmi_timer_stop(pfmi_ctx *ctx, double *milliseconds);
 int32_t pfmi_profile(pfmi_ctx *ctx, int32_t enable);

@@ -16,11 +16,46 @@ void pf_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+// Stage timers.  Mode 1 (pfmi_profile(ctx, 1)) synchronises the host after every stage: each stage then starts on an idle GPU
+// and its figure includes the host's launch latency (~1 ms for the scan's launch sequence).  Mode 2 leaves the event pairs in the
+// stream and reads them when pfmi_kernel_time asks: the pipeline runs as it does unprofiled, the first event of a stage gets its
+// time stamp when the previous stage's last kernel retires, so a stage's figure is its kernels' time.
+static hipEvent_t pf_kev_get(pfmi_ctx *c) {
+    if (!c->kev_pool.empty()) { hipEvent_t e = c->kev_pool.back(); c->kev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+static void pf_kernel_resolve(pfmi_ctx *c, bool keep) {
+    for (auto &p : c->kpending) {
+        float ms = 0.f;
+        if (keep && p.e0 && p.e1 && hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+            KernelStat &s = c->kstats[p.name];
+            s.ms += ms;
+            s.launches += 1;
+        }
+        if (p.e0) c->kev_pool.push_back(p.e0);
+        if (p.e1) c->kev_pool.push_back(p.e1);
+    }
+    c->kpending.clear();
+}
 void pf_kernel_begin(pfmi_ctx *c) {
-    if (c->profile) (void)hipEventRecord(c->kev0, c->stream);
+    if (c->profile == 1) (void)hipEventRecord(c->kev0, c->stream);
+    else if (c->profile == 2) {
+        if (c->kpending.size() >= 4096) pf_kernel_resolve(c, true);
+        c->kcur = pf_kev_get(c);
+        if (c->kcur) (void)hipEventRecord(c->kcur, c->stream);
+    }
 }
 void pf_kernel_end(pfmi_ctx *c, const char *name) {
-    if (!c->profile) return;
+    if (c->profile == 2) {
+        hipEvent_t e1 = pf_kev_get(c);
+        if (e1) (void)hipEventRecord(e1, c->stream);
+        c->kpending.push_back({name, c->kcur, e1});                   // (name: a string literal of the caller)
+        c->kcur = nullptr;
+        return;
+    }
+    if (c->profile != 1) return;
     (void)hipEventRecord(c->kev1, c->stream);
     (void)hipEventSynchronize(c->kev1);
     float ms = 0.f;
@@ -161,6 +196,8 @@ int32_t pfmi_destroy(pfmi_ctx *c) {
     if (c->arena.base) (void)hipHostFree(c->arena.base);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     (void)hipEventDestroy(c->kev0); (void)hipEventDestroy(c->kev1);
+    pf_kernel_resolve(c, false);
+    for (hipEvent_t e : c->kev_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return PFMI_OK;
@@ -187,13 +224,16 @@ int32_t pfmi_timer_stop(pfmi_ctx *c, double *ms) {
 }
 int32_t pfmi_profile(pfmi_ctx *c, int32_t enable) {
     PF_CTX(c);
-    c->profile = enable != 0;
+    PF_CHECK(enable >= 0 && enable <= 2, PFMI_ERR_ARG, "profile: mode %d outside 0..2", enable);
+    pf_kernel_resolve(c, false);
+    c->profile = enable;
     c->kstats.clear();
     return PFMI_OK;
 }
 int32_t pfmi_kernel_time(pfmi_ctx *c, const char *name, double *ms, int64_t *launches) {
     PF_CTX(c);
     PF_CHECK(name != nullptr, PFMI_ERR_ARG, "null name");
+    pf_kernel_resolve(c, true);                                       // mode 2: waits for the recorded stages
     auto it = c->kstats.find(name);
     if (ms) *ms = (it == c->kstats.end()) ? 0.0 : it->second.ms;
     if (launches) *launches = (it == c->kstats.end()) ? 0 : it->second.launches;

@@ -73,8 +73,12 @@ struct pfmi_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, kev0 = nullptr, kev1 = nullptr;
-    bool profile = false;
+    int profile = 0;                        // pfmi_profile: 0 off, 1 = every stage host-synchronised, 2 = event pairs left in the stream
     std::map<std::string, KernelStat> kstats;
+    struct PendingStat { const char *name; hipEvent_t e0, e1; };
+    std::vector<PendingStat> kpending;      // mode 2: pairs recorded but not read yet
+    std::vector<hipEvent_t> kev_pool;
+    hipEvent_t kcur = nullptr;
     std::set<const void *> lds_attr_done;   // kernels whose dynamic-LDS limit was raised on THIS ctx's device (see pf_raise_lds_limit)
     PinArena arena;                         // staging of small uploads (pf_upload)
     int ncu = 0;                            // compute units of the device

@@ -82,7 +82,8 @@ class Engine:
         return ms.value
 
     def profile(self, enable=True):
-        check(self.L.pfmi_profile(self.ctx, C.c_int32(1 if enable else 0)))
+        """True / 1: every stage host-synchronised; 2: event pairs left in the stream (read by kernel_time); False / 0: off"""
+        check(self.L.pfmi_profile(self.ctx, C.c_int32(int(enable))))
 
     def kernel_time(self, name):
         ms, n = C.c_double(), C.c_int64()

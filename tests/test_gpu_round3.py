@@ -518,3 +518,38 @@ def test_device_lbfgs_rejected_pairs_follow_the_host_driver(pfmi_mod, name, d, J
         np.testing.assert_allclose(th[:n], ref.points[:n], rtol=rt, atol=rt / 10)
     finally:
         e3.close()
+
+
+# ---- stage timers: host-synchronised (mode 1) and in-stream (mode 2) ---------------------------------------------------------------
+def test_profile_modes_agree_and_do_not_change_results(pfmi_mod):
+    """pfmi_profile(ctx, 2) leaves the hipEvent pairs in the stream (the pipeline runs as unprofiled) and pfmi_kernel_time reads them:
+    same launch counts as mode 1, times of the same order (mode 1 adds the host's launch latency to every stage), identical results."""
+    d, K, J, N = 64, 6, 6, 256
+    tg = pfmi_mod.t_lowrank(d, 8, 2)
+    x0 = pfmi_mod.HostRNG(4).rand(K * d).reshape(K, d) * 4 - 2
+    out = {}
+    e = pfmi_mod.Engine(0)
+    try:
+        e.set_target(tg)
+        for mode in (0, 1, 2):
+            e.profile(mode)
+            e.optimize_batch(x0, J)
+            seeds = fit_seeds(e.P, 2)
+            for _ in range(3):
+                e.fit_batch(J)
+                e.elbo_batch_enqueue(N, seeds)
+                e.pool_build_best(N, np.arange(K, dtype=np.uint64))
+                res = e.elbo_batch_wait()
+            out[mode] = (res, {n: e.kernel_time(n) for n in ("optimize", "history", "fit", "elbo_draws", "elbo_draws_x", "elbo_reduce")})
+        with pytest.raises(pfmi_mod.PfmiError):
+            e.profile(3)
+    finally:
+        e.close()
+    for mode in (1, 2):
+        for a, b in zip(out[0][0], out[mode][0]):
+            np.testing.assert_array_equal(a, b)
+    assert all(v == (0.0, 0) for v in out[0][1].values())
+    for name, (ms1, n1) in out[1][1].items():
+        ms2, n2 = out[2][1][name]
+        assert n1 == n2 and n1 >= 1, (name, n1, n2)
+        assert 0.0 < ms2 <= ms1 * 1.5 + 0.05, (name, ms1, ms2)       # in-stream figures carry no launch latency: never much above mode 1
