@@ -244,8 +244,9 @@ __device__ __forceinline__ void lb_eval(const LbfgsArgs &A, LbfgsState<EPT, NT, 
 }
 
 // Strong-Wolfe line search: bracketing (step doubling) then bisection zoom, as pfmi/optimize.py.  ONE call site of lb_eval (a state
-// machine instead of nested loops): the function evaluation is the bulk of the iteration's code, and this kernel runs a single wave
-// per SIMD straight through its loop body -- three inlined copies pushed the loop past the 64 KB instruction cache.
+// machine instead of nested loops): the function evaluation is the bulk of the iteration's code; with the nested form (three inlined
+// copies, 37 instead of 26 KB) the kernel is 9 % slower (1.64 against 1.50 ms at config 3: register allocation across the copies --
+// NOT the instruction cache: SQC_ICACHE_MISSES stay ~1000 per launch either way, profiles/r03_experiments.md section 6).
 template <int EPT, int NT, int RPAD>
 __device__ __forceinline__ void lb_search(const LbfgsArgs &A, LbfgsState<EPT, NT, RPAD> &S, double *red, int &flip, double f0, double g0,
                                           double a_init) {
@@ -368,8 +369,8 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
         // ---- direction p = -H g
         double g0 = 0.0;
         if (h > 0) {
-            // the two h x h triangular solves on the lanes of every wave (lane i < h = the pair of age i, 0 = oldest; run-time loops: code
-            // size matters more than instruction count here):  t = R^-1 (S'g);  a = R^-T ((D + gamma Y'Y) t - gamma Y'g);
+            // the two h x h triangular solves on the lanes of every wave (lane i < h = the pair of age i, 0 = oldest; run-time loops: the
+            // unrolled per-thread form on registers was four times slower):  t = R^-1 (S'g);  a = R^-T ((D + gamma Y'Y) t - gamma Y'g);
             // H g = gamma g + S a - gamma Y t
             const int li = lane < h ? lane : 0;
             const int sl = head + li - (head + li >= J ? J : 0);
