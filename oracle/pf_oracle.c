@@ -1036,7 +1036,12 @@ int pfo_optimize_trace(int kind, int d, int r, const double *mean, const double 
         if (!lc.evaluated) break;
         int ok = isfinite(lc.fn);
         for (int i = 0; i < d; ++i) if (!isfinite(gn[i])) ok = 0;
-        if (!ok) break;
+        if (!ok) {                                    /* src/optimize.jl:96-105: the offending iterate is recorded, then the run stops */
+            memcpy(pts + (size_t)n * d, xn, sizeof(double) * d); lps[n] = -lc.fn;
+            for (int i = 0; i < d; ++i) grads[(size_t)n * d + i] = -gn[i];
+            ++n;
+            break;
+        }
         double ys = 0.0, yy = 0.0;
         int moved = 0;
         for (int i = 0; i < d; ++i) {

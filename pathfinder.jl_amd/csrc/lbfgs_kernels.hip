@@ -572,7 +572,14 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
             if (take) break;
         }
         LB_T(6);
-        if (stop) break;
+        if (stop) {                                                  // src/optimize.jl:96-105: the offending iterate is recorded, then the run stops
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) S.x[e] = S.XN(e);
+            S.a_last = 0.0;
+            f = S.fn;
+            record();
+            break;
+        }
         if (take) {
             if (h == J) head = head + 1 == J ? 0 : head + 1; else ++h;
 #pragma unroll

@@ -105,6 +105,9 @@ def optimize_with_trace(target, x0, history_length=6, maxiters=1000, g_tol=1e-8,
             break
         xn, fn, gn = pack
         if not (np.isfinite(fn) and np.all(np.isfinite(gn))):
+            # the reference's callback RECORDS the offending iterate and then stops (src/optimize.jl:96-105: NaN / +Inf log density
+            # or a non-finite gradient; this driver also stops on logp = -Inf, which no line search accepts anyway)
+            pts.append(np.array(xn, dtype=np.float64)); lps.append(-fn); grads.append(-np.array(gn, dtype=np.float64))
             break
         s, y = xn - x, gn - g
         if y @ s > 1e-10 * (y @ y) and not (_reject_every and (it + 1) % _reject_every == 0):

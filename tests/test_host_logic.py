@@ -101,3 +101,30 @@ def test_contiguous_blocks_of_runs_per_engine():
     assert _blocks(64, 8) == [(8 * g, 8 * g + 8) for g in range(8)] and _blocks(5, 1) == [(0, 5)]
     with pytest.raises(ValueError, match="divisible"):
         _blocks(10, 4)
+
+
+def test_host_driver_records_the_nonfinite_iterate_then_stops():
+    """reference src/optimize.jl:96-105: the callback pushes (x, fx, grad) and THEN returns true for NaN / +Inf log density or a
+    non-finite gradient -- the offending iterate is the last point of the trace"""
+    import numpy as np
+    from pfmi.optimize import optimize_with_trace
+
+    class T:
+        def logp_and_grad(self, x):
+            g = -x.copy()
+            if np.max(np.abs(x)) < 0.5:
+                g[0] = np.nan                      # gradient breaks near the optimum
+            return float(-0.5 * (x @ x)), g
+
+    tr = optimize_with_trace(T(), np.array([3.0, -2.0, 1.5]), 6, 100)
+    assert len(tr) >= 2
+    assert np.all(np.isfinite(tr.gradients[:-1])) and np.all(np.isfinite(tr.points))
+    assert not np.all(np.isfinite(tr.gradients[-1]))
+    assert np.isfinite(tr.log_densities[-1])
+
+    class U(T):
+        def logp_and_grad(self, x):
+            return (float("nan") if abs(x[0]) < 1.0 else float(-0.5 * (x @ x))), -x.copy()
+
+    tr = optimize_with_trace(U(), np.array([3.0, -2.0, 1.5]), 6, 100)
+    assert np.isnan(tr.log_densities[-1]) and np.all(np.isfinite(tr.log_densities[:-1]))
