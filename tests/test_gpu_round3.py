@@ -553,3 +553,27 @@ def test_profile_modes_agree_and_do_not_change_results(pfmi_mod):
         ms2, n2 = out[2][1][name]
         assert n1 == n2 and n1 >= 1, (name, n1, n2)
         assert 0.0 < ms2 <= ms1 * 1.5 + 0.05, (name, ms1, ms2)       # in-stream figures carry no launch latency: never much above mode 1
+
+
+# ---- random shapes: every kernel route against its sibling and the history walk against the oracle -------------------------------------
+@pytest.mark.timeout(900)
+def test_fuzz_random_shapes_cross_kernel_consistency():
+    """tests/probes/fuzz_probe.py with a fixed seed: 40 random (d, J, K, N, target) cases, d from 3 to 7000 -- single-pass scan vs
+    lane kernel per draw, register / panel vs memory-resident fit kernel, history walk vs the oracle, on device-made traces."""
+    import json
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "probes", "fuzz_probe.py"), "7", "40"], capture_output=True, text=True,
+                         timeout=800, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("cases")][-1]
+    assert "MISMATCH" not in out.stdout, out.stdout[-2000:]
+    assert re.search(r"cases 40 pattern mismatches 0 ", line), line
+    worst = json.loads(line[line.index("{"):].replace("'", '"'))
+    print(line)
+    for key in ("lp", "lq", "elbo", "alpha"):
+        assert worst[key] <= 1e-9, (key, worst)
+    for key in ("ld", "mu"):
+        assert worst[key] <= 1e-7, (key, worst)
