@@ -682,10 +682,13 @@ function resample(result::Pathfinder.MultiPathfinderResult, ndraws::Int; rng::Ra
     else                                                              # src/resample.jl:102-109
         N_r = ndraws_per_run; seeds = rand(rng, UInt64, K)
     end
-    psis_result = _compute_psis_result(b, pts, seeds, N_r; importance)
+    psis_result = _compute_psis_result(b, pts, seeds, N_r; importance)     # (re)pools on the device; for stored draws the same values
     draws_, ids = _resample(b, rng, psis_result, N_r, K, ndraws; replace)
+    # stored draws + stored PSIS: the reference hands the SAME object on (src/resample.jl:31-41, test/multipath.jl:158)
+    psis_out = (importance && ndraws_per_run === nothing && result.psis_result !== nothing &&
+                length(result.psis_result.weights) == K * N_r) ? result.psis_result : psis_result
     return Pathfinder.MultiPathfinderResult(result.input, result.optimizer, result.rng, result.optim_fun, result.logp,
-                                            result.fit_distribution, draws_, ids, result.fit_distribution, draws_, runs, psis_result)
+                                            result.fit_distribution, draws_, ids, result.fit_distribution, draws_, runs, psis_out)
 end
 
 # ---- multi-GPU collectives (the `Comm` type itself is defined next to `Engine`) ---------------------------------------------------------

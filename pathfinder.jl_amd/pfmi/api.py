@@ -668,7 +668,13 @@ def resample(result, ndraws, *, rng=None, replace=True, importance=True, ndraws_
     res, draws, ids = _resample(rng, _comm_for(engs), importance, npr, ndraws, replace=replace)
     psis_result = None
     if importance:
-        w, lw = engs[0].psis_weights(S)
-        psis_result = PSISResult(w, lw, res["pareto_shape"], res["tail_length"])
+        if ndraws_per_run is None and result.psis_result is not None and len(result.psis_result.weights) == S:
+            # stored draws + stored PSIS: the reference hands the SAME object on (:31-41).  (A result of a fresh-candidate resample
+            # stores weights of ITS candidates, not of pathfinder_results[k].draws: the reference would pair them with the wrong pool
+            # and fail on the length; here the stored pool's PSIS is recomputed instead.)
+            psis_result = result.psis_result
+        else:
+            w, lw = engs[0].psis_weights(S)
+            psis_result = PSISResult(w, lw, res["pareto_shape"], res["tail_length"])
     return MultiPathfinderResult(result.input, result.rng, result.logp, result.fit_distribution, draws, ids,
                                  runs, psis_result, engs[0], npr, engs)

@@ -577,3 +577,58 @@ def test_fuzz_random_shapes_cross_kernel_consistency():
         assert worst[key] <= 1e-9, (key, worst)
     for key in ("ld", "mu"):
         assert worst[key] <= 1e-7, (key, worst)
+
+
+# ---- resample(::MultiPathfinderResult), scenario by scenario as the reference tests it -----------------------------------------------
+def test_resample_multipathfinder_result_like_reference_testset(pfmi_mod):
+    """reference test/multipath.jl:142-230: dim = 5, nruns = 4, ndraws_per_run = 20, ndraws_new = 8, logp = -|x|^2 / 2"""
+    dim, nruns, npr, nnew = 5, 4, 20, 8
+    tg = pfmi_mod.t_iso(dim)
+    result = pfmi_mod.multipathfinder(tg, npr, nruns=nruns, ndraws_per_run=npr, rng=pfmi_mod.HostRNG(42))
+    pool = lambda res: np.concatenate([r.draws for r in res.pathfinder_results], axis=1)                 # mapreduce(x -> x.draws, hcat, ...)
+    in_pool = lambda cols, P: all(any(np.array_equal(c, P[:, q]) for q in range(P.shape[1])) for c in cols.T)
+
+    # resample existing draws with replacement (:153-165)
+    r2 = pfmi_mod.resample(result, nnew)
+    assert isinstance(r2, pfmi_mod.MultiPathfinderResult)
+    assert r2.draws.shape == (dim, nnew) and len(r2.draw_component_ids) == nnew
+    assert len(np.unique(r2.draw_component_ids)) <= nruns
+    assert r2.draws_transformed is r2.draws or np.array_equal(r2.draws_transformed, r2.draws)
+    assert r2.psis_result is result.psis_result
+    assert in_pool(r2.draws, pool(result))
+    # component_ids consistent with draws (test/resample.jl:51-59): every draw is a column of ITS component's block
+    P = pool(result)
+    for c, cid in zip(r2.draws.T, r2.draw_component_ids):
+        blk = P[:, (cid - 1) * npr:cid * npr]
+        assert any(np.array_equal(c, blk[:, q]) for q in range(npr))
+
+    # without replacement (:167-175)
+    r3 = pfmi_mod.resample(result, nnew, replace=False)
+    assert r3.draws.shape == (dim, nnew) and in_pool(r3.draws, pool(result))
+    assert len({c.tobytes() for c in r3.draws.T}) == nnew
+
+    # without importance (:177-184)
+    r4 = pfmi_mod.resample(result, nnew, importance=False)
+    assert r4.psis_result is None and in_pool(r4.draws, pool(result))
+
+    # with importance, no stored PSIS (:186-198)
+    result_no_psis = pfmi_mod.multipathfinder(tg, npr, nruns=nruns, ndraws_per_run=npr, rng=pfmi_mod.HostRNG(42), importance=False,
+                                              engine=result.engine)
+    assert result_no_psis.psis_result is None
+    r5 = pfmi_mod.resample(result_no_psis, nnew)
+    assert isinstance(r5, pfmi_mod.MultiPathfinderResult) and isinstance(r5.psis_result, pfmi_mod.PSISResult)
+    assert in_pool(r5.draws, pool(result_no_psis))
+
+    # generate new draws (:200-207), also without importance (:209-215)
+    r6 = pfmi_mod.resample(result_no_psis, nnew, ndraws_per_run=50, replace=True)
+    assert r6.draws.shape == (dim, nnew) and len(r6.draw_component_ids) == nnew and isinstance(r6.psis_result, pfmi_mod.PSISResult)
+    r7 = pfmi_mod.resample(result_no_psis, nnew, ndraws_per_run=50, importance=False, replace=True)
+    assert r7.draws.shape == (dim, nnew) and r7.psis_result is None
+
+    # non-mutating (:217-221), preserved fields (:223-230)
+    before = result_no_psis.draws.copy()
+    r8 = pfmi_mod.resample(result_no_psis, nnew)
+    np.testing.assert_array_equal(result_no_psis.draws, before)
+    assert r8.input is result_no_psis.input and r8.fit_distribution is result_no_psis.fit_distribution
+    assert r8.fit_distribution_transformed is result_no_psis.fit_distribution_transformed
+    assert r8.pathfinder_results is result_no_psis.pathfinder_results and r8.logp is result_no_psis.logp
