@@ -128,3 +128,23 @@ def test_host_driver_records_the_nonfinite_iterate_then_stops():
 
     tr = optimize_with_trace(U(), np.array([3.0, -2.0, 1.5]), 6, 100)
     assert np.isnan(tr.log_densities[-1]) and np.all(np.isfinite(tr.log_densities[:-1]))
+
+
+def test_uniform_sampler_and_argument_errors_like_reference_testsets():
+    """reference test/singlepath.jl:139-153 (UniformSampler), :166-171 and test/multipath.jl:100-105 (ArgumentErrors)"""
+    import numpy as np
+    import pfmi
+    for bad in (-1.0, 0.0):
+        with pytest.raises(ValueError):                          # DomainError
+            pfmi.UniformSampler(bad)
+    for scale in (1, 2):
+        for seed in (42, 38):
+            sampler = pfmi.UniformSampler(scale)
+            x = sampler(pfmi.HostRNG(seed), np.zeros(100))
+            assert np.all((-scale <= x) & (x <= scale))
+            x2 = pfmi.HostRNG(seed).rand(100) * 2 * scale - scale       # x2 .= rand.(rng) .* 2scale .- scale
+            np.testing.assert_array_equal(x2, x)
+    with pytest.raises(ValueError):                              # pathfinder(logp): neither dim nor init
+        pfmi.pathfinder(pfmi.CallbackTarget(0, lambda x: 0.0))
+    with pytest.raises(ValueError):                              # multipathfinder(l, 10; nruns = 0)
+        pfmi.multipathfinder(pfmi.t_iso(5), 10, nruns=0)

@@ -227,3 +227,53 @@ def test_oracle_lbfgs_driver_matches_host_driver_and_converges():
         for l in (0, len(P) // 2, len(P) - 1):            # the recorded (logp, grad) belong to the recorded point
             lp, g = po.logp_grad(ot, P[l])
             assert abs(lp - L[l]) <= 1e-12 * max(1, abs(lp)) and np.allclose(g, G[l], rtol=1e-12, atol=1e-14)
+
+
+def test_inverse_hessian_reproduces_the_lbfgs_direction_on_the_banana():
+    """reference test/inverse_hessian.jl:46-77: with the optimiser's own initialisation H0 = (y's / y'y) I (`nocedal_wright_scaling`)
+    the compact-form inverse Hessian of every trace point, applied to the gradient, is the direction the L-BFGS optimiser actually
+    took: dot(p, s) / (|p| |s|) = 1, and no update is rejected.  The trace comes from this repo's host driver (two-loop recursion,
+    the same initialisation); the inverse Hessian from the oracle's restatement of src/inverse_hessian.jl:98-133."""
+    from pfmi.optimize import optimize_with_trace
+    n, J, b = 10, 5, 0.03
+    sig = np.r_[100.0, np.ones(n - 1)]
+
+    class Banana:                                           # test/test_utils.jl:29-36
+        def logp_and_grad(self, x):
+            y = x.copy()
+            y[1] = x[1] + b * (x[0] ** 2 - 100.0)
+            w = y / sig
+            g = -w.copy()
+            g[0] += -w[1] * 2 * b * x[0]
+            return float(-0.5 * (y @ w)), g
+
+    rng = np.random.default_rng(7)
+    total = 0
+    for _ in range(4):
+        tr = optimize_with_trace(Banana(), 10 * rng.normal(size=n), J, 1000)
+        total += len(tr)
+        _check_directions(tr, n, J)
+    assert total > 40
+
+
+def _check_directions(tr, n, J):
+    P, G = tr.points, tr.gradients
+    S, Y, nrej, cosines = [], [], 0, []
+    alpha = np.ones(n)                                      # H0 = I before the first update (src/inverse_hessian.jl:38-39)
+    for l in range(len(tr) - 1):
+        if l > 0:
+            s, y = P[l] - P[l - 1], G[l - 1] - G[l]         # :45-46
+            if y @ s > 1e-12 * (y @ y):                     # :47
+                S.append(s); Y.append(y)
+                S, Y = S[-J:], Y[-J:]
+                alpha = np.full(n, (y @ s) / (y @ y))       # nocedal_wright_scaling
+            else:
+                nrej += 1
+        H = np.diag(alpha)
+        if S:
+            B, D = po.lbfgs_inverse_hessian(alpha, np.array(S).T, np.array(Y).T)
+            H = H + B @ D @ B.T
+        p, step = H @ G[l], P[l + 1] - P[l]
+        cosines.append((p @ step) / np.linalg.norm(p) / np.linalg.norm(step))
+    assert nrej == 0
+    np.testing.assert_allclose(cosines, 1.0, rtol=0, atol=1e-8)
