@@ -774,5 +774,12 @@ materialise(W::DeviceWoodbury) = fit_distribution(W.b, W.point).Σ
 Base.inv(W::DeviceWoodbury) = inv(materialise(W))
 Base.:*(W::DeviceWoodbury, c::Real) = materialise(W) * c
 Base.:*(c::Real, W::DeviceWoodbury) = W * c
+# the rest of what test/woodbury.jl:228-309 exercises: symmetric, + UniformScaling through the materialised matrix, right division
+Base.adjoint(W::DeviceWoodbury) = W
+Base.transpose(W::DeviceWoodbury) = W
+Base.:+(W::DeviceWoodbury, c::LinearAlgebra.UniformScaling) = materialise(W) + c
+Base.:+(c::LinearAlgebra.UniformScaling, W::DeviceWoodbury) = c + materialise(W)
+Base.:/(x::AbstractVecOrMat{Float64}, W::DeviceWoodbury) = Matrix(transpose(W \ Matrix(transpose(x))))
+PDMats.dim(W::DeviceWoodbury) = W.b.dim
 
 end # module

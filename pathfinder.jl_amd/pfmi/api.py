@@ -130,6 +130,24 @@ class WoodburyPDMat:                # src/woodbury.jl:246-257
 
     __rmul__ = __mul__
 
+    # the rest of the surface the reference tests (test/woodbury.jl:228-309)
+    @property
+    def dim(self): return len(self.A)                               # PDMats.dim, src/woodbury.jl:367
+
+    @property
+    def T(self): return self                                        # adjoint / transpose: W is symmetric (src/woodbury.jl:313-315)
+
+    def __add__(self, c):
+        """W + c I (src/woodbury.jl:333-338: through PDMats' ScalMat sum, i.e. a dense matrix)"""
+        return self.dense() + float(c) * np.eye(len(self.A))
+
+    __radd__ = __add__
+
+    def rdiv(self, X):
+        """X / W for row vectors / row blocks (n,) or (r, n): (W \\ X')' with the device solve (test/woodbury.jl:299-305)"""
+        X = np.asarray(X, dtype=np.float64)
+        return self.solve(X.T.copy()).T if X.ndim == 2 else self.solve(X)
+
 
 @dataclass
 class MvNormal:

@@ -632,3 +632,22 @@ def test_resample_multipathfinder_result_like_reference_testset(pfmi_mod):
     assert r8.input is result_no_psis.input and r8.fit_distribution is result_no_psis.fit_distribution
     assert r8.fit_distribution_transformed is result_no_psis.fit_distribution_transformed
     assert r8.pathfinder_results is result_no_psis.pathfinder_results and r8.logp is result_no_psis.logp
+
+
+def test_woodbury_remaining_surface_like_reference_testsets(pfmi_mod):
+    """reference test/woodbury.jl:228-309 on a fitted covariance of a real run: adjoint / transpose, + UniformScaling, right division,
+    PDMats.dim (the operators themselves: test_gpu_parity.py::test_woodbury_operator_surface)"""
+    tg = pfmi_mod.t_lowrank(12, 3, 5)
+    res = pfmi_mod.pathfinder(tg, init=np.linspace(-1.0, 1.0, 12), rng=pfmi_mod.HostRNG(3), ndraws=10)
+    W = res.fit_distribution.Sigma
+    Wm = W.dense()
+    n = 12
+    assert W.T is W and W.dim == n
+    c = 0.37
+    np.testing.assert_allclose(W + c, Wm + c * np.eye(n), rtol=1e-12)
+    np.testing.assert_allclose(c + W, c * np.eye(n) + Wm, rtol=1e-12)
+    rng = np.random.default_rng(2)
+    x = rng.normal(size=n)
+    np.testing.assert_allclose(W.rdiv(x), np.linalg.solve(Wm, x), rtol=1e-7, atol=1e-9)          # x' / W = (W \ x)'
+    X = rng.normal(size=(2, n))
+    np.testing.assert_allclose(W.rdiv(X), np.linalg.solve(Wm, X.T).T, rtol=1e-7, atol=1e-9)
