@@ -651,3 +651,36 @@ def test_woodbury_remaining_surface_like_reference_testsets(pfmi_mod):
     np.testing.assert_allclose(W.rdiv(x), np.linalg.solve(Wm, x), rtol=1e-7, atol=1e-9)          # x' / W = (W \ x)'
     X = rng.normal(size=(2, n))
     np.testing.assert_allclose(W.rdiv(X), np.linalg.solve(Wm, X.T).T, rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.parametrize("name,d,J,maxit", [("lr", 40, 1, 60), ("diag", 300, 2, 80), ("lr", 700, 10, 200), ("diag", 90, 16, 200), ("funnel", 20, 16, 60),
+                                            ("lr", 2000, 16, 60), ("diag", 2500, 1, 40)])
+def test_device_lbfgs_history_lengths_1_to_16(pfmi_mod, name, d, J, maxit):
+    """the fused reduction of the device L-BFGS handles the ring in batches of 6 (d <= 1024) or 2 (d > 1024) pairs: history lengths
+    that are one batch, several batches and a ragged last batch, a ring of one pair (every update evicts), on every workgroup shape --
+    against the oracle driver (first iterates to roundoff) and by its own invariants (monotone, converged, recorded values consistent)."""
+    tg = {"lr": lambda: pfmi_mod.t_lowrank(d, 8, 2), "diag": lambda: pfmi_mod.t_diag(d, 1), "funnel": lambda: pfmi_mod.t_funnel(d)}[name]()
+    ot = oracle_target(tg)
+    K = 2
+    sc = 10.0 if name == "funnel" else 2.0
+    x0 = pfmi_mod.HostRNG(13).rand(K * d).reshape(K, d) * 2 * sc - sc
+    e = pfmi_mod.Engine(0)
+    try:
+        e.set_target(tg)
+        npts = e.optimize_batch(x0, J, maxit)
+        assert np.all(npts >= 2)
+        for k in range(K):
+            th, lp, gr = e.get_trace(k)
+            P, L, G = po.optimize_trace(ot, x0[k], J, maxit)
+            n = min(len(P), len(th), 10)
+            rt = 1e-6 if name == "funnel" else 1e-8
+            np.testing.assert_allclose(th[:n], P[:n], rtol=rt, atol=rt)
+            for l in sorted({0, len(th) // 2, len(th) - 1}):
+                lpo, go = po.logp_grad(ot, th[l])
+                assert abs(lpo - lp[l]) <= 1e-10 * max(1.0, abs(lpo))
+                np.testing.assert_allclose(gr[l], go, rtol=1e-9, atol=1e-10 * max(1.0, np.abs(go).max()))
+            assert np.all(np.diff(lp) >= -1e-9 * np.maximum(1.0, np.abs(lp[1:])))
+            if name != "funnel" and npts[k] <= maxit:
+                assert np.abs(gr[-1]).max() <= 1e-8
+    finally:
+        e.close()
