@@ -139,6 +139,96 @@ __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
     }
 }
 
+// Lean variant of the walk for 2048 < d <= 10 240 (1024 threads, EPT = 3 .. 10, 128 registers per thread).  The prefetching kernel
+// above keeps alpha, 1 / alpha and three register sets of rows: at EPT = 10 that is 273 spilled registers and 25 us per trace step
+// (200 steps of config 5's shape = 4.9 ms, 4.5 % of the step).  Here a thread carries alpha, the current point's rows and, in the
+// registers of the previous point, s and y in place (4 + 1 vectors); 1 / alpha lives in LDS (<= 80 KB); the next point is loaded
+// when the step needs it.  Same arithmetic, same reduction, same thread -> element map: bit-identical to the kernel above
+// (tests/probes/history_ab.py: 3.4 against 4.9 ms at d = 10^4, 1.1 against 2.3 ms at d = 6000, 0.92 against 0.97 ms at d = 3000).
+template <int EPT>
+__global__ __launch_bounds__(1024) void pf_history_lean_kernel(
+    int d, int J, double eps, const int64_t *__restrict__ off, const double *__restrict__ theta,
+    const double *__restrict__ grad, double *__restrict__ alpha_all, int *__restrict__ hist_len,
+    int *__restrict__ hist_src, int *__restrict__ n_rej, int *__restrict__ acc_list) {
+    constexpr int HIST_NT = 1024;
+    extern __shared__ double hl_ial[];                        // [EPT][1024]: 1 / alpha, element e of thread tid at e * 1024 + tid
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const int64_t p0 = off[k];
+    const int L = (int)(off[k + 1] - p0 - 1);
+    __shared__ double red[2 * 4 * (HIST_NT / 64)];
+    int flip = 0;
+    int n_acc = 0;
+    int *const acc = acc_list + p0;
+    double al[EPT], tc[EPT], gc[EPT], sv[EPT], yv[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid + HIST_NT * e, ic = i < d ? i : d - 1;
+        al[e] = 1.0; hl_ial[e * HIST_NT + tid] = 1.0;                          // H0 = I  (:38-39)
+        if (i < d) alpha_all[(size_t)p0 * d + i] = 1.0;
+        tc[e] = theta[(size_t)p0 * d + ic]; gc[e] = grad[(size_t)p0 * d + ic];
+    }
+    if (tid == 0) hist_len[p0] = 0;
+    for (int l = 1; l <= L; ++l) {                                              // :43
+        const size_t row = (size_t)(p0 + l) * d;
+        double v[4] = {0.0, 0.0, 0.0, 0.0};   // y.s, y.y, y'diag(a)y, s'diag(1/a)s
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = tid + HIST_NT * e, ic = i < d ? i : d - 1;
+            sv[e] = theta[row + ic]; yv[e] = grad[row + ic];
+        }
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const bool in = tid + HIST_NT * e < d;
+            const double t1 = sv[e], g1 = yv[e];
+            const double s = in ? t1 - tc[e] : 0.0, y = in ? gc[e] - g1 : 0.0;   // :45-46
+            tc[e] = t1; gc[e] = g1;
+            sv[e] = s; yv[e] = y;
+            const double ia = hl_ial[e * HIST_NT + tid];
+            v[0] += y * s;
+            v[1] += y * y;
+            v[2] += y * al[e] * y;
+            v[3] += s * ia * s;
+        }
+        pf_block_sum_mv<4, 4, 0>(v, red, flip);
+        const bool accept = v[0] > eps * v[1];                                  // :47
+        if (accept) {                                                           // gilbert_init :5-10
+            const double a = v[2], b = v[0], c = v[3], aoc = a / c, rb = 1.0 / b;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const double ia = hl_ial[e * HIST_NT + tid];
+                const double sa = sv[e] * ia;
+                const double x = a * ia + yv[e] * yv[e] - aoc * sa * sa;
+                al[e] = b / x;
+                hl_ial[e * HIST_NT + tid] = x * rb;
+            }
+            n_acc += 1;
+        }
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = tid + HIST_NT * e;
+            if (i < d) alpha_all[(size_t)(p0 + l) * d + i] = al[e];
+        }
+        if (tid == 0) {
+            if (accept) acc[n_acc - 1] = l - 1;
+            hist_len[p0 + l] = n_acc < J ? n_acc : J;
+            hist_src[(size_t)(p0 + l) * J] = n_acc;
+        }
+    }
+    if (tid == 0) n_rej[k] = L > 0 ? L - n_acc : 0;                             // :57
+    __threadfence_block();
+    __syncthreads();
+    for (int q = 1 + tid; q <= L; q += HIST_NT) {                               // hist_inds (:105), as above
+        int *row = hist_src + (size_t)(p0 + q) * J;
+        const int na = row[0], re = na < J ? na : J;
+        int first = 0;
+        for (int c = 0; c < re; ++c) {
+            const int v = acc[na - re + c];
+            if (c == 0) first = v; else row[c] = v;
+        }
+        row[0] = re > 0 ? first : 0;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 #include "fit_args.h"
 
@@ -893,8 +983,23 @@ int32_t pf_launch_history(pfmi_ctx *c, double eps) {
     if (c->d <= 64) PF_HIST(1, 64); else if (c->d <= 128) PF_HIST(2, 64); else if (c->d <= 256) PF_HIST(4, 64);
     else if (c->d <= 512) PF_HIST(2, 256); else if (c->d <= 1024) PF_HIST(4, 256);
     else { const int ept = (c->d + 1023) / 1024;
-           if (ept <= 2) PF_HIST(2, 1024); else if (ept <= 4) PF_HIST(4, 1024); else if (ept <= 6) PF_HIST(6, 1024); else if (ept <= 8) PF_HIST(8, 1024);
-           else if (ept <= 10) PF_HIST(10, 1024); else if (ept <= 12) PF_HIST(12, 1024); else PF_HIST(16, 1024); }
+           const char *hk = getenv("PFMI_HISTORY_KERNEL");        // "prefetch": the register-set kernel at every d (tests, A/B)
+           const bool lean = !(hk && hk[0] == 'p');
+#define PF_HIST_LEAN(E)                                                                                                  \
+    do {                                                                                                                \
+        auto kern = pf_history_lean_kernel<E>;                                                                          \
+        PF_TRY(pf_raise_lds_limit(c, reinterpret_cast<const void *>(kern), (int)(sizeof(double) * E * 1024)));           \
+        hipLaunchKernelGGL(kern, dim3(c->K), dim3(1024), sizeof(double) * E * 1024, c->stream, c->d, c->J, eps,         \
+                           c->d_off.as<int64_t>(), c->theta.as<double>(), c->grad.as<double>(), c->alpha_all.as<double>(), \
+                           c->hist_len.as<int>(), c->hist_src.as<int>(), c->n_rej.as<int>(), c->hist_acc.as<int>());    \
+    } while (0)
+           if (ept <= 2) PF_HIST(2, 1024);
+           else if (ept <= 4) { if (lean) PF_HIST_LEAN(4); else PF_HIST(4, 1024); }
+           else if (ept <= 6) { if (lean) PF_HIST_LEAN(6); else PF_HIST(6, 1024); }
+           else if (ept <= 8) { if (lean) PF_HIST_LEAN(8); else PF_HIST(8, 1024); }
+           else if (ept <= 10) { if (lean) PF_HIST_LEAN(10); else PF_HIST(10, 1024); }
+           else if (ept <= 12) PF_HIST(12, 1024); else PF_HIST(16, 1024); }
+#undef PF_HIST_LEAN
 #undef PF_HIST
     pf_kernel_end(c, "history");
     PF_HIP(hipGetLastError());

@@ -684,3 +684,43 @@ def test_device_lbfgs_history_lengths_1_to_16(pfmi_mod, name, d, J, maxit):
                 assert np.abs(gr[-1]).max() <= 1e-8
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("tname,d,J", [("diag", 2500, 6), ("funnel", 6000, 10), ("diag", 10000, 10), ("diag", 8200, 4)])
+def test_lean_history_walk_is_bit_identical_to_the_prefetching_one(pfmi_mod, tname, d, J, monkeypatch):
+    """2048 < d <= 10 240: pf_history_lean_kernel (alpha + two row sets in registers, 1 / alpha in LDS) against pf_history_kernel
+    (PFMI_HISTORY_KERNEL=prefetch): alpha of every point, effective history, ring sources, rejections -- and with them every fit --
+    must be the same bits; both against the oracle's walk."""
+    tg = pfmi_mod.t_funnel(d) if tname == "funnel" else pfmi_mod.t_diag(d, 1)
+    sc = 10.0 if tname == "funnel" else 2.0
+    K = 2
+    x0 = pfmi_mod.HostRNG(17).rand(K * d).reshape(K, d) * 2 * sc - sc
+    out = {}
+    for mode in ("lean", "prefetch"):
+        if mode == "prefetch":
+            monkeypatch.setenv("PFMI_HISTORY_KERNEL", "prefetch")
+        else:
+            monkeypatch.delenv("PFMI_HISTORY_KERNEL", raising=False)
+        e = pfmi_mod.Engine(0)
+        try:
+            e.set_target(tg)
+            e.optimize_batch(x0, J, 30)
+            e.fit_batch(J)
+            st, je, ld, nr = e.fit_status()
+            fits = [e.get_fit(p, int(je[p])) for p in sorted({1, e.P // 2, e.P - 1})]
+            traces = [e.get_trace(k, logp=False) for k in range(K)]
+            out[mode] = (st, je, nr, ld, [f["alpha"] for f in fits], [f["mu"] for f in fits], traces, e.offsets.copy())
+        finally:
+            e.close()
+    a, b = out["lean"], out["prefetch"]
+    for x, y in zip(a[:4], b[:4]):
+        np.testing.assert_array_equal(x, y)
+    for x, y in zip(a[4] + a[5], b[4] + b[5]):
+        np.testing.assert_array_equal(x, y)
+    for k, (th, _, gr) in enumerate(a[6]):
+        alpha_all, hl, hs, nrej = po.lbfgs_history(th, gr, J)
+        p0 = int(a[7][k])
+        np.testing.assert_array_equal(a[1][p0:p0 + len(th)], hl)
+        assert int(a[2][k]) == int(nrej)
+    last = po.lbfgs_history(a[6][K - 1][0], a[6][K - 1][2], J)[0][-1]
+    np.testing.assert_allclose(a[4][-1], last, rtol=1e-10)
