@@ -77,6 +77,11 @@ struct LbfgsState {
 #define LB_E(S, i)
 #endif
 
+// element e of thread tid.  d <= 1024: tid + e NT (LDS ring: consecutive lanes, consecutive 8-byte slots).  XGM variants (ring and trace
+// rows in global memory): thread tid owns the PAIRS 2 (tid + k NT) + {0, 1}, so that its two loads of a pair merge into one 16-byte
+// load -- the ring sweeps of these variants are bound by bytes in flight per wave (43 GB/s per CU with 8-byte loads).
+#define LB_IX(e) (LbfgsState<EPT, NT, RPAD>::XGM ? 2 * (tid + ((e) >> 1) * NT) + ((e) & 1) : tid + (e) * NT)
+
 template <int RPAD> struct LbNv {
     static constexpr int EVAL = (2 * RPAD + 2 + 3) / 4 * 4 < 4 ? 4 : (2 * RPAD + 2 + 3) / 4 * 4;      // values of one function evaluation
 };
@@ -152,7 +157,7 @@ __device__ __forceinline__ void lb_eval(const LbfgsArgs &A, LbfgsState<EPT, NT, 
         LB_E0(S);
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
-            const int i = tid + e * NT;
+            const int i = LB_IX(e);
             const double xn = S.XN(e);
             if (i == 0) { v[1] = xn; v[3] = S.p[e]; }
             else if (i < d) { v[0] += xn * xn; v[2] += xn * S.p[e]; }
@@ -166,7 +171,7 @@ __device__ __forceinline__ void lb_eval(const LbfgsArgs &A, LbfgsState<EPT, NT, 
         const double g0v = 0.5 * (2.0 * tau / 9.0 + dm1 - ee * ss);
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
-            const int i = tid + e * NT;
+            const int i = LB_IX(e);
             S.gn[e] = (i == 0) ? g0v : (i < d ? ee * S.XN(e) : 0.0);
         }
         dphi = g0v * p0 + ee * xp;
@@ -176,7 +181,7 @@ __device__ __forceinline__ void lb_eval(const LbfgsArgs &A, LbfgsState<EPT, NT, 
         LB_E0(S);
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
-            const int i = tid + e * NT;
+            const int i = LB_IX(e);
             ev[e] = S.XN(e) - S.M(e, i, d);
             const double ae = S.AV(e, i, d) * ev[e];
             v[0] += ae * ev[e];
@@ -224,7 +229,7 @@ __device__ __forceinline__ void lb_eval(const LbfgsArgs &A, LbfgsState<EPT, NT, 
         LB_E(S, 2);
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
-            const int i = tid + e * NT;
+            const int i = LB_IX(e);
             double gv = S.AV(e, i, d) * ev[e];
             if (RPAD > 0 && i < d) {
                 if constexpr (LbfgsState<EPT, NT, RPAD>::WD_REG) {
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
     S.tmean = A.kind == PFMI_TARGET_GAUSS ? A.mean : nullptr; S.ta = A.kind == PFMI_TARGET_GAUSS ? A.a : nullptr;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
-        const int i = tid + e * NT;
+        const int i = LB_IX(e);
         const bool act = i < d;
         S.p[e] = 0.0;
         S.x[e] = act ? A.x0[(size_t)k * d + i] : 0.0;
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
     auto record = [&]() {
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
-            const int i = tid + e * NT;
+            const int i = LB_IX(e);
             if (i < d) { tr_theta[(size_t)n * d + i] = S.x[e]; tr_grad[(size_t)n * d + i] = -S.gn[e]; }      // (gn: the gradient at x, see the callers)
         }
         if (tid == 0) tr_lp[n] = -f;
@@ -409,7 +414,7 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
             LB_T(0);
             double q[EPT];
 #pragma unroll
-            for (int e = 0; e < EPT; ++e) q[e] = gam * S.G(e, tid + e * NT, d);
+            for (int e = 0; e < EPT; ++e) q[e] = gam * S.G(e, LB_IX(e), d);
             if constexpr (XGM) {                                     // register-starved variants: no staging, one pair at a time
                 for (int c = 0; c < h; ++c) {
                     const int slot = head + c - (head + c >= J ? J : 0);
@@ -417,12 +422,12 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
                     if constexpr (EPT <= 20) {                        // all loads of the pair in flight before the first use
                         double sr[EPT], yr[EPT];                      // (32 rows per thread: the staging itself spills -- 167 against 134 us)
 #pragma unroll
-                        for (int e = 0; e < EPT; ++e) { sr[e] = ld_s(slot, tid + e * NT); yr[e] = ld_y(slot, tid + e * NT); }
+                        for (int e = 0; e < EPT; ++e) { sr[e] = ld_s(slot, LB_IX(e)); yr[e] = ld_y(slot, LB_IX(e)); }
 #pragma unroll
                         for (int e = 0; e < EPT; ++e) q[e] += cs * sr[e] + cy * yr[e];
                     } else {
 #pragma unroll
-                        for (int e = 0; e < EPT; ++e) q[e] += cs * ld_s(slot, tid + e * NT) + cy * ld_y(slot, tid + e * NT);
+                        for (int e = 0; e < EPT; ++e) q[e] += cs * ld_s(slot, LB_IX(e)) + cy * ld_y(slot, LB_IX(e));
                     }
                 }
             } else
@@ -436,7 +441,7 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
                     cs[cc] = on ? lb_rl(ca, c) : 0.0;
                     cy[cc] = on ? -gam * lb_rl(t, c) : 0.0;
 #pragma unroll
-                    for (int e = 0; e < EPT; ++e) { sr[cc][e] = ld_s(slot, tid + e * NT); yr[cc][e] = ld_y(slot, tid + e * NT); }
+                    for (int e = 0; e < EPT; ++e) { sr[cc][e] = ld_s(slot, LB_IX(e)); yr[cc][e] = ld_y(slot, LB_IX(e)); }
                 }
 #pragma unroll
                 for (int cc = 0; cc < LB; ++cc)
@@ -449,7 +454,7 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
         if (h == 0 || !(g0 < 0)) {                                   // first step, or not a descent direction: restart
             h = 0; head = 0;
 #pragma unroll
-            for (int e = 0; e < EPT; ++e) S.p[e] = -S.G(e, tid + e * NT, d);
+            for (int e = 0; e < EPT; ++e) S.p[e] = -S.G(e, LB_IX(e), d);
             g0 = -gg;
         }
         double a0 = 1.0;
@@ -463,7 +468,7 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
         //      s'y, y'y, #moved, #non-finite, g'g, #{|g_i| > g_tol}, s'g, y'g.
         double yv[EPT];
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) yv[e] = S.gn[e] - S.G(e, tid + e * NT, d);
+        for (int e = 0; e < EPT; ++e) yv[e] = S.gn[e] - S.G(e, LB_IX(e), d);
         const int slot_new = (h == J) ? head : head + h - (head + h >= J ? J : 0);       // h == J: the oldest pair is replaced
         double sy = 0.0, yy = 0.0, moved = 0.0;
         bool take = false, stop = false;
@@ -484,7 +489,7 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
                             for (int e0 = 0; e0 < EPT; e0 += EB) {
                                 double sr[EB], yr[EB];
 #pragma unroll
-                                for (int e = 0; e < EB; ++e) { sr[e] = ld_s(c, tid + (e0 + e) * NT); yr[e] = ld_y(c, tid + (e0 + e) * NT); }
+                                for (int e = 0; e < EB; ++e) { sr[e] = ld_s(c, LB_IX(e0 + e)); yr[e] = ld_y(c, LB_IX(e0 + e)); }
 #pragma unroll
                                 for (int e = 0; e < EB; ++e) {
                                     v[4 * cc + 0] += sr[e] * yv[e0 + e];
@@ -507,7 +512,7 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
                         on[cc] = c < J && c != snew && age < h;               // a live pair of the ring (uniform)
                         if (on[cc]) {
 #pragma unroll
-                            for (int e = 0; e < EPT; ++e) { sr[cc][e] = ld_s(c, tid + e * NT); yr[cc][e] = ld_y(c, tid + e * NT); }
+                            for (int e = 0; e < EPT; ++e) { sr[cc][e] = ld_s(c, LB_IX(e)); yr[cc][e] = ld_y(c, LB_IX(e)); }
                         }
                     }
 #pragma unroll
@@ -583,7 +588,7 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
         if (take) {
             if (h == J) head = head + 1 == J ? 0 : head + 1; else ++h;
 #pragma unroll
-            for (int e = 0; e < EPT; ++e) st_sy(slot_new, tid + e * NT, S.XN(e) - S.x[e], yv[e]);
+            for (int e = 0; e < EPT; ++e) st_sy(slot_new, LB_IX(e), S.XN(e) - S.x[e], yv[e]);
             gam = sy / yy;
         }
 #pragma unroll
