@@ -84,8 +84,14 @@ const char *pfmi_last_error(void);
 int32_t pfmi_version(void);
 int32_t pfmi_device_count(int32_t *count);
 int32_t pfmi_create(int32_t device, pfmi_ctx **out);
-int32_t pfmi_destroy(pfmi_ctx *ctx);
+int32_t pfmi_destroy(pfmi_ctx *ctx);   /* communicators that hold ctx are closed first: any finaliser order is safe */
 int32_t pfmi_sync(pfmi_ctx *ctx);
+/* Test / tuning hooks (kernel selection PFMI_ELBO_KERNEL / PFMI_FIT_KERNEL / PFMI_HISTORY_KERNEL / PFMI_PSIS_KERNEL / PFMI_QF_NO_TAIL,
+ * PFMI_DEVCB_CHUNK_MB, PFMI_LBFGS_REJECT_EVERY, the collective path's PFMI_RCCL_LIB / PFMI_COMM_ALLOW_SHARED_GPU / PFMI_COMM_FORCE_RCCL;
+ * INTEGRATION.md section 3).  A hook is read from this explicit table, or from the environment variable of the same name ONLY when
+ * the process was started with PFMI_DEBUG_HOOKS=1: a production process is never re-configured by a stray environment variable.
+ * value == NULL unsets.  Process-global; set hooks before other threads use the library.  No reference counterpart. */
+int32_t pfmi_debug_set(const char *key, const char *value);
 
 /* device-time instrumentation (hipEvents on the ctx stream).  pfmi_timer_* bracket any sequence of
  * calls; pfmi_kernel_time returns accumulated time and launch count of one named kernel family

@@ -55,7 +55,7 @@ int32_t rccl_load() {
     std::lock_guard<std::mutex> lk(g_rccl_mu);
     if (g_rccl.handle) return PFMI_OK;
     void *h = nullptr;
-    const char *over = getenv("PFMI_RCCL_LIB");
+    const char *over = pf_debug_get("PFMI_RCCL_LIB");
     if (over && over[0]) {
         h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
         PF_CHECK(h != nullptr, PFMI_ERR_UNSUPPORTED, "PFMI_RCCL_LIB=%s could not be loaded: %s", over, dlerror());
@@ -98,14 +98,17 @@ int32_t rccl_load() {
     } while (0)
 
 bool env_on(const char *name) {
-    const char *e = getenv(name);
+    const char *e = pf_debug_get(name);
     return e && e[0] && e[0] != '0';
 }
 
-// out[i] = NaN: a rank whose local stage failed still enters the all-reduce (so nobody blocks) with a poisoned contribution
-__global__ void pf_poison_kernel(double *out, long long n) {
+// A rank whose local stage failed still enters the all-reduce (so nobody blocks).  The result buffer carries ONE extra element behind
+// the d x ndraws columns -- the failure flag: 0 from a healthy rank, 1 from a failed one -- so that after the sum every rank sees how
+// many ranks failed, whatever the draws themselves contain (a NaN draw of a failed run is data, not an error).
+__global__ void pf_flag_kernel(double *flag, double value) { *flag = value; }
+__global__ void pf_zero_kernel(double *out, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = NAN;
+    if (i < n) out[i] = 0.0;
 }
 
 }  // namespace
@@ -124,7 +127,54 @@ struct pfmi_comm {
     bool psis_pending = false;
     int64_t rs_ndraws = 0;               // draws of the enqueued resample stage
     bool rs_local_error = false;
+    bool dead = false;                   // a member context was destroyed: the group is torn down, every call reports PFMI_ERR_STATE
 };
+
+// ---- lifetime registry: a communicator borrows its contexts.  Host languages with unordered finalisers (Julia's GC at
+// exit) may destroy a context before the communicator that uses it; pfmi_destroy therefore announces the context here first and
+// every live communicator that holds it is torn down THEN (streams drained, RCCL handles destroyed, buffers freed) and marked dead,
+// so that a later pfmi_comm_destroy only frees the shell and never touches a dangling pfmi_ctx.
+namespace {
+std::mutex g_comm_mu;
+std::vector<pfmi_comm *> g_comms;
+
+void comm_teardown(pfmi_comm *c) {                                      // g_comm_mu held
+    if (c->dead) return;
+    for (size_t i = 0; i < c->ctx.size(); ++i) {
+        (void)hipSetDevice(c->ctx[i]->device);
+        (void)hipStreamSynchronize(c->ctx[i]->stream);
+    }
+    for (size_t i = 0; i < c->ctx.size(); ++i) {
+        (void)hipSetDevice(c->ctx[i]->device);
+        if (c->comm[i]) (void)g_rccl.CommDestroy(c->comm[i]);
+        c->comm[i] = nullptr;
+        c->lr_all[i].release();
+        c->out[i].release();
+        c->hs[i].release();
+    }
+    c->ctx.clear();
+    c->dead = true;
+}
+void comm_register(pfmi_comm *c) {
+    std::lock_guard<std::mutex> lk(g_comm_mu);
+    g_comms.push_back(c);
+}
+}  // namespace
+
+void pf_comm_ctx_dying(pfmi_ctx *x) {
+    std::lock_guard<std::mutex> lk(g_comm_mu);
+    for (pfmi_comm *c : g_comms) {
+        bool member = false;
+        for (pfmi_ctx *m : c->ctx) member = member || m == x;
+        if (member) comm_teardown(c);
+    }
+}
+
+#define PF_COMM(c)                                                                                                          \
+    do {                                                                                                                    \
+        PF_CHECK((c) != nullptr, PFMI_ERR_ARG, "null pfmi_comm");                                                           \
+        PF_CHECK(!(c)->dead, PFMI_ERR_STATE, "pfmi_comm: a member context was destroyed; the communicator is closed");      \
+    } while (0)
 
 namespace {
 
@@ -162,10 +212,37 @@ int32_t group_all_reduce(pfmi_comm *c, std::vector<DevBuf> &buf, size_t count, n
 
 // Agree on the shard size and on everybody's local status BEFORE a collective whose element count depends on them.  Under
 // pfmi_comm_init_all this process sees every rank and the check is local; under pfmi_comm_init_rank the ranks exchange
-// max{shard, -shard, error} (one 4-double all-reduce): a rank without a pool or with a different K_local * N_r makes EVERY rank return
-// the same error instead of leaving the others blocked in (or corrupting) the all-gather.  `local_err` != 0: this process already
-// knows it cannot take part.
-int32_t agree_on_shard(pfmi_comm *c, int64_t *shard_out) {
+// max{shard, -shard, error} (one 4-double all-reduce): a rank without a pool, with a different K_local * N_r, or whose device buffers
+// for the stage cannot be allocated makes EVERY rank return the same error instead of leaving the others blocked in (or corrupting)
+// the collective.  `out_doubles` > 0: the (d x ndraws + flag) result buffers of the resample stage are allocated here too, so that
+// the fused call has no fallible step left between this handshake and its collectives.
+int32_t handshake(pfmi_comm *c, double v, int local_err, const char *why, double *vmax, double *vmin) {
+    const size_t nl = c->ctx.size();
+    *vmax = *vmin = v;
+    if ((int)nl < c->world) {                                   // one process per GPU: the other ranks are somewhere else
+        double h[4] = {v, -v, (double)local_err, 0.0}, r[4] = {0, 0, 0, 0};
+        for (size_t i = 0; i < nl; ++i) {
+            PF_HIP(hipSetDevice(c->ctx[i]->device));
+            PF_TRY(c->hs[i].ensure(sizeof(h)));                 // 256 bytes, allocated by the first handshake of the communicator
+            PF_TRY(pf_upload(c->ctx[i], c->hs[i].p, h, sizeof(h)));
+        }
+        PF_TRY(group_all_reduce(c, c->hs, 4, ncclMax));
+        PF_HIP(hipSetDevice(c->ctx[0]->device));
+        PF_HIP(hipMemcpyAsync(r, c->hs[0].p, sizeof(r), hipMemcpyDeviceToHost, c->ctx[0]->stream));
+        PF_HIP(hipStreamSynchronize(c->ctx[0]->stream));
+        pf_arena_reset(c->ctx[0]);
+        PF_CHECK(r[2] == 0.0, PFMI_ERR_STATE, "comm: a rank of the group cannot take part in the pooled stage%s%s", local_err ? ": " : "",
+                 local_err ? why : " (see that rank's error)");
+        *vmax = r[0];
+        *vmin = -r[1];
+    } else {
+        PF_CHECK(!local_err, strstr(why, "differ") ? PFMI_ERR_ARG : PFMI_ERR_STATE, "comm: %s%s", why,
+                 strstr(why, "differ") ? ": equal paths per GPU keep the result independent of G" : "");
+    }
+    return PFMI_OK;
+}
+
+int32_t agree_on_shard(pfmi_comm *c, int64_t *shard_out, bool want_lr_all, int64_t out_doubles) {
     const size_t nl = c->ctx.size();
     int64_t shard = -1;
     int local_err = 0;
@@ -184,45 +261,33 @@ int32_t agree_on_shard(pfmi_comm *c, int64_t *shard_out) {
         }
         shard = s;
     }
-    if ((int)nl < c->world) {                                   // one process per GPU: the other ranks are somewhere else
-        double h[4] = {(double)shard, -(double)shard, (double)local_err, 0.0}, r[4] = {0, 0, 0, 0};
-        for (size_t i = 0; i < nl; ++i) {
-            PF_HIP(hipSetDevice(c->ctx[i]->device));
-            PF_TRY(c->hs[i].ensure(sizeof(h)));
-            PF_TRY(pf_upload(c->ctx[i], c->hs[i].p, h, sizeof(h)));
+    // everything the stage allocates, BEFORE the handshake: a failure here is a local error every rank hears about
+    for (size_t i = 0; i < nl && !local_err; ++i) {
+        int32_t rc = hipSetDevice(c->ctx[i]->device) == hipSuccess ? PFMI_OK : PFMI_ERR_HIP;
+        if (rc == PFMI_OK && want_lr_all && c->rccl) rc = c->lr_all[i].ensure(sizeof(double) * (size_t)shard * (size_t)c->world);
+        if (rc == PFMI_OK && out_doubles > 0) rc = c->out[i].ensure(sizeof(double) * (size_t)out_doubles);
+        if (rc != PFMI_OK) {
+            local_err = 1;
+            snprintf(why, sizeof(why), "rank %d could not allocate the buffers of the pooled stage (%s)", c->rank[i], pfmi_last_error());
         }
-        PF_TRY(group_all_reduce(c, c->hs, 4, ncclMax));
-        PF_HIP(hipSetDevice(c->ctx[0]->device));
-        PF_HIP(hipMemcpyAsync(r, c->hs[0].p, sizeof(r), hipMemcpyDeviceToHost, c->ctx[0]->stream));
-        PF_HIP(hipStreamSynchronize(c->ctx[0]->stream));
-        pf_arena_reset(c->ctx[0]);
-        PF_CHECK(r[2] == 0.0, PFMI_ERR_STATE, "comm: a rank of the group cannot take part in the pooled stage%s%s", local_err ? ": " : "",
-                 local_err ? why : " (see that rank's error)");
-        PF_CHECK(r[0] == -r[1], PFMI_ERR_ARG,
-                 "comm: log-ratio shards differ in size across ranks (%lld .. %lld): equal paths per GPU keep the result independent of G",
-                 (long long)-r[1], (long long)r[0]);
-    } else {
-        PF_CHECK(!local_err, strstr(why, "differ") ? PFMI_ERR_ARG : PFMI_ERR_STATE, "comm_pool_psis: %s%s", why,
-                 strstr(why, "differ") ? ": equal paths per GPU keep the result independent of G" : "");
     }
+    double smax = 0.0, smin = 0.0;
+    PF_TRY(handshake(c, (double)shard, local_err, why, &smax, &smin));
+    PF_CHECK(smax == smin, PFMI_ERR_ARG,
+             "comm: log-ratio shards differ in size across ranks (%lld .. %lld): equal paths per GPU keep the result independent of G",
+             (long long)smin, (long long)smax);
     *shard_out = shard;
     return PFMI_OK;
 }
 
 // all-gather + replicated PSIS, enqueued on every local context
-int32_t enqueue_pool_psis(pfmi_comm *c) {
+int32_t enqueue_pool_psis(pfmi_comm *c, int64_t out_doubles) {
     const size_t nl = c->ctx.size();
     int64_t shard = 0;
-    PF_TRY(agree_on_shard(c, &shard));
+    PF_TRY(agree_on_shard(c, &shard, true, out_doubles));
     c->shard = shard;
     const int64_t S = shard * c->world;
-    if (c->rccl) {
-        for (size_t i = 0; i < nl; ++i) {
-            PF_HIP(hipSetDevice(c->ctx[i]->device));
-            PF_TRY(c->lr_all[i].ensure(sizeof(double) * (size_t)S));
-        }
-        PF_TRY(group_all_gather(c));
-    }
+    if (c->rccl) PF_TRY(group_all_gather(c));                  // lr_all was allocated before the handshake
     for (size_t i = 0; i < nl; ++i) {                       // replicated PSIS: same code, same input, fixed reduction order
         pfmi_ctx *x = c->ctx[i];
         PF_HIP(hipSetDevice(x->device));
@@ -258,20 +323,26 @@ int32_t finish_pool_psis(pfmi_comm *c, double *pareto_k, int64_t *tail_len) {
     return PFMI_OK;
 }
 
-// replicated index selection -> owner gather (zeros elsewhere) -> sum all-reduce, enqueued on every local context
+// replicated index selection -> owner gather (zeros elsewhere) -> sum all-reduce, enqueued on every local context.  The result buffers
+// (d x ndraws columns + the failure flag) were allocated before the handshake of the stage (agree_on_shard / resample_handshake): no
+// step between here and the all-reduce returns early, a local failure travels as flag = 1.
 int32_t enqueue_resample(pfmi_comm *c, int64_t ndraws, int32_t importance, int32_t replace, uint64_t seed, const double *uniforms) {
     const size_t nl = c->ctx.size();
     const int64_t S = c->shard * c->world;
     const int d = c->ctx[0]->d;
+    const long long n = (long long)d * ndraws;
     c->rs_ndraws = ndraws;
     c->rs_local_error = false;
     int32_t rc_local = PFMI_OK;
     for (size_t i = 0; i < nl; ++i) {
         pfmi_ctx *x = c->ctx[i];
-        PF_HIP(hipSetDevice(x->device));
-        PF_TRY(c->out[i].ensure(sizeof(double) * (size_t)d * ndraws));
         int32_t rc = PFMI_OK;
-        if (x->d != d) { pf_set_error("comm_resample: dimension differs between ranks"); rc = PFMI_ERR_ARG; }
+        if (hipSetDevice(x->device) != hipSuccess) { pf_set_error("comm_resample: hipSetDevice(%d) failed", x->device); rc = PFMI_ERR_HIP; }
+        if (rc == PFMI_OK && c->out[i].cap < sizeof(double) * (size_t)(n + 1)) {
+            pf_set_error("comm_resample: result buffer of rank %d was not allocated by the handshake", c->rank[i]);
+            rc = PFMI_ERR_STATE;
+        }
+        if (rc == PFMI_OK && x->d != d) { pf_set_error("comm_resample: dimension differs between ranks"); rc = PFMI_ERR_ARG; }
         if (rc == PFMI_OK && importance && x->S_w != S) {
             pf_set_error("comm_resample: importance weights for S=%lld not available on rank %d (run the pooled PSIS first)", (long long)S, c->rank[i]);
             rc = PFMI_ERR_STATE;
@@ -284,14 +355,22 @@ int32_t enqueue_resample(pfmi_comm *c, int64_t ndraws, int32_t importance, int32
         }
         if (rc == PFMI_OK) rc = pf_enqueue_resample(x, S, ndraws, importance, replace, seed, d_uni);
         if (rc == PFMI_OK) rc = pf_launch_gather(x, ndraws, x->idx.as<int64_t>(), (int64_t)c->rank[i] * c->shard, c->out[i].as<double>());
-        if (rc != PFMI_OK) {                                    // still take part in the all-reduce: NaN reaches every rank
+        if (c->out[i].cap >= sizeof(double) * (size_t)(n + 1)) {
+            if (rc != PFMI_OK)                                  // a defined contribution: zeros + flag 1
+                hipLaunchKernelGGL(pf_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, x->stream, c->out[i].as<double>(), n);
+            hipLaunchKernelGGL(pf_flag_kernel, dim3(1), dim3(1), 0, x->stream, c->out[i].as<double>() + n, rc != PFMI_OK ? 1.0 : 0.0);
+        }
+        if (rc != PFMI_OK) {
             rc_local = rc;
             c->rs_local_error = true;
-            const long long n = (long long)d * ndraws;
-            hipLaunchKernelGGL(pf_poison_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, x->stream, c->out[i].as<double>(), n);
         }
     }
-    if (c->rccl) PF_TRY(group_all_reduce(c, c->out, (size_t)d * ndraws, ncclSum));
+    if (c->rccl) {
+        bool all_buffers = true;
+        for (size_t i = 0; i < nl; ++i) all_buffers = all_buffers && c->out[i].cap >= sizeof(double) * (size_t)(n + 1);
+        // (without its buffer a rank cannot enter: only reachable when the caller skipped the handshake, which the entry points never do)
+        if (all_buffers) PF_TRY(group_all_reduce(c, c->out, (size_t)n + 1, ncclSum));
+    }
     return rc_local;
 }
 
@@ -299,9 +378,10 @@ int32_t finish_resample(pfmi_comm *c, int64_t *idx, double *draws) {
     const size_t nl = c->ctx.size();
     const int64_t ndraws = c->rs_ndraws;
     const int d = c->ctx[0]->d;
+    const size_t n = (size_t)d * (size_t)ndraws;
     std::vector<int64_t> h_idx((size_t)ndraws * nl);
     std::vector<int> h_err(nl, 0);
-    double probe = 0.0;
+    double flag = 0.0;
     for (size_t i = 0; i < nl; ++i) {
         pfmi_ctx *x = c->ctx[i];
         PF_HIP(hipSetDevice(x->device));
@@ -312,8 +392,9 @@ int32_t finish_resample(pfmi_comm *c, int64_t *idx, double *draws) {
     {
         pfmi_ctx *x = c->ctx[0];
         PF_HIP(hipSetDevice(x->device));
-        if (draws) PF_HIP(hipMemcpyAsync(draws, c->out[0].p, sizeof(double) * (size_t)d * ndraws, hipMemcpyDeviceToHost, x->stream));
-        else PF_HIP(hipMemcpyAsync(&probe, c->out[0].p, sizeof(double), hipMemcpyDeviceToHost, x->stream));
+        PF_CHECK(c->out[0].cap >= sizeof(double) * (n + 1), PFMI_ERR_STATE, "comm_resample: no result buffer");
+        if (draws) PF_HIP(hipMemcpyAsync(draws, c->out[0].p, sizeof(double) * n, hipMemcpyDeviceToHost, x->stream));
+        PF_HIP(hipMemcpyAsync(&flag, c->out[0].as<double>() + n, sizeof(double), hipMemcpyDeviceToHost, x->stream));
     }
     for (size_t i = 0; i < nl; ++i) {
         PF_HIP(hipSetDevice(c->ctx[i]->device));
@@ -322,14 +403,30 @@ int32_t finish_resample(pfmi_comm *c, int64_t *idx, double *draws) {
     }
     for (size_t i = 0; i < nl; ++i)
         PF_CHECK(h_err[i] == 0, PFMI_ERR_NUMERIC, "resample: weights are all zero / not enough positive weights (rank %d)", c->rank[i]);
-    // a rank whose local stage failed poisoned its contribution: element 0 of the reduced result is NaN on every rank
-    const double first = draws ? draws[0] : probe;
-    PF_CHECK(first == first, PFMI_ERR_COMM, "comm_resample: a rank of the group failed its local stage (poisoned all-reduce)");
+    // the summed failure flag: how many ranks of the group failed their local stage
+    PF_CHECK(flag == 0.0, PFMI_ERR_COMM, "comm_resample: %d rank(s) of the group failed their local stage", (int)flag);
     for (size_t i = 1; i < nl; ++i)
         PF_CHECK(memcmp(&h_idx[(size_t)ndraws * i], h_idx.data(), sizeof(int64_t) * ndraws) == 0, PFMI_ERR_NUMERIC,
                  "comm_resample: replicated index selection disagrees on rank %d", c->rank[i]);
     if (idx) memcpy(idx, h_idx.data(), sizeof(int64_t) * (size_t)ndraws);
     return PFMI_OK;
+}
+
+// the unfused pfmi_comm_resample has no pooled-stage handshake in front of it: allocate the result buffers and let every rank hear
+// about a failure (one 4-double all-reduce under pfmi_comm_init_rank, nothing under pfmi_comm_init_all)
+int32_t resample_handshake(pfmi_comm *c, int64_t out_doubles) {
+    int local_err = 0;
+    char why[256] = "";
+    for (size_t i = 0; i < c->ctx.size(); ++i) {
+        int32_t rc = hipSetDevice(c->ctx[i]->device) == hipSuccess ? PFMI_OK : PFMI_ERR_HIP;
+        if (rc == PFMI_OK) rc = c->out[i].ensure(sizeof(double) * (size_t)out_doubles);
+        if (rc != PFMI_OK) {
+            local_err = 1;
+            snprintf(why, sizeof(why), "rank %d could not allocate the result buffer of the resample stage (%s)", c->rank[i], pfmi_last_error());
+        }
+    }
+    double a, b;
+    return handshake(c, (double)out_doubles, local_err, why, &a, &b);
 }
 
 }  // namespace
@@ -381,6 +478,7 @@ int32_t pfmi_comm_init_all(int32_t G, pfmi_ctx *const *ctxs, pfmi_comm **out) {
             return PFMI_ERR_COMM;
         }
     }
+    comm_register(c);
     *out = c;
     return PFMI_OK;
 }
@@ -408,26 +506,25 @@ int32_t pfmi_comm_init_rank(pfmi_ctx *ctx, int32_t world, int32_t rank, const ui
         delete c;
         return PFMI_ERR_COMM;
     }
+    comm_register(c);
     *out = c;
     return PFMI_OK;
 }
 
 int32_t pfmi_comm_destroy(pfmi_comm *c) {
     if (!c) return PFMI_OK;
-    for (size_t i = 0; i < c->ctx.size(); ++i) {
-        (void)hipSetDevice(c->ctx[i]->device);
-        (void)hipStreamSynchronize(c->ctx[i]->stream);
-        if (c->comm[i]) (void)g_rccl.CommDestroy(c->comm[i]);
-        c->lr_all[i].release();
-        c->out[i].release();
-        c->hs[i].release();
+    {
+        std::lock_guard<std::mutex> lk(g_comm_mu);
+        for (size_t i = 0; i < g_comms.size(); ++i)
+            if (g_comms[i] == c) { g_comms.erase(g_comms.begin() + (long)i); break; }
+        comm_teardown(c);                                               // no-op when a dying member context already closed the group
     }
     delete c;
     return PFMI_OK;
 }
 
 int32_t pfmi_comm_info(pfmi_comm *c, int32_t *world, int32_t *nlocal, int32_t *rccl_version) {
-    PF_CHECK(c != nullptr, PFMI_ERR_ARG, "null pfmi_comm");
+    PF_COMM(c);
     if (world) {
         int n = c->world;
         if (c->rccl) PF_NCCL(g_rccl.CommCount(c->comm[0], &n));       // what RCCL itself says, not what the caller claimed
@@ -444,8 +541,8 @@ int32_t pfmi_comm_info(pfmi_comm *c, int32_t *world, int32_t *nlocal, int32_t *r
 
 // _compute_psis_result over the pooled runs (src/multipath.jl:221): all-gather the log-ratio shards, then PSIS on every GPU.
 int32_t pfmi_comm_pool_psis(pfmi_comm *c, double *pareto_k, int64_t *tail_len) {
-    PF_CHECK(c != nullptr, PFMI_ERR_ARG, "null pfmi_comm");
-    PF_TRY(enqueue_pool_psis(c));
+    PF_COMM(c);
+    PF_TRY(enqueue_pool_psis(c, 0));
     return finish_pool_psis(c, pareto_k, tail_len);
 }
 
@@ -453,9 +550,10 @@ int32_t pfmi_comm_pool_psis(pfmi_comm *c, double *pareto_k, int64_t *tail_len) {
 // sum all-reduce.  idx[ndraws] (0-based, global pool columns) and draws[d * ndraws] (column-major) may be NULL.
 int32_t pfmi_comm_resample(pfmi_comm *c, int64_t ndraws, int32_t importance, int32_t replace, uint64_t seed, const double *uniforms,
                            int64_t *idx, double *draws) {
-    PF_CHECK(c != nullptr, PFMI_ERR_ARG, "null pfmi_comm");
+    PF_COMM(c);
     PF_CHECK(ndraws >= 1, PFMI_ERR_ARG, "comm_resample: ndraws must be positive");
     PF_CHECK(c->shard > 0, PFMI_ERR_STATE, "comm_resample: call pfmi_comm_pool_psis first");
+    PF_TRY(resample_handshake(c, (int64_t)c->ctx[0]->d * ndraws + 1));
     const int32_t rc = enqueue_resample(c, ndraws, importance, replace, seed, uniforms);
     const int32_t rf = finish_resample(c, idx, draws);
     return rc != PFMI_OK ? rc : rf;
@@ -464,12 +562,13 @@ int32_t pfmi_comm_resample(pfmi_comm *c, int64_t ndraws, int32_t importance, int
 // both stages, one synchronisation (src/multipath.jl:221-225)
 int32_t pfmi_comm_psis_resample(pfmi_comm *c, int64_t ndraws, int32_t importance, int32_t replace, uint64_t seed, const double *uniforms,
                                 double *pareto_k, int64_t *tail_len, int64_t *idx, double *draws) {
-    PF_CHECK(c != nullptr, PFMI_ERR_ARG, "null pfmi_comm");
+    PF_COMM(c);
     PF_CHECK(ndraws >= 1, PFMI_ERR_ARG, "comm_psis_resample: ndraws must be positive");
-    if (importance) PF_TRY(enqueue_pool_psis(c));
+    const int64_t out_doubles = (int64_t)c->ctx[0]->d * ndraws + 1;       // d x ndraws columns + the failure flag
+    if (importance) PF_TRY(enqueue_pool_psis(c, out_doubles));
     else {
         int64_t shard = 0;
-        PF_TRY(agree_on_shard(c, &shard));
+        PF_TRY(agree_on_shard(c, &shard, false, out_doubles));
         c->shard = shard;
     }
     const int32_t rc = enqueue_resample(c, ndraws, importance, replace, seed, uniforms);

@@ -398,7 +398,7 @@ int32_t pf_launch_elbo_draws(pfmi_ctx *c, const int32_t *d_points, const uint64_
     const bool mem = d_u != nullptr;
     // production (in-kernel RNG) path: MFMA kernel with register-resident normals when the shape allows;
     // PFMI_ELBO_KERNEL=lane forces the general lane-per-draw kernel (used by the tests to cross-check)
-    const char *force = getenv("PFMI_ELBO_KERNEL");
+    const char *force = pf_debug_get("PFMI_ELBO_KERNEL");
     if (!mem && !(force && force[0] == 'l')) {
         bool handled = false;
         pf_kernel_begin(c);

@@ -627,7 +627,7 @@ static int32_t launch_qf_ng(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
     // (each piece recomputes the per-fit constants in its pseudo-group slot) whenever that finishes sooner.
     int64_t tail = 0;
     int gpw_t = gpw, gx_t = gx;
-    const char *no_tail = getenv("PFMI_QF_NO_TAIL");            // test hook: one launch for every fit (geometry-invariance tests)
+    const char *no_tail = pf_debug_get("PFMI_QF_NO_TAIL");            // test hook: one launch for every fit (geometry-invariance tests)
     if (split == 1 && TGT != 0 && !(no_tail && no_tail[0] == '1')) {
         int ncu = 0;
         PF_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device));

@@ -983,7 +983,7 @@ int32_t pf_launch_history(pfmi_ctx *c, double eps) {
     if (c->d <= 64) PF_HIST(1, 64); else if (c->d <= 128) PF_HIST(2, 64); else if (c->d <= 256) PF_HIST(4, 64);
     else if (c->d <= 512) PF_HIST(2, 256); else if (c->d <= 1024) PF_HIST(4, 256);
     else { const int ept = (c->d + 1023) / 1024;
-           const char *hk = getenv("PFMI_HISTORY_KERNEL");        // "prefetch": the register-set kernel at every d (tests, A/B)
+           const char *hk = pf_debug_get("PFMI_HISTORY_KERNEL");        // "prefetch": the register-set kernel at every d (tests, A/B)
            const bool lean = !(hk && hk[0] == 'p');
 #define PF_HIST_LEAN(E)                                                                                                  \
     do {                                                                                                                \
@@ -1008,7 +1008,7 @@ int32_t pf_launch_history(pfmi_ctx *c, double eps) {
 
 template <int KPAD>
 static void launch_fit_t(pfmi_ctx *c, const FitArgs &a) {
-    const char *force = getenv("PFMI_FIT_KERNEL");            // "mem" forces the general (memory-resident) kernel
+    const char *force = pf_debug_get("PFMI_FIT_KERNEL");            // "mem" forces the general (memory-resident) kernel
     const bool allow_reg = !(force && force[0] == 'm');
     dim3 grid((unsigned)c->P), block(FIT_THREADS);
     if constexpr (KPAD <= 16) {
@@ -1035,7 +1035,7 @@ int32_t pf_launch_fit(pfmi_ctx *c) {
     a.P = c->P;
     pf_kernel_begin(c);
     {
-        const char *force = getenv("PFMI_FIT_KERNEL");        // "mem": column-by-column memory-resident kernel also for d > 1024
+        const char *force = pf_debug_get("PFMI_FIT_KERNEL");        // "mem": column-by-column memory-resident kernel also for d > 1024
         bool handled = false;
         if (!(force && force[0] == 'm')) PF_TRY(pf_launch_fit_panel(c, a, &handled));
         if (handled) {

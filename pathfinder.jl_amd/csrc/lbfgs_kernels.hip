@@ -633,7 +633,7 @@ int32_t pf_launch_lbfgs(pfmi_ctx *c, int K, int J, int maxiters, double g_tol, c
     LbfgsArgs A;
     A.d = d; A.J = J; A.maxiters = maxiters; A.kind = T.kind; A.r = T.r; A.g_tol = g_tol; A.offset = T.offset;
     A.x0 = d_x0;
-    { const char *rj = getenv("PFMI_LBFGS_REJECT_EVERY"); A.reject_every = rj ? atoi(rj) : 0; }
+    { const char *rj = pf_debug_get("PFMI_LBFGS_REJECT_EVERY"); A.reject_every = rj ? atoi(rj) : 0; }
     A.mean = T.mean.as<double>(); A.a = T.a.as<double>(); A.wd = T.wd.as<double>(); A.gm = T.g.as<double>();
     const int nt = d <= 256 ? 64 : d <= 1024 ? 256 : 512, ept = d <= 1024 ? 4 : d <= 10240 ? 20 : 32;
     const size_t hist_bytes = sizeof(double) * 2 * (size_t)J * nt * ept;          // rows padded to EPT * NT

@@ -2,6 +2,10 @@
 #include "pfmi_common.h"
 
 #include <chrono>
+#include <map>
+#include <mutex>
+#include <stdlib.h>
+#include <string>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -43,6 +47,7 @@ void pf_kernel_begin(pfmi_ctx *c) {
     if (c->profile == 1) (void)hipEventRecord(c->kev0, c->stream);
     else if (c->profile == 2) {
         if (c->kpending.size() >= 4096) pf_kernel_resolve(c, true);
+        if (c->kcur) c->kev_pool.push_back(c->kcur);                  // a begin that was never ended (no kernel took the launch): reuse its event
         c->kcur = pf_kev_get(c);
         if (c->kcur) (void)hipEventRecord(c->kcur, c->stream);
     }
@@ -136,9 +141,31 @@ static int32_t ensure_pinned(pfmi_ctx *c, size_t x_bytes, size_t lp_bytes) {
         PF_HIP(hipSetDevice((c)->device));                                 \
     } while (0)
 
+// ---- test / tuning hooks (pfmi_common.h: pf_debug_get) ---------------------------------------------------------------------
+namespace {
+std::mutex g_dbg_mu;
+std::map<std::string, std::string> g_dbg;      // entries are never erased: an unset key keeps an empty-string tombstone
+}
+const char *pf_debug_get(const char *name) {
+    {
+        std::lock_guard<std::mutex> lk(g_dbg_mu);
+        auto it = g_dbg.find(name);
+        if (it != g_dbg.end()) return it->second.empty() ? nullptr : it->second.c_str();
+    }
+    static const bool env_hooks = [] { const char *e = getenv("PFMI_DEBUG_HOOKS"); return e && e[0] == '1'; }();
+    return env_hooks ? getenv(name) : nullptr;
+}
+
 extern "C" {
 
 const char *pfmi_last_error(void) { return g_err; }
+
+int32_t pfmi_debug_set(const char *key, const char *value) {
+    PF_CHECK(key != nullptr && strncmp(key, "PFMI_", 5) == 0, PFMI_ERR_ARG, "debug_set: keys are the PFMI_* hook names");
+    std::lock_guard<std::mutex> lk(g_dbg_mu);
+    g_dbg[key] = value ? value : "";
+    return PFMI_OK;
+}
 int32_t pfmi_version(void) { return 100; }
 
 int32_t pfmi_device_count(int32_t *count) {
@@ -176,6 +203,7 @@ int32_t pfmi_create(int32_t device, pfmi_ctx **out) {
 
 int32_t pfmi_destroy(pfmi_ctx *c) {
     if (!c) return PFMI_OK;
+    pf_comm_ctx_dying(c);                   // communicators that borrow this context close themselves first (any finaliser order is safe)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->theta, &c->grad, &c->d_off, &c->d_path_of, &c->target.mean, &c->target.a, &c->target.wd,
@@ -531,7 +559,7 @@ static int32_t callback_logp(pfmi_ctx *c, const double *d_x, int64_t n, double *
 // chunk of fits whose draws are materialised in HBM at a time for a DEVICE_CALLBACK target (PFMI_DEVCB_CHUNK_MB, default 2048 MB)
 static int64_t devcb_chunk_fits(int64_t per_fit_doubles, int64_t nf) {
     double mb = 2048.0;
-    if (const char *e = getenv("PFMI_DEVCB_CHUNK_MB")) { const double v = atof(e); if (v > 0) mb = v; }
+    if (const char *e = pf_debug_get("PFMI_DEVCB_CHUNK_MB")) { const double v = atof(e); if (v > 0) mb = v; }
     int64_t chunk = (int64_t)(mb * 1048576.0 / (sizeof(double) * (double)per_fit_doubles));
     if (chunk < 1) chunk = 1;
     if (chunk > nf) chunk = nf > 0 ? nf : 1;

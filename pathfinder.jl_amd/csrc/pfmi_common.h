@@ -178,6 +178,12 @@ int32_t pf_launch_elbo_draws(pfmi_ctx *c, const int32_t *d_points, const uint64_
 int32_t pf_launch_elbo_reduce(pfmi_ctx *c);
 int32_t pf_launch_logpdf(pfmi_ctx *c, int64_t point, int64_t N, const double *d_x, double *d_out);
 int32_t pf_launch_psis(pfmi_ctx *c, const double *d_lr, int64_t S);
+// Test / tuning hooks (kernel selection, the RCCL stand-in, ...): a value set with pfmi_debug_set(), or -- ONLY when the process was
+// started with PFMI_DEBUG_HOOKS=1 -- the environment variable of that name.  A production process therefore never has its numerics or
+// its dlopen path changed by a stray environment variable.  NULL when unset.
+const char *pf_debug_get(const char *name);
+// comm_rccl.hip: pfmi_destroy announces a dying context; every live communicator that holds it is torn down first
+void pf_comm_ctx_dying(pfmi_ctx *c);
 int32_t pf_launch_resample(pfmi_ctx *c, int64_t S, int64_t ndraws, int importance, int replace,
                            uint64_t seed, const double *d_uniforms);
 // the same without the final synchronisation: the error flag stays in c->rs_err until pf_resample_check reads it

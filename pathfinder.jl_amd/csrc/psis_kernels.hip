@@ -661,7 +661,7 @@ int32_t pf_launch_psis(pfmi_ctx *c, const double *d_lr, int64_t S) {
     PF_TRY(c->w.ensure(sizeof(double) * S));
     PF_TRY(c->psis_out.ensure(sizeof(double) * 4));
     pf_kernel_begin(c);
-    const char *force = getenv("PFMI_PSIS_KERNEL");              // "single": the one-workgroup kernel for every S (tests)
+    const char *force = pf_debug_get("PFMI_PSIS_KERNEL");              // "single": the one-workgroup kernel for every S (tests)
     if (S >= PSIS_MULTI_MIN && M >= 5 && !(force && force[0] == 's')) {
         PF_TRY(c->psis_aux.ensure(sizeof(PsisAux)));
         PsisAux *aux = c->psis_aux.as<PsisAux>();

@@ -52,9 +52,26 @@ mutable struct Engine
         ref = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:pfmi_create, libpfmi), Int32, (Int32, Ref{Ptr{Cvoid}}), device, ref))
         eng = new(ref[], device, 0, nothing)
-        finalizer(e -> ccall((:pfmi_destroy, libpfmi), Int32, (Ptr{Cvoid},), e.ptr), eng)
+        finalizer(close, eng)
         return eng
     end
+end
+"""
+    close(eng::Engine)
+
+Destroy the context now (idempotent; also the finalizer).  Communicators that hold this engine are closed FIRST: the cached ones on
+this side (`_COMM_CACHE`), and -- whatever order the GC runs finalizers in -- `pfmi_destroy` itself tears down every live `pfmi_comm`
+that borrows the context before freeing it (csrc/comm_rccl.hip: pf_comm_ctx_dying), so a later `pfmi_comm_destroy` never dereferences
+a dead `pfmi_ctx`.
+"""
+function Base.close(eng::Engine)
+    eng.ptr == C_NULL && return nothing
+    for (key, c) in collect(_COMM_CACHE)
+        eng.ptr in key && (close(c); delete!(_COMM_CACHE, key))
+    end
+    ccall((:pfmi_destroy, libpfmi), Int32, (Ptr{Cvoid},), eng.ptr)
+    eng.ptr = C_NULL
+    return nothing
 end
 struct StaleHandleError <: Exception end
 _live(eng::Engine, gen::Int) = eng.generation == gen || throw(StaleHandleError())
@@ -68,9 +85,28 @@ mutable struct Comm
         check(ccall((:pfmi_comm_init_all, libpfmi), Int32, (Int32, Ptr{Ptr{Cvoid}}, Ref{Ptr{Cvoid}}),
                     length(engines), [e.ptr for e in engines], ref))
         c = new(ref[], engines)
-        finalizer(x -> ccall((:pfmi_comm_destroy, libpfmi), Int32, (Ptr{Cvoid},), x.ptr), c)
+        finalizer(close, c)
         return c
     end
+end
+"destroy the RCCL group now (idempotent; also the finalizer)"
+function Base.close(c::Comm)
+    c.ptr == C_NULL && return nothing
+    ccall((:pfmi_comm_destroy, libpfmi), Int32, (Ptr{Cvoid},), c.ptr)
+    c.ptr = C_NULL
+    return nothing
+end
+# One communicator per SET of engines, created at first use and kept (an ncclCommInitAll per multipathfinder call would cost more than
+# the pooled stage itself); `close(eng)` removes the entries its engine is part of.  Same policy as the Python host's `_comm_for`.
+const _COMM_CACHE = Dict{Vector{Ptr{Cvoid}},Comm}()
+function comm_for(engines::Vector{Engine})
+    key = [e.ptr for e in engines]
+    c = get(_COMM_CACHE, key, nothing)
+    if c === nothing || c.ptr == C_NULL
+        c = Comm(engines)
+        _COMM_CACHE[key] = c
+    end
+    return c
 end
 
 # ---- target: arbitrary Julia closure through @cfunction (the reference's general logp, src/elbo.jl:15) --------------------
@@ -410,22 +446,23 @@ function multipathfinder(eng::Engine, optim_fun::SciMLBase.OptimizationFunction,
                          optimizer=Pathfinder.default_optimizer(history_length),
                          importance::Bool=true, ntries::Int=1_000, init_scale=2,
                          init_sampler=Pathfinder.UniformSampler(init_scale), statsbase_indices::Union{Bool,Symbol}=false, kwargs...)
-    _init = if init === nothing
+    if init === nothing
         nruns > 0 || throw(ArgumentError("A positive `nruns` must be set or `init` must be provided."))      # :148-150
         dim > 0 || throw(ArgumentError("An initial point `init` or dimension `dim` must be provided."))     # src/singlepath.jl:171
-        [init_sampler(rng, Vector{Float64}(undef, dim)) for _ in 1:nruns]                                  # src/singlepath.jl:167-168
     else
-        collect(init)
+        nruns = length(init)
     end
-    nruns = length(_init)
-    d = length(first(_init))
+    d = init === nothing ? dim : length(first(init))
     if ndraws > ndraws_per_run * nruns
         @warn "More draws requested than total number of draws across replicas. Draws will not be unique."
     end
     logp(x) = -optim_fun.f(x, nothing)                                                                      # :159
     set_target!(eng, logp, d)
+    # the reference keeps `init = nothing` per run (:151) and each run samples its own start inside `pathfinder` with the run's
+    # seeded rng (src/singlepath.jl:167-168, called at :190-193): run_seeds FIRST, then x0[k] from rngs[k] -- as pfmi/api.py does
     run_seeds = rand!(rng, Vector{UInt64}(undef, nruns))                                                    # :162
     rngs = [Random.seed!(copy(rng), s) for s in run_seeds]                                                  # :189-193
+    _init = init === nothing ? [init_sampler(rngs[k], Vector{Float64}(undef, d)) for k in 1:nruns] : collect(init)
     probs = [SciMLBase.OptimizationProblem(optim_fun, x0, nothing) for x0 in _init]
     itry = ones(Int, nruns); pending = collect(1:nruns)
     sols = Vector{Any}(undef, nruns); traces = Vector{Any}(undef, nruns)
@@ -542,13 +579,11 @@ function multipathfinder(engines::Vector{Engine}, target::DeviceTarget, ndraws::
                          optimizer=Pathfinder.default_optimizer(history_length), maxiters::Int=1_000, g_tol::Float64=1e-8,
                          comm::Union{Nothing,Comm}=nothing, kwargs...)
     d = dimension(target)
-    _init = if init === nothing
+    if init === nothing
         nruns > 0 || throw(ArgumentError("A positive `nruns` must be set or `init` must be provided."))      # :148-150
-        [init_sampler(rng, Vector{Float64}(undef, d)) for _ in 1:nruns]                                     # src/singlepath.jl:167-168
     else
-        collect(init)
+        nruns = length(init)
     end
-    nruns = length(_init)
     G = length(engines); blocks = _blocks(nruns, G)
     if ndraws > ndraws_per_run * nruns
         @warn "More draws requested than total number of draws across replicas. Draws will not be unique."
@@ -559,12 +594,13 @@ function multipathfinder(engines::Vector{Engine}, target::DeviceTarget, ndraws::
     foreach(e -> set_target!(e, target), engines)
     run_seeds = rand!(rng, Vector{UInt64}(undef, nruns))                                                    # :162
     rngs = [Random.seed!(copy(rng), s) for s in run_seeds]                                                  # :189-193
-    x0 = [copy(x) for x in _init]
+    # each run samples its own start with its seeded rng (src/singlepath.jl:167-168 inside the run of :190-193), after run_seeds
+    x0 = init === nothing ? [init_sampler(rngs[k], Vector{Float64}(undef, d)) for k in 1:nruns] : [copy(x) for x in init]
     itry = ones(Int, nruns); pending = collect(1:nruns); success = falses(nruns)
     fit_seeds = [UInt64[] for _ in 1:nruns]; fail_seeds = zeros(UInt64, nruns)
     traces = Vector{Any}(undef, nruns); sols = Vector{Any}(undef, nruns)
     batches = Vector{Batch}(undef, G); elbos = Vector{ElboBatch}(undef, G)
-    cm = comm === nothing ? Comm(engines) : comm
+    cm = comm === nothing ? comm_for(engines) : comm               # cached per engine set (ADVICE r3)
     local k̂::Float64, M::Int, idx::Vector{Int64}, draws_::Matrix{Float64}
     rs_seed = rand(rng, UInt64)                                       # _resample's draw from the top-level rng (:225)
     while true                                                        # the retry loop of src/singlepath.jl:259-283, batched

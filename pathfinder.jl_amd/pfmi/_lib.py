@@ -37,7 +37,7 @@ SYMBOLS = [
     "pfmi_comm_unique_id", "pfmi_comm_init_all", "pfmi_comm_init_rank", "pfmi_comm_destroy", "pfmi_comm_info",
     "pfmi_comm_pool_psis", "pfmi_comm_resample", "pfmi_host_rand_u64",
     "pfmi_optimize_batch_enqueue", "pfmi_optimize_batch_wait", "pfmi_elbo_batch_enqueue", "pfmi_elbo_batch_wait",
-    "pfmi_callback_stats_dev", "pfmi_pool_build_best", "pfmi_pool_winners", "pfmi_psis_weights", "pfmi_comm_psis_resample",
+    "pfmi_callback_stats_dev", "pfmi_pool_build_best", "pfmi_pool_winners", "pfmi_psis_weights", "pfmi_comm_psis_resample", "pfmi_debug_set",
 ]
 
 

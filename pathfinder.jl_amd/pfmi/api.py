@@ -435,6 +435,7 @@ def _run_paths(engs, target, inits, run_rngs, *, dim, history_length, ndraws_elb
     okw = {k: v for k, v in optimizer_kwargs.items() if k in ("maxiters", "g_tol")}
     pooled = None
     while pending:
+        pooled_error = None
         need = []
         for k in pending:
             st = state[k]
@@ -493,9 +494,12 @@ def _run_paths(engs, target, inits, run_rngs, *, dim, history_length, ndraws_elb
             for eng, (k0, k1) in zip(engs, blocks):
                 eng.pool_build_best(pool["N_r"], np.array([s["fail_seed"] for s in state[k0:k1]], dtype=np.uint64))
             comm = _comm_for(engs)
-            res, idx, draws = comm.psis_resample(pool["ndraws"], importance=pool["importance"], replace=pool.get("replace", True),
-                                                 seed=pool["seed"])
-            pooled = dict(psis=res, idx=idx, draws=draws, comm=comm)
+            try:
+                res, idx, draws = comm.psis_resample(pool["ndraws"], importance=pool["importance"], replace=pool.get("replace", True),
+                                                     seed=pool["seed"])
+                pooled = dict(psis=res, idx=idx, draws=draws, comm=comm)
+            except Exception as ex:                                 # surfaced AFTER the fit statuses: the reference would have thrown
+                pooled_error = ex                                   # PosDefException from fit_mvnormals before it ever pooled
         # ---- first wait of this try: everything above is in flight on every engine
         new_pending = []
         all_status, all_jeff = [], []
@@ -529,6 +533,8 @@ def _run_paths(engs, target, inits, run_rngs, *, dim, history_length, ndraws_elb
                     new_pending.append(k)
                 else:
                     st["done"] = True
+        if pooled_error is not None:                                # every engine's fit status has been inspected (and was clean)
+            raise pooled_error
         pending = new_pending
     return state, pooled
 

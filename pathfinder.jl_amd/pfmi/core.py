@@ -56,6 +56,14 @@ class Engine:
         except Exception:
             pass
 
+    def _raise_target_error(self):
+        """An exception raised by a Python `logp` closure inside the library's callback cannot cross the C frames: the closure's
+        wrapper records it (and fills its output block with NaN); it is re-raised here, after the C call that invoked the closure."""
+        ex = getattr(self.target, "pending_error", None)
+        if ex is not None:
+            self.target.pending_error = None
+            raise ex
+
     # ---- generations of the device state lazy handles point into ------------------------------------
     def trace_token(self):
         return (self.gen_traces,)
@@ -185,6 +193,7 @@ class Engine:
         best = np.empty(self.K, dtype=np.int64)
         check(self.L.pfmi_elbo_batch(self.ctx, C.c_int64(N), seeds.ctypes.data_as(_u64p), _d(u), _d(elbo), _d(se),
                                      best.ctypes.data_as(_i64p)))
+        self._raise_target_error()
         return elbo, se, best
 
     def elbo_batch_enqueue(self, N, seeds, u=None):
@@ -195,11 +204,13 @@ class Engine:
             u = np.ascontiguousarray(u, dtype=np.float64)
             assert u.size == self.P * self.d * N
         check(self.L.pfmi_elbo_batch_enqueue(self.ctx, C.c_int64(N), seeds.ctypes.data_as(_u64p), _d(u)))
+        self._raise_target_error()
 
     def elbo_batch_wait(self):
         elbo, se = np.empty(self.P), np.empty(self.P)
         best = np.empty(self.K, dtype=np.int64)
         check(self.L.pfmi_elbo_batch_wait(self.ctx, _d(elbo), _d(se), best.ctypes.data_as(_i64p)))
+        self._raise_target_error()
         return elbo, se, best
 
     def callback_stats_dev(self):
@@ -225,6 +236,7 @@ class Engine:
             u = np.asfortranarray(u, dtype=np.float64)
         check(self.L.pfmi_draws(self.ctx, C.c_int64(p), C.c_uint64(int(seed)), C.c_int64(n0), C.c_int64(N), _d(u),
                                 _d(X), _d(lp), _d(lq)))
+        self._raise_target_error()
         return X, lp, lq
 
     def logpdf(self, p, X):
@@ -263,6 +275,7 @@ class Engine:
         self.gen_pool += 1
         check(self.L.pfmi_pool_build(self.ctx, C.c_int64(N_r), points.ctypes.data_as(_i64p),
                                      seeds.ctypes.data_as(_u64p)))
+        self._raise_target_error()
 
     def pool_build_best(self, N_r, fail_seeds=None):
         """pool of the winners picked on the device from the last elbo_batch[_enqueue]; only enqueues"""
@@ -273,6 +286,7 @@ class Engine:
         self.gen_pool += 1
         check(self.L.pfmi_pool_build_best(self.ctx, C.c_int64(N_r),
                                           fail_seeds.ctypes.data_as(_u64p) if fail_seeds is not None else None))
+        self._raise_target_error()
 
     def pool_winners(self):
         pts = np.empty(self.K, dtype=np.int64)

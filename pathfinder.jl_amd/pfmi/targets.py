@@ -110,14 +110,21 @@ class CallbackTarget:
         self._grad = grad
         self._logp_batch = logp_batch
 
+        self.pending_error = None       # an exception raised inside the ctypes callback (ctypes would print and swallow it)
+
         def _cb(Xp, d_, n, outp, _user):
-            X = np.ctypeslib.as_array(Xp, shape=(n, d_))
             out = np.ctypeslib.as_array(outp, shape=(n,))
-            if self._logp_batch is not None:
-                out[:] = np.asarray(self._logp_batch(X.T), dtype=np.float64)
-                return
-            for i in range(n):
-                out[i] = self._logp(X[i])
+            try:
+                X = np.ctypeslib.as_array(Xp, shape=(n, d_))
+                if self._logp_batch is not None:
+                    out[:] = np.asarray(self._logp_batch(X.T), dtype=np.float64)
+                    return
+                for i in range(n):
+                    out[i] = self._logp(X[i])
+            except BaseException as ex:  # noqa: BLE001 -- recorded, re-raised by the Engine once the C call has returned
+                out[:] = np.nan           # never leave stale memory to be reduced into an ELBO
+                if self.pending_error is None:
+                    self.pending_error = ex
 
         self._cfn = _lib.LOGP_FN(_cb)   # keep alive
 
@@ -196,12 +203,22 @@ class TorchDeviceTarget(DeviceCallbackTarget):
             def __init__(self, ptr, shape):
                 self.__cuda_array_interface__ = {"shape": shape, "typestr": "<f8", "data": (ptr, False), "version": 2}
 
+        self.pending_error = None       # an exception raised inside the ctypes callback (ctypes would print and swallow it)
+
         def _cb(xp, d_, n, outp, stream, _user):
-            dev = torch.device("cuda", device)
-            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=dev)):
-                X = torch.as_tensor(_View(xp, (n, d_)), device=dev)
-                out = torch.as_tensor(_View(outp, (n,)), device=dev)
-                out.copy_(fn(X).to(torch.float64).reshape(n))
+            try:
+                dev = torch.device("cuda", device)
+                with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=dev)):
+                    out = torch.as_tensor(_View(outp, (n,)), device=dev)
+                    try:
+                        X = torch.as_tensor(_View(xp, (n, d_)), device=dev)
+                        out.copy_(fn(X).to(torch.float64).reshape(n))
+                    except BaseException:
+                        out.fill_(float("nan"))   # never leave stale memory to be reduced into an ELBO
+                        raise
+            except BaseException as ex:  # noqa: BLE001 -- recorded, re-raised by the Engine once the C call has returned
+                if self.pending_error is None:
+                    self.pending_error = ex
 
         self._cfn = _lib.LOGP_DEV_FN(_cb)
         super().__init__(d, self._cfn, None, host)

@@ -9,6 +9,11 @@ for p in (ROOT, os.path.join(ROOT, "pathfinder.jl_amd")):
         sys.path.insert(0, p)
 
 
+# the library honours its PFMI_* test hooks from the environment only in a process started with PFMI_DEBUG_HOOKS=1 (include/pfmi.h:
+# pfmi_debug_set); the tests select kernels / the RCCL stand-in through them, also in the subprocesses they spawn
+os.environ.setdefault("PFMI_DEBUG_HOOKS", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
 
