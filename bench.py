@@ -138,6 +138,33 @@ def _pmc_traffic(argv_tail, kernels):
     return out, None
 
 
+def _single_gpu_reference(pfmi, tg, x0_all, run_seeds, J, maxiters, N_e, N_r, ndraws, master, device, free_bytes=None):
+    """ALL K paths on ONE context (a world of one: no collective), the answer a sharded run must reproduce bit for bit
+    (test/multipath.jl:107-140 extended from `ntasks` to the GPU count).  Returns (fingerprint | None, note)."""
+    from pfmi.distributed import result_fingerprint
+    from pfmi.hostrng import rand_u64
+    K, d = x0_all.shape
+    kc = next(o for o in (4, 8, 12, 16, 20, 32) if 2 * J <= o)
+    need = 8.0 * d * (K * (maxiters + 1) * (kc + 9))               # factors + alpha / sqrt(alpha) / mu + traces and their staging, upper bound
+    if free_bytes is not None and need > 0.8 * free_bytes:
+        return None, f"all {K} paths need up to {need / 1e9:.0f} GB on one GPU ({free_bytes / 1e9:.0f} GB free): not verifiable on one device"
+    e = pfmi.Engine(device)
+    try:
+        e.set_target(tg)
+        npts = e.optimize_batch(x0_all, J, maxiters)
+        seeds = np.concatenate([rand_u64(int(run_seeds[k]), np.arange(n, dtype=np.uint64), 10) for k, n in enumerate(npts)])
+        e.fit_batch(J)
+        e.elbo_batch_enqueue(N_e, seeds)
+        e.pool_build_best(N_r)
+        cm = pfmi.Comm.init_all([e])
+        res, idx, draws = cm.psis_resample(ndraws, seed=master)
+        e.elbo_batch_wait()
+        cm.close()
+        return result_fingerprint(res["pareto_shape"], res["tail_length"], idx, draws), f"all {K} paths recomputed on GPU {device} (no collective)"
+    finally:
+        e.close()
+
+
 def main_single_process(args):
     """--gpus N --single-process: ONE host process (thread) drives N contexts, one per GPU -- what a single Julia caller of
     multipathfinder does (north star).  pfmi_comm_init_all; every stage is enqueued on all GPUs before the first wait."""
@@ -177,7 +204,7 @@ def main_single_process(args):
             e.pool_build_best(N_r)
         res, idx, state["draws"] = comm.psis_resample(ndraws, seed=master)
         state["best"] = [e.elbo_batch_wait()[2] for e in engs]
-        state.update(pareto_k=res["pareto_shape"], idx=idx)
+        state.update(pareto_k=res["pareto_shape"], tail=res["tail_length"], idx=idx)
 
     for _ in range(args.warmup):
         step()
@@ -189,6 +216,13 @@ def main_single_process(args):
     for e in engs:
         e.sync()
     ms_per_step = (time.perf_counter() - t0) / args.steps * 1e3
+    verdict, vnote = None, "not requested"
+    if args.verify_sharding or (G > 1 and not args.no_verify_sharding):
+        from pfmi.distributed import result_fingerprint, sharded_equals_single
+        ref, vnote = _single_gpu_reference(pfmi, tg, x0, run_seeds, J, args.maxiters, N_e, N_r, ndraws, master, engs[0].device)
+        verdict, bad = sharded_equals_single(None, result_fingerprint(state["pareto_k"], state["tail"], state["idx"], state["draws"]), ref)
+        if bad:
+            vnote += f"; MISMATCH in {bad}"
     line = {"metric": "ELBO draws/sec (multipathfinder hot path: fit + ELBO + pool + PSIS + resample)",
             "value": round(total_draws / (ms_per_step * 1e-3), 1), "unit": "ELBO draws/s", "n_gpus": G, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
@@ -197,7 +231,8 @@ def main_single_process(args):
                        "npaths": K, "paths_per_gpu": Kl, "fits_total": int(total_draws // N_e), "elbo_draws_per_step": int(total_draws),
                        "parallelism": f"paths sharded x{G}, ONE host process / thread (pfmi_comm_init_all)",
                        "ranks_in_collective": info["world"], "rccl_version": info["rccl_version"]},
-            "pareto_k": state.get("pareto_k"), "roofline": None, "cpu_baseline": None}
+            "pareto_k": state.get("pareto_k"), "sharded_equals_single": verdict, "sharded_equals_single_note": vnote,
+            "rccl_version": info["rccl_version"], "roofline": None, "cpu_baseline": None}
     comm.close()
     for e in engs:
         e.close()
@@ -226,6 +261,10 @@ def main():
     ap.add_argument("--minimal", action="store_true", help="timed steps only (the rocprofv3 counter passes re-run bench.py this way)")
     ap.add_argument("--with-devcb", action="store_true", help="with --minimal: also one device-closure scan (counter passes)")
     ap.add_argument("--no-pmc", action="store_true", help="do not re-run a step under rocprofv3 --pmc for roofline.traffic")
+    ap.add_argument("--verify-sharding", action="store_true",
+                    help="after the timed steps rank 0 recomputes ALL paths on one GPU and every rank compares k-hat, the indices and a hash "
+                         "of the d x ndraws result with its sharded answer (default when --gpus > 1; this flag forces it at --gpus 1)")
+    ap.add_argument("--no-verify-sharding", action="store_true")
     ap.add_argument("--maxiters", type=int, default=1000)
     ap.add_argument("--init-scale", type=float, default=2.0)
     args = ap.parse_args()
@@ -348,7 +387,7 @@ def main():
                 sync_fn=torch.cuda.synchronize, min_world=1)
             state["draws"] = out_dev
         elbo, se, best = eng.elbo_batch_wait()                      # already complete: plain downloads
-        state.update(elbo=elbo, best=best, pareto_k=res["pareto_shape"], idx=idx)
+        state.update(elbo=elbo, best=best, pareto_k=res["pareto_shape"], tail=res["tail_length"], idx=idx)
 
     def barrier():
         eng.sync()
@@ -392,6 +431,42 @@ def main():
         ranks_seen = 1
     ms_per_step = dt / args.steps * 1e3
     value = total_draws / (ms_per_step * 1e-3)
+
+    # ---- self-verification of the sharded run: the first real multi-GPU run says whether it is CORRECT, not only how
+    #      fast.  Rank 0 recomputes all K paths on its own GPU (a world of one context, no collective); every rank compares k-hat, the
+    #      tail length, the resample indices and a hash of the d x ndraws result of ITS copy of the sharded answer with it.
+    verdict, vnote, rccl_version = None, "not requested", None
+    if comm is not None:
+        try:
+            rccl_version = comm.info()["rccl_version"]
+        except Exception:
+            pass
+    if (args.verify_sharding or (world > 1 and not args.no_verify_sharding)) and not args.minimal and not args.host_traces:
+        from pfmi.distributed import result_fingerprint, sharded_equals_single
+        dr = state["draws"]
+        if not isinstance(dr, np.ndarray):                              # fallback collective path: a flat device tensor, draw-major
+            dr = np.asfortranarray(dr.cpu().numpy().reshape(ndraws, d).T)
+        mine = result_fingerprint(state["pareto_k"], state["tail"], state["idx"], dr)
+        ref = None
+        if rank == 0:
+            x0_all = np.stack([pfmi.HostRNG(int(run_seeds[k])).rand(d) * 2 * sc - sc for k in range(K)])
+            free_b = None
+            try:
+                import torch
+                free_b = torch.cuda.mem_get_info(local_rank)[0]
+            except Exception:
+                pass
+            try:
+                ref, vnote = _single_gpu_reference(pfmi, tg, x0_all, run_seeds, J, args.maxiters, N_e, N_r, ndraws, master, local_rank, free_b)
+            except Exception as ex:                                     # the other ranks are waiting in the broadcast: never raise here
+                ref, vnote = None, f"reference run failed: {ex!r}"
+        dev = None
+        if use_dist:
+            import torch
+            dev = torch.device("cuda", local_rank)
+        verdict, bad = sharded_equals_single(dist if use_dist else None, mine, ref, device=dev)
+        if bad:
+            vnote = (vnote or "") + f"; rank {rank} MISMATCH in {bad}"
 
     # ---- metric (ii): end-to-end wall-clock incl. trajectory generation (x0 on the host -> resampled draws on the host)
     wall_e2e = None
@@ -625,6 +700,7 @@ def main():
             "multipathfinder_api_wall_ms": None if api_wall is None else round(api_wall, 3),
             "traces": "host numpy L-BFGS driver" if args.host_traces else "device L-BFGS (pfmi_optimize_batch)",
             "pareto_k": state.get("pareto_k"),
+            "sharded_equals_single": verdict, "sharded_equals_single_note": vnote, "rccl_version": rccl_version,
             "stages_ms": stages,
             "callback_target": callback_line,
             "device_callback_target": devcb_line,

@@ -57,3 +57,41 @@ def pooled_psis_resample(dist, lr_local, lr_all, out, *, psis_fn, sample_fn, gat
         if sync_fn:
             sync_fn()
     return res, idx
+
+
+# ---- self-verification of a sharded run ---------------------------------------------------------------------
+def result_fingerprint(pareto_k, tail_length, idx, draws):
+    """What must be IDENTICAL for any GPU count (test/multipath.jl:107-140 extended to G): k-hat (bit pattern, NaN included), the
+    PSIS tail length, the resample indices and the (d x ndraws) result, the arrays as SHA-256 of their bytes."""
+    import hashlib
+    import numpy as np
+    return {"pareto_k_bits": np.float64(pareto_k).view(np.uint64).item(), "tail_length": int(tail_length),
+            "idx_sha256": hashlib.sha256(np.ascontiguousarray(idx, dtype=np.int64).tobytes()).hexdigest(),
+            "draws_sha256": hashlib.sha256(np.ascontiguousarray(draws, dtype=np.float64).tobytes()).hexdigest()}
+
+
+def sharded_equals_single(dist, mine, reference, device=None):
+    """Every rank compares the fingerprint of ITS copy of the sharded result with rank 0's single-GPU reference.
+
+    dist       torch.distributed (initialised) or None
+    mine       result_fingerprint(...) of this rank's sharded answer
+    reference  result_fingerprint(...) of all K paths on one context -- needed on rank 0 only (None elsewhere); None on rank 0 too
+               means "could not be computed" and the answer is None on every rank
+    device     torch device for the flag all-reduce (None: CPU, for gloo)
+    returns    (True | False | None, per-field mismatches seen by THIS rank)
+    """
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        if reference is None:
+            return None, []
+        bad = [k for k in reference if mine.get(k) != reference[k]]
+        return not bad, bad
+    import torch
+    box = [reference if dist.get_rank() == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    ref = box[0]
+    if ref is None:
+        return None, []
+    bad = [k for k in ref if mine.get(k) != ref[k]]
+    flag = torch.tensor([0.0 if bad else 1.0], dtype=torch.float64, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)                 # one rank that disagrees makes the verdict False everywhere
+    return bool(flag.item() == 1.0), bad

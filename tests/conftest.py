@@ -21,3 +21,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """parity margins recorded by tests/margins.py -> gpurun_out/parity_margins.json (merged back by gpurun)"""
+    try:
+        import margins
+        margins.dump(os.path.join(ROOT, "gpurun_out", "parity_margins.json"))
+    except Exception as ex:  # pragma: no cover
+        print(f"parity margins not written: {ex!r}")

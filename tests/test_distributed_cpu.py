@@ -106,3 +106,48 @@ def test_shard_paths_contract():
     assert [shard_paths(64, 8, r) for r in (0, 7)] == [(0, 8), (56, 64)]
     with pytest.raises(ValueError):
         shard_paths(10, 4, 0)
+
+
+def _verify_worker(rank, world, port, q, tamper):
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "pathfinder.jl_amd"))
+    from pfmi.distributed import result_fingerprint, sharded_equals_single
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        idx = np.arange(50, dtype=np.int64) * 3
+        draws = np.linspace(-1, 1, 200).reshape(4, 50)
+        ref = result_fingerprint(float("nan"), 17, idx, draws) if rank == 0 else None       # NaN k-hat compares by bit pattern
+        mine_draws = draws.copy()
+        if tamper and rank == 1:
+            mine_draws[3, 49] = np.nextafter(mine_draws[3, 49], 2.0)                         # ONE bit on ONE rank
+        ok, bad = sharded_equals_single(dist, result_fingerprint(float("nan"), 17, idx, mine_draws), ref)
+        q.put((rank, ok, bad))
+        ok2, _ = sharded_equals_single(dist, result_fingerprint(1.0, 17, idx, draws), None)  # no reference: None everywhere
+        q.put((rank, ok2, ["second"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("tamper", [False, True])
+def test_sharded_equals_single_verdict_is_collective(tamper):
+    """bench.py's self-check of a multi-GPU run (VERDICT r3 next #8): every rank compares its copy of the sharded answer with rank 0's
+    single-GPU reference; one differing bit on one rank makes the verdict False on EVERY rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_verify_worker, args=(r, 2, port, q, tamper)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    first = [g for g in got if g[2] != ["second"]]
+    second = [g for g in got if g[2] == ["second"]]
+    assert len(first) == 2 and all(g[1] is (not tamper) for g in first), first
+    if tamper:
+        assert [g[2] for g in first if g[0] == 1] == [["draws_sha256"]] and [g[2] for g in first if g[0] == 0] == [[]]
+    assert all(g[1] is None for g in second)

@@ -17,6 +17,7 @@ import pytest
 
 from helpers import demo_device_target, fit_seeds, make_traces, oracle_target
 from oracle import pf_oracle as po
+import margins as mg
 from test_gpu_parity_r2 import _factor, _wc
 
 pytestmark = pytest.mark.gpu
@@ -73,13 +74,14 @@ def test_config3_whole_trace_best_iter_and_winner_logs_vs_oracle(pfmi_mod, eng):
         np.testing.assert_array_equal(status[p0:p1], ref["status"][r0:r1])
         np.testing.assert_array_equal(jeff[p0:p1], ref["j_eff"][r0:r1])
         assert nrej[k] == ref["n_rejected"][i]
-        assert np.all(np.abs(logdet[p0:p1] - ref["logdet"][r0:r1]) <= 1e-10 * (1 + np.abs(ref["logdet"][r0:r1])))
+        mg.check("C3:whole-trace", "logdet", mg.rel(logdet[p0:p1], ref["logdet"][r0:r1]))
+        mg.record("C3:whole-trace", "logdet_abs", np.abs(logdet[p0:p1] - ref["logdet"][r0:r1]), np.inf)
         alpha_all, hl, hs, _ = po.lbfgs_history(ths[i], grs[i], J)
         wc = np.array([_wc(_factor(ths[i], grs[i], alpha_all, hl, hs, l, d)) for l in range(1, L + 1)])
         x, y = elbo[p0 + 1:p1], ref["elbo"][r0 + 1:r1]
         sx, sy = se[p0 + 1:p1], ref["se"][r0 + 1:r1]
-        assert np.all(np.abs(x[wc] - y[wc]) <= 1e-9 * (1 + np.abs(y[wc]))), (k, np.abs(x[wc] - y[wc]).max())
-        assert np.all(np.abs(sx[wc] - sy[wc]) <= 1e-9 * (1 + sy[wc]))
+        mg.check("C3:whole-trace", "elbo", mg.rel(x[wc], y[wc]), ctx=k)
+        mg.check("C3:whole-trace", "se", mg.rel(sx[wc], sy[wc]))
         lo = ~wc
         assert np.all(np.abs(x[lo] - y[lo]) <= 8 * np.maximum(sx[lo], sy[lo]) + 1e-9 * (1 + np.abs(y[lo])))
         mid = L // 2
@@ -95,9 +97,9 @@ def test_config3_whole_trace_best_iter_and_winner_logs_vs_oracle(pfmi_mod, eng):
         b = int(ref["best_iter"][i])
         refd = po.path_fit_elbo(ths[i][:b + 1], grs[i][:b + 1], J, otg, N, sds[i][:b + 1], want_draws=True)
         lp, lq = eng.elbo_logs(p0 + b, N)
-        assert np.max(np.abs(lq - refd["logq"]) / (1 + np.abs(refd["logq"]))) <= 1e-9
+        mg.check("C3:whole-trace", "logq@scan", mg.rel(lq, refd["logq"]))
         if wc[b - 1]:
-            assert np.max(np.abs(lp - refd["logp"]) / (1 + np.abs(refd["logp"]))) <= 1e-9
+            mg.check("C3:whole-trace", "logp@scan", mg.rel(lp, refd["logp"]))
     print(f"config 3 whole trace: {n_fits} fits of {KF} full paths, {n_strict} strict; per section (first/middle/last 20): "
           f"{n_sec.tolist()}; best_iter compared on {n_best} paths")
     assert n_strict >= n_fits * 3 // 4, (n_strict, n_fits)
@@ -138,21 +140,23 @@ def test_config5_share_full_ring_vs_oracle(pfmi_mod, eng, tname):
             n_fits += 1
             n_full += int(jeff[p0 + l] == J)
             a, b = elbo[p0 + l], ref["elbo"][p0 + l]
-            assert abs(logdet[p0 + l] - ref["logdet"][p0 + l]) <= 1e-9 * (1 + abs(ref["logdet"][p0 + l]))
+            cfg = f"C5-shape:{tname}-4x60"
+            mg.check(cfg, "logdet", mg.rel(logdet[p0 + l], ref["logdet"][p0 + l]))
+            mg.record(cfg, "logdet_abs", abs(logdet[p0 + l] - ref["logdet"][p0 + l]), np.inf)
             F = _factor(th[p0:p1], gr[p0:p1], alpha_all, hl, hs, l, d)
             # the mean mu = theta + Sigma grad goes through the factor but is a function of Sigma alone: STRICT for every fit,
             # however ill-conditioned the Householder block is
             mu_ref = F.fit_mean(th[p0 + l], gr[p0 + l])
             mu_gpu = eng.get_fit(p0 + l, int(jeff[p0 + l]))["mu"]
-            assert np.max(np.abs(mu_gpu - mu_ref)) <= 1e-9 * (1 + np.abs(mu_ref).max()), (k, l)
+            mg.check(cfg, "mu", np.max(np.abs(mu_gpu - mu_ref)) / (1 + np.abs(mu_ref).max()), ctx=(k, l))
             n_mu += 1
             if not (np.isfinite(a) and np.isfinite(b)):         # logp overflows on both sides (funnel: exp(-tau) of a far draw): same value
                 assert (np.isnan(a) and np.isnan(b)) or a == b, (k, l, a, b)
                 continue
             if _wc(F):
                 n_strict += 1
-                assert abs(a - b) <= 1e-8 * (1 + abs(b)), (k, l, a, b)
-                assert abs(se[p0 + l] - ref["se"][p0 + l]) <= 1e-7 * (1 + ref["se"][p0 + l])
+                mg.check(cfg, "elbo", mg.rel(a, b), ctx=(k, l, a, b))
+                mg.check(cfg, "se", mg.rel(se[p0 + l], ref["se"][p0 + l]))
             else:
                 assert abs(a - b) <= 8 * max(se[p0 + l], ref["se"][p0 + l]) + 1e-8 * (1 + abs(b)), (k, l, a, b)
     print(f"config 5 share ({tname}): {n_fits} fits, {n_mu} strict means, {n_strict} strict ELBOs, {n_full} with a full ring (j = {J})")
@@ -168,10 +172,10 @@ def test_config5_share_full_ring_vs_oracle(pfmi_mod, eng, tname):
         b = int(ref["best_iter"][k])
         refd = po.path_fit_elbo(th[p0:p0 + b + 1], gr[p0:p0 + b + 1], J, otg, N, seeds[p0:p0 + b + 1], want_draws=True)
         lp, lq = eng.elbo_logs(p0 + b, N)
-        assert np.max(np.abs(lq - refd["logq"]) / (1 + np.abs(refd["logq"]))) <= 1e-9
+        mg.check(f"C5-shape:{tname}-4x60", "logq@scan", mg.rel(lq, refd["logq"]))
         alpha_all, hl, hs, _ = po.lbfgs_history(th[p0:p1], gr[p0:p1], J)
         if _wc(_factor(th[p0:p1], gr[p0:p1], alpha_all, hl, hs, b, d)):
-            assert np.max(np.abs(lp - refd["logp"]) / (1 + np.abs(refd["logp"]))) <= 1e-8
+            mg.check(f"C5-shape:{tname}-4x60", "logp@scan", mg.rel(lp, refd["logp"]))
         else:                                                   # rank-deficient block: x(u) is not well defined, logp's law is
             assert abs(lp.mean() - refd["logp"].mean()) <= 8 * (lp.std() + refd["logp"].std()) / np.sqrt(N) + 1e-8 * abs(lp.mean())
 
