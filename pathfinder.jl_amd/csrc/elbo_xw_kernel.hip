@@ -15,42 +15,32 @@
 // split over the 8 waves: two barriers and an LDS reduction per 16 draws, 16 draws in flight per CU, 8-byte stores scattered over
 // 16 columns.  Here the second Philox + table pass buys 128 draws in flight per CU and no synchronisation.
 //
-// Stores: a draw is a column of d contiguous doubles.  Lane (q, c) ends up with 4 consecutive rows of column c; written directly
-// that is 16 columns x four 8-byte pieces per instruction.  Instead a block (16 rows x 16 draws; XW_SB = 2: two blocks) goes through a
-// wave-private, XOR-swizzled LDS tile and leaves as 4 instructions of 4 x 128 contiguous bytes -- whole 128-byte lines.
+// Stores (round 4): a draw is a column of d contiguous doubles and lane (q, c) ends up with rows 4q .. 4q+3 of column c -- 32 contiguous
+// bytes -- which leave as two 16-byte stores per lane (every instruction touches 16 columns, 64 of each 128-byte line; L2 merges the
+// halves).  Round 3 sent each block through a wave-private, XOR-swizzled LDS tile to form whole lines first: measured alone the two
+// store patterns sustain the same 4.7 - 5.5 TB/s (tools/write_bench.hip), and without the tile the kernel has 32 KB of LDS back:
+// sqrt(alpha) / mu are staged there with the factor block, so the block loop contains no vector-memory LOAD at all (on gfx9 stores and
+// loads share vmcnt: a load issued behind a block's stores cannot be waited for without waiting for their write acknowledgements).
+// Two 16-draw groups per wave, 8 waves: config-3 sample 5.9 -> 5.5 ms, config-5 shape 75 -> 53 ms (profiles/r04_experiments.md).
 // logq is accumulated exactly as the scan does (same lane ownership, same order), so it is bit-identical to the scan's.
 #include <type_traits>
 #include "pfmi_common.h"
 #include "elbo_args.h"
 
 #ifndef XW_WAVES
-#define XW_WAVES 16                    // waves per workgroup (4 per SIMD: measured 5.5 ms against 6.0 with 8 on the config-3 sample)
+#define XW_WAVES 8                     // waves per workgroup (2 per SIMD, 256 VGPRs each)
 #endif
 #define XW_THREADS (XW_WAVES * 64)
-#ifndef XW_SB
-#define XW_SB 1                        // blocks (of 16 rows) per store burst: 2 -> 256 contiguous bytes per column and instruction
-#endif
 #ifndef XW_NG
-#define XW_NG 1                        // 16-draw groups per wave (2 share the operand fetches but measured slower: 6.4 ms with 8 waves)
-#endif
-#ifndef XW_SM_LDS
-#define XW_SM_LDS 0                    // 1: sqrt(alpha) / mu of a chunk staged in LDS (measured slower: 5.85 vs 5.47 ms, LDS is the scarcer resource)
+#define XW_NG 2                        // 16-draw groups per wave: they share the operand fetches of a block
 #endif
 #ifndef XW_ABLATE
-#define XW_ABLATE 0                    // timing experiments only: 1 = no global stores, 2 = pass 2 without generator, 3 = no pass 1
+#define XW_ABLATE 0                    // timing experiments only, bit mask: 1 no global stores, 2 pass 2 without generator, 4 no pass 1,
+                                       // 8 pass 1 without generator, 16 generator without table look-ups, 32 generator without Philox, 64 pass 2 without MFMAs
 #endif
 #define XW_MIN_FRONT 1024              // doubles in front of the inverse-CDF table (>= (32 - 19) * 32 * 2 = 832)
-#define XW_SR (16 * XW_SB)
-#define XW_LD XW_SR                    // leading dimension of the 16 x XW_SR transposition tile (no padding: rows are XOR-swizzled)
-// binades of the inverse-CDF table kept in LDS: all 19 with 8 waves; 12 (12 KB) with 16 waves, whose tiles need the room at d = 1000
-// (words below 2^19, probability 2^-12 per normal, then take the global-table path -- same values)
-#ifndef XW_NB
-#define XW_NB ((XW_SM_LDS && XW_WAVES * XW_NG > 8) ? 12 : PF_ICDF_NB_LDS)
-#endif
-// row `row` (0 .. XW_SR-1) of column `col` inside a tile: the XOR spreads both the (q, c)-ordered writes and the row-ordered reads over
-// all 32 bank pairs (two passes per 64-lane access, the minimum for 8-byte words)
-__device__ __forceinline__ int xw_tile_pos(int col, int row) { return col * XW_LD + (row ^ ((col >> 1) & 7)); }
-// blocks per streamed chunk (a multiple of XW_SB: a store burst never straddles chunks); KC = 32 halves it to stay inside 160 KB of LDS
+#define XW_NB PF_ICDF_NB_LDS           // all 19 binades of the inverse-CDF table in LDS
+// blocks per streamed chunk; KC = 32 halves it to stay inside 160 KB of LDS
 template <int KC> struct xw_chb { static constexpr int v = (KC > 20) ? 8 : 16; };
 
 // fused operations are explicit fma(); nothing else may be contracted (results must not depend on the launch geometry)
@@ -90,15 +80,14 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
         return;
     }
     // ---- LDS carve-up (offsets in doubles)
-    // a staged chunk = the Householder block (MFMA operand order) [+ per block of 16 rows: sqrt(alpha)[16], mu[16] when XW_SM_LDS]
-    const int vh_sz = ch_blocks * 16 * KC, sm_sz = XW_SM_LDS ? ch_blocks * 32 : 0;
+    // a staged chunk = the Householder block (MFMA operand order) + per block of 16 rows: sqrt(alpha)[16], mu[16]
+    const int vh_sz = ch_blocks * 16 * KC, sm_sz = ch_blocks * 32;
     const int buf_stride = (nchunks > 1) ? vh_sz + sm_sz : 0;
     const int stage_sz = (nchunks > 1 ? 2 : 1) * (vh_sz + sm_sz);
     // the index-clamped fast look-up (pf_icdf_issue_adj) may read up to (32 - XW_NB) binades x 32 x 16 B = 6.5 KB in FRONT of the table:
     // keep at least that much staged data before it (only matters for d < 64)
     double *t_s = lds + (stage_sz > XW_MIN_FRONT ? stage_sz : XW_MIN_FRONT);   // [KC][KC]
     double2 *icdf = reinterpret_cast<double2 *>(t_s + KC * KC);                 // [2 * 32 XW_NB]
-    double *xt0 = reinterpret_cast<double *>(icdf + 2 * (XW_NB << PF_ICDF_B)) + wv * (NG * 16 * XW_LD);   // this wave's 16 x XW_SR tiles
 
     const double *Vh = A.vh + (size_t)p * d * KC, *mu = A.mu + (size_t)p * d, *sqa = A.sqrt_alpha + (size_t)p * d;
     {
@@ -109,7 +98,7 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
             const int lrow = idx / KC, col = idx - lrow * KC;
             lds[xw_vh_pos<KC>(lrow, col)] = (lrow < d) ? Vh[(size_t)lrow * KC + col] : 0.0;
         }
-        for (int lrow = tid; XW_SM_LDS && lrow < ch_blocks * 16; lrow += XW_THREADS) {
+        for (int lrow = tid; lrow < ch_blocks * 16; lrow += XW_THREADS) {
             double *o = lds + vh_sz + (lrow >> 4) * 32 + (lrow & 15);
             o[0] = (lrow < d) ? sqa[lrow] : 0.0; o[16] = (lrow < d) ? mu[lrow] : 0.0;
         }
@@ -117,28 +106,34 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
     // head transform z_head = V'u_head on 16x16x4 MFMAs: lane (q, c) supplies A_r[i' = c][k = q] = H[rho(c)][4 q + r], H = V'
     // identity padded (rho: the row permutation that makes result register r of lane (q, c) row 4 q + r); block 1 when KC > 16
     const int rho = 4 * (c & 3) + (c >> 2);
-    double a_h00[4], a_h10[4], a_h11[4];
-    {
-        const double *Vc = A.vchol + (size_t)p * KC * KC;
+    // KC <= 16: the four operands of H00 live in registers; KC > 16 (two groups per wave leave no room for 24 more registers) fetches
+    // the operands of H00 / H10 / H11 from the Cholesky factor when one of the two head blocks of a walk comes up
+    constexpr bool HREG = KC <= 16;
+    const double *Vc = A.vchol + (size_t)p * KC * KC;
+    auto head_op = [&](const int which, const int r) -> double {          // which: 0 = H00, 1 = H10, 2 = H11
+        const int b = 4 * q + r;
+        if (which == 0) { double v = (rho == b) ? 1.0 : 0.0; if (rho < KC && b < KC) v = Vc[b * KC + rho]; return v; }
+        const int i1 = 16 + rho, b1 = 16 + b;
+        if (which == 1) return (i1 < KC) ? Vc[b * KC + i1] : 0.0;
+        double v1 = (i1 == b1) ? 1.0 : 0.0;
+        if (i1 < KC && b1 < KC) v1 = Vc[b1 * KC + i1];
+        return v1;
+    };
+    double a_h00[HREG ? 4 : 1];
+    if (HREG) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int b = 4 * q + r;
-            double v = (rho == b) ? 1.0 : 0.0;
-            if (rho < KC && b < KC) v = Vc[b * KC + rho];
-            a_h00[r] = v;
-            if (KC > 16) {
-                const int i1 = 16 + rho, b1 = 16 + b;
-                a_h10[r] = (i1 < KC) ? Vc[b * KC + i1] : 0.0;
-                double v1 = (i1 == b1) ? 1.0 : 0.0;
-                if (i1 < KC && b1 < KC) v1 = Vc[b1 * KC + i1];
-                a_h11[r] = v1;
-            } else { a_h10[r] = 0.0; a_h11[r] = 0.0; }
-        }
+        for (int r = 0; r < 4; ++r) a_h00[HREG ? r : 0] = head_op(0, r);
     }
+    auto hop = [&](const int which, const int r) -> double {
+        if (HREG && which == 0) return a_h00[HREG ? r : 0];
+        return head_op(which, r);
+    };
     const uint64_t seed = A.seeds[slot];
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     const double logdet = A.logdet[p];
     const uint32_t icdf_adj = pf_icdf_adj<XW_NB>(icdf);
+    // every draw of this launch starts on a 32-byte boundary: the 16-byte stores are aligned
+    const bool x_aligned = ((d & 3) == 0) && ((A.x_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(A.x) & 31) == 0);
     __syncthreads();
 
     int cur = 0;
@@ -159,7 +154,7 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
             nact += act[g] ? 1 : 0;
             nl0[g] = (int64_t)grp * 16;
             n[g] = (uint32_t)(A.n0 + nl0[g] + c);
-            fullc[g] = nl0[g] + 16 <= A.N;
+            fullc[g] = act[g] && nl0[g] + 16 <= A.N;
             xg[g] = act[g] ? A.x + (size_t)slot * A.x_stride + (size_t)nl0[g] * d : A.x;   // draw nl0 + col starts at xg + col * d
             usq[g] = 0.0;
 #pragma unroll
@@ -181,8 +176,19 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
                 double dp[4];
                 double2 c01[4], c23[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pf_icdf_issue_adj<XW_NB>(x[r], icdf_adj, dp[r], c01[r], c23[r]);
+                for (int r = 0; r < 4; ++r) {
+#if XW_ABLATE & 16
+                    dp[r] = (double)(x[r] & 0x7FFFFFFFu); c01[r] = make_double2(0.5, 1e-9); c23[r] = make_double2(1e-19, 1e-29);
+#else
+                    pf_icdf_issue_adj<XW_NB>(x[r], icdf_adj, dp[r], c01[r], c23[r]);
+#endif
+                }
+#if XW_ABLATE & 32
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xnext[g][r] = (x[r] * 2654435761u + (uint32_t)blk) ^ (n[g] + r * 0x9E3779B9u);
+#else
                 pf_philox_normals(n[g], (uint32_t)((blk + 1) * 4 + q), 0u, 0u, k0, k1, xnext[g]);   // (one call past the last block: discarded)
+#endif
 #pragma unroll
                 for (int r = 0; r < 4; ++r) z[r] = pf_icdf_finish(x[r], dp[r], c01[r], c23[r]);
                 if (__builtin_expect(__any(pf_icdf_miss4<XW_NB>(x)), 0))         // probability 2^-XW_NB per normal
@@ -200,15 +206,15 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
                 if (blk == 0) {                                                // z[1:k] = V'u[1:k] (src/woodbury.jl:139)
                     xw_d4 h = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { u0[g][r] = z[r]; h = xw_mfma16(a_h00[r], z[r], h); }
+                    for (int r = 0; r < 4; ++r) { u0[g][r] = z[r]; h = xw_mfma16(hop(0, r), z[r], h); }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) z[r] = h[r];
                 } else if (KC > 16 && blk == 1) {
                     xw_d4 h = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) h = xw_mfma16(a_h10[r], u0[g][r], h);
+                    for (int r = 0; r < 4; ++r) h = xw_mfma16(hop(1, r), u0[g][r], h);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) h = xw_mfma16(a_h11[r], z[r], h);
+                    for (int r = 0; r < 4; ++r) h = xw_mfma16(hop(2, r), z[r], h);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) z[r] = h[r];
                 }
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
                         const int lrow = idx / KC, row = row0 + lrow;
                         pre[e] = (idx < XW_CHB * 16 * KC && row < d) ? Vh[(size_t)row0 * KC + idx] : 0.0;
                     }
-                    if (XW_SM_LDS && tid < XW_CHB * 16 && row0 + tid < d) { pr_s = sqa[row0 + tid]; pr_m = mu[row0 + tid]; }
+                    if (tid < XW_CHB * 16 && row0 + tid < d) { pr_s = sqa[row0 + tid]; pr_m = mu[row0 + tid]; }
                 }
                 if (nact > 0) {
                     const double *vs = lds + cur * buf_stride;
@@ -240,32 +246,50 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
                         // ---- pass 1: w += Vh'z   (NGA = groups of this wave that exist: the last batch may have fewer)
                         auto body1 = [&](const int bl, auto special_tag, auto nga_tag) {
                             constexpr int NGA = decltype(nga_tag)::value;
-                            double av[4][NT];
                             const double *ap = vs + ((bl * 4) * NT << 4) + q * 4 + l3;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                                for (int T = 0; T < NT; ++T) av[r][T] = ap[(r * NT + T) << 4];
-                            double z[NGA][4];
-#pragma unroll
-                            for (int g = 0; g < NGA; ++g) normals(g, blk0 + bl, z[g], std::true_type{}, special_tag);
-#pragma unroll
-                            for (int g = 0; g < NGA; ++g)
+                            if (KC <= 16) {                      // the A tiles of the whole block are fetched before the generator runs
+                                double av[4][NT];
 #pragma unroll
                                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                                    for (int T = 0; T < NT; ++T) accw[g][T] = xw_mfma4(av[r][T], z[g][r], accw[g][T]);
+                                    for (int T = 0; T < NT; ++T) av[r][T] = ap[(r * NT + T) << 4];
+                                double z[NGA][4];
+#pragma unroll
+                                for (int g = 0; g < NGA; ++g) {
+#if XW_ABLATE & 8
+                                    z[g][0] = av[0][0]; z[g][1] = av[1][0]; z[g][2] = av[2][0]; z[g][3] = av[3][0];
+#else
+                                    normals(g, blk0 + bl, z[g], std::true_type{}, special_tag);
+#endif
+                                }
+#pragma unroll
+                                for (int g = 0; g < NGA; ++g)
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                                        for (int T = 0; T < NT; ++T) accw[g][T] = xw_mfma4(av[r][T], z[g][r], accw[g][T]);
+                            } else {                             // KC = 20, 32: the A tiles of ONE k-step live at a time, shared by the groups
+                                double z[NGA][4];
+#pragma unroll
+                                for (int g = 0; g < NGA; ++g) normals(g, blk0 + bl, z[g], std::true_type{}, special_tag);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    double a1[NT];
+#pragma unroll
+                                    for (int T = 0; T < NT; ++T) a1[T] = ap[(r * NT + T) << 4];
+#pragma unroll
+                                    for (int g = 0; g < NGA; ++g)
+#pragma unroll
+                                        for (int T = 0; T < NT; ++T) accw[g][T] = xw_mfma4(a1[T], z[g][r], accw[g][T]);
+                                }
+                            }
                         };
-                        for (int bl = 0; bl < (XW_ABLATE == 3 ? 1 : nb); ++bl) {
+                        for (int bl = 0; bl < ((XW_ABLATE & 4) ? 1 : nb); ++bl) {
                             const int blk = blk0 + bl;
                             const bool special = (blk == 0) | (blk == nblk - 1) | (KC > 16 && blk == 1);
-                            if (NG == 2 && nact == 2) {
-                                if (__builtin_expect(special, 0)) body1(bl, std::true_type{}, std::integral_constant<int, NG>{});
-                                else body1(bl, std::false_type{}, std::integral_constant<int, NG>{});
-                            } else {
-                                if (__builtin_expect(special, 0)) body1(bl, std::true_type{}, std::integral_constant<int, 1>{});
-                                else body1(bl, std::false_type{}, std::integral_constant<int, 1>{});
-                            }
+                            // (the groups of a wave that lie beyond the last one are computed too -- their stores are predicated off)
+                            if (__builtin_expect(special, 0)) body1(bl, std::true_type{}, std::integral_constant<int, NG>{});
+                            else body1(bl, std::false_type{}, std::integral_constant<int, NG>{});
                         }
                     } else {
                         // ---- pass 2: the same normals again, x~ = z - Vh tv, x = mu + sqrt(alpha) x~, full-line stores
@@ -278,73 +302,48 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
                             double a2v[NT], s4[4], m4[4];
 #pragma unroll
                             for (int s = 0; s < NT; ++s) a2v[s] = a2p[s << 4];
-                            if (XW_SM_LDS) {
+                            {
                                 const double *smp = vs + vh_sz + bl * 32 + 4 * q;        // rows >= d hold zeros: x = 0 there, never stored
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) { s4[r] = smp[r]; m4[r] = smp[16 + r]; }
-                            } else if (SPECIAL && blk == nblk - 1) {                     // rows >= d exist only in the last block
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    const int row = (blk * 16 + 4 * q + r < d) ? blk * 16 + 4 * q + r : d - 1;
-                                    s4[r] = sqa[row]; m4[r] = mu[row];
-                                }
-                            } else {
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) { s4[r] = sqa[blk * 16 + 4 * q + r]; m4[r] = mu[blk * 16 + 4 * q + r]; }
                             }
                             double z[NGA][4];
 #pragma unroll
                             for (int g = 0; g < NGA; ++g) {
-#if XW_ABLATE == 2
+#if XW_ABLATE & 2
                                 z[g][0] = s4[0]; z[g][1] = s4[1]; z[g][2] = m4[2]; z[g][3] = m4[3];
 #else
                                 normals(g, blk, z[g], std::false_type{}, special_tag);
 #endif
                             }
-                            const int sb = blk % XW_SB;                                  // position inside the store burst
 #pragma unroll
                             for (int g = 0; g < NGA; ++g) {
                                 xw_d4 xa = {z[g][0], z[g][1], z[g][2], z[g][3]};
 #pragma unroll
-                                for (int s = 0; s < NT; ++s) xa = xw_mfma16(a2v[s], ntv[g][s], xa);
-                                double *tp = xt0 + g * (16 * XW_LD);
+                                for (int s = 0; s < ((XW_ABLATE & 64) ? 0 : NT); ++s) xa = xw_mfma16(a2v[s], ntv[g][s], xa);
+                                double xv[4];
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) tp[xw_tile_pos(c, sb * 16 + 4 * q + r)] = fma(s4[r], xa[r], m4[r]);  // x = mu + sqrt(alpha) x~
-                            }
-                            if (sb == XW_SB - 1 || (SPECIAL && blk == nblk - 1)) {       // XW_SR rows x 16 draws staged: store them
-                                __builtin_amdgcn_wave_barrier();
-                                constexpr int CPI = 64 / XW_SR;                          // columns per store instruction
-                                const int r0 = (blk - sb) * 16, lr = lane % XW_SR;
+                                for (int r = 0; r < 4; ++r) xv[r] = fma(s4[r], xa[r], m4[r]);       // x = mu + sqrt(alpha) x~
+                                double *xo = xg[g] + (size_t)c * d + blk * 16 + 4 * q;              // rows 4q .. 4q+3 of draw c: 32 contiguous bytes
+                                if ((XW_ABLATE & 1) && xv[0] != 1.2345e301) continue;
+                                if (!SPECIAL && fullc[g] && x_aligned) {
+                                    typedef double xw_d2 __attribute__((ext_vector_type(2)));
+                                    xw_d2 lo = {xv[0], xv[1]}, hi = {xv[2], xv[3]};
+                                    *reinterpret_cast<xw_d2 *>(xo) = lo;
+                                    *reinterpret_cast<xw_d2 *>(xo + 2) = hi;
+                                } else {
 #pragma unroll
-                                for (int g = 0; g < NGA; ++g) {
-                                    const double *tr = xt0 + g * (16 * XW_LD);
-                                    double *xo = xg[g] + (lane / XW_SR) * d + r0 + lr;
-                                    if (!SPECIAL && fullc[g] && XW_ABLATE != 1) {        // whole burst, whole group: no predicates
-#pragma unroll
-                                        for (int it = 0; it < 16 / CPI; ++it) xo[it * CPI * d] = tr[xw_tile_pos(CPI * it + lane / XW_SR, lr)];
-                                    } else {
-#pragma unroll
-                                        for (int it = 0; it < 16 / CPI; ++it) {
-                                            const int col = CPI * it + lane / XW_SR;
-                                            const double v = tr[xw_tile_pos(col, lr)];
-                                            if (r0 + lr < d && lr < 16 * (sb + 1) && nl0[g] + col < A.N && (XW_ABLATE != 1 || v == 1.2345e301))
-                                                xo[it * CPI * d] = v;
-                                        }
-                                    }
+                                    for (int r = 0; r < 4; ++r)
+                                        if (act[g] && blk * 16 + 4 * q + r < d && nl0[g] + c < A.N) xo[r] = xv[r];
                                 }
-                                __builtin_amdgcn_wave_barrier();
                             }
                         };
                         for (int bl = 0; bl < nb; ++bl) {
                             const int blk = blk0 + bl;
-                            const bool special = (blk == 0) | (blk >= nblk - XW_SB) | (KC > 16 && blk == 1);
-                            if (NG == 2 && nact == 2) {
-                                if (__builtin_expect(special, 0)) body2(bl, std::true_type{}, std::integral_constant<int, NG>{});
-                                else body2(bl, std::false_type{}, std::integral_constant<int, NG>{});
-                            } else {
-                                if (__builtin_expect(special, 0)) body2(bl, std::true_type{}, std::integral_constant<int, 1>{});
-                                else body2(bl, std::false_type{}, std::integral_constant<int, 1>{});
-                            }
+                            const bool special = (blk == 0) | (blk == nblk - 1) | (KC > 16 && blk == 1);
+                            // (the groups of a wave that lie beyond the last one are computed too -- their stores are predicated off)
+                            if (__builtin_expect(special, 0)) body2(bl, std::true_type{}, std::integral_constant<int, NG>{});
+                            else body2(bl, std::false_type{}, std::integral_constant<int, NG>{});
                         }
                     }
                 }
@@ -356,7 +355,7 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
                             const int idx = tid + e * XW_THREADS;
                             if (idx < XW_CHB * 16 * KC) { const int lrow = idx / KC; vs[xw_vh_pos<KC>(lrow, idx - lrow * KC)] = pre[e]; }
                         }
-                        if (XW_SM_LDS && tid < XW_CHB * 16) {
+                        if (tid < XW_CHB * 16) {
                             double *o = vs + vh_sz + (tid >> 4) * 32 + (tid & 15);
                             o[0] = pr_s; o[16] = pr_m;
                         }
@@ -370,7 +369,6 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
                 // result (rows q + 4 reg) layout at once; A = T[row 16 rt + c][4 s + q] from LDS
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
-                    if (!act[g]) continue;
 #pragma unroll
                     for (int rt = 0; rt < (NT + 3) / 4; ++rt) {
                         xw_d4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -402,9 +400,9 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
 
 // ---------------------------------------------------------------------------------------------------
 static size_t xw_lds_bytes(int ch_blocks, int nchunks, int kc) {
-    size_t stage = ((size_t)ch_blocks * 16 * kc + (XW_SM_LDS ? (size_t)ch_blocks * 32 : 0)) * (nchunks > 1 ? 2 : 1);
+    size_t stage = ((size_t)ch_blocks * 16 * kc + (size_t)ch_blocks * 32) * (nchunks > 1 ? 2 : 1);
     if (stage < XW_MIN_FRONT) stage = XW_MIN_FRONT;
-    return sizeof(double) * (stage + (size_t)kc * kc + 4 * (XW_NB << PF_ICDF_B) + (size_t)XW_WAVES * XW_NG * 16 * XW_LD);
+    return sizeof(double) * (stage + (size_t)kc * kc + 4 * (XW_NB << PF_ICDF_B));
 }
 
 template <int KC>
