@@ -17,7 +17,6 @@
 //   pf_logpdf_kernel      : Distributions.logpdf of arbitrary points through the factor
 //       (src/resample.jl:85-89 -> invquad, src/woodbury.jl:378-382,158-165).
 #include "pfmi_common.h"
-#include "pfmi_fastmath.h"
 #include "elbo_args.h"
 #include <stdlib.h>
 

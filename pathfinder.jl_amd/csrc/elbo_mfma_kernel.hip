@@ -20,7 +20,6 @@
 // Results are identical (to fp64 roundoff) to the lane-per-draw kernel in elbo_kernels.hip, which remains the
 // general path (d > 1024, history_length > 8, parity mode with host-supplied normals).
 #include "pfmi_common.h"
-#include "pfmi_fastmath.h"
 #include "elbo_args.h"
 
 #define MF_THREADS 512

@@ -24,7 +24,6 @@
 #include <type_traits>
 #include <stdlib.h>
 #include "pfmi_common.h"
-#include "pfmi_fastmath.h"
 #include "elbo_args.h"
 
 #ifndef QF_WAVES

@@ -7,7 +7,6 @@
 #include <stdio.h>
 #include <math.h>
 #include "../csrc/pfmi_common.h"
-#include "../csrc/pfmi_fastmath.h"
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
