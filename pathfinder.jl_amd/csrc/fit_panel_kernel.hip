@@ -18,16 +18,28 @@
 //             V'b = w1 - (V'V) t1.  Last pass: scratch -> row-major Vh (what the draw kernels read) + mu.
 //
 // Traffic per fit at d = 10^4, J = 10: ~14 MB read + ~4 MB written instead of ~80 MB.
+#include <type_traits>
 #include "pfmi_common.h"
+#include <stdlib.h>
 #include "fit_args.h"
 
+#ifndef FP_NT
 #define FP_NT 512
+#endif
 #define FP_NW (FP_NT / 64)
 #define FP_NVMAX 8
 typedef double fp_d4 __attribute__((ext_vector_type(4)));
 // Hides a thread index from loop-invariant code motion: without it the compiler precomputes the row addresses of every phase once per
 // kernel and keeps ~200 VGPRs of pointers alive next to the register panel.
 #define FP_OPAQUE(x) asm volatile("" : "+v"(x))
+#ifndef FP_PROF
+#define FP_PROF 0                      // 1: workgroup 0 accumulates cycle counts per section and prints them (experiments only)
+#endif
+#if FP_PROF
+#define FP_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long t_ = wall_clock64(); prof[k] += t_ - tlast; tlast = t_; } } while (0)
+#else
+#define FP_STAMP(k) do { } while (0)
+#endif
 
 static int fp_ntile(int KPAD) { return (KPAD + 15) / 16; }
 // dynamic LDS (doubles): red | 6 KPAD^2 matrices (T R D V G Gv) | tile staging [NW][NT16][256] | C [NT16][256] | vectors
@@ -59,13 +71,22 @@ __global__ __launch_bounds__(FP_NT, 1) void pf_fit_panel_kernel(FitArgs A, const
     __shared__ int sNext, sStatus;
     __shared__ double sLogdetV;
     int flip = 0;
+#if FP_PROF
+    long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = wall_clock64();
+    int nfit = 0;
+#endif
 
     for (;;) {
         __syncthreads();
+        FP_STAMP(11);
+#if FP_PROF
+        ++nfit;
+#endif
         if (tid == 0) sNext = atomicAdd(counter, 1);
         __syncthreads();
         const int64_t p = sNext;
         if (p >= A.P) break;
+        FP_STAMP(0);
 
         const int path = A.path_of[p];
         const int64_t p0 = A.off[path];
@@ -147,12 +168,14 @@ __global__ __launch_bounds__(FP_NT, 1) void pf_fit_panel_kernel(FitArgs A, const
             continue;
         }
 
+        FP_STAMP(1);                                               // phase A
         // ---- left-looking panel loop; iteration npan is the final MFMA sweep only
         for (int pi = 0; pi <= npan; ++pi) {
             const int c0 = pi * PW;                                // first column of this panel = number of finished columns
             if (pi > 0) {
                 __threadfence_block();
                 __syncthreads();                                   // scratch columns < c0 written by the whole workgroup
+                FP_STAMP(7);
                 // sweep 1: C[t] = V[:, 16 t .. 16 t + 15]' B,  B columns: [0, PW) raw panel pi, [PW, 2 PW) V panel pi - 1, 2 PW: U g
                 int ln = lane, wv_ = wave;
                 FP_OPAQUE(ln); FP_OPAQUE(wv_);
@@ -169,6 +192,9 @@ __global__ __launch_bounds__(FP_NT, 1) void pf_fit_panel_kernel(FitArgs A, const
 #pragma unroll
                 for (int t = 0; t < NT16; ++t) acc[t] = fp_d4{0.0, 0.0, 0.0, 0.0};
                 const int roff = 64 * wv_ + 2 * kq;                // this wave's 64-row slab of every 512-row slice, rows r, r + 1 per lane
+                // (round 4: sweeping only the column tiles that hold finished columns -- at m = 20 the second tile is all zeros for four
+                //  of the five sweeps -- shortens this section by 20 % and makes the kernel 5 % SLOWER as a whole: 9.96 against 9.46 ms
+                //  for 1 600 fits on one box, both code versions of the loop resident; profiles/r04_experiments.md)
 #pragma unroll 1
                 for (int h = 0; h < RPT * 2; ++h) {
                     const int r0 = FP_NT * (h >> 1) + 32 * (h & 1) + roff;
@@ -192,6 +218,7 @@ __global__ __launch_bounds__(FP_NT, 1) void pf_fit_panel_kernel(FitArgs A, const
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) sTile[(wv_ * NT16 + t) * 256 + rg * 64 + ln] = acc[t][rg];
                 __syncthreads();
+                FP_STAMP(2);                                       // sweep 1
                 if (tid < NT16 * 256) {                            // fixed summation order over the 16 waves
                     const int t = tid >> 8, e = tid & 255, rg = e >> 6, l = e & 63;
                     double s = 0.0;
@@ -231,6 +258,7 @@ __global__ __launch_bounds__(FP_NT, 1) void pf_fit_panel_kernel(FitArgs A, const
                     sZ[a * PW + cc] = v;
                 }
                 __syncthreads();
+                FP_STAMP(3);                                       // tile sum, T columns, Z
                 // sweep 2: P = P_raw - V_prev Z
                 int tc = tid;
                 FP_OPAQUE(tc);
@@ -262,6 +290,7 @@ __global__ __launch_bounds__(FP_NT, 1) void pf_fit_panel_kernel(FitArgs A, const
                         P[0][cc] = 0.0;
                     }
                 }
+                FP_STAMP(4);                                       // sweep 2
             } else if (npan == 0) break;
             // ---- dgeqr2 on the register panel: one block reduction per column
             const int ncol = (m - c0 < PW) ? m - c0 : PW;
@@ -317,6 +346,7 @@ __global__ __launch_bounds__(FP_NT, 1) void pf_fit_panel_kernel(FitArgs A, const
                     }
                 }
             }
+            FP_STAMP(5);                                           // panel QR
             // explicit Householder vectors of the panel -> scratch
             int td = tid;
             FP_OPAQUE(td);
@@ -329,8 +359,10 @@ __global__ __launch_bounds__(FP_NT, 1) void pf_fit_panel_kernel(FitArgs A, const
 #pragma unroll
                 for (int cc = 0; cc < PW; ++cc) oc[cc][row] = P[i][cc];
             }
+            FP_STAMP(6);                                           // panel write-back
         }
         __syncthreads();
+        FP_STAMP(3);
 
         // ---- small algebra.  G = B~'B~ = R'R:  G[c][b] (c, b < j) = Y'alpha Y,  G[j + a][b] = S'Y
         double *X1 = sTile, *X2 = sTile + KPAD * KPAD, *X3 = sTile + 2 * KPAD * KPAD;    // tile staging is free now
@@ -427,6 +459,7 @@ __global__ __launch_bounds__(FP_NT, 1) void pf_fit_panel_kernel(FitArgs A, const
         for (int t = tid; t < KPAD * KPAD; t += FP_NT) {
             A.tmat[sm + t] = sT[t]; A.vchol[sm + t] = sV[t]; A.rq[sm + t] = sR[t]; A.dmat[sm + t] = sD[t];
         }
+        FP_STAMP(8);                                               // small algebra + Cholesky
         const bool ok = (sStatus == PFMI_FIT_OK);
         // ---- mean through the factor: b = Q'Ug = Ug - V t1 (t1 = T'w1), head <- V_c'V_c head, x = b' - V t2, t2 = T V'b',
         //      V'b' = w1 - (V'V) t1 - V[0:k,:]'(head_b - head')   -- no sweep over the block
@@ -471,6 +504,7 @@ __global__ __launch_bounds__(FP_NT, 1) void pf_fit_panel_kernel(FitArgs A, const
             }
         }
         __syncthreads();
+        FP_STAMP(9);                                               // mean (wave 0)
         // ---- last pass: scratch (column-major) -> Vh (row-major [d][KPAD], what the draw kernels read) and mu.  A wave takes 16 rows
         //      at a time: lane (r = lane & 15, q = lane >> 4) reads columns q, q + 4, .. of row r (128 contiguous bytes per column),
         //      the 16 x KPAD tile is transposed through LDS and leaves as one contiguous run of full cache lines.
@@ -529,11 +563,19 @@ __global__ __launch_bounds__(FP_NT, 1) void pf_fit_panel_kernel(FitArgs A, const
                 th = th2; sq = sq2; ug = ug2;
             }
         }
+        FP_STAMP(10);                                              // last pass
         if (tid == 0) {
             A.status[p] = ok ? PFMI_FIT_OK : sStatus;
             A.logdet[p] = ok ? 2.0 * (ldu + sLogdetV) : NAN;
         }
     }
+#if FP_PROF
+    if (blockIdx.x == 0 && tid == 0)
+        printf("FP_PROF fits %d (100 MHz ticks per fit): fetch %lld  phaseA %lld  sweep1 %lld  tile/T/Z %lld  sweep2 %lld  panelQR %lld  writeback %lld  "
+               "barrier-before-sweep1 %lld  small+chol %lld  mean %lld  lastpass %lld  loop %lld\n", nfit - 1, prof[0] / (nfit - 1), prof[1] / (nfit - 1),
+               prof[2] / (nfit - 1), prof[3] / (nfit - 1), prof[4] / (nfit - 1), prof[5] / (nfit - 1), prof[6] / (nfit - 1), prof[7] / (nfit - 1),
+               prof[8] / (nfit - 1), prof[9] / (nfit - 1), prof[10] / (nfit - 1), prof[11] / (nfit - 1));
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -546,7 +588,8 @@ static int32_t launch_panel_t(pfmi_ctx *c, const FitArgs &a, int ncu) {
     int occ = 1;
     PF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, FP_NT, lds));
     if (occ < 1) occ = 1;
-    const int64_t slots = (int64_t)ncu * occ;
+    int64_t slots = (int64_t)ncu * occ;
+    if (const char *g = pf_debug_get("PFMI_FIT_PANEL_GRID")) { const int v = atoi(g); if (v > 0) slots = v; }   // experiment hook: resident workgroups
     const int grid = slots < a.P ? (int)slots : (int)a.P;
     const size_t scr_bytes = (size_t)grid * (KPAD + 4) * (size_t)(FP_NT * RPT) * sizeof(double);
     PF_TRY(c->fit_scratch.ensure(scr_bytes + 256));

@@ -79,3 +79,7 @@ def test_bench_single_process_drives_several_contexts():
         assert out[G]["n_gpus"] == G and out[G]["config"]["ranks_in_collective"] == G
     assert out[2]["config"]["rccl_version"] == 99999 and out[1]["config"]["rccl_version"] == 0
     assert out[1]["pareto_k"] == out[2]["pareto_k"] and out[1]["config"]["elbo_draws_per_step"] == out[2]["config"]["elbo_draws_per_step"]
+    # round 4: the sharded run verifies ITSELF -- all paths recomputed on one context, k-hat / tail length / indices / a hash of the
+    # d x ndraws result compared with the sharded answer (default for G > 1)
+    assert out[2]["sharded_equals_single"] is True, out[2].get("sharded_equals_single_note")
+    assert out[1]["sharded_equals_single"] is None and out[2]["rccl_version"] == 99999

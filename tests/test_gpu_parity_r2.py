@@ -586,11 +586,16 @@ def test_bench_force_dist_counts_its_ranks(comm_mode):
     if comm_mode == "torch":
         env["PFMI_BENCH_COMM"] = "torch"                              # the reported fallback: torch.distributed collectives
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "1", "--warmup", "1",
-                        "--npaths", "8", "--dim", "100", "--target", "diag", "--no-cpu-baseline"], capture_output=True, text=True,
-                       env=env, timeout=600, cwd=root)
+                        "--npaths", "8", "--dim", "100", "--target", "diag", "--no-cpu-baseline", "--verify-sharding"], capture_output=True,
+                       text=True, env=env, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["config"]["ranks_in_collective"] == 1
+    # round 4: --verify-sharding through the torch.distributed world (broadcast of rank 0's single-GPU reference, MIN all-reduce of the
+    # per-rank verdicts) -- here the "sharded" run IS a world of one, so it must equal the recomputation bit for bit
+    assert line["sharded_equals_single"] is True, line.get("sharded_equals_single_note")
+    if comm_mode == "c_abi":
+        assert line["rccl_version"] and line["rccl_version"] > 0
     assert line["config"]["collective_backend"].startswith("RCCL" if comm_mode == "c_abi" else "torch.distributed")
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
 
