@@ -49,3 +49,23 @@ def demo_device_target(tg):
     assert h, "pfx_gauss_create failed"
     fn = C.cast(L.pfx_gauss_logp, C.c_void_p).value
     return pfmi.DeviceCallbackTarget(tg.d, fn, C.c_void_p(h), host=tg, keepalive=(L, h))
+
+
+def oracle_factor_from_gpu(f):
+    """An oracle Factor whose arrays ARE the GPU's factor of one fit (pfmi_get_fit: U = sqrt(alpha), the Householder vectors, tau =
+    diag(T), V).  x(u) = mu + U'Q[V'u_1; u_2] is a function of exactly these arrays, so the oracle's reflector-by-reflector apply
+    (LAPACK dorm2r, oracle/pf_oracle.c:pfo_apply_q) on them pins the DRAW kernels' arithmetic for every fit -- also where the
+    Householder block is numerically rank deficient and the factor itself is only defined up to roundoff (the factor is
+    then pinned through the quantities that are functions of Sigma: W, logdet, mu, logq)."""
+    F = po.Factor.__new__(po.Factor)
+    d = len(f["alpha"])
+    m = f["qr_factors"].shape[1]
+    k = min(d, m)
+    F.d, F.m, F.k = d, m, k
+    F.alpha, F.B, F.D = np.asfortranarray(f["alpha"]), f["B"], f["D"]
+    F.sqrt_alpha = np.sqrt(F.alpha)
+    F.QR = np.asfortranarray(f["qr_factors"]) if m else np.zeros((d, 1), order="F")
+    F.tau = np.ascontiguousarray(np.diag(f["T"])) if k else np.zeros(1)
+    F.V = np.asfortranarray(f["V"]) if k else np.zeros((1, 1), order="F")
+    F.status, F.logdet = 0, float(f["logdet"])
+    return F

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import fit_seeds, make_traces, oracle_target
+from helpers import fit_seeds, make_traces, oracle_factor_from_gpu, oracle_target
 from oracle import pf_oracle as po
 import margins as mg
 
@@ -160,7 +160,7 @@ def test_draws_and_logq_match_oracle_same_u_and_rng(pfmi_mod, eng, name, K, J):
     status, jeff, logdet, _ = eng.fit_status()
     N = 130
     rng = np.random.default_rng(0)
-    n_strict = n_wide = 0
+    n_strict = n_wide = n_loose = 0
     for k, tr in enumerate(traces):
         p0 = int(eng.offsets[k])
         alpha_all, hl, hs, _ = po.lbfgs_history(tr.points, tr.gradients, J)
@@ -173,7 +173,19 @@ def test_draws_and_logq_match_oracle_same_u_and_rng(pfmi_mod, eng, name, K, J):
             B, D = po.lbfgs_inverse_hessian(alpha_all[l], S, Y)
             F = po.Factor(alpha_all[l], B, D)
             if not _well_conditioned(F):
-                continue                      # draw-level parity is only defined for a well-conditioned QR
+                # x(u) of the ORACLE's factor is roundoff-defined here.  Round 4: the draw kernels are still pinned strictly,
+                # against the oracle's reflector-by-reflector apply on the GPU's own factor of this fit
+                fg = eng.get_fit(p0 + l, j)
+                Fg = oracle_factor_from_gpu(fg)
+                for mode in ("mem", "rng"):
+                    U = rng.normal(size=(tg.d, N)) if mode == "mem" else po.randn_fill(1000 + 17 * l + k, tg.d, N)
+                    Xr, lqr = Fg.rand_and_logpdf(fg["mu"], U)
+                    X, lp, lq = eng.draws(p0 + l, 1000 + 17 * l + k, N, u=U if mode == "mem" else None)
+                    mg.check(f"small:{name}", "draws@gpu_factor_" + mode, np.abs(X - Xr) / (1 + np.abs(Xr).max(axis=0)), ctx=(l, mode))
+                    mg.check(f"small:{name}", "logq@gpu_factor_" + mode, mg.rel(lq, lqr))
+                    mg.check(f"small:{name}", "logp@gpu_factor_" + mode, mg.rel(lp, otg.logp(Xr)))
+                n_loose += 1
+                continue
             n_strict += 1
             n_wide += int(2 * j > tg.d)
             mu = F.fit_mean(tr.points[l], tr.gradients[l])

@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 import pytest
 
-from helpers import fit_seeds, oracle_target
+from helpers import fit_seeds, oracle_factor_from_gpu, oracle_target
 from oracle import pf_oracle as po
 import margins as mg
 from test_gpu_parity_r2 import _factor, _wc
@@ -169,6 +169,16 @@ def test_config5_full_single_gpu_share(pfmi_mod):
                 mg.check(cfg, "logp@scan", mg.rel(glp, lp), ctx=(k, l))
             else:
                 assert abs(glp.mean() - lp.mean()) <= 8 * (glp.std() + lp.std()) / np.sqrt(N) + 1e-8 * abs(lp.mean())
+            # STRICT per-draw check at config 5's own target whatever the conditioning: the oracle's apply on the
+            # GPU's OWN factor of this fit -- x(u), logq and logp(x) are functions of exactly these arrays
+            fg = eng.get_fit(int(off[k]) + l, int(jeff[int(off[k]) + l]))
+            Fg = oracle_factor_from_gpu(fg)
+            Xg, lqg = Fg.rand_and_logpdf(fg["mu"], po.randn_fill(int(seeds[int(off[k]) + l]), d, N))
+            mg.check(cfg, "logq@scan_vs_oracle_on_gpu_factor", mg.rel(glq, lqg), ctx=(k, l))
+            mg.check(cfg, "logp@scan_vs_oracle_on_gpu_factor", mg.rel(glp, otg.logp(Xg)), ctx=(k, l))
+            Xd, lpd, lqd = eng.draws(int(off[k]) + l, int(seeds[int(off[k]) + l]), 48, n0=N - 48)
+            mg.check(cfg, "draws@writer_vs_oracle_on_gpu_factor", np.abs(Xd - Xg[:, N - 48:]) / (1 + np.abs(Xg[:, N - 48:]).max(axis=0)), ctx=(k, l))
+            np.testing.assert_array_equal(lqd, glq[N - 48:])              # the writer's logq IS the scan's (same order of operations)
             # the oracle agrees that this fit beats the sampled ones of its path (best_iter, src/elbo.jl:8)
             for (k2, l2), _, v2, s2, _, _ in outs[:len(some)]:
                 if k2 == k and np.isfinite(v2):
