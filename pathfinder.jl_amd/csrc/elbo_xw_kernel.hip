@@ -230,13 +230,15 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
                 const bool do_pre = (nchunks > 1) && (ck + 1 < nchunks || pass == 0 || lb + 1 < nlb);
                 if (do_pre) {
                     const int row0 = nck * XW_CHB * 16;
+                    int tid_p = tid;                               // opaque: keeps the per-thread offsets of the chunk prefetch out of the prologue (spills)
+                    asm volatile("" : "+v"(tid_p));
 #pragma unroll
                     for (int e = 0; e < PRE; ++e) {
-                        const int idx = tid + e * XW_THREADS;
+                        const int idx = tid_p + e * XW_THREADS;
                         const int lrow = idx / KC, row = row0 + lrow;
                         pre[e] = (idx < XW_CHB * 16 * KC && row < d) ? Vh[(size_t)row0 * KC + idx] : 0.0;
                     }
-                    if (tid < XW_CHB * 16 && row0 + tid < d) { pr_s = sqa[row0 + tid]; pr_m = mu[row0 + tid]; }
+                    if (tid_p < XW_CHB * 16 && row0 + tid_p < d) { pr_s = sqa[row0 + tid_p]; pr_m = mu[row0 + tid_p]; }
                 }
                 if (nact > 0) {
                     const double *vs = lds + cur * buf_stride;
@@ -350,13 +352,15 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
                 if (nchunks > 1) {
                     if (do_pre) {
                         double *vs = lds + (cur ^ 1) * buf_stride;
+                        int tid_e = tid;
+                        asm volatile("" : "+v"(tid_e));
 #pragma unroll
                         for (int e = 0; e < PRE; ++e) {
-                            const int idx = tid + e * XW_THREADS;
+                            const int idx = tid_e + e * XW_THREADS;
                             if (idx < XW_CHB * 16 * KC) { const int lrow = idx / KC; vs[xw_vh_pos<KC>(lrow, idx - lrow * KC)] = pre[e]; }
                         }
-                        if (tid < XW_CHB * 16) {
-                            double *o = vs + vh_sz + (tid >> 4) * 32 + (tid & 15);
+                        if (tid_e < XW_CHB * 16) {
+                            double *o = vs + vh_sz + (tid_e >> 4) * 32 + (tid_e & 15);
                             o[0] = pr_s; o[16] = pr_m;
                         }
                     }
@@ -365,6 +369,9 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
                 }
             }
             if (pass == 0) {
+                int lane_t = lane;                                 // opaque lane coordinates: the LDS offsets of T are not kept alive across the walks
+                asm volatile("" : "+v"(lane_t));
+                const int qt = lane_t >> 4, ct = lane_t & 15;
                 // tv = T w on v_mfma_f64_16x16x4: lane (q, c) holds entries 4 s + q of draw c -- B operand (k = q, column = draw) and
                 // result (rows q + 4 reg) layout at once; A = T[row 16 rt + c][4 s + q] from LDS
 #pragma unroll
@@ -372,10 +379,10 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
 #pragma unroll
                     for (int rt = 0; rt < (NT + 3) / 4; ++rt) {
                         xw_d4 acc = {0.0, 0.0, 0.0, 0.0};
-                        const int row = 16 * rt + c;
+                        const int row = 16 * rt + ct;
 #pragma unroll
                         for (int st = 0; st < NT; ++st) {
-                            const int col = 4 * st + q;
+                            const int col = 4 * st + qt;
                             const double av = (row < KC) ? t_s[row * KC + col] : 0.0;
                             acc = xw_mfma16(av, accw[g][st], acc);
                         }

@@ -159,13 +159,17 @@ __global__ __launch_bounds__(1024) void pf_history_lean_kernel(
     int flip = 0;
     int n_acc = 0;
     int *const acc = acc_list + p0;
-    double al[EPT], tc[EPT], gc[EPT], sv[EPT], yv[EPT];
+    // EPT >= 9 (d > 8192): the previous point's rows are RE-READ (they were fetched one step earlier: L2 hits) instead of carried --
+    // 5 EPT doubles of state did not fit the 128 registers of a 1024-thread workgroup (24 spilled, 17 us per step at d = 10^4
+    // against 6 us at d = 7500; round 4)
+    constexpr bool REREAD = EPT >= 9;
+    double al[EPT], tc[REREAD ? 1 : EPT], gc[REREAD ? 1 : EPT], sv[EPT], yv[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int i = tid + HIST_NT * e, ic = i < d ? i : d - 1;
         al[e] = 1.0; hl_ial[e * HIST_NT + tid] = 1.0;                          // H0 = I  (:38-39)
         if (i < d) alpha_all[(size_t)p0 * d + i] = 1.0;
-        tc[e] = theta[(size_t)p0 * d + ic]; gc[e] = grad[(size_t)p0 * d + ic];
+        if (!REREAD) { tc[REREAD ? 0 : e] = theta[(size_t)p0 * d + ic]; gc[REREAD ? 0 : e] = grad[(size_t)p0 * d + ic]; }
     }
     if (tid == 0) hist_len[p0] = 0;
     for (int l = 1; l <= L; ++l) {                                              // :43
@@ -180,8 +184,13 @@ __global__ __launch_bounds__(1024) void pf_history_lean_kernel(
         for (int e = 0; e < EPT; ++e) {
             const bool in = tid + HIST_NT * e < d;
             const double t1 = sv[e], g1 = yv[e];
-            const double s = in ? t1 - tc[e] : 0.0, y = in ? gc[e] - g1 : 0.0;   // :45-46
-            tc[e] = t1; gc[e] = g1;
+            double t0, g0;
+            if (REREAD) {
+                const int i = tid + HIST_NT * e, ic = i < d ? i : d - 1;
+                t0 = theta[row - d + ic]; g0 = grad[row - d + ic];
+            } else { t0 = tc[REREAD ? 0 : e]; g0 = gc[REREAD ? 0 : e]; }
+            const double s = in ? t1 - t0 : 0.0, y = in ? g0 - g1 : 0.0;         // :45-46
+            if (!REREAD) { tc[REREAD ? 0 : e] = t1; gc[REREAD ? 0 : e] = g1; }
             sv[e] = s; yv[e] = y;
             const double ia = hl_ial[e * HIST_NT + tid];
             v[0] += y * s;
