@@ -169,10 +169,84 @@ __global__ __launch_bounds__(FP_NT, 1) void pf_fit_panel_kernel(FitArgs A, const
         }
 
         FP_STAMP(1);                                               // phase A
-        // ---- left-looking panel loop; iteration npan is the final MFMA sweep only
-        for (int pi = 0; pi <= npan; ++pi) {
+        // ---- left-looking panel loop.  The factorisation of a register panel is a lambda called for panel 0 in FRONT of the loop and for
+        //      the later panels inside it: with the first iteration peeled, the register panel P is plainly dead across sweep 1 (it is
+        //      reloaded by sweep 2), which the compiler could not see through the loop-carried value (36 of its registers were spilled
+        //      around every sweep 1; round 4)
+        auto factor_panel = [&](const int c0) {
+            // ---- dgeqr2 on the register panel: one block reduction per column
+            const int ncol = (m - c0 < PW) ? m - c0 : PW;
+#pragma unroll
+            for (int cl = 0; cl < PW; ++cl) {
+                if (cl >= ncol) break;
+                const int c = c0 + cl;
+                double *srow = sRowc + 4 * (cl & 1);
+                double dots[PW];
+#pragma unroll
+                for (int cc = 0; cc < PW; ++cc) dots[cc] = 0.0;
+#pragma unroll
+                for (int i = 0; i < RPT; ++i) {
+                    const double xc = (i > 0 || tid > c) ? P[i][cl] : 0.0;      // rows below the diagonal
+#pragma unroll
+                    for (int cc = cl; cc < PW; ++cc) dots[cc] += xc * P[i][cc];
+                }
+                if (tid == c) {
+#pragma unroll
+                    for (int cc = 0; cc < PW; ++cc) srow[cc] = P[0][cc];
+                }
+                if constexpr (PW % 4 == 0) pf_block_sum_mv<PW, FP_NVMAX>(dots, red, flip);     // its barrier also publishes srow (double buffered)
+                else pf_block_sum_pp<PW, FP_NVMAX>(dots, red, flip);
+                const double xn2 = dots[cl];
+                const double alpha_c = srow[cl];
+                const double xnorm = sqrt(xn2);
+                double tau, scal, beta;
+                if (xnorm == 0.0) { tau = 0.0; scal = 0.0; beta = alpha_c; }
+                else {
+                    beta = -copysign(sqrt(fma(alpha_c, alpha_c, xn2)), alpha_c);
+                    tau = (beta - alpha_c) / beta;
+                    scal = 1.0 / (alpha_c - beta);
+                }
+                double wv[PW];
+#pragma unroll
+                for (int cc = 0; cc < PW; ++cc) wv[cc] = tau * (srow[cc] + scal * dots[cc]);
+#pragma unroll
+                for (int i = 0; i < RPT; ++i) {
+                    const bool below = (i > 0 || tid > c);
+                    const double v = P[i][cl] * scal;
+                    P[i][cl] = below ? v : P[i][cl];
+#pragma unroll
+                    for (int cc = cl + 1; cc < PW; ++cc) P[i][cc] = below ? P[i][cc] - wv[cc] * v : P[i][cc];
+                }
+                if (tid == c) {                                    // row c: R entries out, explicit unit diagonal / zeros in
+                    sTau[c] = tau;
+                    sR[c * KPAD + c] = beta;
+                    P[0][cl] = 1.0;
+#pragma unroll
+                    for (int cc = cl + 1; cc < PW; ++cc) {
+                        if (c0 + cc < m) sR[c * KPAD + c0 + cc] = P[0][cc] - wv[cc];
+                        P[0][cc] = 0.0;
+                    }
+                }
+            }
+            FP_STAMP(5);                                           // panel QR
+            // explicit Householder vectors of the panel -> scratch
+            int td = tid;
+            FP_OPAQUE(td);
+            double *oc[PW];
+#pragma unroll
+            for (int cc = 0; cc < PW; ++cc) oc[cc] = (c0 + cc < m) ? scr + (size_t)(c0 + cc) * DPAD : scr_sink;
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const int row = td + FP_NT * i;
+#pragma unroll
+                for (int cc = 0; cc < PW; ++cc) oc[cc][row] = P[i][cc];
+            }
+            FP_STAMP(6);                                           // panel write-back
+        };
+        if (npan > 0) factor_panel(0);
+        for (int pi = 1; pi <= npan; ++pi) {                       // iteration npan is the final MFMA sweep only
             const int c0 = pi * PW;                                // first column of this panel = number of finished columns
-            if (pi > 0) {
+            {
                 __threadfence_block();
                 __syncthreads();                                   // scratch columns < c0 written by the whole workgroup
                 FP_STAMP(7);
@@ -291,75 +365,8 @@ __global__ __launch_bounds__(FP_NT, 1) void pf_fit_panel_kernel(FitArgs A, const
                     }
                 }
                 FP_STAMP(4);                                       // sweep 2
-            } else if (npan == 0) break;
-            // ---- dgeqr2 on the register panel: one block reduction per column
-            const int ncol = (m - c0 < PW) ? m - c0 : PW;
-#pragma unroll
-            for (int cl = 0; cl < PW; ++cl) {
-                if (cl >= ncol) break;
-                const int c = c0 + cl;
-                double *srow = sRowc + 4 * (cl & 1);
-                double dots[PW];
-#pragma unroll
-                for (int cc = 0; cc < PW; ++cc) dots[cc] = 0.0;
-#pragma unroll
-                for (int i = 0; i < RPT; ++i) {
-                    const double xc = (i > 0 || tid > c) ? P[i][cl] : 0.0;      // rows below the diagonal
-#pragma unroll
-                    for (int cc = cl; cc < PW; ++cc) dots[cc] += xc * P[i][cc];
-                }
-                if (tid == c) {
-#pragma unroll
-                    for (int cc = 0; cc < PW; ++cc) srow[cc] = P[0][cc];
-                }
-                if constexpr (PW % 4 == 0) pf_block_sum_mv<PW, FP_NVMAX>(dots, red, flip);     // its barrier also publishes srow (double buffered)
-                else pf_block_sum_pp<PW, FP_NVMAX>(dots, red, flip);
-                const double xn2 = dots[cl];
-                const double alpha_c = srow[cl];
-                const double xnorm = sqrt(xn2);
-                double tau, scal, beta;
-                if (xnorm == 0.0) { tau = 0.0; scal = 0.0; beta = alpha_c; }
-                else {
-                    beta = -copysign(sqrt(fma(alpha_c, alpha_c, xn2)), alpha_c);
-                    tau = (beta - alpha_c) / beta;
-                    scal = 1.0 / (alpha_c - beta);
-                }
-                double wv[PW];
-#pragma unroll
-                for (int cc = 0; cc < PW; ++cc) wv[cc] = tau * (srow[cc] + scal * dots[cc]);
-#pragma unroll
-                for (int i = 0; i < RPT; ++i) {
-                    const bool below = (i > 0 || tid > c);
-                    const double v = P[i][cl] * scal;
-                    P[i][cl] = below ? v : P[i][cl];
-#pragma unroll
-                    for (int cc = cl + 1; cc < PW; ++cc) P[i][cc] = below ? P[i][cc] - wv[cc] * v : P[i][cc];
-                }
-                if (tid == c) {                                    // row c: R entries out, explicit unit diagonal / zeros in
-                    sTau[c] = tau;
-                    sR[c * KPAD + c] = beta;
-                    P[0][cl] = 1.0;
-#pragma unroll
-                    for (int cc = cl + 1; cc < PW; ++cc) {
-                        if (c0 + cc < m) sR[c * KPAD + c0 + cc] = P[0][cc] - wv[cc];
-                        P[0][cc] = 0.0;
-                    }
-                }
             }
-            FP_STAMP(5);                                           // panel QR
-            // explicit Householder vectors of the panel -> scratch
-            int td = tid;
-            FP_OPAQUE(td);
-            double *oc[PW];
-#pragma unroll
-            for (int cc = 0; cc < PW; ++cc) oc[cc] = (c0 + cc < m) ? scr + (size_t)(c0 + cc) * DPAD : scr_sink;
-#pragma unroll
-            for (int i = 0; i < RPT; ++i) {
-                const int row = td + FP_NT * i;
-#pragma unroll
-                for (int cc = 0; cc < PW; ++cc) oc[cc][row] = P[i][cc];
-            }
-            FP_STAMP(6);                                           // panel write-back
+            factor_panel(c0);
         }
         __syncthreads();
         FP_STAMP(3);
