@@ -557,9 +557,24 @@ static int32_t callback_logp(pfmi_ctx *c, const double *d_x, int64_t n, double *
 }
 
 // chunk of fits whose draws are materialised in HBM at a time for a DEVICE_CALLBACK target (PFMI_DEVCB_CHUNK_MB, default 2048 MB)
-static int64_t devcb_chunk_fits(int64_t per_fit_doubles, int64_t nf) {
+static int64_t devcb_chunk_fits(const pfmi_ctx *c, int64_t per_fit_doubles, int64_t nf, int64_t N) {
+    // the draws of a block of fits live in one scratch buffer: 2 GB by default (config 3: 256 fits of 8 MB).  When a fit's draws are
+    // large (config 5: 160 MB) such a block holds a dozen fits and the writer has to cut every fit into workgroups of a few draw groups,
+    // each of which streams the whole factor block (857 GB/s written at one GPU's share of config 5); the block then grows until a
+    // launch has 16 draw groups per workgroup on two workgroups per CU -- bounded by a quarter of the free device memory
     double mb = 2048.0;
-    if (const char *e = pf_debug_get("PFMI_DEVCB_CHUNK_MB")) { const double v = atof(e); if (v > 0) mb = v; }
+    const char *e = pf_debug_get("PFMI_DEVCB_CHUNK_MB");
+    if (e && atof(e) > 0) mb = atof(e);
+    else {
+        const int64_t ngroups = (N + 15) / 16, ncu = c->ncu > 0 ? c->ncu : 256;
+        const int64_t split = ngroups / 16 > 0 ? ngroups / 16 : 1;              // workgroups a fit can be cut into
+        const double want_mb = (double)((2 * ncu + split - 1) / split) * sizeof(double) * (double)per_fit_doubles / 1048576.0;
+        size_t free_b = 0, total_b = 0;
+        if (want_mb > mb && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const double cap_mb = (double)free_b / 4.0 / 1048576.0;
+            mb = want_mb < cap_mb ? want_mb : (cap_mb > mb ? cap_mb : mb);
+        }
+    }
     int64_t chunk = (int64_t)(mb * 1048576.0 / (sizeof(double) * (double)per_fit_doubles));
     if (chunk < 1) chunk = 1;
     if (chunk > nf) chunk = nf > 0 ? nf : 1;
@@ -617,7 +632,7 @@ int32_t pfmi_elbo_batch_enqueue(pfmi_ctx *c, int64_t N, const uint64_t *seeds, c
         // (8 d bytes written per draw), the user's kernel reads them on the same stream (8 d bytes read per draw) and its log
         // densities are scattered into the point-indexed table.  Nothing crosses PCIe, nothing synchronises.
         const int64_t per = (int64_t)d * N;
-        const int64_t chunk = devcb_chunk_fits(per, nf);
+        const int64_t chunk = devcb_chunk_fits(c, per, nf, N);
         PF_TRY(c->cb_x[0].ensure(sizeof(double) * (size_t)chunk * per));
         PF_TRY(c->cb_lp[0].ensure(sizeof(double) * (size_t)chunk * N));
         c->cb_bytes_dev = 0.0;
