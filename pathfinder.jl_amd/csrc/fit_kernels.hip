@@ -238,6 +238,70 @@ __global__ __launch_bounds__(1024) void pf_history_lean_kernel(
     }
 }
 
+// Memory-resident walk for ANY d (the default beyond 16 384 coordinates, where neither register kernel applies; PFMI_HISTORY_KERNEL=mem
+// selects it at every d for the tests).  Nothing is carried in registers: alpha of the previous point is read from its row of alpha_all,
+// the rows of the two points are swept twice per step (dot products, then the gilbert_init update; the second sweep hits L2).  The
+// divisions are the reference's own (a / alpha, s / alpha: src/inverse_hessian.jl:5-10), not the carried reciprocal of the register kernels.
+__global__ __launch_bounds__(1024) void pf_history_mem_kernel(
+    int d, int J, double eps, const int64_t *__restrict__ off, const double *__restrict__ theta,
+    const double *__restrict__ grad, double *__restrict__ alpha_all, int *__restrict__ hist_len,
+    int *__restrict__ hist_src, int *__restrict__ n_rej, int *__restrict__ acc_list) {
+    constexpr int HIST_NT = 1024;
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const int64_t p0 = off[k];
+    const int L = (int)(off[k + 1] - p0 - 1);
+    __shared__ double red[2 * 4 * (HIST_NT / 64)];
+    int flip = 0;
+    int n_acc = 0;
+    int *const acc = acc_list + p0;
+    for (int i = tid; i < d; i += HIST_NT) alpha_all[(size_t)p0 * d + i] = 1.0;      // H0 = I  (:38-39)
+    if (tid == 0) hist_len[p0] = 0;
+    for (int l = 1; l <= L; ++l) {                                                  // :43
+        const size_t row = (size_t)(p0 + l) * d;
+        double v[4] = {0.0, 0.0, 0.0, 0.0};   // y.s, y.y, y'diag(a)y, s'diag(1/a)s
+        for (int i = tid; i < d; i += HIST_NT) {                                    // (a thread reads back only what it wrote itself: no barrier)
+            const double s = theta[row + i] - theta[row - d + i], y = grad[row - d + i] - grad[row + i];   // :45-46
+            const double al = alpha_all[row - d + i];
+            v[0] += y * s;
+            v[1] += y * y;
+            v[2] += y * al * y;
+            v[3] += s * s / al;
+        }
+        pf_block_sum_mv<4, 4, 0>(v, red, flip);
+        const bool accept = v[0] > eps * v[1];                                      // :47
+        const double a = v[2], b = v[0], c = v[3], aoc = a / c;
+        for (int i = tid; i < d; i += HIST_NT) {
+            const double al = alpha_all[row - d + i];
+            double an = al;
+            if (accept) {                                                           // gilbert_init :5-10
+                const double s = theta[row + i] - theta[row - d + i], y = grad[row - d + i] - grad[row + i];
+                const double sa = s / al;
+                an = b / (a / al + y * y - aoc * sa * sa);
+            }
+            alpha_all[row + i] = an;
+        }
+        if (accept) n_acc += 1;
+        if (tid == 0) {
+            if (accept) acc[n_acc - 1] = l - 1;
+            hist_len[p0 + l] = n_acc < J ? n_acc : J;
+            hist_src[(size_t)(p0 + l) * J] = n_acc;
+        }
+    }
+    if (tid == 0) n_rej[k] = L > 0 ? L - n_acc : 0;                                 // :57
+    __threadfence_block();
+    __syncthreads();
+    for (int q = 1 + tid; q <= L; q += HIST_NT) {                                   // hist_inds (:105), as above
+        int *rowp = hist_src + (size_t)(p0 + q) * J;
+        const int na = rowp[0], re = na < J ? na : J;
+        int first = 0;
+        for (int cc = 0; cc < re; ++cc) {
+            const int vv = acc[na - re + cc];
+            if (cc == 0) first = vv; else rowp[cc] = vv;
+        }
+        rowp[0] = re > 0 ? first : 0;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 #include "fit_args.h"
 
@@ -980,8 +1044,18 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
 // ---------------------------------------------------------------------------------------------------
 int32_t pf_launch_history(pfmi_ctx *c, double eps) {
     PF_CHECK(c->J <= 64, PFMI_ERR_UNSUPPORTED, "history_length %d > 64 unsupported", c->J);
-    PF_CHECK(c->d <= 16 * 1024, PFMI_ERR_UNSUPPORTED, "dimension %d > %d unsupported", c->d, 16 * 1024);
     pf_kernel_begin(c);
+    {
+        const char *hk = pf_debug_get("PFMI_HISTORY_KERNEL");            // "mem": the memory-resident walk at every d (tests)
+        if (c->d > 16 * 1024 || (hk && hk[0] == 'm')) {
+            hipLaunchKernelGGL(pf_history_mem_kernel, dim3(c->K), dim3(1024), 0, c->stream, c->d, c->J, eps, c->d_off.as<int64_t>(),
+                               c->theta.as<double>(), c->grad.as<double>(), c->alpha_all.as<double>(), c->hist_len.as<int>(),
+                               c->hist_src.as<int>(), c->n_rej.as<int>(), c->hist_acc.as<int>());
+            pf_kernel_end(c, "history");
+            PF_HIP(hipGetLastError());
+            return PFMI_OK;
+        }
+    }
 #define PF_HIST(E, NT)                                                                                           \
     hipLaunchKernelGGL((pf_history_kernel<E, NT>), dim3(c->K), dim3(NT), 0, c->stream, c->d, c->J, eps,           \
                        c->d_off.as<int64_t>(), c->theta.as<double>(), c->grad.as<double>(),                      \

@@ -391,7 +391,9 @@ def _use_device_optimizer(target, optimizer):
     builtin = getattr(target, "kind", 2) in (0, 1)
     if optimizer == "device" and not builtin:
         raise ValueError("optimizer='device' needs a built-in target (analytic gradient on the GPU)")
-    return builtin if optimizer == "auto" else optimizer == "device"
+    if optimizer == "auto":                                  # the device L-BFGS keeps a path's vectors in registers: d <= 16 384
+        return builtin and getattr(target, "d", 0) <= 16384
+    return optimizer == "device"
 
 
 # ---- batched driver shared by pathfinder / multipathfinder ------------------------------------------------
