@@ -276,7 +276,9 @@ __global__ __launch_bounds__(PSIS_MT) void pf_psis_sum_kernel(long long S, const
 }
 __global__ __launch_bounds__(PSIS_MT) void pf_psis_norm_kernel(long long S, const double *__restrict__ lr, const PsisAux *aux,
                                                               double *__restrict__ lw, double *__restrict__ wout,
-                                                              double *__restrict__ out) {
+                                                              double *__restrict__ out, const double *__restrict__ tail_val,
+                                                              const unsigned *__restrict__ tail_idx) {
+    if (tail_val == nullptr) { tail_val = aux->tail_val; tail_idx = aux->tail_idx; }     // (the large-tail route keeps them in its own buffers)
     const double mx = aux->mx;
     double se = aux->se_tail;
     for (int b = 0; b < PSIS_MW; ++b) se += aux->partial[b];      // fixed order: identical in every thread
@@ -288,8 +290,8 @@ __global__ __launch_bounds__(PSIS_MT) void pf_psis_norm_kernel(long long S, cons
     if (blockIdx.x == 0) {
         if (aux->replaced)
             for (int t = threadIdx.x; t < aux->M; t += PSIS_MT) {
-                const double v = aux->tail_val[t] - lse;
-                lw[aux->tail_idx[t]] = v; wout[aux->tail_idx[t]] = exp(v);
+                const double v = tail_val[t] - lse;
+                lw[tail_idx[t]] = v; wout[tail_idx[t]] = exp(v);
             }
         if (threadIdx.x == 0) { out[0] = aux->pareto_k; out[1] = (double)aux->M; out[2] = aux->sigma; out[3] = lse; }
     }
@@ -645,6 +647,113 @@ __global__ void pf_gather_kernel(int d, long long ndraws, long long ncols_local,
         out[(size_t)t * d + i] = own ? pool[(size_t)g * d + i] : 0.0;
 }
 
+
+// ---- PSIS with a tail beyond the LDS capacity (M + 1 > TAILCAP, i.e. pools of more than 1 863 225 draws; round 4) -----------------
+// The (key, index) pairs of ALL log ratios are sorted in global memory (the bitonic kernels above; padding keys 0 sort to the front),
+// the M + 1 largest are then the last entries, ascending by (key, index) like the LDS route's tail.  One workgroup fits the tail with
+// the arithmetic of pf_psis_kernel (same loops, same summation order; w[] lives in a global buffer instead of LDS), the passes over
+// S are the multi-workgroup kernels of the regular route.
+__global__ void pf_sortkeys_init_lr_kernel(long long S, long long n2, const double *__restrict__ lr, uint64_t *__restrict__ keys,
+                                           uint32_t *__restrict__ ids) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n2) return;
+    keys[i] = (i < S) ? pf_key_of(lr[i]) : 0ull;
+    ids[i] = (i < S) ? (uint32_t)i : 0u;
+}
+__global__ __launch_bounds__(PSIS_THREADS) void pf_psis_bigtail_kernel(int M, const uint64_t *__restrict__ tkeys,
+                                                                       const uint32_t *__restrict__ tidx, double *__restrict__ w,
+                                                                       PsisAux *aux) {
+    // tkeys[0] = cutoff, tkeys[1..M] = the M largest, ascending
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    __shared__ double red[PSIS_THREADS / 64];
+    __shared__ double s_theta[640], s_ll[640];                     // 30 + sqrt(M) grid points: M <= 196 608 at S < 2^32
+    __shared__ double s_sigma, s_mu;
+    double pareto_k = NAN;
+    bool replaced = false;
+    const double logu = pf_val_of(tkeys[0]), lmax = pf_val_of(tkeys[M]);
+    if (tid == 0) s_sigma = NAN;
+    __syncthreads();
+    double bad = 0.0;
+    for (int t = 1 + tid; t <= M; t += nt) if (!isfinite(pf_val_of(tkeys[t]))) bad = 1.0;
+    bad = pf_block_sum1(bad, red);
+    __syncthreads();
+    if (bad == 0.0) {
+        const double mu_s = exp(logu - lmax);
+        double nz = 0.0;
+        for (int t = tid; t < M; t += nt) {
+            const double v = exp(pf_val_of(tkeys[t + 1]) - lmax) - mu_s;
+            w[t] = v;
+            if (v != 0.0) nz = 1.0;
+        }
+        nz = pf_block_sum1(nz, red);
+        __threadfence_block();
+        __syncthreads();
+        if (nz > 0.0) {
+            const int mest = 30 + (int)floor(sqrt((double)M));
+            const double xstar = w[(M + 2) / 4 - 1], xmax = w[M - 1];
+            for (int i = wave; i < mest; i += nw) {
+                const double p = ((double)(i + 1) - 0.5) / (double)mest;
+                const double theta = 1.0 / xmax + (1.0 - sqrt(1.0 / p)) / (3.0 * xstar);
+                double kk = 0.0;
+                for (int t = lane; t < M; t += 64) kk += log1p(-theta * w[t]);
+                kk = pf_wave_sum(kk) / (double)M;
+                if (lane == 0) {
+                    s_theta[i] = theta;
+                    s_ll[i] = (double)M * (log(-theta / kk) - kk - 1.0);
+                }
+            }
+            __syncthreads();
+            if (tid < 64) {
+                double lmx = -INFINITY;
+                for (int i = lane; i < mest; i += 64) lmx = fmax(lmx, s_ll[i]);
+                lmx = pf_wave_max(lmx);
+                double ws = 0.0, ts = 0.0;
+                for (int i = lane; i < mest; i += 64) { const double e = exp(s_ll[i] - lmx); ws += e; ts += e * s_theta[i]; }
+                ws = pf_wave_sum(ws); ts = pf_wave_sum(ts);
+                if (lane == 0) s_mu = ts / ws;
+            }
+            __syncthreads();
+            const double th = s_mu;
+            double kk = 0.0;
+            for (int t = tid; t < M; t += nt) kk += log1p(-th * w[t]);
+            kk = pf_block_sum1(kk, red) / (double)M;
+            const double sigma = -kk / th;
+            double kadj = kk;
+            if (isfinite(kk)) kadj = (kk * (double)M + 5.0) / ((double)M + 10.0);   // prior adjustment
+            pareto_k = kadj;
+            if (isfinite(kadj) && isfinite(sigma)) {
+                __syncthreads();
+                for (int t = tid; t < M; t += nt) {
+                    const double p = ((double)(t + 1) - 0.5) / (double)M;
+                    const double nl = -log1p(-p);
+                    const double z = (kadj == 0.0) ? nl : expm1(kadj * nl) / kadj;
+                    double v = log(sigma * z + mu_s);
+                    if (v > 0.0) v = 0.0;
+                    w[t] = v + lmax;
+                }
+                replaced = true;
+            }
+            if (tid == 0) s_sigma = sigma;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    double mx = lmax;
+    if (replaced) {
+        mx = -INFINITY;
+        for (int t = tid; t < M; t += nt) mx = fmax(mx, w[t]);
+        mx = fmax(pf_block_max1(mx, red), logu);
+    }
+    __syncthreads();
+    double se = 0.0;
+    if (replaced && isfinite(mx)) for (int t = tid; t < M; t += nt) se += exp(w[t] - mx);
+    se = pf_block_sum1(se, red);
+    if (tid == 0) {
+        aux->mx = mx; aux->se_tail = se; aux->replaced = replaced ? 1u : 0u; aux->tk0 = tkeys[0]; aux->ti0 = tidx[0];
+        aux->pareto_k = pareto_k; aux->sigma = s_sigma; aux->M = M;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 static long long psis_tail_length(long long S) {
     long long a = (S + 4) / 5;
@@ -656,13 +765,36 @@ int32_t pf_launch_psis(pfmi_ctx *c, const double *d_lr, int64_t S) {
     PF_CHECK(S > 0, PFMI_ERR_ARG, "psis: empty log-ratio vector");
     PF_CHECK(S < (1ll << 32), PFMI_ERR_UNSUPPORTED, "psis: S too large");
     const long long M = psis_tail_length(S);
-    PF_CHECK(M + 1 <= TAILCAP, PFMI_ERR_UNSUPPORTED, "psis: tail length %lld exceeds %d", M, TAILCAP - 1);
     PF_TRY(c->lw.ensure(sizeof(double) * S));
     PF_TRY(c->w.ensure(sizeof(double) * S));
     PF_TRY(c->psis_out.ensure(sizeof(double) * 4));
     pf_kernel_begin(c);
-    const char *force = pf_debug_get("PFMI_PSIS_KERNEL");              // "single": the one-workgroup kernel for every S (tests)
-    if (S >= PSIS_MULTI_MIN && M >= 5 && !(force && force[0] == 's')) {
+    const char *force = pf_debug_get("PFMI_PSIS_KERNEL");              // "single": the one-workgroup kernel for every S (tests); "big": the large-tail route
+    if (M + 1 > TAILCAP || (force && force[0] == 'b' && M >= 5 && M + 1 <= S)) {
+        // tail beyond the LDS capacity: global sort of every (key, index) pair, tail fit on the sorted run
+        long long n2 = 1;
+        while (n2 < S) n2 <<= 1;
+        PF_TRY(c->sortk.ensure(sizeof(uint64_t) * (size_t)n2));
+        PF_TRY(c->sorti.ensure(sizeof(uint32_t) * (size_t)n2));
+        PF_TRY(c->psis_aux.ensure(sizeof(PsisAux)));
+        PF_TRY(c->scratch.ensure(sizeof(double) * (size_t)(M + 1)));
+        PsisAux *aux = c->psis_aux.as<PsisAux>();
+        PF_HIP(hipMemsetAsync(aux, 0, offsetof(PsisAux, cand_key), c->stream));
+        const dim3 grid((unsigned)((n2 + 255) / 256));
+        hipLaunchKernelGGL(pf_sortkeys_init_lr_kernel, grid, dim3(256), 0, c->stream, (long long)S, n2, d_lr, c->sortk.as<uint64_t>(),
+                           c->sorti.as<uint32_t>());
+        for (long long k = 2; k <= n2; k <<= 1)
+            for (long long j = k >> 1; j > 0; j >>= 1)
+                hipLaunchKernelGGL(pf_bitonic_step_kernel, grid, dim3(256), 0, c->stream, n2, j, k, c->sortk.as<uint64_t>(),
+                                   c->sorti.as<uint32_t>());
+        const uint64_t *tk = c->sortk.as<uint64_t>() + (n2 - (M + 1));
+        const uint32_t *ti = c->sorti.as<uint32_t>() + (n2 - (M + 1));
+        hipLaunchKernelGGL(pf_psis_bigtail_kernel, dim3(1), dim3(PSIS_THREADS), 0, c->stream, (int)M, tk, ti, c->scratch.as<double>(), aux);
+        hipLaunchKernelGGL(pf_psis_sum_kernel, dim3(PSIS_MW), dim3(PSIS_MT), 0, c->stream, (long long)S, d_lr, aux);
+        hipLaunchKernelGGL(pf_psis_norm_kernel, dim3(PSIS_MW), dim3(PSIS_MT), 0, c->stream, (long long)S, d_lr, aux,
+                           c->lw.as<double>(), c->w.as<double>(), c->psis_out.as<double>(), (const double *)c->scratch.as<double>(),
+                           (const unsigned *)(ti + 1));
+    } else if (S >= PSIS_MULTI_MIN && M >= 5 && !(force && force[0] == 's')) {
         PF_TRY(c->psis_aux.ensure(sizeof(PsisAux)));
         PsisAux *aux = c->psis_aux.as<PsisAux>();
         PF_HIP(hipMemsetAsync(aux, 0, offsetof(PsisAux, cand_key), c->stream));
@@ -673,7 +805,7 @@ int32_t pf_launch_psis(pfmi_ctx *c, const double *d_lr, int64_t S) {
                            c->lw.as<double>(), c->w.as<double>(), c->psis_out.as<double>(), (int)M, aux);
         hipLaunchKernelGGL(pf_psis_sum_kernel, dim3(PSIS_MW), dim3(PSIS_MT), 0, c->stream, (long long)S, d_lr, aux);
         hipLaunchKernelGGL(pf_psis_norm_kernel, dim3(PSIS_MW), dim3(PSIS_MT), 0, c->stream, (long long)S, d_lr, aux,
-                           c->lw.as<double>(), c->w.as<double>(), c->psis_out.as<double>());
+                           c->lw.as<double>(), c->w.as<double>(), c->psis_out.as<double>(), (const double *)nullptr, (const unsigned *)nullptr);
     } else
         hipLaunchKernelGGL(pf_psis_kernel<false>, dim3(1), dim3(PSIS_THREADS), 0, c->stream, (long long)S, d_lr,
                            c->lw.as<double>(), c->w.as<double>(), c->psis_out.as<double>(), (int)M, (PsisAux *)nullptr);
