@@ -410,6 +410,11 @@ __device__ __forceinline__ double pf_dpp_add(double v) {
     const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
     return v + __hiloint2double(hi2, lo2);
 }
+// lane `lane`'s value of x in every lane (two v_readlane_b32 through SGPRs; `lane` must be wave-uniform)
+__device__ __forceinline__ double pf_readlane_f64(double x, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane), hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double pf_wave_sum(double v) {
     v = pf_dpp_add<0x111, 0xf>(v);   // row_shr:1
     v = pf_dpp_add<0x112, 0xf>(v);   // row_shr:2
