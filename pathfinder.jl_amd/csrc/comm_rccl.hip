@@ -228,9 +228,8 @@ int32_t handshake(pfmi_comm *c, double v, int local_err, const char *why, double
         }
         PF_TRY(group_all_reduce(c, c->hs, 4, ncclMax));
         PF_HIP(hipSetDevice(c->ctx[0]->device));
-        PF_HIP(hipMemcpyAsync(r, c->hs[0].p, sizeof(r), hipMemcpyDeviceToHost, c->ctx[0]->stream));
-        PF_HIP(hipStreamSynchronize(c->ctx[0]->stream));
-        pf_arena_reset(c->ctx[0]);
+        PF_TRY(pf_download(c->ctx[0], r, c->hs[0].p, sizeof(r)));
+        PF_TRY(pf_stream_sync(c->ctx[0]));
         PF_CHECK(r[2] == 0.0, PFMI_ERR_STATE, "comm: a rank of the group cannot take part in the pooled stage%s%s", local_err ? ": " : "",
                  local_err ? why : " (see that rank's error)");
         *vmax = r[0];
@@ -303,12 +302,11 @@ int32_t finish_pool_psis(pfmi_comm *c, double *pareto_k, int64_t *tail_len) {
     for (size_t i = 0; i < nl; ++i) {
         pfmi_ctx *x = c->ctx[i];
         PF_HIP(hipSetDevice(x->device));
-        PF_HIP(hipMemcpyAsync(&out[4 * i], x->psis_out.p, 4 * sizeof(double), hipMemcpyDeviceToHost, x->stream));
+        PF_TRY(pf_download(x, &out[4 * i], x->psis_out.p, 4 * sizeof(double)));
     }
     for (size_t i = 0; i < nl; ++i) {
         PF_HIP(hipSetDevice(c->ctx[i]->device));
-        PF_HIP(hipStreamSynchronize(c->ctx[i]->stream));
-        pf_arena_reset(c->ctx[i]);
+        PF_TRY(pf_stream_sync(c->ctx[i]));
     }
     c->psis_pending = false;
     const double k0 = out[0];
@@ -386,20 +384,21 @@ int32_t finish_resample(pfmi_comm *c, int64_t *idx, double *draws) {
         pfmi_ctx *x = c->ctx[i];
         PF_HIP(hipSetDevice(x->device));
         if (x->idx.cap >= sizeof(int64_t) * (size_t)ndraws)
-            PF_HIP(hipMemcpyAsync(&h_idx[(size_t)ndraws * i], x->idx.p, sizeof(int64_t) * ndraws, hipMemcpyDeviceToHost, x->stream));
-        if (x->rs_err.p) PF_HIP(hipMemcpyAsync(&h_err[i], x->rs_err.p, sizeof(int), hipMemcpyDeviceToHost, x->stream));
+            PF_TRY(pf_download(x, &h_idx[(size_t)ndraws * i], x->idx.p, sizeof(int64_t) * ndraws));
+        if (x->rs_err.p) PF_TRY(pf_download(x, &h_err[i], x->rs_err.p, sizeof(int)));
     }
     {
+        // the small results are staged (pinned, asynchronous); the draws -- megabytes into the caller's pageable array, a blocking
+        // call -- are queued LAST, so this entry point costs ONE host round trip
         pfmi_ctx *x = c->ctx[0];
         PF_HIP(hipSetDevice(x->device));
         PF_CHECK(c->out[0].cap >= sizeof(double) * (n + 1), PFMI_ERR_STATE, "comm_resample: no result buffer");
-        if (draws) PF_HIP(hipMemcpyAsync(draws, c->out[0].p, sizeof(double) * n, hipMemcpyDeviceToHost, x->stream));
-        PF_HIP(hipMemcpyAsync(&flag, c->out[0].as<double>() + n, sizeof(double), hipMemcpyDeviceToHost, x->stream));
+        PF_TRY(pf_download(x, &flag, c->out[0].as<double>() + n, sizeof(double)));
+        if (draws) PF_TRY(pf_download(x, draws, c->out[0].p, sizeof(double) * n));
     }
     for (size_t i = 0; i < nl; ++i) {
         PF_HIP(hipSetDevice(c->ctx[i]->device));
-        PF_HIP(hipStreamSynchronize(c->ctx[i]->stream));
-        pf_arena_reset(c->ctx[i]);
+        PF_TRY(pf_stream_sync(c->ctx[i]));
     }
     for (size_t i = 0; i < nl; ++i)
         PF_CHECK(h_err[i] == 0, PFMI_ERR_NUMERIC, "resample: weights are all zero / not enough positive weights (rank %d)", c->rank[i]);

@@ -101,16 +101,37 @@ int32_t pf_upload(pfmi_ctx *c, void *dst, const void *src, size_t bytes) {
     return PFMI_OK;
 }
 static int32_t h2d(pfmi_ctx *c, void *dst, const void *src, size_t bytes) { return pf_upload(c, dst, src, bytes); }
-static int32_t d2h_async(pfmi_ctx *c, void *dst, const void *src, size_t bytes) {
+#define PF_DL_BYTES (4u << 20)
+#define PF_DL_MAX (1u << 20)
+int32_t pf_download(pfmi_ctx *c, void *dst, const void *src, size_t bytes) {
     if (bytes == 0) return PFMI_OK;
-    PF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    PinArena &a = c->dl;
+    if (bytes <= PF_DL_MAX) {
+        if (!a.base) {
+            void *pp = nullptr;
+            PF_HIP(hipHostMalloc(&pp, PF_DL_BYTES, hipHostMallocDefault));
+            a.base = reinterpret_cast<char *>(pp); a.cap = PF_DL_BYTES; a.off = 0;
+        }
+        if (a.off + bytes <= a.cap) {
+            PF_HIP(hipMemcpyAsync(a.base + a.off, src, bytes, hipMemcpyDeviceToHost, c->stream));
+            c->dl_pending.push_back(DlPending{dst, a.base + a.off, bytes});
+            a.off += (bytes + 255) & ~(size_t)255;
+            return PFMI_OK;
+        }
+    }
+    PF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));    // pageable destination: blocks until the copy is done
     return PFMI_OK;
 }
-static int32_t stream_sync(pfmi_ctx *c) {
+int32_t pf_stream_sync(pfmi_ctx *c) {
     PF_HIP(hipStreamSynchronize(c->stream));
+    for (const DlPending &q : c->dl_pending) memcpy(q.dst, q.slot, q.bytes);
+    c->dl_pending.clear();
+    c->dl.off = 0;
     pf_arena_reset(c);
     return PFMI_OK;
 }
+static int32_t d2h_async(pfmi_ctx *c, void *dst, const void *src, size_t bytes) { return pf_download(c, dst, src, bytes); }
+static int32_t stream_sync(pfmi_ctx *c) { return pf_stream_sync(c); }
 static int32_t d2h(pfmi_ctx *c, void *dst, const void *src, size_t bytes) {
     if (bytes == 0) return PFMI_OK;
     PF_TRY(d2h_async(c, dst, src, bytes));
@@ -222,6 +243,7 @@ int32_t pfmi_destroy(pfmi_ctx *c) {
         if (c->cb_ev[b]) (void)hipEventDestroy(c->cb_ev[b]);
     }
     if (c->arena.base) (void)hipHostFree(c->arena.base);
+    if (c->dl.base) (void)hipHostFree(c->dl.base);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     (void)hipEventDestroy(c->kev0); (void)hipEventDestroy(c->kev1);
     pf_kernel_resolve(c, false);

@@ -57,6 +57,8 @@ struct KernelStat { double ms = 0.0; int64_t launches = 0; };
 // upload never forces a stream synchronisation in the middle of an enqueued pipeline (pf_upload in pfmi_api.hip).  Bump allocated;
 // rewound whenever the stream is known to be idle (pf_arena_reset after a full synchronisation).
 struct PinArena { char *base = nullptr; size_t cap = 0, off = 0; };
+// a small device -> host download staged in the ctx's pinned download arena: delivered to `dst` by pf_stream_sync
+struct DlPending { void *dst; const char *slot; size_t bytes; };
 
 // device-resident target description (Gaussian family rows are stored row-major for scalar loads)
 struct TargetDev {
@@ -81,6 +83,8 @@ struct pfmi_ctx {
     hipEvent_t kcur = nullptr;
     std::set<const void *> lds_attr_done;   // kernels whose dynamic-LDS limit was raised on THIS ctx's device (see pf_raise_lds_limit)
     PinArena arena;                         // staging of small uploads (pf_upload)
+    PinArena dl;                            // staging of small downloads (pf_download)
+    std::vector<DlPending> dl_pending;
     int ncu = 0;                            // compute units of the device
 
     // traces
@@ -167,6 +171,12 @@ struct pfmi_ctx {
 int32_t pf_upload(pfmi_ctx *c, void *dst, const void *src, size_t bytes);
 // the stream is idle: the arena may be reused from its start
 void pf_arena_reset(pfmi_ctx *c);
+// device -> host download on the ctx stream that does NOT block the host: up to 1 MB goes through a pinned arena and reaches `dst` in
+// pf_stream_sync (a hipMemcpyAsync into pageable memory is a blocking call: each of an entry point's result downloads used to cost a
+// host round trip of 20 - 70 us, ~0.3 ms per step; round 4).  Larger blocks are copied directly (blocking), so queue them last.
+int32_t pf_download(pfmi_ctx *c, void *dst, const void *src, size_t bytes);
+// hipStreamSynchronize + delivery of the staged downloads + arena rewind
+int32_t pf_stream_sync(pfmi_ctx *c);
 
 // ---- launch helpers (implemented in the .hip files) ----------------------------------------------
 int32_t pf_launch_history(pfmi_ctx *c, double eps);

@@ -864,9 +864,8 @@ int32_t pf_enqueue_resample(pfmi_ctx *c, int64_t S, int64_t ndraws, int importan
 // blocks: reads the error flag of the last pf_enqueue_resample
 int32_t pf_resample_check(pfmi_ctx *c) {
     int err = 0;
-    PF_HIP(hipMemcpyAsync(&err, c->rs_err.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    PF_HIP(hipStreamSynchronize(c->stream));
-    pf_arena_reset(c);
+    PF_TRY(pf_download(c, &err, c->rs_err.p, sizeof(int)));
+    PF_TRY(pf_stream_sync(c));
     PF_CHECK(err == 0, PFMI_ERR_NUMERIC, "resample: weights are all zero / not enough positive weights");
     return PFMI_OK;
 }
