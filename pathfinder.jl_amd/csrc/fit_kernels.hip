@@ -688,11 +688,13 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
     const double *theta_p = A.theta + (size_t)p * d, *grad_p = A.grad + (size_t)p * d;
 
     constexpr int NVMAX = KPAD;
-    __shared__ double red[2 * (NT / 64) * NVMAX];       // two halves: one barrier per block reduction (pf_block_sum_pp)
+    __shared__ __attribute__((aligned(16))) double red[2 * (NT / 64) * NVMAX];       // two halves: one barrier per block reduction (pf_block_sum_pp)
     int flip = 0;
-    __shared__ double sRow[2][KPAD], sHead[KPAD];
+    __shared__ double sRow[2][KPAD];
     __shared__ double sD[KPAD * KPAD], sR[KPAD * KPAD], sT[KPAD * KPAD], sV[KPAD * KPAD], sG[KPAD * KPAD];
     __shared__ double sX1[(KPAD / 2) * KPAD], sX2[(KPAD / 2) * KPAD], sX3[(KPAD / 2) * KPAD];     // j x j scratch of the D computation
+    __shared__ double sGv[KPAD * KPAD], sVt[KPAD * KPAD];   // V'V (by-product of the column reductions) and the top k x k block of V: the mean needs no second sweep
+    __shared__ double sT12[KPAD], sDl[KPAD];
     __shared__ double sLogdetV;
     __shared__ int sStatus;
 
@@ -714,7 +716,7 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
         pf_block_sum_pp<2, NVMAX>(v, red, flip);
         bad = v[0]; ldu = v[1];
     }
-    for (int t = tid; t < KPAD * KPAD; t += NT) { sD[t] = 0.0; sR[t] = 0.0; sT[t] = 0.0; sV[t] = 0.0; sG[t] = 0.0; }
+    for (int t = tid; t < KPAD * KPAD; t += NT) { sD[t] = 0.0; sR[t] = 0.0; sT[t] = 0.0; sV[t] = 0.0; sG[t] = 0.0; sGv[t] = 0.0; sVt[t] = 0.0; }
     const size_t sm = (size_t)p * KPAD * KPAD;
     if (bad > 0.0) {                                           // A not positive definite (src/woodbury.jl:202)
 #pragma unroll
@@ -784,7 +786,7 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
                 for (int cc = 0; cc < KPAD; ++cc) acc[cc] += xc * a[i][cc];
             }
         }
-        pf_block_sum_mv<KPAD, NVMAX>(acc, red, flip);     // (run-time wave count on purpose: the static form makes the compiler hoist 4 KPAD LDS reads and spill)       // its barriers also publish srow (double buffered: no trailing barrier)
+        pf_block_sum_mv<KPAD, NVMAX>(acc, red, flip);       // its barriers also publish srow (double buffered: no trailing barrier)
         double xn2 = 0.0;
 #pragma unroll
         for (int cc = 0; cc < KPAD; ++cc) if (cc == c) xn2 = acc[cc];
@@ -809,6 +811,11 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
             for (int b = 0; b < KPAD; ++b) if (b >= tid && b < c) v += sT[tid * KPAD + b] * wv[b];
             const double tnew = (tid == c) ? tau : -tau * v;
             sT[tid * KPAD + c] = tnew;
+            if (tid == c) {                  // row / column c of V'V: wv[cc < c] = v_c . v_cc, |v_c|^2 = 1 + scal^2 |x|^2
+#pragma unroll
+                for (int cc = 0; cc < KPAD; ++cc) if (cc < c) { sGv[c * KPAD + cc] = wv[cc]; sGv[cc * KPAD + c] = wv[cc]; }
+                sGv[c * KPAD + c] = fma(scal * scal, xn2, 1.0);
+            }
         }
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
@@ -839,6 +846,7 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
                 sR[tid * KPAD + cc] = (cc < m) ? a[0][cc] : 0.0;
                 a[0][cc] = (cc == tid) ? 1.0 : 0.0;
             }
+            if (cc < k) sVt[tid * KPAD + cc] = a[0][cc];            // top k x k block of V (unit lower triangular)
         }
     }
     __syncthreads();
@@ -970,6 +978,10 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
     }
     if (FITREG_ABLATE & 2) return;
     // ---- mu = theta + U' Q [V'V 0;0 I] Q' U g     (sqrt(alpha) and sqrt(alpha) * grad are re-read rather than kept in VGPRs)
+    // b = Q'(U g) = U g - V t1 (t1 = T'w1, w1 = V'U g: the ONE sweep + block reduction); head' = Vc'Vc head; x = Q b' = b' - V t2,
+    // t2 = T V'b'.  V'b' needs no second sweep (round 4): V'b = w1 - (V'V) t1 with V'V from the column reductions, and b' differs from
+    // b in the head rows only: V'b' = V'b + Vtop'(head' - head).  So x = U g - V (t1 + t2) + e_head (head' - head): every thread needs
+    // t1 + t2 and the head rows their increment, both made by wave 0 with one entry per lane (broadcasts by v_readlane).
     double agv[RPT];
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
@@ -982,65 +994,50 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
     for (int i = 0; i < RPT; ++i)
 #pragma unroll
         for (int cc = 0; cc < KPAD; ++cc) acc[cc] += agv[i] * a[i][cc];
-    pf_block_sum_mv<KPAD, NVMAX>(acc, red, flip);     // (run-time wave count on purpose: the static form makes the compiler hoist 4 KPAD LDS reads and spill)
-    double t1[KPAD];                          // t1 = T' w1 (every thread, from LDS T)
+    pf_block_sum_mv<KPAD, NVMAX>(acc, red, flip);
+    if (tid < 64) {
+        const int aa = tid < KPAD ? tid : KPAD - 1;                // lanes >= KPAD compute a harmless copy of lane KPAD - 1
+        const bool live = tid < k;
+        double w1l = 0.0, t1l = 0.0;
 #pragma unroll
-    for (int aa = 0; aa < KPAD; ++aa) {
-        double v = 0.0;
-#pragma unroll
-        for (int b = 0; b < KPAD; ++b) if (b <= aa) v += sT[b * KPAD + aa] * acc[b];
-        t1[aa] = v;
-    }
-    double bv[RPT];
-#pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-        double v = agv[i];
-#pragma unroll
-        for (int cc = 0; cc < KPAD; ++cc) v -= a[i][cc] * t1[cc];
-        bv[i] = v;
-    }
-    if (tid < k) sHead[tid] = bv[0];
-    __syncthreads();
-    if (tid < 64) {                          // head <- V'(V head), lane a owns entry a (two ordered LDS phases of wave 0)
-        const int aa = tid;
-        volatile double *tmp = sRow[0];
-        volatile double *hd = sHead;
-        double v = 0.0;
-        if (aa < k) for (int b = aa; b < k; ++b) v += sV[aa * KPAD + b] * hd[b];
-        if (aa < k) tmp[aa] = v;
-        __builtin_amdgcn_wave_barrier();
-        double v2 = 0.0;
-        if (aa < k) for (int b = 0; b <= aa; ++b) v2 += sV[b * KPAD + aa] * tmp[b];
-        __builtin_amdgcn_wave_barrier();
-        if (aa < k) hd[aa] = v2;
-    }
-    __syncthreads();
-    if (tid < k) bv[0] = sHead[tid];
-#pragma unroll
-    for (int cc = 0; cc < KPAD; ++cc) acc[cc] = 0.0;
-#pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-        const int row = tid + NT * i;
-        if (row < d) {
-#pragma unroll
-            for (int cc = 0; cc < KPAD; ++cc) acc[cc] += bv[i] * a[i][cc];
+        for (int b = 0; b < KPAD; ++b) {
+            w1l = (b == aa) ? acc[b] : w1l;
+            t1l += sT[b * KPAD + aa] * acc[b];                     // t1 = T'w1 (T is upper triangular, zero filled)
         }
-    }
-    pf_block_sum_mv<KPAD, NVMAX>(acc, red, flip);     // (run-time wave count on purpose: the static form makes the compiler hoist 4 KPAD LDS reads and spill)
+        double hbl = live ? agv[0] : 0.0;                          // head of b = U g - V t1: row aa of thread aa
 #pragma unroll
-    for (int aa = 0; aa < KPAD; ++aa) {       // t2 = T w2
-        double v = 0.0;
+        for (int cc = 0; cc < KPAD; ++cc) hbl -= sVt[aa * KPAD + cc] * pf_readlane_f64(t1l, cc);
+        hbl = live ? hbl : 0.0;
+        double tmpl = 0.0;
 #pragma unroll
-        for (int b = 0; b < KPAD; ++b) if (b >= aa) v += sT[aa * KPAD + b] * acc[b];
-        t1[aa] = v;
+        for (int b = 0; b < KPAD; ++b) tmpl += sV[aa * KPAD + b] * pf_readlane_f64(hbl, b);       // Vc head
+        double hdl = 0.0;
+#pragma unroll
+        for (int b = 0; b < KPAD; ++b) hdl += sV[b * KPAD + aa] * pf_readlane_f64(tmpl, b);       // Vc'(Vc head)
+        const double dll = live ? hdl - hbl : 0.0;
+        double w2l = w1l;                                          // V'b' = w1 - (V'V) t1 + Vtop'(head' - head)
+#pragma unroll
+        for (int b = 0; b < KPAD; ++b) w2l -= sGv[aa * KPAD + b] * pf_readlane_f64(t1l, b);
+#pragma unroll
+        for (int r = 0; r < KPAD; ++r) w2l += sVt[r * KPAD + aa] * pf_readlane_f64(dll, r);
+        double t2l = 0.0;
+#pragma unroll
+        for (int b = 0; b < KPAD; ++b) t2l += sT[aa * KPAD + b] * pf_readlane_f64(w2l, b);        // t2 = T V'b'
+        if (tid < KPAD) { sT12[tid] = t1l + t2l; sDl[tid] = dll; }
     }
+    __syncthreads();
+    double t12[KPAD];
+#pragma unroll
+    for (int cc = 0; cc < KPAD; ++cc) t12[cc] = sT12[cc];
+    const double dl0 = (tid < k) ? sDl[tid < KPAD ? tid : 0] : 0.0;
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
         const int row = tid + NT * i;
         if (row < d) {
-            double v = bv[i];
+            double v = agv[i];
 #pragma unroll
-            for (int cc = 0; cc < KPAD; ++cc) v -= a[i][cc] * t1[cc];
+            for (int cc = 0; cc < KPAD; ++cc) v -= a[i][cc] * t12[cc];
+            if (i == 0) v += dl0;
             mu[row] = theta_p[row] + sqa[row] * v;
         }
     }

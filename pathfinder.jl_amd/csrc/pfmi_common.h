@@ -473,10 +473,12 @@ __device__ __forceinline__ void pf_block_sum(double (&v)[NV], double *red) {
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        double s = red[i];
-        for (int w = 1; w < nw; ++w) s += red[w * NV + i];
-        v[i] = s;
+    for (int i = 0; i < NV; ++i) v[i] = red[i];
+#pragma unroll 1
+    for (int w = 1; w < nw; ++w) {                 // wave loop outermost and rolled: NV reads per LDS round trip (see pf_block_sum_mv)
+        const double *bw = red + w * NV;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] += bw[i];
     }
 }
 // Same with ONE barrier per reduction: consecutive reductions alternate between two scratch halves (`flip`), so the barrier
@@ -504,12 +506,14 @@ __device__ __forceinline__ void pf_block_sum_pp(double (&v)[NV], double *red, in
             for (int w = 1; w < (NW ? NW : 1); ++w) s += buf[w * NV + i];
             v[i] = s;
         }
-    } else {
+    } else {                                   // wave loop outermost and rolled: see pf_block_sum_mv
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            double s = buf[i];
-            for (int w = 1; w < nw; ++w) s += buf[w * NV + i];
-            v[i] = s;
+        for (int i = 0; i < NV; ++i) v[i] = buf[i];
+#pragma unroll 1
+        for (int w = 1; w < nw; ++w) {
+            const double *bw = buf + w * NV;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v[i] += bw[i];
         }
     }
 }
@@ -563,11 +567,18 @@ __device__ __forceinline__ void pf_block_sum_mv(double (&v)[NV], double *red, in
             v[i] = s;
         }
     } else {
+        // run-time wave count: the WAVE loop is the outer, rolled one -- NV independent reads per trip and one wait, nw - 1 round trips
+        // per reduction.  (Until round 4 the value loop was the outer one: every partial was its own LDS round trip with an s_waitcnt,
+        // 48 dependent trips per 12-value reduction of the fit kernel, ~4 000 cycles of a fit's critical path 15 times per fit.  The
+        // fully static form makes the register allocator spill ~600 dwords there: the rolled loop also fences the scheduler.)
+        // Same order ((w0 + w1) + w2) + ...: the same bits.
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            double s = buf[i];
-            for (int w = 1; w < nw; ++w) s += buf[w * NV + i];
-            v[i] = s;
+        for (int i = 0; i < NV; ++i) v[i] = buf[i];
+#pragma unroll 1
+        for (int w = 1; w < nw; ++w) {
+            const double *bw = buf + w * NV;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v[i] += bw[i];
         }
     }
 }

@@ -1,4 +1,5 @@
 import os, sys, time
+os.environ["PFMI_DEBUG_HOOKS"] = "1"          # the library reads PFMI_HISTORY_KERNEL only then
 sys.path.insert(0, "pathfinder.jl_amd")
 import numpy as np, pfmi
 out = {}
