@@ -48,7 +48,7 @@ __device__ __forceinline__ double pf_mfma4(double a, double b, double c) {
 // TGT: 0 none, 1 Gaussian family (RPAD = 0 or 8 or 16 low-rank columns), 2 funnel
 template <int KC, int NBW, int TGT, int RPAD, bool WX>
 __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, int groups_per_block, int ngroups) {
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr bool FOLD = (TGT == 1) && !WX;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, q = lane >> 4, c = lane & 15;
     const int d = A.d;
@@ -88,7 +88,20 @@ __global__ __launch_bounds__(MF_THREADS) void pf_elbo_mfma_kernel(ElboArgs A, in
 
     {
         const double *Vh = A.vh + (size_t)p * d * KC;
-        for (int i = tid; i < rows * KC; i += MF_THREADS) vh_s[i] = (i < d * KC) ? Vh[i] : 0.0;
+        {   // six 16-byte loads in flight per thread (a guarded load per element was a global round trip per element; round 4)
+            const int npair = rows * KC / 2, lim = d * KC;
+            const double2 *src = reinterpret_cast<const double2 *>(Vh);
+            for (int j0 = tid; j0 < npair; j0 += MF_THREADS * 6) {
+                double2 v[6];
+#pragma unroll
+                for (int u = 0; u < 6; ++u) { const int j = j0 + u * MF_THREADS; v[u] = src[(2 * j + 1 < lim) ? j : (lim >> 1) - 1]; }
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    const int j = j0 + u * MF_THREADS;
+                    if (j < npair) *reinterpret_cast<double2 *>(vh_s + 2 * j) = (2 * j < lim) ? v[u] : make_double2(0.0, 0.0);
+                }
+            }
+        }
         const double *mu = A.mu + (size_t)p * d, *sqa = A.sqrt_alpha + (size_t)p * d;
         // ELBO scan of a Gaussian-family target (no draws written): only e = x - m is needed, so the three per-row LDS
         // vectors hold (mu - m, sqrt(alpha), a); otherwise (mu, sqrt(alpha), m) and the diagonal precision comes from L2

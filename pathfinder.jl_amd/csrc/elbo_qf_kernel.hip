@@ -81,7 +81,7 @@ __device__ __forceinline__ int qf_vh_pos(int lrow, int col) {
 
 template <int KC, int TGT, int RPAD, int NG>
 __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int ch_blocks, int nchunks, int groups_per_wg, int ngroups) {
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int NT = KC / 4, TR = RPAD / 4, NC = qf_nconst(KC, RPAD);
     constexpr int QF_CHB = qf_chb<KC>::v;
     constexpr int PRE = (QF_CHB * 16 * KC + QF_THREADS - 1) / QF_THREADS;      // prefetch registers per thread (streaming)
@@ -119,18 +119,50 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
 
     const double *Vh = A.vh + (size_t)p * d * KC, *mu = A.mu + (size_t)p * d, *sqa = A.sqrt_alpha + (size_t)p * d;
     auto stage_direct = [&](int ck, int buf) {
+        // (round 4: the loads of a trip are issued together.  As plain loops with a guarded load per element these were one global round
+        //  trip per element -- `global_load; s_waitcnt vmcnt(0); ds_write` 24 times per thread for the factor block of config 3, ~7 % of
+        //  a workgroup's time, with nothing to overlap it: one workgroup per CU.)
         const int row0 = ck * ch_blocks * 16;
         double *vs = lds + buf * buf_stride, *rs = vs + vh_sz;
-        for (int idx = tid; idx < ch_blocks * 16 * KC; idx += QF_THREADS) {
-            const int lrow = idx / KC, col = idx - lrow * KC, row = row0 + lrow;
-            vs[qf_vh_pos<KC>(lrow, col)] = (row < d) ? Vh[(size_t)row * KC + col] : 0.0;
+        // the chunk is contiguous in the row-major factor block: 16-byte loads of column pairs (KC is even: a pair never straddles rows)
+        const int npair = ch_blocks * 8 * KC;
+        const int lim = (d - row0) * KC;                                       // doubles of this chunk that exist (rows < d)
+        const double2 *src = reinterpret_cast<const double2 *>(Vh + (size_t)row0 * KC);
+        constexpr int U = 6;
+        for (int j0 = tid; j0 < npair; j0 += QF_THREADS * U) {
+            double2 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + u * QF_THREADS, jc = (2 * j + 1 < lim) ? j : (lim >> 1) - 1;
+                v[u] = src[jc];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + u * QF_THREADS, idx = 2 * j;
+                if (j < npair) {
+                    const int lrow = idx / KC, col = idx - lrow * KC;
+                    const double2 val = (idx < lim) ? v[u] : make_double2(0.0, 0.0);
+                    *reinterpret_cast<double2 *>(vs + qf_vh_pos<KC>(lrow, col)) = val;
+                }
+            }
         }
-        for (int lrow = tid; lrow < ch_blocks * 16; lrow += QF_THREADS) {
-            const int row = row0 + lrow;
-            double a = 0.0, cc = 0.0, s = 0.0;
-            if (row < d) { qf_row_ac<TGT>(A, mu, row, a, cc); s = sqa[row]; }
-            double *o = rs + (lrow >> 4) * 48 + (lrow & 15);
-            o[0] = a * s * s; o[16] = 2.0 * a * cc * s; o[32] = s;
+        for (int l0 = tid; l0 < ch_blocks * 16; l0 += QF_THREADS * 2) {
+            double a[2], cc[2], s[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int lrow = l0 + u * QF_THREADS, row = row0 + lrow, rc = row < d ? row : d - 1;
+                qf_row_ac<TGT>(A, mu, rc, a[u], cc[u]);
+                s[u] = sqa[rc];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int lrow = l0 + u * QF_THREADS, row = row0 + lrow;
+                if (lrow < ch_blocks * 16) {
+                    const bool in = row < d;
+                    double *o = rs + (lrow >> 4) * 48 + (lrow & 15);
+                    o[0] = in ? a[u] * s[u] * s[u] : 0.0; o[16] = in ? 2.0 * a[u] * cc[u] * s[u] : 0.0; o[32] = in ? s[u] : 0.0;
+                }
+            }
         }
     };
     {

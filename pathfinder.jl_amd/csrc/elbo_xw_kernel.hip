@@ -60,7 +60,7 @@ __device__ __forceinline__ int xw_vh_pos(int lrow, int col) {
 
 template <int KC>
 __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int ch_blocks, int nchunks, int groups_per_wg, int ngroups) {
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int NT = KC / 4, NG = XW_NG;
     constexpr int XW_CHB = xw_chb<KC>::v;
     constexpr int PRE = (XW_CHB * 16 * KC + XW_THREADS - 1) / XW_THREADS;      // prefetch registers per thread (streaming)
@@ -94,13 +94,40 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
         const double *T = A.tmat + (size_t)p * KC * KC;
         for (int i = tid; i < KC * KC; i += XW_THREADS) t_s[i] = T[i];
         pf_icdf_load<XW_NB>(icdf);
-        for (int idx = tid; idx < ch_blocks * 16 * KC; idx += XW_THREADS) {   // chunk 0 (the whole block when resident)
-            const int lrow = idx / KC, col = idx - lrow * KC;
-            lds[xw_vh_pos<KC>(lrow, col)] = (lrow < d) ? Vh[(size_t)lrow * KC + col] : 0.0;
+        {   // chunk 0 (the whole block when resident): 16-byte loads of column pairs, six in flight per thread (as a plain loop with a
+            // guarded load per element this was one global round trip per element: load, s_waitcnt vmcnt(0), ds_write; round 4)
+            const int npair = ch_blocks * 8 * KC, lim = d * KC;
+            const double2 *src = reinterpret_cast<const double2 *>(Vh);
+            constexpr int U = 6;
+            for (int j0 = tid; j0 < npair; j0 += XW_THREADS * U) {
+                double2 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int j = j0 + u * XW_THREADS, jc = (2 * j + 1 < lim) ? j : (lim >> 1) - 1;
+                    v[u] = src[jc];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int j = j0 + u * XW_THREADS, idx = 2 * j;
+                    if (j < npair) {
+                        const int lrow = idx / KC, col = idx - lrow * KC;
+                        *reinterpret_cast<double2 *>(lds + xw_vh_pos<KC>(lrow, col)) = (idx < lim) ? v[u] : make_double2(0.0, 0.0);
+                    }
+                }
+            }
         }
-        for (int lrow = tid; lrow < ch_blocks * 16; lrow += XW_THREADS) {
-            double *o = lds + vh_sz + (lrow >> 4) * 32 + (lrow & 15);
-            o[0] = (lrow < d) ? sqa[lrow] : 0.0; o[16] = (lrow < d) ? mu[lrow] : 0.0;
+        for (int l0 = tid; l0 < ch_blocks * 16; l0 += XW_THREADS * 2) {
+            double sv[2], mv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { const int lrow = l0 + u * XW_THREADS, rc = lrow < d ? lrow : d - 1; sv[u] = sqa[rc]; mv[u] = mu[rc]; }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int lrow = l0 + u * XW_THREADS;
+                if (lrow < ch_blocks * 16) {
+                    double *o = lds + vh_sz + (lrow >> 4) * 32 + (lrow & 15);
+                    o[0] = (lrow < d) ? sv[u] : 0.0; o[16] = (lrow < d) ? mv[u] : 0.0;
+                }
+            }
         }
     }
     // head transform z_head = V'u_head on 16x16x4 MFMAs: lane (q, c) supplies A_r[i' = c][k = q] = H[rho(c)][4 q + r], H = V'

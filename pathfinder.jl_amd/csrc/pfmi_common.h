@@ -299,7 +299,14 @@ __device__ __forceinline__ void pf_icdf_load(double2 *tab) {
     const double2 *src = reinterpret_cast<const double2 *>(&PF_ICDF_TAB_DEV[0][0]);
     // LDS order is ASCENDING in p (entry NENT - 1 - i of the generated table at slot i): the slot is then (hi32(P) >> 15) minus a
     // constant, one shift + one shift-add per look-up
-    for (int i = threadIdx.x; i < 2 * NENT; i += blockDim.x) tab[(i & 1) * NENT + (NENT - 1 - (i >> 1))] = src[i];
+    // (four independent loads per trip: as a plain loop every entry was its own global round trip -- load, s_waitcnt vmcnt(0), ds_write)
+    for (int i0 = threadIdx.x; i0 < 2 * NENT; i0 += 4 * blockDim.x) {
+        double2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * (int)blockDim.x; v[u] = src[i < 2 * NENT ? i : 2 * NENT - 1]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * (int)blockDim.x; if (i < 2 * NENT) tab[(i & 1) * NENT + (NENT - 1 - (i >> 1))] = v[u]; }
+    }
 }
 // any word, full table in global memory (slow path / kernels without an LDS copy)
 __device__ __forceinline__ double pf_icdf_any(uint32_t x, uint32_t x2) {
