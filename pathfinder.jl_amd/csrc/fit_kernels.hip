@@ -20,6 +20,17 @@
 #ifndef FITREG_ABLATE
 #define FITREG_ABLATE 0                // timing experiments only: 1 no Cholesky, 2 no mean
 #endif
+#ifndef FITREG_XCD
+#define FITREG_XCD 1                   // 0: point = workgroup index (A/B of the XCD-aware order)
+#endif
+#ifndef FITREG_PROF
+#define FITREG_PROF 0                  // 1: one workgroup in 512 prints the 100 MHz ticks of its sections (experiments only)
+#endif
+#if FITREG_PROF
+#define FR_STAMP(k) do { if ((blockIdx.x & 511) == 7 && threadIdx.x == 0) { const long long t_ = wall_clock64(); prof[k] = t_ - tlast; tlast = t_; } } while (0)
+#else
+#define FR_STAMP(k) do { } while (0)
+#endif
 #define HIST_THREADS 256
 #define FIT_THREADS 256
 
@@ -676,7 +687,17 @@ __global__ __launch_bounds__(FIT_THREADS) void pf_fit_kernel(FitArgs A) {
 // (fp64 roundoff), which the parity tests cover.
 template <int KPAD, int RPT, int NT>
 __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_fit_reg_kernel(FitArgs A) {   // measured best occupancy per KPAD (J = 6: 3 waves per SIMD, 168 VGPRs + 19 spilled dwords beat 2 waves with 221)
-    const int p = blockIdx.x, tid = threadIdx.x;
+    // XCD-aware point order (round 4): workgroup b runs on XCD b % 8 and every XCD has its own L2.  A fit reads 4 J trace rows, all but two
+    // of which its neighbours p - 1, p + 1, ... read as well: with p = b those neighbours sit on eight different L2s and the rows came from
+    // HBM / MALL again and again (FETCH_SIZE 1.5 GB per launch for 0.18 GB of distinct rows; the row loads were a third of the kernel).  XCD x
+    // now walks its own contiguous eighth of the points, so the ring's rows stay in that XCD's L2.
+    int p;
+    {
+        const int P = (int)gridDim.x, x = blockIdx.x & 7, slot = blockIdx.x >> 3, q8 = P >> 3, r8 = P & 7;
+        p = x * q8 + (x < r8 ? x : r8) + slot;
+        if (FITREG_XCD == 0) p = blockIdx.x;
+    }
+    const int tid = threadIdx.x;
     const int d = A.d, J = A.J;
     const int path = A.path_of[p];
     const int64_t p0 = A.off[path];
@@ -698,15 +719,25 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
     __shared__ double sLogdetV;
     __shared__ int sStatus;
 
+#if FITREG_PROF
+    long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = wall_clock64();
+#endif
     double a[RPT][KPAD];       // this thread's rows of B~ (later: Householder vectors)
     double bad = 0.0, ldu = 0.0;
+    double isa_r[RPT], al_r[RPT];                                 // alpha and 1 / sqrt(alpha) of this thread's rows (kept for the rows of B~)
+    int rl_r[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) { const int row = tid + NT * i; rl_r[i] = row < d ? row : d - 1; }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) al_r[i] = alpha[rl_r[i]];      // (all RPT loads in flight: guarded loads were one round trip each)
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
         const int row = tid + NT * i;
+        const double al = al_r[i];
+        const double s = sqrt(al);
+        isa_r[i] = 1.0 / s;                                        // one reciprocal per row instead of 2 j divisions
         if (row < d) {
-            const double al = alpha[row];
             if (!(al > 0.0) || !isfinite(al)) bad = 1.0;
-            const double s = sqrt(al);
             sqa[row] = s;
             ldu += log(s);
         }
@@ -731,34 +762,40 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
         if (tid == 0) { A.status[p] = PFMI_FIT_A_NOT_PD; A.logdet[p] = NAN; }
         return;
     }
+    FR_STAMP(0);                                               // prologue: sqrt / log of alpha, first reduction, LDS zero fill
     // ---- rows of B~ = U' \ [alpha.Y  S]   (src/inverse_hessian.jl:117-118, src/woodbury.jl:204)
+    // (round 4: the four rows of a history pair are loaded for all RPT rows of the thread at once, unconditionally from clamped
+    //  addresses -- 16 loads in flight, 6 round trips per fit.  With a guarded block per (row, pair) the compiler waited with vmcnt(0) after
+    //  every 4 loads: 24 dependent round trips, a third of the kernel.  Same arithmetic.)
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-        const int row = tid + NT * i;
+    for (int i = 0; i < RPT; ++i)
 #pragma unroll
         for (int c = 0; c < KPAD; ++c) a[i][c] = 0.0;
-        if (row < d) {
-            const double al = alpha[row], isa = 1.0 / sqrt(al);       // one reciprocal per row instead of 2 j divisions
 #pragma unroll
-            for (int c = 0; c < KPAD / 2; ++c) {
-                if (c < j) {
-                    const int src = A.hist_src[(size_t)p * J + c];
-                    const size_t q0 = (size_t)(p0 + src) * d + row, q1 = (size_t)(p0 + src + 1) * d + row;
-                    const double y = A.grad[q0] - A.grad[q1];
-                    const double s = A.theta[q1] - A.theta[q0];
-                    const double by = (al * y) * isa, bs = s * isa;
-                    // columns c and j + c.  j is a run-time value: the usual full history (j = KPAD / 2: all but the first points of a
-                    // path) takes a static slot, shorter ones select among the statically unrolled targets
-                    a[i][c] = by;
-                    if (j == KPAD / 2) a[i][KPAD / 2 + c] = bs;
-                    else {
+    for (int c = 0; c < KPAD / 2; ++c) {
+        if (c >= j) continue;                                               // wave-uniform
+        const int src = A.hist_src[(size_t)p * J + c];
+        const double *g0 = A.grad + (size_t)(p0 + src) * d, *g1 = g0 + d, *t0 = A.theta + (size_t)(p0 + src) * d, *t1 = t0 + d;
+        double vg0[RPT], vg1[RPT], vt0[RPT], vt1[RPT];
 #pragma unroll
-                        for (int cc = 0; cc < KPAD; ++cc) if (cc == j + c) a[i][cc] = bs;
-                    }
-                }
+        for (int i = 0; i < RPT; ++i) { vg0[i] = g0[rl_r[i]]; vg1[i] = g1[rl_r[i]]; vt0[i] = t0[rl_r[i]]; vt1[i] = t1[rl_r[i]]; }
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const bool in = tid + NT * i < d;
+            const double y = vg0[i] - vg1[i];                               // y = grad_l - grad_{l+1}   :46
+            const double sx = vt1[i] - vt0[i];                              // s = theta_{l+1} - theta_l :45
+            const double by = in ? (al_r[i] * y) * isa_r[i] : 0.0, bs = in ? sx * isa_r[i] : 0.0;
+            // columns c and j + c.  j is a run-time value: the usual full history (j = KPAD / 2: all but the first points of a
+            // path) takes a static slot, shorter ones select among the statically unrolled targets
+            a[i][c] = by;
+            if (j == KPAD / 2) a[i][KPAD / 2 + c] = bs;
+            else {
+#pragma unroll
+                for (int cc = 0; cc < KPAD; ++cc) if (cc == j + c) a[i][cc] = bs;
             }
         }
     }
+    FR_STAMP(1);                                               // rows of B~
     double acc[KPAD];
     // ---- Householder QR, one block reduction per column.  Thread aa < KPAD keeps row aa of the compact-WY T in
     //      registers (dlarft: T[0:c, c] = -tau T[0:c,0:c] (Vh' v_c)), so the column loop has no serial section.
@@ -838,6 +875,7 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
             }
         }
     }
+    FR_STAMP(2);                                               // QR
     // ---- split: R (k x m) -> sR; Householder vectors get an explicit unit diagonal
     if (tid < k) {
 #pragma unroll
@@ -909,6 +947,7 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
         }
     }
     __syncthreads();
+    FR_STAMP(3);                                               // Gram, D
     // ---- C = I + R D R' (k x k): RD -> sG, then C -> sV (upper), all threads; Cholesky on one lane
     for (int t = tid; t < k * m; t += NT) {
         const int aa = t / m, b = t % m;
@@ -926,6 +965,7 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
         }
     }
     __syncthreads();
+    FR_STAMP(4);                                               // C
     if (tid < 64) {                          // wave 0: Cholesky C = V'V in REGISTERS, lane b owns column b of the upper factor.
         // Row c of V needs column c (lane c's registers) in every lane: v_readlane broadcasts instead of the LDS round trips of the
         // left-looking loop this replaces (round 4: 37 000 of a fit's 257 000 cycles, and the fit kernel's time follows its critical
@@ -957,6 +997,7 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
         if (b == 0) { sStatus = status; sLogdetV = ldv; }
     }
     __syncthreads();
+    FR_STAMP(5);                                               // Cholesky
     for (int t = tid; t < KPAD * KPAD; t += NT) {
         A.tmat[sm + t] = sT[t]; A.vchol[sm + t] = sV[t]; A.rq[sm + t] = sR[t]; A.dmat[sm + t] = sD[t];
     }
@@ -965,9 +1006,9 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
     for (int i = 0; i < RPT; ++i) {
         const int row = tid + NT * i;
         if (row < d) {
-            double *o = Vh + (size_t)row * KPAD;
+            double2 *o = reinterpret_cast<double2 *>(Vh + (size_t)row * KPAD);       // 16-byte stores (rows are KPAD * 8 bytes, KPAD even)
 #pragma unroll
-            for (int cc = 0; cc < KPAD; ++cc) o[cc] = a[i][cc];
+            for (int cc = 0; cc < KPAD; cc += 2) o[cc >> 1] = make_double2(a[i][cc], a[i][cc + 1]);
         }
     }
     if (sStatus != PFMI_FIT_OK) {
@@ -976,6 +1017,7 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
         if (tid == 0) { A.status[p] = sStatus; A.logdet[p] = NAN; }
         return;
     }
+    FR_STAMP(6);                                               // outputs
     if (FITREG_ABLATE & 2) return;
     // ---- mu = theta + U' Q [V'V 0;0 I] Q' U g     (sqrt(alpha) and sqrt(alpha) * grad are re-read rather than kept in VGPRs)
     // b = Q'(U g) = U g - V t1 (t1 = T'w1, w1 = V'U g: the ONE sweep + block reduction); head' = Vc'Vc head; x = Q b' = b' - V t2,
@@ -1041,6 +1083,12 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
             mu[row] = theta_p[row] + sqa[row] * v;
         }
     }
+    FR_STAMP(7);                                               // mean
+#if FITREG_PROF
+    if ((blockIdx.x & 511) == 7 && tid == 0)
+        printf("FITREG_PROF wg %d (10 ns ticks): prologue %lld rows %lld QR %lld gram+D %lld C %lld chol %lld out %lld mean %lld\n", (int)blockIdx.x, prof[0],
+               prof[1], prof[2], prof[3], prof[4], prof[5], prof[6], prof[7]);
+#endif
     if (tid == 0) {
         A.status[p] = PFMI_FIT_OK;
         A.logdet[p] = 2.0 * (ldu + sLogdetV);

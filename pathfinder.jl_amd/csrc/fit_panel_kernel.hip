@@ -82,10 +82,23 @@ __global__ __launch_bounds__(FP_NT, 1) void pf_fit_panel_kernel(FitArgs A, const
 #if FP_PROF
         ++nfit;
 #endif
-        if (tid == 0) sNext = atomicAdd(counter, 1);
+        if (tid == 0) {
+            // XCD-aware work order (round 4): workgroup b runs on XCD b % 8, each XCD has its own L2, and a fit shares all but two of its
+            // 4 J trace rows with its neighbours -- XCD x therefore walks its own contiguous eighth of the points (one counter per
+            // XCD) and helps the following XCDs' ranges once its own is exhausted.
+            const int P = (int)A.P, q8 = P >> 3, r8 = P & 7;
+            int next = -1;
+            for (int t = 0; t < 8 && next < 0; ++t) {
+                const int x = ((int)blockIdx.x + t) & 7, cnt = q8 + (x < r8 ? 1 : 0);
+                if (cnt == 0) continue;
+                const int l = atomicAdd(counter + x, 1);
+                if (l < cnt) next = x * q8 + (x < r8 ? x : r8) + l;
+            }
+            sNext = next;
+        }
         __syncthreads();
         const int64_t p = sNext;
-        if (p >= A.P) break;
+        if (p < 0) break;
         FP_STAMP(0);
 
         const int path = A.path_of[p];
@@ -601,7 +614,7 @@ static int32_t launch_panel_t(pfmi_ctx *c, const FitArgs &a, int ncu) {
     const size_t scr_bytes = (size_t)grid * (KPAD + 4) * (size_t)(FP_NT * RPT) * sizeof(double);
     PF_TRY(c->fit_scratch.ensure(scr_bytes + 256));
     int *counter = reinterpret_cast<int *>(c->fit_scratch.as<char>() + scr_bytes);
-    PF_HIP(hipMemsetAsync(counter, 0, sizeof(int), c->stream));
+    PF_HIP(hipMemsetAsync(counter, 0, 8 * sizeof(int), c->stream));               // one work counter per XCD
     hipLaunchKernelGGL(kern, dim3(grid), dim3(FP_NT), lds, c->stream, a, KPAD, c->fit_scratch.as<double>(), counter);
     return PFMI_OK;
 }
