@@ -25,6 +25,9 @@
 #include <stdlib.h>
 #include "pfmi_common.h"
 #include "elbo_args.h"
+#ifndef QF_PROF
+#define QF_PROF 0                       // 1: waves 0 and 5 of one workgroup in 1024 print the 10 ns ticks of their phases (experiments only)
+#endif
 
 #ifndef QF_WAVES
 #define QF_WAVES 8                     // waves per workgroup = 16-draw groups in flight per fit
@@ -38,6 +41,17 @@
 #endif
 #ifndef QF_NG2_MAXKC
 #define QF_NG2_MAXKC 20                // two groups per wave up to this KC (round 2: 12; KC = 16, 20 take the register-lean block body)
+#endif
+// Wave balance (round 4).  The two waves of a SIMD (w and w + 4) do the same work, but the instruction arbiter prefers the OLDER wave and
+// the kernel is issue bound (one wave alone keeps the SIMD ~96 % busy): in-kernel timers showed waves 0 - 3 done after 355 us and waves
+// 4 - 7 after 540 us, i.e. the younger waves ran the last third of the workgroup's time alone, without a partner to fill their stalls.
+// The waves therefore take turns at s_setprio 1, QF_PRIO_FAIR blocks at a time, and finish together: scan 22.04 -> 21.69 ms (periods of
+// 8 / 16 / 32 blocks alike, 4: 21.77, 1: 21.87).  (Raising the priority of one wave's MFMA burst -- round 3's QF_SETPRIO -- was slower.)
+#ifndef QF_PRIO_FAIR
+#define QF_PRIO_FAIR 8                 // 0: off; power of two
+#endif
+#ifndef QF_PRIO_YOUNG
+#define QF_PRIO_YOUNG 0                // 1: waves 4 .. 7 (the younger wave of every SIMD) run at s_setprio 1 for the whole kernel (experiment)
 #endif
 #ifndef QF_SETPRIO
 #define QF_SETPRIO 0                   // s_setprio level during a group's MFMA burst (0 = off; A/B in profiles/r03_scan_experiments.md)
@@ -82,6 +96,10 @@ __device__ __forceinline__ int qf_vh_pos(int lrow, int col) {
 template <int KC, int TGT, int RPAD, int NG>
 __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int ch_blocks, int nchunks, int groups_per_wg, int ngroups) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+#if QF_PROF
+    const long long qf_t0 = wall_clock64();
+    long long qf_tb = 0, qf_te = 0, qf_tp = 0, qf_last = 0;
+#endif
     constexpr int NT = KC / 4, TR = RPAD / 4, NC = qf_nconst(KC, RPAD);
     constexpr int QF_CHB = qf_chb<KC>::v;
     constexpr int PRE = (QF_CHB * 16 * KC + QF_THREADS - 1) / QF_THREADS;      // prefetch registers per thread (streaming)
@@ -206,6 +224,12 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     const double logdet = A.logdet[p];
     __syncthreads();
+#if QF_PROF
+    qf_tp = wall_clock64() - qf_t0; qf_last = wall_clock64();
+#endif
+#if QF_PRIO_YOUNG
+    if (wv >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     if (TGT == 2) {                                                 // funnel: tau = x_1 needs row 0 of the factor
         if (tid == 0) { cn_s[1] = mu[0]; cn_s[2] = sqa[0]; }
         if (tid < KC) cn_s[4 + KC + KC * KC + RPAD + RPAD * KC + tid] = Vh[tid];
@@ -496,6 +520,13 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
                     };
                     for (int bl = 0; bl < nb; ++bl) {
                         const int blk = blk0 + bl;
+#if QF_PRIO_FAIR
+                        // the two waves of a SIMD (w and w + 4) take turns at the higher issue priority, QF_PRIO_FAIR blocks at a time (see the
+                        // note on wave balance at the launch code)
+                        if ((blk & (QF_PRIO_FAIR - 1)) == 0) {
+                            if (((blk / QF_PRIO_FAIR) ^ (wv >> 2) ^ lb) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+                        }
+#endif
                         if (__builtin_expect((blk == 0) | (blk == nblk - 1) | (KC > 16 && blk == 1), 0)) block_body(bl, std::true_type{});
                         else block_body(bl, std::false_type{});
                     }
@@ -522,6 +553,9 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
                 cur ^= 1;
             }
         }
+#if QF_PROF
+        { const long long t_ = wall_clock64(); qf_tb += t_ - qf_last; qf_last = t_; }
+#endif
         if (NPG > 0 && lb == 0) {                                  // publish the per-fit constants before any draw is finished
             int lane_p = lane;                                     // opaque lane coordinates (see the finishing section below)
             asm volatile("" : "+v"(lane_p));
@@ -628,7 +662,15 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
                 out_lp[nl[g]] = lp;
             }
         }
+#if QF_PROF
+        { const long long t_ = wall_clock64(); qf_te += t_ - qf_last; qf_last = t_; }
+#endif
     }
+#if QF_PROF
+    if (blockIdx.x == 0 && (blockIdx.y & 1023) == 3 && lane == 0)
+        printf("QF_PROF fit %d wave %d (10 ns ticks): prologue %lld blocks %lld epilogue+publish %lld total %lld batches %d\n", (int)blockIdx.y, wv, qf_tp, qf_tb,
+               qf_te, (long long)(wall_clock64() - qf_t0), nlb);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------

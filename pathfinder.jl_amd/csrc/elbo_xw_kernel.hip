@@ -34,6 +34,9 @@
 #ifndef XW_NG
 #define XW_NG 2                        // 16-draw groups per wave: they share the operand fetches of a block
 #endif
+#ifndef XW_PRIO_FAIR
+#define XW_PRIO_FAIR 8                 // the waves of a SIMD alternate at s_setprio 1 every XW_PRIO_FAIR blocks (0: off)
+#endif
 #ifndef XW_ABLATE
 #define XW_ABLATE 0                    // timing experiments only, bit mask: 1 no global stores, 2 pass 2 without generator, 4 no pass 1,
                                        // 8 pass 1 without generator, 16 generator without table look-ups, 32 generator without Philox, 64 pass 2 without MFMAs
@@ -315,6 +318,11 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
                         };
                         for (int bl = 0; bl < ((XW_ABLATE & 4) ? 1 : nb); ++bl) {
                             const int blk = blk0 + bl;
+#if XW_PRIO_FAIR
+                            if ((blk & (XW_PRIO_FAIR - 1)) == 0) {           // the two waves of a SIMD take turns at the higher issue priority (see elbo_qf_kernel.hip)
+                                if (((blk / XW_PRIO_FAIR) ^ (wv >> 2) ^ lb ^ pass) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+                            }
+#endif
                             const bool special = (blk == 0) | (blk == nblk - 1) | (KC > 16 && blk == 1);
                             // (the groups of a wave that lie beyond the last one are computed too -- their stores are predicated off)
                             if (__builtin_expect(special, 0)) body1(bl, std::true_type{}, std::integral_constant<int, NG>{});
@@ -369,6 +377,11 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
                         };
                         for (int bl = 0; bl < nb; ++bl) {
                             const int blk = blk0 + bl;
+#if XW_PRIO_FAIR
+                            if ((blk & (XW_PRIO_FAIR - 1)) == 0) {           // the two waves of a SIMD take turns at the higher issue priority (see elbo_qf_kernel.hip)
+                                if (((blk / XW_PRIO_FAIR) ^ (wv >> 2) ^ lb ^ pass) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+                            }
+#endif
                             const bool special = (blk == 0) | (blk == nblk - 1) | (KC > 16 && blk == 1);
                             // (the groups of a wave that lie beyond the last one are computed too -- their stores are predicated off)
                             if (__builtin_expect(special, 0)) body2(bl, std::true_type{}, std::integral_constant<int, NG>{});
