@@ -540,6 +540,7 @@ int32_t pfmi_comm_info(pfmi_comm *c, int32_t *world, int32_t *nlocal, int32_t *r
 
 // _compute_psis_result over the pooled runs (src/multipath.jl:221): all-gather the log-ratio shards, then PSIS on every GPU.
 int32_t pfmi_comm_pool_psis(pfmi_comm *c, double *pareto_k, int64_t *tail_len) {
+    if (c) for (pfmi_ctx *x : c->ctx) pf_download_forget(x);      // staged downloads of an entry point that failed half-way
     PF_COMM(c);
     PF_TRY(enqueue_pool_psis(c, 0));
     return finish_pool_psis(c, pareto_k, tail_len);
@@ -549,6 +550,7 @@ int32_t pfmi_comm_pool_psis(pfmi_comm *c, double *pareto_k, int64_t *tail_len) {
 // sum all-reduce.  idx[ndraws] (0-based, global pool columns) and draws[d * ndraws] (column-major) may be NULL.
 int32_t pfmi_comm_resample(pfmi_comm *c, int64_t ndraws, int32_t importance, int32_t replace, uint64_t seed, const double *uniforms,
                            int64_t *idx, double *draws) {
+    if (c) for (pfmi_ctx *x : c->ctx) pf_download_forget(x);      // staged downloads of an entry point that failed half-way
     PF_COMM(c);
     PF_CHECK(ndraws >= 1, PFMI_ERR_ARG, "comm_resample: ndraws must be positive");
     PF_CHECK(c->shard > 0, PFMI_ERR_STATE, "comm_resample: call pfmi_comm_pool_psis first");
@@ -561,6 +563,7 @@ int32_t pfmi_comm_resample(pfmi_comm *c, int64_t ndraws, int32_t importance, int
 // both stages, one synchronisation (src/multipath.jl:221-225)
 int32_t pfmi_comm_psis_resample(pfmi_comm *c, int64_t ndraws, int32_t importance, int32_t replace, uint64_t seed, const double *uniforms,
                                 double *pareto_k, int64_t *tail_len, int64_t *idx, double *draws) {
+    if (c) for (pfmi_ctx *x : c->ctx) pf_download_forget(x);      // staged downloads of an entry point that failed half-way
     PF_COMM(c);
     PF_CHECK(ndraws >= 1, PFMI_ERR_ARG, "comm_psis_resample: ndraws must be positive");
     const int64_t out_doubles = (int64_t)c->ctx[0]->d * ndraws + 1;       // d x ndraws columns + the failure flag

@@ -123,13 +123,17 @@ int32_t pf_download(pfmi_ctx *c, void *dst, const void *src, size_t bytes) {
     return PFMI_OK;
 }
 int32_t pf_stream_sync(pfmi_ctx *c) {
-    PF_HIP(hipStreamSynchronize(c->stream));
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { pf_download_forget(c); PF_HIP(e); }      // nothing is delivered after a failed wait
     for (const DlPending &q : c->dl_pending) memcpy(q.dst, q.slot, q.bytes);
     c->dl_pending.clear();
     c->dl.off = 0;
     pf_arena_reset(c);
     return PFMI_OK;
 }
+// Staged downloads are delivered by the pf_stream_sync of the entry point that queued them.  An entry point that FAILED between queuing and
+// waiting leaves entries whose destinations (stack variables, a caller's array) may be gone: every public entry point forgets them first.
+void pf_download_forget(pfmi_ctx *c) { c->dl_pending.clear(); c->dl.off = 0; }
 static int32_t d2h_async(pfmi_ctx *c, void *dst, const void *src, size_t bytes) { return pf_download(c, dst, src, bytes); }
 static int32_t stream_sync(pfmi_ctx *c) { return pf_stream_sync(c); }
 static int32_t d2h(pfmi_ctx *c, void *dst, const void *src, size_t bytes) {
@@ -160,6 +164,7 @@ static int32_t ensure_pinned(pfmi_ctx *c, size_t x_bytes, size_t lp_bytes) {
     do {                                                                   \
         PF_CHECK((c) != nullptr, PFMI_ERR_ARG, "null pfmi_ctx");           \
         PF_HIP(hipSetDevice((c)->device));                                 \
+        pf_download_forget(c);                                             \
     } while (0)
 
 // ---- test / tuning hooks (pfmi_common.h: pf_debug_get) ---------------------------------------------------------------------

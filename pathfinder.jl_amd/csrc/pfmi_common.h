@@ -177,6 +177,8 @@ void pf_arena_reset(pfmi_ctx *c);
 int32_t pf_download(pfmi_ctx *c, void *dst, const void *src, size_t bytes);
 // hipStreamSynchronize + delivery of the staged downloads + arena rewind
 int32_t pf_stream_sync(pfmi_ctx *c);
+// drops staged downloads that were never delivered (an entry point failed between queuing and waiting); called on entry by every public call
+void pf_download_forget(pfmi_ctx *c);
 
 // ---- launch helpers (implemented in the .hip files) ----------------------------------------------
 int32_t pf_launch_history(pfmi_ctx *c, double eps);
