@@ -828,9 +828,8 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
 #pragma unroll
         for (int cc = 0; cc < KPAD; ++cc) if (cc == c) xn2 = acc[cc];
         const double alpha_c = srow[c];
-        const double xnorm = sqrt(xn2);
         double tau, scal, beta;
-        if (xnorm == 0.0) { tau = 0.0; scal = 0.0; beta = alpha_c; }
+        if (xn2 == 0.0) { tau = 0.0; scal = 0.0; beta = alpha_c; }     // dlarfg's xnorm == 0 test (sqrt(xn2) == 0 iff xn2 == 0: xn2 is a sum of squares)
         else {
             beta = -copysign(sqrt(fma(alpha_c, alpha_c, xn2)), alpha_c);
             tau = (beta - alpha_c) / beta;
