@@ -1,6 +1,7 @@
 """fuzz (not a test): random shapes -- single-pass scan vs lane kernel (per-draw logp / logq), register / panel vs memory-resident fit
 kernel (logdet, mu), history walk (effective history, sources, rejections, alpha) vs the oracle, device L-BFGS sanity.  Prints the worst discrepancies; any NaN pattern mismatch is reported."""
 import os, sys
+os.environ["PFMI_DEBUG_HOOKS"] = "1"          # the library reads the PFMI_*_KERNEL selectors only then
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "pathfinder.jl_amd")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np, pfmi
 from helpers import fit_seeds
