@@ -628,25 +628,30 @@ int32_t pfmi_elbo_batch_enqueue(pfmi_ctx *c, int64_t N, const uint64_t *seeds, c
     const int64_t P = c->P;
     const int d = c->d;
     c->N_e = N;
-    PF_TRY(c->seeds.ensure(sizeof(uint64_t) * P));
-    PF_TRY(h2d(c, c->seeds.p, seeds, sizeof(uint64_t) * P));
     PF_TRY(c->logp.ensure(sizeof(double) * P * N));
     PF_TRY(c->logq.ensure(sizeof(double) * P * N));
     PF_TRY(c->elbo.ensure(sizeof(double) * P));
     PF_TRY(c->se.ensure(sizeof(double) * P));
     PF_TRY(c->best_iter.ensure(sizeof(int64_t) * c->K));
-    // list of fits = every point that is not the first of its path (fit_distributions[2:end])
-    std::vector<int32_t> list;
-    std::vector<uint64_t> lseeds;
-    list.reserve((size_t)P);
-    for (int k = 0; k < c->K; ++k)
-        for (int64_t p = c->off[k] + 1; p < c->off[k + 1]; ++p) { list.push_back((int32_t)p); lseeds.push_back(seeds[p]); }
-    const int64_t nf = (int64_t)list.size();
-    PF_TRY(c->fit_list.ensure(sizeof(int32_t) * (nf > 0 ? nf : 1) + sizeof(uint64_t) * (nf > 0 ? nf : 1) + 16));
-    int32_t *d_list = c->fit_list.as<int32_t>();
-    uint64_t *d_lseeds = reinterpret_cast<uint64_t *>(c->fit_list.as<char>() + ((sizeof(int32_t) * (nf > 0 ? nf : 1) + 7) / 8) * 8);
-    PF_TRY(h2d(c, d_list, list.data(), sizeof(int32_t) * nf));
-    PF_TRY(h2d(c, d_lseeds, lseeds.data(), sizeof(uint64_t) * nf));
+    // ONE upload (round 4; three copies in the stream cost three 12-us hand-overs between the fit and the scan): the per-point seeds, then
+    // the list of fits = every point that is not the first of its path (fit_distributions[2:end]) -- their seeds, then their indices
+    int64_t nf = 0;
+    for (int k = 0; k < c->K; ++k) nf += c->off[k + 1] - c->off[k] - 1;
+    const size_t off_ls = sizeof(uint64_t) * (size_t)P, off_li = off_ls + sizeof(uint64_t) * (size_t)(nf > 0 ? nf : 1);
+    const size_t up_bytes = off_li + sizeof(int32_t) * (size_t)(nf > 0 ? nf : 1);
+    std::vector<char> stage(up_bytes);
+    memcpy(stage.data(), seeds, sizeof(uint64_t) * (size_t)P);
+    {
+        uint64_t *ls = reinterpret_cast<uint64_t *>(stage.data() + off_ls);
+        int32_t *li = reinterpret_cast<int32_t *>(stage.data() + off_li);
+        int64_t t = 0;
+        for (int k = 0; k < c->K; ++k)
+            for (int64_t p = c->off[k] + 1; p < c->off[k + 1]; ++p, ++t) { li[t] = (int32_t)p; ls[t] = seeds[p]; }
+    }
+    PF_TRY(c->seeds.ensure(up_bytes + 16));
+    PF_TRY(h2d(c, c->seeds.p, stage.data(), up_bytes));
+    uint64_t *d_lseeds = reinterpret_cast<uint64_t *>(c->seeds.as<char>() + off_ls);
+    int32_t *d_list = reinterpret_cast<int32_t *>(c->seeds.as<char>() + off_li);
     const double *d_u = nullptr;
     if (u_host) {
         PF_TRY(c->ubuf.ensure(sizeof(double) * (size_t)P * d * N));
