@@ -621,8 +621,8 @@ def main():
                             "8 d bytes per draw of the block; FETCH_SIZE x 2 (gfx950), WRITE_SIZE as reported"}
         roofline = {"bound": "mfma", "achieved": round(mfma_tf, 2), "peak": 78.6, "unit": "TFLOP/s", "frac": round(mfma_tf / 78.6, 4),
                     "traffic": traffic, "traffic_detail": traffic_meta,
-                    "kernel": "pf_elbo_qf_kernel (single-pass ELBO scan; one scan = the main launch + a short tail launch for the fits beyond "
-                              "the last full round of CUs, timed together by a hipEvent pair in the engine's stream in each of the timed steps)",
+                    "kernel": "pf_elbo_qf_kernel (single-pass ELBO scan; one scan = one launch: a workgroup per fit, and behind them the one-batch "
+                              "pieces of the fits beyond the last full round of CUs; timed by a hipEvent pair in the engine's stream in each of the timed steps)",
                     "launches": int(n), "avg_launch_ms": round(ms / max(n, 1), 4),
                     "label": "f64 matrix flops of the scan / launch time against the 78.6 TF f64 MFMA peak.  The kernel is fp64-ISSUE bound: "
                              "its floor is the SUM of the MFMA and VALU issue streams (see issue_floor), not the matrix peak alone",

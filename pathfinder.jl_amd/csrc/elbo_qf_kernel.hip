@@ -94,7 +94,8 @@ __device__ __forceinline__ int qf_vh_pos(int lrow, int col) {
 }
 
 template <int KC, int TGT, int RPAD, int NG>
-__global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int ch_blocks, int nchunks, int groups_per_wg, int ngroups) {
+__global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int ch_blocks, int nchunks, int groups_per_wg, int ngroups, int n_whole,
+                                                                  int gpw_tail, int gx_tail) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
 #if QF_PROF
     const long long qf_t0 = wall_clock64();
@@ -105,7 +106,14 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
     constexpr int PRE = (QF_CHB * 16 * KC + QF_THREADS - 1) / QF_THREADS;      // prefetch registers per thread (streaming)
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, q = lane >> 4, c = lane & 15, l3 = lane & 3;
     const int d = A.d, nblk = (d + 15) >> 4;
-    const int slot = blockIdx.y;
+    // gx_tail == 0: workgroup (x, y) = piece x of fit y.  gx_tail > 0 (grid.x == 1): the first n_whole workgroups take one fit each,
+    // the ones behind them are the gx_tail one-batch pieces of each remaining fit -- dispatched last, they fill the CUs that the
+    // last round of whole fits leaves idle
+    int slot = blockIdx.y, piece = blockIdx.x;
+    if (gx_tail > 0 && slot >= n_whole) {
+        const int t = slot - n_whole, f = t / gx_tail;
+        slot = n_whole + f; piece = t - f * gx_tail; groups_per_wg = gpw_tail;
+    }
     const int p = A.points[slot];
     const size_t blkidx = A.by_point ? (size_t)p : (size_t)slot;
     double *out_lp = A.logp + blkidx * A.log_stride, *out_lq = A.logq + blkidx * A.log_stride;
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
     //   A3(Vh[:, j]) = M[:, j], A4(Vh[:, j]) = Nn[:, j], A3(c/s) = v, A4(c/s) = t0, q12(c/s) = 3 C0
     // in the first batch, for one wave-slot (the 63 real groups of N = 1000 leave exactly one of 64 slots free)
     constexpr int NPG = (TGT != 0) ? (KC + 1 + 15) / 16 : 0;
-    const int g_begin = blockIdx.x * groups_per_wg;
+    const int g_begin = piece * groups_per_wg;
     const int g_end = (g_begin + groups_per_wg < ngroups) ? g_begin + groups_per_wg : ngroups;
     const int nlb = (NPG + (g_end - g_begin) + QF_WAVES * NG - 1) / (QF_WAVES * NG);   // batches of this workgroup
     if (A.status[p] != PFMI_FIT_OK) {
@@ -667,8 +675,8 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
 #endif
     }
 #if QF_PROF
-    if (blockIdx.x == 0 && (blockIdx.y & 1023) == 3 && lane == 0)
-        printf("QF_PROF fit %d wave %d (10 ns ticks): prologue %lld blocks %lld epilogue+publish %lld total %lld batches %d\n", (int)blockIdx.y, wv, qf_tp, qf_tb,
+    if (piece == 0 && (slot & 1023) == 3 && lane == 0)
+        printf("QF_PROF fit %d wave %d (10 ns ticks): prologue %lld blocks %lld epilogue+publish %lld total %lld batches %d\n", slot, wv, qf_tp, qf_tb,
                qf_te, (long long)(wall_clock64() - qf_t0), nlb);
 #endif
 }
@@ -708,7 +716,7 @@ static int32_t launch_qf_ng(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
             b.points = a.points + s0; b.seeds = a.seeds + s0;
             if (!a.by_point) { b.logp += s0 * a.log_stride; b.logq += s0 * a.log_stride; }
             hipLaunchKernelGGL(kern, dim3((unsigned)gx_, (unsigned)ns), dim3(QF_THREADS), lds_bytes, c->stream, b, ch_blocks, nchunks, gpw_,
-                               ngroups);
+                               ngroups, 0, 0, 0);
         }
     };
     // Workgroups of one launch all take the same time, so the fits beyond the last full round of CUs (nfits mod #CU) would keep a
@@ -725,6 +733,13 @@ static int32_t launch_qf_ng(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
         gpw_t = slots - NPG;
         gx_t = gpw_t > 0 ? (ngroups + gpw_t - 1) / gpw_t : 0;
         if (rem > 0 && nfits > ncu && gpw_t > 0 && nb_full > 1 && (rem * gx_t + ncu - 1) / ncu < nb_full) tail = rem;
+    }
+    const char *two = pf_debug_get("PFMI_QF_TWO_LAUNCHES");          // test hook: the pieces in a launch of their own
+    if (tail > 0 && gx == 1 && (nfits - tail) + tail * gx_t <= 65535 && !(two && two[0] == '1')) {
+        // one launch: whole fits first, the pieces of the last `tail` fits behind them
+        hipLaunchKernelGGL(kern, dim3(1, (unsigned)((nfits - tail) + tail * gx_t)), dim3(QF_THREADS), lds_bytes, c->stream, a, ch_blocks, nchunks,
+                           gpw, ngroups, (int)(nfits - tail), gpw_t, gx_t);
+        return PFMI_OK;
     }
     if (nfits - tail > 0) launch(0, nfits - tail, gpw, gx);
     if (tail > 0) launch(nfits - tail, tail, gpw_t, gx_t);

@@ -401,6 +401,17 @@ def test_scan_is_bitwise_independent_of_launch_geometry(pfmi_mod, eng, N):
     np.testing.assert_array_equal(elbo_a, elbo_b)
     np.testing.assert_array_equal(se_a, se_b)
     np.testing.assert_array_equal(best_a, best_b)
+    # the pieces ride behind the whole fits in ONE launch; the same cut as two launches gives the same bits
+    os.environ["PFMI_QF_TWO_LAUNCHES"] = "1"
+    try:
+        elbo_t, se_t, best_t = eng.elbo_batch(N, seeds)
+        logs_t = eng.elbo_logs(last, N)
+    finally:
+        os.environ.pop("PFMI_QF_TWO_LAUNCHES", None)
+    np.testing.assert_array_equal(logs_a[0], logs_t[0])
+    np.testing.assert_array_equal(logs_a[1], logs_t[1])
+    np.testing.assert_array_equal(elbo_a, elbo_t)
+    np.testing.assert_array_equal(best_a, best_t)
     # the same fits as a 2-path batch on a fresh engine (few fits: the groups of a fit are split over several workgroups)
     e2 = pfmi_mod.Engine(0)
     try:
