@@ -93,9 +93,16 @@ __device__ __forceinline__ int qf_vh_pos(int lrow, int col) {
     return (((bl * 4 + r) * (KC / 4) + T) << 4) + q * 4 + i;
 }
 
+// the kernel's argument block (same members, same order: the kernarg segment is laid out like this struct).  The hand-over pointers are
+// read from the segment where they are needed -- as named parameters they would sit in SGPRs across the whole block loop, and the scan
+// has none to spare (measured: +0.1 ms per config-3 scan from the extra spills)
+struct QfKernArgs { ElboArgs A; int ch_blocks, nchunks, groups_per_wg, ngroups, n_whole, n_tail, ndep; double *cshare; unsigned *cflag; unsigned epoch; };
+#ifndef QF_SHARE_SPINS
+#define QF_SHARE_SPINS 2000000          // x ~1 us: how long a dependent piece waits for its fit's constants before it gives up
+#endif
 template <int KC, int TGT, int RPAD, int NG>
 __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int ch_blocks, int nchunks, int groups_per_wg, int ngroups, int n_whole,
-                                                                  int gpw_tail, int gx_tail) {
+                                                                  int n_tail, int ndep, double *, unsigned *, unsigned) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
 #if QF_PROF
     const long long qf_t0 = wall_clock64();
@@ -106,13 +113,23 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
     constexpr int PRE = (QF_CHB * 16 * KC + QF_THREADS - 1) / QF_THREADS;      // prefetch registers per thread (streaming)
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, q = lane >> 4, c = lane & 15, l3 = lane & 3;
     const int d = A.d, nblk = (d + 15) >> 4;
-    // gx_tail == 0: workgroup (x, y) = piece x of fit y.  gx_tail > 0 (grid.x == 1): the first n_whole workgroups take one fit each,
-    // the ones behind them are the gx_tail one-batch pieces of each remaining fit -- dispatched last, they fill the CUs that the
-    // last round of whole fits leaves idle
-    int slot = blockIdx.y, piece = blockIdx.x;
-    if (gx_tail > 0 && slot >= n_whole) {
-        const int t = slot - n_whole, f = t / gx_tail;
-        slot = n_whole + f; piece = t - f * gx_tail; groups_per_wg = gpw_tail;
+    // cshare == nullptr: workgroup (x, y) = piece x of fit y.  Otherwise (grid.x == 1) the first n_whole workgroups take one fit each;
+    // behind them every one of the n_tail remaining fits is cut into one-batch pieces that fill the CUs the last round of whole fits
+    // leaves idle: first the n_tail PUBLISHERS (role 1: the pseudo groups + the first groups of the fit; they hand the per-fit
+    // constants over through `cshare` / `cflag`), then the ndep DEPENDENTS of each fit (role 2: a full batch of real groups, the
+    // constants fetched before the first draw is finished).  A workgroup that waits was dispatched after every publisher.
+    int slot = blockIdx.y, role = 0;
+    int g_begin = blockIdx.x * groups_per_wg, g_cap = groups_per_wg;
+    if (n_tail > 0 && slot >= n_whole) {
+        constexpr int SL = QF_WAVES * NG, NPG_ = (TGT != 0) ? (KC + 1 + 15) / 16 : 0;
+        int tail_f;
+        if (slot < n_whole + n_tail) { role = 1; tail_f = slot - n_whole; g_begin = 0; g_cap = SL - NPG_; }
+        else {
+            const int t = slot - n_whole - n_tail;
+            role = 2; tail_f = t / ndep;
+            g_begin = (SL - NPG_) + (t - tail_f * ndep) * SL; g_cap = SL;
+        }
+        slot = n_whole + tail_f;
     }
     const int p = A.points[slot];
     const size_t blkidx = A.by_point ? (size_t)p : (size_t)slot;
@@ -122,9 +139,9 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
     //   A3(Vh[:, j]) = M[:, j], A4(Vh[:, j]) = Nn[:, j], A3(c/s) = v, A4(c/s) = t0, q12(c/s) = 3 C0
     // in the first batch, for one wave-slot (the 63 real groups of N = 1000 leave exactly one of 64 slots free)
     constexpr int NPG = (TGT != 0) ? (KC + 1 + 15) / 16 : 0;
-    const int g_begin = piece * groups_per_wg;
-    const int g_end = (g_begin + groups_per_wg < ngroups) ? g_begin + groups_per_wg : ngroups;
-    const int nlb = (NPG + (g_end - g_begin) + QF_WAVES * NG - 1) / (QF_WAVES * NG);   // batches of this workgroup
+    const int npg = (role == 2) ? 0 : NPG;                         // a dependent gets the constants from its fit's publisher
+    const int g_end = (g_begin + g_cap < ngroups) ? g_begin + g_cap : ngroups;
+    const int nlb = (npg + (g_end - g_begin) + QF_WAVES * NG - 1) / (QF_WAVES * NG);   // batches of this workgroup
     if (A.status[p] != PFMI_FIT_OK) {
         for (int64_t n = (int64_t)g_begin * 16 + tid; n < (int64_t)g_end * 16 && n < A.N; n += QF_THREADS) {
             out_lp[n] = NAN; out_lq[n] = NAN;
@@ -257,8 +274,8 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             sl[g] = (lb * QF_WAVES + wv) * NG + g;                  // wave-uniform slot
-            pseudo[g] = sl[g] < NPG;
-            const int grp = g_begin + sl[g] - NPG;
+            pseudo[g] = sl[g] < npg;
+            const int grp = g_begin + sl[g] - npg;
             active[g] = pseudo[g] || grp < g_end;
             nl[g] = (int64_t)grp * 16 + c;
             n[g] = (uint32_t)(A.n0 + nl[g]);
@@ -526,6 +543,10 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
 #endif
                         }
                     };
+                    // nothing of the LDS / scalar-memory queue may be pending when the block loop is entered: otherwise the compiler's wait
+                    // counts at the loop head have to cover the unknown entry state and become a full `s_waitcnt lgkmcnt(0)` in EVERY
+                    // block (the previous block's table reads drained before the next block's operand reads issue: +0.7 % per scan)
+                    __builtin_amdgcn_s_waitcnt(0xC07F);
                     for (int bl = 0; bl < nb; ++bl) {
                         const int blk = blk0 + bl;
 #if QF_PRIO_FAIR
@@ -588,7 +609,53 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
                 }
                 if (j == KC && qp == 0) cn_s[0] = q4 / 3.0;         // q12(c/s) = sum a c^2 + 2 sum a c^2
             }
+            // (hand-over state re-read from the argument block, see QfKernArgs)
+            double *cshare = nullptr; unsigned *cflag = nullptr; unsigned epoch = 0u; int tail_f = 0, n_tail_l = 0;
+            if (role != 0) {
+                const char *ka = (const char *)__builtin_amdgcn_kernarg_segment_ptr();
+                asm volatile("" : "+s"(ka));
+                cshare = *reinterpret_cast<double *const *>(ka + offsetof(QfKernArgs, cshare));
+                cflag = *reinterpret_cast<unsigned *const *>(ka + offsetof(QfKernArgs, cflag));
+                epoch = *reinterpret_cast<const unsigned *>(ka + offsetof(QfKernArgs, epoch));
+                n_tail_l = *reinterpret_cast<const int *>(ka + offsetof(QfKernArgs, n_tail));
+                const int n_whole_l = *reinterpret_cast<const int *>(ka + offsetof(QfKernArgs, n_whole));
+                tail_f = slot - n_whole_l;
+            }
+            if (role == 2) {
+                // the constants come from the fit's publisher (the same code on the same inputs: the same bits as computed here)
+                if (tid == 0) {
+                    int spins = 0;
+                    while (__hip_atomic_load(cflag + tail_f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch && spins < QF_SHARE_SPINS) {
+                        __builtin_amdgcn_s_sleep(32); ++spins;
+                    }
+                    // (never seen: every publisher is dispatched before any dependent.  Draws finished without the constants would be
+                    //  silently wrong, so a publisher that does not show up poisons them and is counted for the host.)
+                    if (spins >= QF_SHARE_SPINS) { cn_s[3] = NAN; atomicAdd(cflag + n_tail_l, 1u); }
+                }
+                __syncthreads();
+                const bool lost = cn_s[3] != 0.0;
+                const double *src = cshare + (size_t)tail_f * NC;
+                double cv[(NC + QF_THREADS - 1) / QF_THREADS];
+#pragma unroll
+                for (int u = 0; u < (NC + QF_THREADS - 1) / QF_THREADS; ++u) {
+                    const int i = tid + u * QF_THREADS;
+                    cv[u] = __hip_atomic_load(src + (i < NC ? i : NC - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();                                   // everybody has read cn_s[3]
+#pragma unroll
+                for (int u = 0; u < (NC + QF_THREADS - 1) / QF_THREADS; ++u) {
+                    const int i = tid + u * QF_THREADS;
+                    if (i < NC) cn_s[i] = lost ? NAN : cv[u];
+                }
+            }
             __syncthreads();
+            if (role == 1) {
+                double *dst = cshare + (size_t)tail_f * NC;
+                for (int i = tid; i < NC; i += QF_THREADS) __hip_atomic_store(dst + i, cn_s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __threadfence();
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(cflag + tail_f, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         if (!any_real) continue;
         // The lane coordinates of this section come from an OPAQUE copy of the lane index: otherwise the compiler hoists the ~30 per-lane
@@ -675,7 +742,7 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
 #endif
     }
 #if QF_PROF
-    if (piece == 0 && (slot & 1023) == 3 && lane == 0)
+    if (g_begin == 0 && (slot & 1023) == 3 && lane == 0)
         printf("QF_PROF fit %d wave %d (10 ns ticks): prologue %lld blocks %lld epilogue+publish %lld total %lld batches %d\n", slot, wv, qf_tp, qf_tb,
                qf_te, (long long)(wall_clock64() - qf_t0), nlb);
 #endif
@@ -716,15 +783,21 @@ static int32_t launch_qf_ng(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
             b.points = a.points + s0; b.seeds = a.seeds + s0;
             if (!a.by_point) { b.logp += s0 * a.log_stride; b.logq += s0 * a.log_stride; }
             hipLaunchKernelGGL(kern, dim3((unsigned)gx_, (unsigned)ns), dim3(QF_THREADS), lds_bytes, c->stream, b, ch_blocks, nchunks, gpw_,
-                               ngroups, 0, 0, 0);
+                               ngroups, 0, 0, 0, (double *)nullptr, (unsigned *)nullptr, 0u);
         }
     };
     // Workgroups of one launch all take the same time, so the fits beyond the last full round of CUs (nfits mod #CU) would keep a
-    // few CUs busy for a whole workgroup time while the rest idle.  Those fits go into a second launch cut into one-batch pieces
-    // (each piece recomputes the per-fit constants in its pseudo-group slot) whenever that finishes sooner.
+    // few CUs busy for a whole workgroup time while the rest idle.  Those fits are cut into one-batch pieces whenever that finishes
+    // sooner.  Regular route (round 4): ONE launch -- a workgroup per whole fit, then the pieces; only a fit's first piece (the
+    // "publisher") spends a slot on the pseudo groups and hands the per-fit constants to the others through global memory, so that
+    // N = 1000 (63 groups + 1 pseudo group = 4 batches) is 4 pieces of one full batch, no work added.  (Round 3: a second launch
+    // in which every piece recomputed the constants -- 5 pieces per fit; kept behind PFMI_QF_TWO_LAUNCHES for the invariance tests
+    // and for scans of more than 65 535 workgroups.)
     int64_t tail = 0;
-    int gpw_t = gpw, gx_t = gx;
-    const char *no_tail = pf_debug_get("PFMI_QF_NO_TAIL");            // test hook: one launch for every fit (geometry-invariance tests)
+    int gpw_t = gpw, gx_t = gx, ndep = 0;
+    const char *no_tail = pf_debug_get("PFMI_QF_NO_TAIL");            // test hook: one workgroup per fit (geometry-invariance tests)
+    const char *two = pf_debug_get("PFMI_QF_TWO_LAUNCHES");          // test hook: the round-3 cut
+    const bool two_launches = two && two[0] == '1';
     if (split == 1 && TGT != 0 && !(no_tail && no_tail[0] == '1')) {
         int ncu = 0;
         PF_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device));
@@ -732,14 +805,24 @@ static int32_t launch_qf_ng(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
         const int64_t rem = ncu > 0 ? nfits % ncu : 0;
         gpw_t = slots - NPG;
         gx_t = gpw_t > 0 ? (ngroups + gpw_t - 1) / gpw_t : 0;
-        if (rem > 0 && nfits > ncu && gpw_t > 0 && nb_full > 1 && (rem * gx_t + ncu - 1) / ncu < nb_full) tail = rem;
-    }
-    const char *two = pf_debug_get("PFMI_QF_TWO_LAUNCHES");          // test hook: the pieces in a launch of their own
-    if (tail > 0 && gx == 1 && (nfits - tail) + tail * gx_t <= 65535 && !(two && two[0] == '1')) {
-        // one launch: whole fits first, the pieces of the last `tail` fits behind them
-        hipLaunchKernelGGL(kern, dim3(1, (unsigned)((nfits - tail) + tail * gx_t)), dim3(QF_THREADS), lds_bytes, c->stream, a, ch_blocks, nchunks,
-                           gpw, ngroups, (int)(nfits - tail), gpw_t, gx_t);
-        return PFMI_OK;
+        ndep = (ngroups > gpw_t) ? (ngroups - gpw_t + slots - 1) / slots : 0;
+        const bool share_ok = !two_launches && gpw_t > 0 && (nfits - rem) + rem * (1 + ndep) <= 65535;
+        const int pieces = share_ok ? 1 + ndep : gx_t;
+        if (rem > 0 && nfits > ncu && gpw_t > 0 && nb_full > 1 && (rem * pieces + ncu - 1) / ncu < nb_full) tail = rem;
+        if (tail > 0 && share_ok) {
+            constexpr int NC = qf_nconst(KC, RPAD);
+            const size_t cbytes = (size_t)tail * NC * sizeof(double), fbytes = ((size_t)tail + 1) * sizeof(unsigned);
+            if (c->qf_share.cap < cbytes + fbytes || c->qf_epoch == 0xFFFFFFFFu) {          // (new flags start at 0 = "never published")
+                PF_TRY(c->qf_share.ensure(cbytes + fbytes + (64 << 10)));
+                PF_HIP(hipMemsetAsync(c->qf_share.p, 0, c->qf_share.cap, c->stream));
+                c->qf_epoch = 0;
+            }
+            // flags live at the END of the buffer so that a larger tail of a later launch never reads constants as flags
+            unsigned *cflag = reinterpret_cast<unsigned *>(c->qf_share.as<char>() + c->qf_share.cap) - (tail + 1);
+            hipLaunchKernelGGL(kern, dim3(1, (unsigned)((nfits - tail) + tail * (1 + ndep))), dim3(QF_THREADS), lds_bytes, c->stream, a, ch_blocks,
+                               nchunks, gpw, ngroups, (int)(nfits - tail), (int)tail, ndep, c->qf_share.as<double>(), cflag, ++c->qf_epoch);
+            return PFMI_OK;
+        }
     }
     if (nfits - tail > 0) launch(0, nfits - tail, gpw, gx);
     if (tail > 0) launch(nfits - tail, tail, gpw_t, gx_t);

@@ -235,7 +235,7 @@ int32_t pfmi_destroy(pfmi_ctx *c) {
     DevBuf *bufs[] = {&c->theta, &c->grad, &c->d_off, &c->d_path_of, &c->target.mean, &c->target.a, &c->target.wd,
                       &c->target.g, &c->target.wd16, &c->alpha_all, &c->hist_len, &c->hist_src, &c->hist_acc, &c->n_rej, &c->vh, &c->tmat, &c->vchol,
                       &c->rq, &c->dmat, &c->sqrt_alpha, &c->mu, &c->logdet, &c->status, &c->seeds, &c->logp, &c->logq,
-                      &c->elbo, &c->se, &c->best_iter, &c->fit_list, &c->ubuf, &c->xbuf, &c->scratch, &c->fit_scratch, &c->pool,
+                      &c->elbo, &c->se, &c->best_iter, &c->fit_list, &c->ubuf, &c->xbuf, &c->scratch, &c->qf_share, &c->fit_scratch, &c->pool,
                       &c->pool_lr, &c->pool_lp, &c->pool_lq, &c->pool_points, &c->pool_seeds, &c->lw, &c->w,
                       &c->psis_out, &c->psis_aux, &c->tailbuf, &c->cdf, &c->idx, &c->gbuf, &c->trace_lp, &c->st_theta, &c->st_grad,
                       &c->st_lp, &c->st_npts, &c->lb_hs, &c->lb_hy, &c->lb_x0, &c->sortk, &c->sorti,
@@ -730,7 +730,15 @@ int32_t pfmi_elbo_batch_wait(pfmi_ctx *c, double *elbo, double *se, int64_t *bes
     if (elbo) PF_TRY(d2h_async(c, elbo, c->elbo.p, sizeof(double) * c->P));
     if (se) PF_TRY(d2h_async(c, se, c->se.p, sizeof(double) * c->P));
     if (best_iter) PF_TRY(d2h_async(c, best_iter, c->best_iter.p, sizeof(int64_t) * c->K));
-    return stream_sync(c);
+    // pieces of the scan that gave up waiting for their fit's constants (they poison their draws; elbo_qf_kernel.hip): the counter is
+    // the last word of the hand-over buffer
+    uint32_t lost = 0;
+    if (c->qf_share.cap >= sizeof(uint32_t))
+        PF_TRY(d2h_async(c, &lost, c->qf_share.as<char>() + c->qf_share.cap - sizeof(uint32_t), sizeof(uint32_t)));
+    PF_TRY(stream_sync(c));
+    if (lost != 0) (void)hipMemsetAsync(c->qf_share.as<char>() + c->qf_share.cap - sizeof(uint32_t), 0, sizeof(uint32_t), c->stream);
+    PF_CHECK(lost == 0, PFMI_ERR_HIP, "ELBO scan: %u workgroup(s) never received their fit's constants", lost);
+    return PFMI_OK;
 }
 
 int32_t pfmi_elbo_batch(pfmi_ctx *c, int64_t N, const uint64_t *seeds, const double *u_host, double *elbo,

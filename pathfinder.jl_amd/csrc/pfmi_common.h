@@ -130,6 +130,8 @@ struct pfmi_ctx {
     DevBuf ubuf;        // parity-mode normals
     DevBuf xbuf;        // scratch draws (callback path / pfmi_draws)
     DevBuf scratch;     // misc
+    DevBuf qf_share;    // scan: per-fit constants handed from a tail fit's first piece to its other pieces, + one flag per tail fit
+    uint32_t qf_epoch = 0;   // launch counter of the shared-constants scan: a flag equal to it means "published in THIS launch"
 
     // pool / PSIS / resample state
     bool pooled = false;
