@@ -301,6 +301,14 @@ int32_t pfmi_free_dev(pfmi_ctx *ctx, void *dev_ptr);
 int32_t pfmi_memcpy_h2d(pfmi_ctx *ctx, void *dev_dst, const void *host_src, int64_t bytes);
 int32_t pfmi_memcpy_d2h(pfmi_ctx *ctx, void *host_dst, const void *dev_src, int64_t bytes);
 
+/* Page-locked host memory for LARGE result buffers (the draws of pfmi_pool_gather / pfmi_comm_resample / pfmi_comm_psis_resample, the
+ * pool of pfmi_pool_get).  Every entry point accepts any host pointer; into ordinary (pageable) memory the runtime copies a large result
+ * in 32 MB pieces through its own staging buffer, DMA and host copy one after the other (measured 16 GB/s: 9.7 ms for the 160 MB of draws
+ * of a d = 10^4, ndraws = 2000 call), into a buffer from pfmi_host_alloc it is one DMA transfer at the link rate (54 GB/s).  Below ~16 MB
+ * there is nothing to gain (measured at 8 MB).  Allocation costs milliseconds: recycle the buffers (the Python host keeps a pool). */
+int32_t pfmi_host_alloc(int64_t bytes, void **host_ptr);
+int32_t pfmi_host_free(void *host_ptr);
+
 #ifdef __cplusplus
 }
 #endif

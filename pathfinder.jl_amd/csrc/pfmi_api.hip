@@ -1083,6 +1083,16 @@ int32_t pfmi_free_dev(pfmi_ctx *c, void *dev_ptr) {
     if (dev_ptr) PF_HIP(hipFree(dev_ptr));
     return PFMI_OK;
 }
+int32_t pfmi_host_alloc(int64_t bytes, void **host_ptr) {
+    PF_CHECK(bytes > 0 && host_ptr, PFMI_ERR_ARG, "host_alloc: bad arguments");
+    *host_ptr = nullptr;
+    PF_HIP(hipHostMalloc(host_ptr, (size_t)bytes, hipHostMallocPortable));
+    return PFMI_OK;
+}
+int32_t pfmi_host_free(void *host_ptr) {
+    if (host_ptr) PF_HIP(hipHostFree(host_ptr));
+    return PFMI_OK;
+}
 int32_t pfmi_memcpy_h2d(pfmi_ctx *c, void *dst, const void *src, int64_t bytes) {
     PF_CTX(c);
     return h2d(c, dst, src, (size_t)bytes);

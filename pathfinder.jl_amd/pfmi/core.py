@@ -1,6 +1,7 @@
 """Engine: thin Python handle over a pfmi_ctx (one GPU, one stream).  All numerics run in
 libpfmi.so on the MI355X; this file only marshals arrays across the C ABI."""
 import ctypes as C
+import os
 import weakref
 
 import numpy as np
@@ -16,6 +17,43 @@ _u64p = C.POINTER(C.c_uint64)
 
 def _d(a):
     return a.ctypes.data_as(_dp) if a is not None else None
+
+
+# ---- large result arrays live in page-locked memory (include/pfmi.h: pfmi_host_alloc) --------------------------------------------
+# A result of tens of megabytes downloaded into an ordinary numpy array is copied by the runtime in 32 MB pieces, DMA and host copy one
+# after the other (16 GB/s); into page-locked memory it is one DMA transfer (54 GB/s).  Allocating such memory costs milliseconds, so
+# blocks are recycled: when the last array that views a block is garbage collected the block goes back to a small pool.
+_PIN_MIN_BYTES = int(float(os.environ.get("PFMI_PIN_MIN_MB", "16")) * (1 << 20))      # (override: A/B runs of tests/probes)
+_PIN_KEEP = 2                            # blocks kept per size class
+_pin_free = {}                           # size class (bytes, power of two) -> [addresses]
+
+
+def _pin_release(cls_bytes, addr):
+    keep = _pin_free.setdefault(cls_bytes, [])
+    if len(keep) < _PIN_KEEP:
+        keep.append(addr)
+    else:
+        _lib.lib().pfmi_host_free(C.c_void_p(addr))
+
+
+def result_empty(shape, dtype=np.float64):
+    """np.empty(shape, order='F') for a result the library downloads into; page-locked when large (falls back to ordinary memory
+    when page-locked memory is refused)"""
+    nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+    if nbytes < _PIN_MIN_BYTES:
+        return np.empty(shape, dtype=dtype, order="F")
+    cls_bytes = 1 << (nbytes - 1).bit_length()
+    free = _pin_free.get(cls_bytes)
+    if free:
+        addr = free.pop()
+    else:
+        p = C.c_void_p()
+        if _lib.lib().pfmi_host_alloc(C.c_int64(cls_bytes), C.byref(p)) != 0 or not p.value:
+            return np.empty(shape, dtype=dtype, order="F")
+        addr = p.value
+    buf = (C.c_char * nbytes).from_address(addr)
+    weakref.finalize(buf, _pin_release, cls_bytes, addr).atexit = False     # (at exit the process's memory goes anyway)
+    return np.frombuffer(buf, dtype=dtype).reshape(shape, order="F")
 
 
 _LIVE_COMMS = weakref.WeakSet()          # a pfmi_comm holds raw pointers to its contexts: it must go before any of them does
@@ -302,7 +340,7 @@ class Engine:
 
     def pool_get(self, draws=True):
         S = self.K * self.N_r
-        X = np.empty((self.d, self.N_r, self.K), order="F") if draws else None
+        X = result_empty((self.d, self.N_r, self.K)) if draws else None
         lr = np.empty(S)
         check(self.L.pfmi_pool_get(self.ctx, _d(X), _d(lr)))
         return X, lr
@@ -348,7 +386,7 @@ class Engine:
 
     def pool_gather(self, idx, col_offset=0):
         idx = np.ascontiguousarray(idx, dtype=np.int64)
-        out = np.empty((self.d, len(idx)), order="F")
+        out = result_empty((self.d, len(idx)))
         check(self.L.pfmi_pool_gather(self.ctx, C.c_int64(len(idx)), idx.ctypes.data_as(_i64p),
                                       C.c_int64(col_offset), _d(out)))
         return out
@@ -418,7 +456,7 @@ class Comm:
     def resample(self, ndraws, importance=True, replace=True, seed=0, uniforms=None, want_draws=True):
         d = self.engines[0].d
         idx = np.empty(ndraws, dtype=np.int64)
-        out = np.empty((d, ndraws), order="F") if want_draws else None
+        out = result_empty((d, ndraws)) if want_draws else None
         if uniforms is not None:
             uniforms = np.ascontiguousarray(uniforms, dtype=np.float64)
         check(self.L.pfmi_comm_resample(self.h, C.c_int64(ndraws), C.c_int32(int(importance)), C.c_int32(int(replace)),
@@ -429,7 +467,7 @@ class Comm:
         """pooled PSIS + index selection + owner gather + all-reduce, enqueued on every local context, ONE synchronisation"""
         d = self.engines[0].d
         idx = np.empty(ndraws, dtype=np.int64)
-        out = np.empty((d, ndraws), order="F") if want_draws else None
+        out = result_empty((d, ndraws)) if want_draws else None
         if uniforms is not None:
             uniforms = np.ascontiguousarray(uniforms, dtype=np.float64)
         k, M = C.c_double(), C.c_int64()

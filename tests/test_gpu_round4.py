@@ -433,3 +433,43 @@ def test_psis_large_tail_route(pfmi_mod, case, monkeypatch):
         assert a["tail_length"] == b["tail_length"]
         assert abs(a["pareto_shape"] - b["pareto_shape"]) <= 1e-13 * (1 + abs(b["pareto_shape"]))
         assert np.max(np.abs(a["log_weights"][fin] - b["log_weights"][fin])) <= 1e-12 * (1 + np.abs(b["log_weights"][fin]).max())
+
+
+# ---- large results in page-locked memory (include/pfmi.h: pfmi_host_alloc) ------------------------------------------------------------
+def test_large_results_arrive_in_page_locked_memory(pfmi_mod, monkeypatch):
+    """The draws / pool arrays that the Python host hands to the library are page-locked above 16 MB (one DMA transfer instead of the
+    runtime's staged copy): the same bytes as into ordinary memory, the block is recycled when its arrays die."""
+    import gc
+    from pfmi import core
+    d, K, J, N_r = 600, 3, 5, 2000                                            # pool: 600 x 2000 x 3 doubles = 28.8 MB
+    tg = pfmi_mod.t_lowrank(d, r=8, seed=4)
+    eng = pfmi_mod.Engine(0)
+    try:
+        eng.set_target(tg)
+        x0 = pfmi_mod.HostRNG(5).rand(K * d).reshape(K, d) * 4 - 2
+        eng.optimize_batch(x0, J)
+        eng.fit_batch(J)
+        eng.elbo_batch(64, fit_seeds(eng.P, 3))
+        pts = np.array([int(eng.offsets[k]) + 2 for k in range(K)], dtype=np.int64)
+        eng.pool_build(N_r, pts, fit_seeds(K, 9))
+        monkeypatch.setattr(core, "_PIN_MIN_BYTES", 1 << 62)
+        X_plain, lr_plain = eng.pool_get()
+        monkeypatch.setattr(core, "_PIN_MIN_BYTES", 16 << 20)
+        core._pin_free.clear()
+        X_pin, lr_pin = eng.pool_get()
+        assert X_pin.flags["F_CONTIGUOUS"] and X_pin.shape == X_plain.shape
+        np.testing.assert_array_equal(X_pin, X_plain)
+        np.testing.assert_array_equal(lr_pin, lr_plain)
+        # the block returns to the pool with its last view and is handed out again
+        view = X_pin[:, :10, 0]
+        del X_pin
+        gc.collect()
+        assert sum(len(v) for v in core._pin_free.values()) == 0
+        del view
+        gc.collect()
+        assert sum(len(v) for v in core._pin_free.values()) == 1
+        addr = next(v[0] for v in core._pin_free.values() if v)
+        Y = core.result_empty((d, N_r, K))
+        assert Y.ctypes.data == addr and sum(len(v) for v in core._pin_free.values()) == 0
+    finally:
+        eng.close()
