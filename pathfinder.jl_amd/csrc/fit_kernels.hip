@@ -31,6 +31,9 @@
 #else
 #define FR_STAMP(k) do { } while (0)
 #endif
+#ifndef HIST_PROF
+#define HIST_PROF 0                     // 1: section cycle counters in pf_history_kernel (experiment builds)
+#endif
 #define HIST_THREADS 256
 #define FIT_THREADS 256
 
@@ -86,7 +89,14 @@ __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
     for (int q = 0; q < NS; ++q) load_point(q, tq[q], gq[q]);                    // points 0 .. NS - 1
     if (tid == 0) hist_len[p0] = 0;
     // one trace step: (t0, g0) = point l - 1, (t1, g1) = point l; afterwards the set of point l - 1 is refilled
+#if HIST_PROF
+    long long hp[5] = {0, 0, 0, 0, 0}, hp_last = clock64();
+#define HP_STAMP(k) do { const long long t_ = clock64(); hp[k] += t_ - hp_last; hp_last = t_; } while (0)
+#else
+#define HP_STAMP(k) do { } while (0)
+#endif
     auto step = [&](const int l, double (&t0)[EPT], double (&g0)[EPT], const double (&t1)[EPT], const double (&g1)[EPT]) {
+        HP_STAMP(4);
         double v[4] = {0.0, 0.0, 0.0, 0.0};   // y.s, y.y, y'diag(a)y, s'diag(1/a)s
         double sv[EPT], yv[EPT];
 #pragma unroll
@@ -100,7 +110,9 @@ __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
             v[3] += s * ial[e] * s;
         }
         load_point(l - 1 + NS, t0, g0);                                         // refill: first needed NS - 2 steps from now
+        HP_STAMP(0);
         pf_block_sum_mv<4, 4, (HIST_NT <= 256 ? HIST_NT / 64 : 0)>(v, red, flip);   // static wave count only for <= 4 waves (16 waves: register pressure)
+        HP_STAMP(1);
         const bool accept = v[0] > eps * v[1];                                  // :47
         if (accept) {                                                           // gilbert_init :5-10
             const double a = v[2], b = v[0], c = v[3], aoc = a / c, rb = 1.0 / b;
@@ -117,6 +129,7 @@ __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
             }
             n_acc += 1;
         }
+        HP_STAMP(2);
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             const int i = tid + HIST_NT * e;
@@ -127,6 +140,7 @@ __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
             hist_len[p0 + l] = n_acc < J ? n_acc : J;                           // r_eff = max r_ind so far (:49-50)
             hist_src[(size_t)(p0 + l) * J] = n_acc;                             // parked in the row's first slot until the expansion below
         }
+        HP_STAMP(3);
     };
     int l = 1;
     for (; l + NS - 1 <= L; l += NS) {                                          // :43
@@ -137,6 +151,11 @@ __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
 #pragma unroll
     for (int q = 0; q < NS - 1; ++q)
         if (q < rem) step(l + q, tq[q], gq[q], tq[(q + 1) % NS], gq[(q + 1) % NS]);
+#if HIST_PROF
+    if (k == 0 && (tid & 63) == 0)
+        printf("HIST_PROF wave %d: %d steps, cycles per step: dots+loads %lld block sum %lld update %lld stores %lld loop %lld\n", tid >> 6, L,
+               hp[0] / L, hp[1] / L, hp[2] / L, hp[3] / L, hp[4] / L);
+#endif
     if (tid == 0) n_rej[k] = L > 0 ? L - n_acc : 0;                             // :57
     // ---- hist_inds (:105) of every point from the accepted list: row l = the last min(n_acc(l), J) accepted steps, oldest first
     __threadfence_block();

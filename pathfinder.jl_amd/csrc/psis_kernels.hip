@@ -16,6 +16,14 @@
 #include <stddef.h>
 
 #define PSIS_THREADS 1024
+#ifndef PSIS_PROF
+#define PSIS_PROF 0                     // 1: thread 0 of pf_psis_kernel prints its section times (10 ns ticks); experiment builds only
+#endif
+#if PSIS_PROF
+#define PS_STAMP(k) do { if (threadIdx.x == 0) { const long long t_ = wall_clock64(); ps_t[k] = t_ - ps_last; ps_last = t_; } } while (0)
+#else
+#define PS_STAMP(k) do { } while (0)
+#endif
 #define TAILCAP 4096
 
 __device__ __forceinline__ uint64_t pf_key_of(double x) {   // order-preserving map double -> u64
@@ -312,6 +320,9 @@ __global__ __launch_bounds__(PSIS_THREADS) void pf_psis_kernel(long long S, cons
     __shared__ double s_theta[128], s_ll[128];
     __shared__ double s_sigma, s_mu;
 
+#if PSIS_PROF
+    long long ps_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ps_last = wall_clock64();
+#endif
     double pareto_k = NAN;
     // lw is written once, at the end: everything but the M tail entries is lr - logsumexp, and the smoothed tail sits in LDS until then
     bool have_sel = false, replaced = false;
@@ -357,6 +368,7 @@ __global__ __launch_bounds__(PSIS_THREADS) void pf_psis_kernel(long long S, cons
             }
             __syncthreads();
         } else pf_select_top_sorted(lr, S, M + 1, tkeys, tidx, &st);
+        PS_STAMP(0);
         // tkeys[0] = cutoff, tkeys[1..M] = the M largest, ascending
         double *w = reinterpret_cast<double *>(tkeys);
         const double logu = pf_val_of(tkeys[0]);
@@ -384,6 +396,7 @@ __global__ __launch_bounds__(PSIS_THREADS) void pf_psis_kernel(long long S, cons
                 if (t < M) w[t] = vals[q];           // tail idx t is tidx[t + 1]
             }
             __syncthreads();
+            PS_STAMP(1);
             if (nz > 0.0) {
                 // ---- Zhang & Stephens (2009) profile likelihood on a grid of m theta values
                 const int mest = 30 + (int)floor(sqrt((double)M));
@@ -400,6 +413,7 @@ __global__ __launch_bounds__(PSIS_THREADS) void pf_psis_kernel(long long S, cons
                     }
                 }
                 __syncthreads();
+                PS_STAMP(2);
                 if (tid < 64) {                                    // posterior-mean theta: wave 0, lanes over the grid
                     double lmx = -INFINITY;
                     for (int i = lane; i < mest; i += 64) lmx = fmax(lmx, s_ll[i]);
@@ -418,6 +432,7 @@ __global__ __launch_bounds__(PSIS_THREADS) void pf_psis_kernel(long long S, cons
                 double kadj = kk;
                 if (isfinite(kk)) kadj = (kk * (double)M + 5.0) / ((double)M + 10.0);   // prior adjustment
                 pareto_k = kadj;
+                PS_STAMP(3);
                 if (isfinite(kadj) && isfinite(sigma)) {
                     __syncthreads();                               // everybody is done reading w[] (the kk sum above)
                     for (int t = tid; t < M; t += nt) {
@@ -436,6 +451,7 @@ __global__ __launch_bounds__(PSIS_THREADS) void pf_psis_kernel(long long S, cons
     }
     __threadfence_block();
     __syncthreads();
+    PS_STAMP(4);
     // ---- log-normalise: lw = (smoothed) log ratios - logsumexp; weights = exp(lw).  Two passes over lr: the maximum needs none --
     //      the largest untouched element is the cutoff (or the overall maximum when nothing was replaced).
     const double *wt = reinterpret_cast<const double *>(tkeys);
@@ -462,6 +478,10 @@ __global__ __launch_bounds__(PSIS_THREADS) void pf_psis_kernel(long long S, cons
             aux->mx = mx; aux->se_tail = se; aux->replaced = replaced ? 1u : 0u; aux->tk0 = tk0; aux->ti0 = ti0;
             aux->pareto_k = pareto_k; aux->sigma = s_sigma; aux->M = M;
         }
+#if PSIS_PROF
+        PS_STAMP(5);
+        if (tid == 0) printf("PSIS_PROF multi S %lld M %d (10 ns): select+sort %lld vals %lld grid %lld mean+k %lld smooth %lld hand-over %lld\n", S, M, ps_t[0], ps_t[1], ps_t[2], ps_t[3], ps_t[4], ps_t[5]);
+#endif
         return;
     }
     double se = 0.0;
@@ -484,6 +504,10 @@ __global__ __launch_bounds__(PSIS_THREADS) void pf_psis_kernel(long long S, cons
         wout[tidx[t + 1]] = exp(v);
     }
     if (tid == 0) { out[0] = pareto_k; out[1] = (double)M; out[2] = s_sigma; out[3] = lse; }
+#if PSIS_PROF
+    PS_STAMP(5);
+    if (tid == 0) printf("PSIS_PROF single S %lld M %d (10 ns): select+sort %lld vals %lld grid %lld mean+k %lld smooth %lld normalise %lld\n", S, M, ps_t[0], ps_t[1], ps_t[2], ps_t[3], ps_t[4], ps_t[5]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
