@@ -19,7 +19,7 @@ try:
         "select name, grid_x, grid_y, workgroup_x, count(*), sum(duration), avg(duration) from kernels "
         "where name like '%pf_elbo_qf_kernel%' group by name, grid_x, grid_y order by sum(duration) desc"))
     if len(per_grid) > 1:
-        print("\nELBO scan by launch grid (threads; one scan per step = one main + one tail launch):\n")
+        print("\nELBO scan by launch grid (threads; one scan per step = ONE launch since the shared-constants cut: grid y = whole fits + pieces of the last round; the larger grids are the public-API runs of bench.py):\n")
         print("| kernel | grid x, y (threads) | calls | total (ms) | avg (ms) |\n|---|---|---|---|---|")
         tot = 0.0
         gx_main = min(r[1] for r in per_grid)        # the main launch has one workgroup column (grid x = workgroup size)
@@ -27,6 +27,6 @@ try:
         for name, gx, gy, wx, calls, sm, avg in per_grid:
             print(f"| `{name[:60]}` | {gx}, {gy} | {calls} | {sm / 1e6:.3f} | {avg / 1e6:.4f} |")
             tot += sm
-        print(f"\nscans: {nscan}; time per scan (main + tail launch): {tot / 1e6 / max(nscan, 1):.4f} ms")
+        print(f"\nscans: {nscan}; time per scan: {tot / 1e6 / max(nscan, 1):.4f} ms")
 except sqlite3.Error as ex:                      # older rocprofv3 schema without the per-dispatch view
     print(f"\n(per-grid breakdown unavailable: {ex})")
