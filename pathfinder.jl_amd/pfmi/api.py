@@ -535,7 +535,12 @@ def _run_paths(engs, target, inits, run_rngs, *, dim, history_length, ndraws_elb
                     new_pending.append(k)
                 else:
                     st["done"] = True
-        if pooled_error is not None:                                # every engine's fit status has been inspected (and was clean)
+        if new_pending:
+            # some run failed this try and is retried (src/singlepath.jl:259-283: the reference retries every run up to `ntries`
+            # BEFORE it ever pools): the optimistic pooled stage above ran on that failed try's draws -- whatever it returned or
+            # raised (e.g. "weights are all zero" when every run's ELBO was NaN) is stale; the retry iteration recomputes it
+            pooled, pooled_error = None, None
+        elif pooled_error is not None:                              # no retry pending: the pooled stage's failure is the call's failure
             raise pooled_error
         pending = new_pending
     return state, pooled

@@ -47,6 +47,10 @@ CASES = [("iso10", 3, 6), ("diag30", 4, 6), ("lr50", 3, 6), ("lr64r3", 2, 2), ("
 # never go vacuous.  iso: y == s makes U'\B rank deficient for every fit and funnel12's scaled block is
 # numerically rank deficient too (measured on the oracle: 0 / 6 and 3 / 75 fits pass the gate) -- those two cases are pinned
 # through the dense W / logdet / mu and the statistical ELBO branch, and say so here instead of silently skipping.
+# iso10 / funnel12: every Householder block is numerically rank deficient (y = s on the iso target), so the strict same-u / ELBO
+# branches of the gated loops see no fit there (their margins rows read "0 comparisons"); those cases are covered instead by the
+# `*_gpu_factor_*` tests, where the oracle applies the GPU's OWN factor reflector by reflector (strict per-draw parity whatever the
+# conditioning), and by the dense W / logdet / mu comparisons above, which have no gate.
 MIN_STRICT = {"iso10": 0, "funnel12": 0}
 
 
@@ -120,8 +124,9 @@ def test_fit_batch_matches_oracle(pfmi_mod, eng, name, K, J):
             B, D = po.lbfgs_inverse_hessian(alpha_all[l], S, Y)
             Wref = np.diag(alpha_all[l]) + B @ D @ B.T
             Wgpu = np.diag(f["alpha"]) + f["B"] @ f["D"] @ f["B"].T
-            # (the dense products B D B' themselves carry cond(D)^(1/2) * eps of rounding on BOTH sides: the bound scales with it)
-            mg.check(cfg, "W", np.max(np.abs(Wgpu - Wref)) / np.abs(Wref).max() / max(1.0, np.linalg.cond(D) ** 0.5 if j else 1.0))
+            # SURVEY 8(d) as written: max |dW| <= 1e-11 max |W|, no conditioning allowance (until round 4 the
+            # deviation was divided by cond(D)^(1/2) before the comparison; the recorded margins never needed it)
+            mg.check(cfg, "W", np.max(np.abs(Wgpu - Wref)) / np.abs(Wref).max())
             assert f["B"].shape == (tg.d, 2 * j)                       # size(Σ.B) == (d, 2j), test/singlepath.jl:41
             # the factor itself: R = [V 0;0 I] Q' U,  W = R'R   (src/woodbury.jl:178-187)
             F = po.Factor(alpha_all[l], B, D)
