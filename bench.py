@@ -411,9 +411,11 @@ def main():
     dt = time.perf_counter() - t0
     stages, scan_ms, scan_n = {}, 0.0, 0
     if timed_stages:
-        for name in ("history", "fit", "elbo_draws", "elbo_draws_x", "elbo_reduce", "psis", "resample"):
+        for name in ("history", "fit", "elbo_draws", "elbo_draws_x", "elbo_reduce", "psis", "resample", "comm_handshake_host", "comm_allgather",
+                     "comm_allreduce"):
             ms_, n_ = eng.kernel_time(name)
-            stages[name] = {"ms": round(ms_ / max(n_, 1), 4), "launches": int(n_)}      # average per launch
+            stages[name] = {"ms": round(ms_ / max(n_, 1), 4), "launches": int(n_),      # average per launch
+                            "ms_per_step": round(ms_ / max(args.steps, 1), 4)}
         scan_ms, scan_n = eng.kernel_time("elbo_draws")                                # the ELBO-scan launches only (total, count)
         eng.profile(2 if not args.host_traces else 0)                                 # reset: the end-to-end loop adds "optimize"
     if use_dist:
@@ -633,13 +635,20 @@ def main():
                                                 "never forms x, so these bytes are NOT moved (see traffic: a few % of them) and this is not a "
                                                 "utilisation; the path where they do move is device_callback_target"}}
 
-    # ---- CPU baseline: the oracle (a port of the reference algorithm) on this box's host cores ------------
+    # ---- CPU baseline: the reference algorithm on this box's host cores, two legs ------------
+    #   "port":   oracle/pf_oracle.c (scalar C restatement, reflector-by-reflector Q apply), OpenMP over paths
+    #   "lapack": tests/cpu_lapack_baseline.py -- the same per-fit pipeline through dgeqrf / dormqr / dtrmm on d x N blocks + NumPy
+    #             reductions, threads over paths, BLAS pinned to 1 thread per path: what Julia's lmul!(Q, .) does (src/woodbury.jl:136-143)
+    # `cores` = the cores this process can really use (affinity mask, capped by a cgroup CPU quota), NOT os.cpu_count(); the scaling of
+    # the port from 1 thread to all cores is reported so that a reader can see where it stops.
     cpu = None
     if rank == 0 and G == 1 and not args.no_cpu_baseline:          # contract: rank 0 at N = 1 only
         try:
             from helpers import oracle_target
             from oracle import pf_oracle as po
-            cores = os.cpu_count() or 1
+            import cpu_lapack_baseline as cl
+            aff, logical, quota = cl.usable_cores()
+            cores = max(1, min(aff, int(quota)) if quota else aff)
             otg = oracle_target(tg)
             if traces is None:                                         # device-made traces: download a sample for the CPU leg
                 from types import SimpleNamespace
@@ -647,40 +656,76 @@ def main():
                 for kk in range(min(Kl, cores)):
                     th_k, _, gr_k = eng.get_trace(kk, logp=False)
                     traces.append(SimpleNamespace(points=th_k, gradients=gr_k))
-            # bounded sample: `cores` paths (this rank's traces re-used cyclically), first `nf` fits of each; `nf` is
-            # calibrated with a 2-fit probe so that the timed sample costs about args.cpu_seconds of wall-clock
-            sel = [traces[i % len(traces)] for i in range(cores)]
+            minlen = min(len(t.points) for t in traces) - 1
 
-            def run(nf):
+            def run(nf, nthr):
+                # bounded sample: `nthr` paths (this rank's traces re-used cyclically), first `nf` fits of each, one path per thread
+                sel = [traces[i % len(traces)] for i in range(nthr)]
                 th = np.concatenate([t.points[:nf + 1] for t in sel])
                 gr = np.concatenate([t.gradients[:nf + 1] for t in sel])
-                off = np.arange(cores + 1, dtype=np.int64) * (nf + 1)
+                off = np.arange(nthr + 1, dtype=np.int64) * (nf + 1)
                 sd = np.arange(len(th), dtype=np.uint64) + np.uint64(1)
                 t1 = time.perf_counter()
-                r = po.multipath_fit_elbo(off, th, gr, J, otg, N_e, sd, nthreads=cores)
-                return r, time.perf_counter() - t1
+                r = po.multipath_fit_elbo(off, th, gr, J, otg, N_e, sd, nthreads=nthr)
+                return r["total_draws"], time.perf_counter() - t1
 
-            _, t_probe = run(2)
-            nf = int(max(2, min(args.cpu_seconds / max(t_probe / 2, 1e-3), min(len(t.points) for t in traces) - 1)))
-            r, t_cpu = run(nf)
-            # single-thread figure (SURVEY 8d asks for 1 thread and all cores): one path, a few fits
-            one = None
+            budget = args.cpu_seconds
+            n_probe, t_probe = run(min(8, minlen), cores)
+            per_fit = t_probe / min(8, minlen)                        # wall seconds per fit and path with every core busy
+            nf = int(max(2, min(0.45 * budget / max(per_fit, 1e-3), minlen)))
+            n_all, t_all = run(nf, cores)
+            # the SAME per-thread work (first nf fits of a path: early fits have a shorter history and are cheaper, so only equal windows
+            # compare) on 1 thread and on a ladder of thread counts: where the port stops scaling is visible in the line
+            n_one, t_one = run(nf, 1)
+            one = round(n_one / t_one, 1)
+            scaling = {"1": one, str(cores): round(n_all / t_all, 1)}
+            nf_s = nf if t_all < 2.0 else int(max(8, nf // 6))
+            for nthr in (2, 8, 32, 128):
+                if nthr < cores:
+                    n_s, t_s = run(nf_s, nthr)
+                    scaling[str(nthr)] = round(n_s / t_s, 1)
+            # LAPACK leg: warm-up (SciPy import, workspace queries), calibrate with two fits per path, then ~0.3 of the budget
+            lap = None
             try:
-                nf1 = max(2, min(int(2.0 / max(t_probe / 2 / 1.0, 1e-3) * cores / max(cores, 1)), 12))
-                th1, gr1 = sel[0].points[:nf1 + 1], sel[0].gradients[:nf1 + 1]
-                t1 = time.perf_counter()
-                r1 = po.multipath_fit_elbo(np.array([0, nf1 + 1], dtype=np.int64), th1, gr1, J, otg, N_e,
-                                           np.arange(nf1 + 1, dtype=np.uint64) + np.uint64(1), nthreads=1)
-                one = round(r1["total_draws"] / (time.perf_counter() - t1), 1)
-            except Exception:
-                pass
-            cpu = {"value": round(r["total_draws"] / t_cpu, 1), "unit": "ELBO draws/s", "cores": cores,
+                cl.timed_run(traces, J, tg, N_e, 1, 1)
+                n_p, t_p = cl.timed_run(traces, J, tg, N_e, 2, cores)
+                nf_l = int(max(2, min(0.3 * budget / max(t_p / 2, 1e-3), minlen)))
+                n_l, t_l = cl.timed_run(traces, J, tg, N_e, nf_l, cores)
+                n_1, t_1 = cl.timed_run(traces, J, tg, N_e, nf_l, 1)
+                lap = {"value": round(n_l / t_l, 1), "unit": "ELBO draws/s", "cores": cores, "kind": "lapack", "value_1_thread": round(n_1 / t_1, 1),
+                       "sample": f"{cores} paths x first {nf_l} fits x {N_e} draws (d={d}, J={J}) = {n_l} draws in {t_l:.1f} s; SciPy dgeqrf / dormqr / dtrmm "
+                                 "on d x N blocks + NumPy randn / reductions, one thread per path, BLAS pinned to 1 thread per path"}
+            except Exception as ex:  # pragma: no cover
+                lap = {"value": None, "kind": "lapack", "sample": f"failed: {ex!r}"}
+            cpu = {"value": round(n_all / t_all, 1), "unit": "ELBO draws/s", "cores": cores,
                    "kind": "port", "value_1_thread": one,
                    "sample": f"{cores} paths x first {nf} fits x {N_e} draws (d={d}, J={J}) = "
-                             f"{r['total_draws']} draws in {t_cpu:.1f} s, OpenMP over paths"}
+                             f"{n_all} draws in {t_all:.1f} s, OpenMP over paths (oracle/pf_oracle.c, scalar reflector-by-reflector Q apply)",
+                   "usable_cores": {"sched_getaffinity": aff, "os_cpu_count": logical, "cgroup_cpu_quota": quota, "used": cores},
+                   "port_scaling_draws_per_s_by_threads": scaling,
+                   "port_scaling_note": f"1 and {cores} threads: first {nf} fits per path; the other rungs: first {nf_s} (early fits are cheaper: compare like "
+                                        f"with like); speed-up all cores / 1 thread = {(n_all / t_all) / one if one else float('nan'):.1f}x",
+                   "lapack": lap}
         except Exception as e:  # pragma: no cover
             cpu = {"value": None, "unit": "ELBO draws/s", "cores": os.cpu_count(), "kind": "port",
                    "sample": f"failed: {e!r}"}
+
+    # ---- where the curve bends: the parts of a step / of the end-to-end call that do NOT shrink with the GPU count, on
+    #      rank 0, per step, next to the parts that do (fit, ELBO scan, pool)
+    non_sharding = None
+    if rank == 0 and stages:
+        ps = lambda n: stages.get(n, {}).get("ms_per_step", 0.0)        # noqa: E731
+        shard_ms = ps("fit") + ps("elbo_draws") + ps("elbo_draws_x") + ps("elbo_reduce")
+        fixed = {"history_walk": ps("history"), "psis_replicated": ps("psis"), "index_selection_and_owner_gather": ps("resample"),
+                 "collective_handshake_host": ps("comm_handshake_host"), "all_gather_log_ratios": ps("comm_allgather"),
+                 "result_all_reduce": ps("comm_allreduce")}
+        fixed["host_launch_gaps_and_result_download"] = round(ms_per_step - shard_ms - sum(fixed.values()), 4)
+        non_sharding = {"per_step_ms": fixed, "sharding_stages_ms": round(shard_ms, 4), "step_ms": round(ms_per_step, 4),
+                        "non_sharding_total_ms": round(ms_per_step - shard_ms, 4),
+                        "outside_the_hot_path_ms": {"optimize_device_lbfgs": stages.get("optimize", {}).get("ms"),
+                                                    "trace_pack": stages.get("trace_pack", {}).get("ms")},
+                        "note": "rank 0; stage figures are hipEvent pairs left in the engine's stream during the timed steps (the handshake of the "
+                                "process-per-GPU mode is host wall-clock: it synchronises); with N ranks the sharding stages shrink ~1/N, these do not"}
 
     if rank == 0:
         line = {
@@ -702,6 +747,7 @@ def main():
             "pareto_k": state.get("pareto_k"),
             "sharded_equals_single": verdict, "sharded_equals_single_note": vnote, "rccl_version": rccl_version,
             "stages_ms": stages,
+            "non_sharding_ms": non_sharding,
             "callback_target": callback_line,
             "device_callback_target": devcb_line,
             "roofline": roofline,

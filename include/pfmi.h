@@ -43,6 +43,7 @@ typedef struct pfmi_ctx pfmi_ctx;
 #define PFMI_ERR_UNSUPPORTED (-4)
 #define PFMI_ERR_NUMERIC (-5)
 #define PFMI_ERR_COMM (-6)
+#define PFMI_ERR_RETRY (-7)   /* transient: the enqueued step was discarded (e.g. the GPU is shared and an in-kernel hand-over timed out); enqueue it again */
 
 /* per-fit status (src/woodbury.jl:189-190, 202, 205) */
 #define PFMI_FIT_OK 0

@@ -24,6 +24,7 @@
 // implements the 11 entry points below among contexts of one process), PFMI_COMM_ALLOW_SHARED_GPU=1 lets several ranks sit on the
 // same GPU -- together they execute the G > 1 data path (rank offsets, G-way gather, zero fill, reduce) on a 1-GPU box.
 #include "pfmi_common.h"
+#include <chrono>
 
 #include <dlfcn.h>
 #include <math.h>
@@ -178,8 +179,18 @@ void pf_comm_ctx_dying(pfmi_ctx *x) {
 
 namespace {
 
+// stage timers of the collectives (pfmi_profile): an event pair around the group call on every local context's stream; the handshake of
+// the process-per-GPU mode synchronises the host, so its figure is host wall-clock ("comm_handshake_host", rank's first context)
+void prof_begin_all(pfmi_comm *c) {
+    for (pfmi_ctx *x : c->ctx) if (x->profile) { (void)hipSetDevice(x->device); pf_kernel_begin(x); }
+}
+void prof_end_all(pfmi_comm *c, const char *name) {
+    for (pfmi_ctx *x : c->ctx) if (x->profile) { (void)hipSetDevice(x->device); pf_kernel_end(x, name); }
+}
+
 int32_t group_all_gather(pfmi_comm *c) {
     const size_t nl = c->ctx.size();
+    prof_begin_all(c);
     PF_NCCL(g_rccl.GroupStart());
     for (size_t i = 0; i < nl; ++i) {
         pfmi_ctx *x = c->ctx[i];
@@ -191,11 +202,13 @@ int32_t group_all_gather(pfmi_comm *c) {
         }
     }
     PF_NCCL(g_rccl.GroupEnd());
+    prof_end_all(c, "comm_allgather");
     return PFMI_OK;
 }
 
-int32_t group_all_reduce(pfmi_comm *c, std::vector<DevBuf> &buf, size_t count, ncclRedOp_t op) {
+int32_t group_all_reduce(pfmi_comm *c, std::vector<DevBuf> &buf, size_t count, ncclRedOp_t op, const char *stage = nullptr) {
     const size_t nl = c->ctx.size();
+    if (stage) prof_begin_all(c);
     PF_NCCL(g_rccl.GroupStart());
     for (size_t i = 0; i < nl; ++i) {
         pfmi_ctx *x = c->ctx[i];
@@ -207,6 +220,7 @@ int32_t group_all_reduce(pfmi_comm *c, std::vector<DevBuf> &buf, size_t count, n
         }
     }
     PF_NCCL(g_rccl.GroupEnd());
+    if (stage) prof_end_all(c, stage);
     return PFMI_OK;
 }
 
@@ -221,6 +235,7 @@ int32_t handshake(pfmi_comm *c, double v, int local_err, const char *why, double
     *vmax = *vmin = v;
     if ((int)nl < c->world) {                                   // one process per GPU: the other ranks are somewhere else
         double h[4] = {v, -v, (double)local_err, 0.0}, r[4] = {0, 0, 0, 0};
+        const auto hs_t0 = std::chrono::steady_clock::now();
         for (size_t i = 0; i < nl; ++i) {
             PF_HIP(hipSetDevice(c->ctx[i]->device));
             PF_TRY(c->hs[i].ensure(sizeof(h)));                 // 256 bytes, allocated by the first handshake of the communicator
@@ -230,6 +245,11 @@ int32_t handshake(pfmi_comm *c, double v, int local_err, const char *why, double
         PF_HIP(hipSetDevice(c->ctx[0]->device));
         PF_TRY(pf_download(c->ctx[0], r, c->hs[0].p, sizeof(r)));
         PF_TRY(pf_stream_sync(c->ctx[0]));
+        if (c->ctx[0]->profile) {
+            KernelStat &ks = c->ctx[0]->kstats["comm_handshake_host"];
+            ks.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - hs_t0).count();
+            ks.launches += 1;
+        }
         PF_CHECK(r[2] == 0.0, PFMI_ERR_STATE, "comm: a rank of the group cannot take part in the pooled stage%s%s", local_err ? ": " : "",
                  local_err ? why : " (see that rank's error)");
         *vmax = r[0];
@@ -367,7 +387,7 @@ int32_t enqueue_resample(pfmi_comm *c, int64_t ndraws, int32_t importance, int32
         bool all_buffers = true;
         for (size_t i = 0; i < nl; ++i) all_buffers = all_buffers && c->out[i].cap >= sizeof(double) * (size_t)(n + 1);
         // (without its buffer a rank cannot enter: only reachable when the caller skipped the handshake, which the entry points never do)
-        if (all_buffers) PF_TRY(group_all_reduce(c, c->out, (size_t)n + 1, ncclSum));
+        if (all_buffers) PF_TRY(group_all_reduce(c, c->out, (size_t)n + 1, ncclSum, "comm_allreduce"));
     }
     return rc_local;
 }

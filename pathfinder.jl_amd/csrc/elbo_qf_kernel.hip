@@ -628,8 +628,13 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
                     while (__hip_atomic_load(cflag + tail_f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch && spins < QF_SHARE_SPINS) {
                         __builtin_amdgcn_s_sleep(32); ++spins;
                     }
-                    // (never seen: every publisher is dispatched before any dependent.  Draws finished without the constants would be
-                    //  silently wrong, so a publisher that does not show up poisons them and is counted for the host.)
+                    // (never seen.  Why a dependent cannot starve its publisher: publishers precede dependents in the grid, and a publisher never
+                    //  blocks -- it needs nothing from anybody -- so once dispatched it always finishes; dispatch order is per XCD queue, not
+                    //  device-wide, so a dependent may START first, but it only spins, it holds nothing a publisher waits for.  What the
+                    //  time-out guards against is the publisher not being dispatched AT ALL for seconds: another process holding the CUs, CU
+                    //  masking, a debugger / profiler serialising dispatch.  Draws finished without the constants would be silently wrong, so
+                    //  they are poisoned and counted; pfmi_elbo_batch_wait turns the count into the retryable PFMI_ERR_RETRY and switches this
+                    //  ctx to the two-launch cut, which has no in-kernel wait.)
                     if (spins >= QF_SHARE_SPINS) { cn_s[3] = NAN; atomicAdd(cflag + n_tail_l, 1u); }
                 }
                 __syncthreads();
@@ -797,7 +802,7 @@ static int32_t launch_qf_ng(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
     int gpw_t = gpw, gx_t = gx, ndep = 0;
     const char *no_tail = pf_debug_get("PFMI_QF_NO_TAIL");            // test hook: one workgroup per fit (geometry-invariance tests)
     const char *two = pf_debug_get("PFMI_QF_TWO_LAUNCHES");          // test hook: the round-3 cut
-    const bool two_launches = two && two[0] == '1';
+    const bool two_launches = (two && two[0] == '1') || c->qf_no_share;   // (qf_no_share: a hand-over timed out on this ctx before, pfmi_elbo_batch_wait)
     if (split == 1 && TGT != 0 && !(no_tail && no_tail[0] == '1')) {
         int ncu = 0;
         PF_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device));

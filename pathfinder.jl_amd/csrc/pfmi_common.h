@@ -132,6 +132,8 @@ struct pfmi_ctx {
     DevBuf scratch;     // misc
     DevBuf qf_share;    // scan: per-fit constants handed from a tail fit's first piece to its other pieces, + one flag per tail fit
     uint32_t qf_epoch = 0;   // launch counter of the shared-constants scan: a flag equal to it means "published in THIS launch"
+    bool qf_no_share = false; // a hand-over of the shared-constants scan timed out on this ctx: later scans take the two-launch cut (no in-kernel wait)
+    int64_t qf_lost_total = 0; // pieces that ever gave up waiting (pfmi_kernel_time("qf_handover_lost") reports it as `launches`)
 
     // pool / PSIS / resample state
     bool pooled = false;

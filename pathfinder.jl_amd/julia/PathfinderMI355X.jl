@@ -48,10 +48,11 @@ mutable struct Engine
     device::Int
     generation::Int                 # bumped whenever traces / fits change: lazy handles made earlier refuse to read
     keepalive::Any                  # the boxed logp closure handed to the C side
+    comms::Dict{Vector{Ptr{Cvoid}},Any}   # communicators whose FIRST member is this engine, by member list (see comm_for)
     function Engine(device::Integer=0)
         ref = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:pfmi_create, libpfmi), Int32, (Int32, Ref{Ptr{Cvoid}}), device, ref))
-        eng = new(ref[], device, 0, nothing)
+        eng = new(ref[], device, 0, nothing, Dict{Vector{Ptr{Cvoid}},Any}())
         finalizer(close, eng)
         return eng
     end
@@ -60,15 +61,18 @@ end
     close(eng::Engine)
 
 Destroy the context now (idempotent; also the finalizer).  Communicators that hold this engine are closed FIRST: the cached ones on
-this side (`_COMM_CACHE`), and -- whatever order the GC runs finalizers in -- `pfmi_destroy` itself tears down every live `pfmi_comm`
+this side (`eng.comms`), and -- whatever order the GC runs finalizers in -- `pfmi_destroy` itself tears down every live `pfmi_comm`
 that borrows the context before freeing it (csrc/comm_rccl.hip: pf_comm_ctx_dying), so a later `pfmi_comm_destroy` never dereferences
 a dead `pfmi_ctx`.
 """
 function Base.close(eng::Engine)
     eng.ptr == C_NULL && return nothing
-    for (key, c) in collect(_COMM_CACHE)
-        eng.ptr in key && (close(c); delete!(_COMM_CACHE, key))
+    # the communicators cached on this engine go first (those cached on OTHER engines that contain this one are torn down by pfmi_destroy
+    # itself on the C side -- pf_comm_ctx_dying -- and replaced at the next comm_for, which checks their members)
+    for c in values(eng.comms)
+        close(c)
     end
+    empty!(eng.comms)
     ccall((:pfmi_destroy, libpfmi), Int32, (Ptr{Cvoid},), eng.ptr)
     eng.ptr = C_NULL
     return nothing
@@ -98,15 +102,18 @@ function Base.close(c::Comm)
 end
 # One communicator per SET of engines, created at first use and kept (an ncclCommInitAll per multipathfinder call would cost more than
 # the pooled stage itself); `close(eng)` removes the entries its engine is part of.  Same policy as the Python host's `_comm_for`.
-const _COMM_CACHE = Dict{Vector{Ptr{Cvoid}},Comm}()
+# The cache lives ON the first engine of the set, not in a global (ADVICE r4: a global Dict was mutated from finalizers without a lock and
+# kept every engine ever passed to multipathfinder(engines, ...) alive): Comm -> engines -> comms -> Comm is an ordinary reference cycle,
+# collected as a whole once the caller drops the engines.  One Engine belongs to one host thread, so no lock is needed.
 function comm_for(engines::Vector{Engine})
     key = [e.ptr for e in engines]
-    c = get(_COMM_CACHE, key, nothing)
-    if c === nothing || c.ptr == C_NULL
+    cache = engines[1].comms
+    c = get(cache, key, nothing)
+    if c === nothing || c.ptr == C_NULL || any(e.ptr == C_NULL for e in c.engines)
         c = Comm(engines)
-        _COMM_CACHE[key] = c
+        cache[key] = c
     end
-    return c
+    return c::Comm
 end
 
 # ---- target: arbitrary Julia closure through @cfunction (the reference's general logp, src/elbo.jl:15) --------------------

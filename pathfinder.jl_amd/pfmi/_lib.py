@@ -15,6 +15,12 @@ class PfmiError(RuntimeError):
     pass
 
 
+class PfmiRetry(PfmiError):
+    """PFMI_ERR_RETRY (-7): a transient condition voided the enqueued step (the GPU is shared with another process / a profiler serialises
+    dispatch and an in-kernel hand-over of the scan timed out).  The library has switched the context to the route without in-kernel
+    waits; enqueue the step again."""
+
+
 class pfmi_target(C.Structure):
     _fields_ = [("kind", C.c_int32), ("d", C.c_int32), ("r", C.c_int32), ("reserved", C.c_int32),
                 ("mean", C.POINTER(C.c_double)), ("a", C.POINTER(C.c_double)),
@@ -77,5 +83,7 @@ def lib():
 
 
 def check(rc):
+    if rc == -7:
+        raise PfmiRetry(f"libpfmi: {lib().pfmi_last_error().decode()}")
     if rc != 0:
         raise PfmiError(f"libpfmi error {rc}: {lib().pfmi_last_error().decode()}")

@@ -20,12 +20,14 @@ from typing import Any, List, Optional
 
 import numpy as np
 
+from ._lib import PfmiRetry
 from .core import Engine, StaleHandleError  # noqa: F401
 from .hostrng import HostRNG, rand_u64_multi
 from .optimize import OptimizationTrace, optimize_with_trace
 
 DEFAULT_HISTORY_LENGTH = 6     # src/Pathfinder.jl:24
 DEFAULT_NDRAWS_ELBO = 5        # src/Pathfinder.jl:27
+_RETRIES = 2                   # how often a call is re-enqueued after PFMI_ERR_RETRY (pfmi._lib.PfmiRetry)
 
 
 class _LazySeq(Sequence):
@@ -593,9 +595,17 @@ def pathfinder(target, *, rng=None, init=None, dim=-1, init_scale=2, init_sample
         dim = len(init)
     eng = engine or Engine()
     eng.set_target(target)
-    state, _ = _run_paths([eng], target, [init], [rng], dim=dim, history_length=history_length,
-                          ndraws_elbo=ndraws_elbo, ntries=ntries, init_sampler=init_sampler,
-                          optimizer_kwargs=optimizer_kwargs, materialise=materialise, optimizer=optimizer, strict=strict)
+    rng_state = (rng.seed, rng.counter) if isinstance(rng, HostRNG) else None
+    for attempt in range(_RETRIES + 1):
+        try:
+            state, _ = _run_paths([eng], target, [init], [rng], dim=dim, history_length=history_length,
+                                  ndraws_elbo=ndraws_elbo, ntries=ntries, init_sampler=init_sampler,
+                                  optimizer_kwargs=optimizer_kwargs, materialise=materialise, optimizer=optimizer, strict=strict)
+            break
+        except PfmiRetry:       # transient (GPU shared / dispatch serialised): the library switched to its wait-free route; same seeds again
+            if attempt == _RETRIES or rng_state is None:
+                raise
+            rng.seed, rng.counter = rng_state
     st = state[0]
     a = _assemble_path(st, rng, ndraws_elbo, materialise)
     X = eng.draws(a["fit_point"], a["draw_seed"], ndraws)[0]     # src/singlepath.jl:226-233
@@ -634,10 +644,17 @@ def multipathfinder(target, ndraws, *, init=None, nruns=-1, ndraws_elbo=DEFAULT_
         e.set_target(target)
     resample_seed = int(rng.rand_u64(1)[0])                                                     # _resample's draw from the top-level rng (:225)
     # draws_per_component = stack(draws) (:217), _compute_psis_result (:221), _resample (:225): enqueued behind the ELBO scan
-    state, pooled = _run_paths(engs, target, inits, run_rngs, dim=dim, history_length=history_length,
-                               ndraws_elbo=ndraws_elbo, ntries=ntries, init_sampler=init_sampler,
-                               optimizer_kwargs=optimizer_kwargs, materialise=materialise, optimizer=optimizer, strict=strict,
-                               pool=dict(N_r=ndraws_per_run, ndraws=ndraws, importance=importance, seed=resample_seed))
+    for attempt in range(_RETRIES + 1):
+        try:
+            state, pooled = _run_paths(engs, target, inits, run_rngs, dim=dim, history_length=history_length,
+                                       ndraws_elbo=ndraws_elbo, ntries=ntries, init_sampler=init_sampler,
+                                       optimizer_kwargs=optimizer_kwargs, materialise=materialise, optimizer=optimizer, strict=strict,
+                                       pool=dict(N_r=ndraws_per_run, ndraws=ndraws, importance=importance, seed=resample_seed))
+            break
+        except PfmiRetry:       # transient (GPU shared / dispatch serialised): every run again from its own seed, the same answer
+            if attempt == _RETRIES:
+                raise
+            run_rngs = [rng.copy().seed_(int(s)) for s in run_seeds]
     parts = [_assemble_path(st, r, ndraws_elbo, materialise) for st, r in zip(state, run_rngs)]
     # the per-run draws (d, N_r, K) stay on the device.  A run's block is a pure function of (fit, draw_seed, N_r): when it is
     # looked at it is REGENERATED from the seed (bit-identical to the pool block, tests: pool == eng.draws), so the handle

@@ -24,14 +24,17 @@ def _d(a):
 # after the other (16 GB/s); into page-locked memory it is one DMA transfer (54 GB/s).  Allocating such memory costs milliseconds, so
 # blocks are recycled: when the last array that views a block is garbage collected the block goes back to a small pool.
 _PIN_MIN_BYTES = int(float(os.environ.get("PFMI_PIN_MIN_MB", "16")) * (1 << 20))      # (override: A/B runs of tests/probes)
-_PIN_KEEP = 2                            # blocks kept per size class
-_pin_free = {}                           # size class (bytes, power of two) -> [addresses]
+_PIN_MAX_BYTES = int(float(os.environ.get("PFMI_PIN_MAX_MB", "512")) * (1 << 20))     # larger results go to ordinary (pageable) memory
+_PIN_KEEP_BYTES = int(float(os.environ.get("PFMI_PIN_KEEP_MB", "1024")) * (1 << 20))  # page-locked bytes kept for reuse, all classes together
+_PIN_GRAIN = 2 << 20                     # blocks are whole multiples of 2 MB (power-of-two classes wasted up to 2x)
+_pin_free = {}                           # block size (bytes) -> [addresses]
+_pin_kept = [0]                          # bytes currently parked in _pin_free
 
 
 def _pin_release(cls_bytes, addr):
-    keep = _pin_free.setdefault(cls_bytes, [])
-    if len(keep) < _PIN_KEEP:
-        keep.append(addr)
+    if _pin_kept[0] + cls_bytes <= _PIN_KEEP_BYTES:
+        _pin_free.setdefault(cls_bytes, []).append(addr)
+        _pin_kept[0] += cls_bytes
     else:
         _lib.lib().pfmi_host_free(C.c_void_p(addr))
 
@@ -40,12 +43,13 @@ def result_empty(shape, dtype=np.float64):
     """np.empty(shape, order='F') for a result the library downloads into; page-locked when large (falls back to ordinary memory
     when page-locked memory is refused)"""
     nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
-    if nbytes < _PIN_MIN_BYTES:
+    if nbytes < _PIN_MIN_BYTES or nbytes > _PIN_MAX_BYTES:     # (multi-GB page-locked blocks starve the host and take seconds to allocate)
         return np.empty(shape, dtype=dtype, order="F")
-    cls_bytes = 1 << (nbytes - 1).bit_length()
+    cls_bytes = -(-nbytes // _PIN_GRAIN) * _PIN_GRAIN
     free = _pin_free.get(cls_bytes)
     if free:
         addr = free.pop()
+        _pin_kept[0] -= cls_bytes
     else:
         p = C.c_void_p()
         if _lib.lib().pfmi_host_alloc(C.c_int64(cls_bytes), C.byref(p)) != 0 or not p.value:

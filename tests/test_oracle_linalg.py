@@ -277,3 +277,41 @@ def _check_directions(tr, n, J):
         cosines.append((p @ step) / np.linalg.norm(p) / np.linalg.norm(step))
     assert nrej == 0
     np.testing.assert_allclose(cosines, 1.0, rtol=0, atol=1e-8)
+
+
+def test_lapack_baseline_leg_equals_oracle_on_same_normals():
+    """tests/cpu_lapack_baseline.py (bench.py's `kind: "lapack"` CPU leg: dgeqrf / dormqr / dtrmm on d x N blocks) against the scalar
+    oracle on identical standard normals: same Householder convention => same draws, logq, mean, logdet."""
+    import cpu_lapack_baseline as cl
+    import pfmi
+    from helpers import make_traces
+    tg = pfmi.t_lowrank(40, r=4, seed=3)
+    tr = make_traces(tg, 1, 5)[0]
+    J, N = 6, 64
+    alpha_all, hl, hs, _ = po.lbfgs_history(tr.points, tr.gradients, J)
+    rng = np.random.default_rng(0)
+    nchk = 0
+    for l in (1, 2, len(tr) // 2, len(tr) - 1):
+        j = int(hl[l])
+        S = np.stack([tr.points[s + 1] - tr.points[s] for s in hs[l, :j]], axis=1)
+        Y = np.stack([tr.gradients[s] - tr.gradients[s + 1] for s in hs[l, :j]], axis=1)
+        B, D = po.lbfgs_inverse_hessian(alpha_all[l], S, Y)
+        Fo = po.Factor(alpha_all[l], B, D)
+        Fl = cl.factor(alpha_all[l], B, D)
+        assert abs(Fl["logdet"] - Fo.logdet) <= 1e-10 * (1 + abs(Fo.logdet))
+        mu_o = Fo.fit_mean(tr.points[l], tr.gradients[l])
+        mu_l = cl.fit_mean(Fl, tr.points[l], tr.gradients[l])
+        np.testing.assert_allclose(mu_l, mu_o, rtol=1e-9, atol=1e-10)
+        U = np.asfortranarray(rng.standard_normal((tg.d, N)))
+        Xo, lqo = Fo.rand_and_logpdf(mu_o, U)
+        Xl, lql = cl.rand_and_logpdf(Fl, mu_l, U.copy(order="F"))
+        np.testing.assert_allclose(lql, lqo, rtol=1e-10, atol=1e-10)
+        W = Fo.dense()
+        # the draws agree up to the sign convention of the reflectors only when R's diagonal is well separated from 0; the law always does
+        np.testing.assert_allclose(np.cov(Xl), np.cov(Xo), atol=0.5 * np.abs(W).max())
+        if np.abs(np.diag(Fo.QR[:Fo.k, :Fo.k])).min() > 1e-6 * np.abs(np.diag(Fo.QR[:Fo.k, :Fo.k])).max():
+            np.testing.assert_allclose(Xl, Xo, rtol=1e-7, atol=1e-8)
+            nchk += 1
+    assert nchk >= 2
+    elbo, nd = cl.path_elbo(tr.points, tr.gradients, J, tg, 200, 1, nfits=5)
+    assert nd == 5 * 200 and np.all(np.isfinite(elbo[1:6]))
