@@ -658,12 +658,12 @@ def main():
                     traces.append(SimpleNamespace(points=th_k, gradients=gr_k))
             minlen = min(len(t.points) for t in traces) - 1
 
-            def run(nf, nthr):
-                # bounded sample: `nthr` paths (this rank's traces re-used cyclically), first `nf` fits of each, one path per thread
-                sel = [traces[i % len(traces)] for i in range(nthr)]
+            def run(nf, nthr, reps=1):
+                # bounded sample: `nthr * reps` paths (this rank's traces re-used cyclically), first `nf` fits of each, `nthr` at a time
+                sel = [traces[i % len(traces)] for i in range(nthr * reps)]
                 th = np.concatenate([t.points[:nf + 1] for t in sel])
                 gr = np.concatenate([t.gradients[:nf + 1] for t in sel])
-                off = np.arange(nthr + 1, dtype=np.int64) * (nf + 1)
+                off = np.arange(nthr * reps + 1, dtype=np.int64) * (nf + 1)
                 sd = np.arange(len(th), dtype=np.uint64) + np.uint64(1)
                 t1 = time.perf_counter()
                 r = po.multipath_fit_elbo(off, th, gr, J, otg, N_e, sd, nthreads=nthr)
@@ -673,13 +673,14 @@ def main():
             n_probe, t_probe = run(min(8, minlen), cores)
             per_fit = t_probe / min(8, minlen)                        # wall seconds per fit and path with every core busy
             nf = int(max(2, min(0.45 * budget / max(per_fit, 1e-3), minlen)))
-            n_all, t_all = run(nf, cores)
+            reps = int(max(1, min(8, 0.45 * budget / max(per_fit * nf, 1e-3))))      # short traces: several paths per thread, one after the other
+            n_all, t_all = run(nf, cores, reps)
             # the SAME per-thread work (first nf fits of a path: early fits have a shorter history and are cheaper, so only equal windows
             # compare) on 1 thread and on a ladder of thread counts: where the port stops scaling is visible in the line
-            n_one, t_one = run(nf, 1)
+            n_one, t_one = run(nf, 1, reps)
             one = round(n_one / t_one, 1)
             scaling = {"1": one, str(cores): round(n_all / t_all, 1)}
-            nf_s = nf if t_all < 2.0 else int(max(8, nf // 6))
+            nf_s = nf if t_all < 3.0 else int(max(8, nf // 4))
             for nthr in (2, 8, 32, 128):
                 if nthr < cores:
                     n_s, t_s = run(nf_s, nthr)
@@ -699,7 +700,7 @@ def main():
                 lap = {"value": None, "kind": "lapack", "sample": f"failed: {ex!r}"}
             cpu = {"value": round(n_all / t_all, 1), "unit": "ELBO draws/s", "cores": cores,
                    "kind": "port", "value_1_thread": one,
-                   "sample": f"{cores} paths x first {nf} fits x {N_e} draws (d={d}, J={J}) = "
+                   "sample": f"{cores * reps} paths x first {nf} fits x {N_e} draws (d={d}, J={J}) = "
                              f"{n_all} draws in {t_all:.1f} s, OpenMP over paths (oracle/pf_oracle.c, scalar reflector-by-reflector Q apply)",
                    "usable_cores": {"sched_getaffinity": aff, "os_cpu_count": logical, "cgroup_cpu_quota": quota, "used": cores},
                    "port_scaling_draws_per_s_by_threads": scaling,

@@ -50,6 +50,7 @@ typedef struct pfmi_ctx pfmi_ctx;
 #define PFMI_FIT_A_NOT_PD 1
 #define PFMI_FIT_C_NOT_PD 2
 #define PFMI_FIT_NONFINITE 3
+#define PFMI_FIT_ABSENT 4       /* streaming layout (pfmi_stream_enqueue): the path ended before this slot -- there is no such trace point */
 
 /* target kinds: the hot path only ever sees logp(x) = -f(x) (src/singlepath.jl:186, src/multipath.jl:159) */
 #define PFMI_TARGET_GAUSS 0          /* offset - 1/2 [ sum a_i e_i^2 - || G Wd' e ||^2 ], e = x - mean  */
@@ -133,6 +134,22 @@ int32_t pfmi_optimize_batch_wait(pfmi_ctx *ctx, int64_t *npoints);
 /* OptimizationTrace of path k (src/optimize.jl:94-100): theta/grad (L_k+1) x d point-major, logp L_k+1; any may be
  * NULL.  logp is only available for traces made by pfmi_optimize_batch. */
 int32_t pfmi_get_trace(pfmi_ctx *ctx, int32_t k, double *theta, double *logp, double *grad);
+
+/* ---- streaming pipeline (round 5): optimise + fit + ELBO scan as ONE enqueued dataflow ---------------------------------------
+ * What src/singlepath.jl:285-325 does for one run -- optimise (:285-297), fit_mvnormals (:301-303), maximize_elbo (:306-308) -- for K
+ * runs at once, with the fits and scans of the trace points a path has ALREADY produced running while the paths are still being
+ * optimised (the reference overlaps whole runs over tasks, src/multipath.jl:190-208).  Equivalent to, and bit-identical with,
+ *     pfmi_optimize_batch(K, x0, J, maxiters, g_tol) ; pfmi_fit_batch(J, eps) ; pfmi_elbo_batch_enqueue(N, seeds')
+ * except for the LAYOUT: trace point l of path k is slot  p = k * (maxiters + 1) + l  in every per-point array of the context (status,
+ * j_eff, logdet, elbo, se, ... have K * (maxiters + 1) entries; the slots a path did not reach carry status PFMI_FIT_ABSENT / NaN), and
+ * `seeds` is laid out the same way: seeds[k * (maxiters + 1) + l] = the UInt64 seed of the ELBO estimate of fit l of run k
+ * (src/elbo.jl:2; entries beyond a path's end are never used -- draw maxiters + 1 per run from a COPY of its rng, advance the rng by the
+ * path's length afterwards).  Only enqueues; pfmi_stream_wait returns the points per path, pfmi_elbo_batch_wait the ELBO table, and
+ * pfmi_pool_build_best / pfmi_comm_psis_resample may be enqueued in between.  Built-in targets, history_length <= 16, 2 K <= #CU;
+ * PFMI_ERR_UNSUPPORTED otherwise (use the three calls above). */
+int32_t pfmi_stream_enqueue(pfmi_ctx *ctx, int32_t K, const double *x0, int32_t history_length, int32_t maxiters, double g_tol,
+                            double eps, int64_t N, const uint64_t *seeds);
+int32_t pfmi_stream_wait(pfmi_ctx *ctx, int64_t *npoints);
 
 /* ---- fit_mvnormals / lbfgs_inverse_hessians / pdfactorize --------------------------------------- */
 /* replaces fit_mvnormals (src/mvnormal.jl:14-21) = lbfgs_inverse_hessians (src/inverse_hessian.jl:25-66)

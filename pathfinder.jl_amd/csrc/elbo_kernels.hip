@@ -226,12 +226,13 @@ __global__ __launch_bounds__(256) void pf_elbo_reduce_kernel(int64_t N, const in
 // later NaNs are skipped, strict > so the first maximum wins).  1-based result, 0 when L == 0.
 // One wave per path (round 1 walked each path with one thread: ~175 dependent loads, 65 us): lane-local candidates, then a
 // butterfly that keeps the larger value and, among equal values, the smaller index.
-__global__ __launch_bounds__(64) void pf_elbo_argmax_kernel(int K, const int64_t *__restrict__ off, const double *__restrict__ elbo,
-                                                           int64_t *__restrict__ best_iter) {
+// (npts != nullptr: the streaming layout -- path k owns npts[k] points from off[k] on, not everything up to off[k + 1])
+__global__ __launch_bounds__(64) void pf_elbo_argmax_kernel(int K, const int64_t *__restrict__ off, const int32_t *__restrict__ npts,
+                                                           const double *__restrict__ elbo, int64_t *__restrict__ best_iter) {
     const int k = blockIdx.x, lane = threadIdx.x;
     if (k >= K) return;
     const int64_t p0 = off[k];
-    const int L = (int)(off[k + 1] - p0 - 1);
+    const int L = npts ? npts[k] - 1 : (int)(off[k + 1] - p0 - 1);
     if (L <= 0) { if (lane == 0) best_iter[k] = 0; return; }
     double xmax = 0.0;
     int imax = 0x7FFFFFFF, have = 0;
@@ -280,13 +281,13 @@ __global__ void pf_nan_failed_kernel(int64_t ns, int64_t N, const int32_t *__res
 // Winners of the ELBO scan picked on the device (pfmi_pool_build_best): fit_distributions[fit_iteration + 1] (src/singlepath.jl:224),
 // success = L > 0 && ELBO finite and != -Inf (src/singlepath.jl:299, 309-314); a successful path reuses the seed of its winning
 // fit (src/singlepath.jl:226-230), a failed one takes fail_seeds[k] (rand(rng, fit_distribution, ndraws), :231-233).
-__global__ void pf_pool_pick_kernel(int K, const int64_t *__restrict__ off, const int64_t *__restrict__ best_iter,
+__global__ void pf_pool_pick_kernel(int K, const int64_t *__restrict__ off, const int32_t *__restrict__ npts, const int64_t *__restrict__ best_iter,
                                     const double *__restrict__ elbo, const uint64_t *__restrict__ seeds,
                                     const uint64_t *__restrict__ fail_seeds, int32_t *__restrict__ points, uint64_t *__restrict__ pseeds,
                                     int32_t *__restrict__ ok) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
-    const int64_t p0 = off[k], L = off[k + 1] - p0 - 1, b = best_iter[k];
+    const int64_t p0 = off[k], L = npts ? (int64_t)npts[k] - 1 : off[k + 1] - p0 - 1, b = best_iter[k];
     const int64_t p = p0 + b;
     const double v = (b > 0) ? elbo[p] : NAN;
     const int good = (L > 0 && b > 0 && !isnan(v) && v != -INFINITY) ? 1 : 0;
@@ -466,7 +467,8 @@ int32_t pf_launch_elbo_reduce(pfmi_ctx *c) {
                        c->d_off.as<int64_t>(), c->d_path_of.as<int32_t>(), c->status.as<int32_t>(),
                        c->logp.as<double>(), c->logq.as<double>(), c->elbo.as<double>(), c->se.as<double>());
     hipLaunchKernelGGL(pf_elbo_argmax_kernel, dim3((unsigned)c->K), dim3(64), 0, c->stream, c->K,
-                       c->d_off.as<int64_t>(), c->elbo.as<double>(), c->best_iter.as<int64_t>());
+                       c->d_off.as<int64_t>(), c->virt ? c->st_npts.as<int32_t>() : (const int32_t *)nullptr, c->elbo.as<double>(),
+                       c->best_iter.as<int64_t>());
     pf_kernel_end(c, "elbo_reduce");
     PF_HIP(hipGetLastError());
     return PFMI_OK;
@@ -495,7 +497,7 @@ int32_t pf_launch_nan_failed(pfmi_ctx *c, int64_t ns, int64_t N, const int32_t *
 
 int32_t pf_launch_pool_pick(pfmi_ctx *c, int have_fail_seeds) {
     hipLaunchKernelGGL(pf_pool_pick_kernel, dim3((unsigned)((c->K + 63) / 64)), dim3(64), 0, c->stream, c->K, c->d_off.as<int64_t>(),
-                       c->best_iter.as<int64_t>(), c->elbo.as<double>(), c->seeds.as<uint64_t>(),
+                       c->virt ? c->st_npts.as<int32_t>() : (const int32_t *)nullptr, c->best_iter.as<int64_t>(), c->elbo.as<double>(), c->seeds.as<uint64_t>(),
                        have_fail_seeds ? c->fail_seeds.as<uint64_t>() : (const uint64_t *)nullptr, c->pool_points.as<int32_t>(),
                        c->pool_seeds.as<uint64_t>(), c->pool_ok.as<int32_t>());
     PF_HIP(hipGetLastError());

@@ -806,6 +806,7 @@ static int32_t launch_qf_ng(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
     if (split == 1 && TGT != 0 && !(no_tail && no_tail[0] == '1')) {
         int ncu = 0;
         PF_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device));
+        if (c->ncu_eff > 0 && c->ncu_eff < ncu) ncu = c->ncu_eff;           // streaming segments: the optimiser's workgroups hold some CUs
         const int slots = QF_WAVES * NG, nb_full = (ngroups + NPG + slots - 1) / slots;
         const int64_t rem = ncu > 0 ? nfits % ncu : 0;
         gpw_t = slots - NPG;
@@ -817,15 +818,18 @@ static int32_t launch_qf_ng(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
         if (tail > 0 && share_ok) {
             constexpr int NC = qf_nconst(KC, RPAD);
             const size_t cbytes = (size_t)tail * NC * sizeof(double), fbytes = ((size_t)tail + 1) * sizeof(unsigned);
-            if (c->qf_share.cap < cbytes + fbytes || c->qf_epoch == 0xFFFFFFFFu) {          // (new flags start at 0 = "never published")
-                PF_TRY(c->qf_share.ensure(cbytes + fbytes + (64 << 10)));
-                PF_HIP(hipMemsetAsync(c->qf_share.p, 0, c->qf_share.cap, c->stream));
-                c->qf_epoch = 0;
+            DevBuf &share = c->qf_share_s[c->qf_slot];
+            uint32_t &epoch = c->qf_epoch_s[c->qf_slot];
+            if (share.cap < cbytes + fbytes || epoch == 0xFFFFFFFFu) {          // (new flags start at 0 = "never published")
+                PF_CHECK(!c->stream_pending, PFMI_ERR_STATE, "scan: the hand-over buffer of a streaming call must be allocated before its first launch");
+                PF_TRY(share.ensure(cbytes + fbytes + (64 << 10)));
+                PF_HIP(hipMemsetAsync(share.p, 0, share.cap, c->stream));
+                epoch = 0;
             }
             // flags live at the END of the buffer so that a larger tail of a later launch never reads constants as flags
-            unsigned *cflag = reinterpret_cast<unsigned *>(c->qf_share.as<char>() + c->qf_share.cap) - (tail + 1);
+            unsigned *cflag = reinterpret_cast<unsigned *>(share.as<char>() + share.cap) - (tail + 1);
             hipLaunchKernelGGL(kern, dim3(1, (unsigned)((nfits - tail) + tail * (1 + ndep))), dim3(QF_THREADS), lds_bytes, c->stream, a, ch_blocks,
-                               nchunks, gpw, ngroups, (int)(nfits - tail), (int)tail, ndep, c->qf_share.as<double>(), cflag, ++c->qf_epoch);
+                               nchunks, gpw, ngroups, (int)(nfits - tail), (int)tail, ndep, share.as<double>(), cflag, ++epoch);
             return PFMI_OK;
         }
     }

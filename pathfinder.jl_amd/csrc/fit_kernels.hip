@@ -15,6 +15,8 @@
 // and is what the draw kernel later scalar-loads per row.  Column padding (zeros) sits at the END of
 // the column list only (a zero column in the middle would shift later pivots).
 #include "pfmi_common.h"
+#include "fit_args.h"
+#include <limits.h>
 #include <stdlib.h>
 
 #ifndef FITREG_ABLATE
@@ -45,10 +47,14 @@ template <int EPT, int HIST_NT>
 __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
     int d, int J, double eps, const int64_t *__restrict__ off, const double *__restrict__ theta,
     const double *__restrict__ grad, double *__restrict__ alpha_all, int *__restrict__ hist_len,
-    int *__restrict__ hist_src, int *__restrict__ n_rej, int *__restrict__ acc_list) {
+    int *__restrict__ hist_src, int *__restrict__ n_rej, int *__restrict__ acc_list, HistSeg sg) {
     const int k = blockIdx.x, tid = threadIdx.x;
     const int64_t p0 = off[k];
-    const int L = (int)(off[k + 1] - p0 - 1);
+    // the steps of THIS launch: b + 1 .. L (HistSeg above; the packed route: b = 0, L = the path's last point)
+    const int Ltot = sg.npts ? sg.npts[k] - 1 : (int)(off[k + 1] - p0 - 1);
+    const int L = Ltot < sg.l_end - 1 ? Ltot : sg.l_end - 1;
+    const int b = sg.l_begin > 0 ? sg.l_begin - 1 : 0;
+    if (sg.l_begin > 0 && b >= L) return;                   // the path ended before this segment
     __shared__ double red[2 * 4 * (HIST_NT / 64)];          // two halves: one barrier per iteration (pf_block_sum_pp)
     int flip = 0;
     // ring bookkeeping (src/inverse_hessian.jl:49-52, 105): every thread sees the same `accept` (the block sums are bit-identical
@@ -81,13 +87,18 @@ __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
     };
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
-        const int i = tid + HIST_NT * e;
-        al[e] = 1.0; ial[e] = 1.0;                                             // H0 = I  (:38-39)
-        if (i < d) alpha_all[(size_t)p0 * d + i] = 1.0;
+        const int i = tid + HIST_NT * e, ic = i < d ? i : d - 1;
+        if (sg.l_begin > 0) {                                                  // resume: alpha of point b as stored, the CARRIED 1 / alpha from the state
+            al[e] = alpha_all[(size_t)(p0 + b) * d + ic]; ial[e] = sg.ial_state[(size_t)k * d + ic];
+        } else {
+            al[e] = 1.0; ial[e] = 1.0;                                         // H0 = I  (:38-39)
+            if (i < d) alpha_all[(size_t)p0 * d + i] = 1.0;
+        }
     }
 #pragma unroll
-    for (int q = 0; q < NS; ++q) load_point(q, tq[q], gq[q]);                    // points 0 .. NS - 1
-    if (tid == 0) hist_len[p0] = 0;
+    for (int q = 0; q < NS; ++q) load_point(b + q, tq[q], gq[q]);                // points b .. b + NS - 1
+    if (sg.l_begin > 0) n_acc = sg.nacc_state[k];
+    else if (tid == 0) hist_len[p0] = 0;
     // one trace step: (t0, g0) = point l - 1, (t1, g1) = point l; afterwards the set of point l - 1 is refilled
 #if HIST_PROF
     long long hp[5] = {0, 0, 0, 0, 0}, hp_last = clock64();
@@ -142,7 +153,7 @@ __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
         }
         HP_STAMP(3);
     };
-    int l = 1;
+    int l = b + 1;
     for (; l + NS - 1 <= L; l += NS) {                                          // :43
 #pragma unroll
         for (int q = 0; q < NS; ++q) step(l + q, tq[q], gq[q], tq[(q + 1) % NS], gq[(q + 1) % NS]);
@@ -156,11 +167,16 @@ __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
         printf("HIST_PROF wave %d: %d steps, cycles per step: dots+loads %lld block sum %lld update %lld stores %lld loop %lld\n", tid >> 6, L,
                hp[0] / L, hp[1] / L, hp[2] / L, hp[3] / L, hp[4] / L);
 #endif
-    if (tid == 0) n_rej[k] = L > 0 ? L - n_acc : 0;                             // :57
+    if (tid == 0) n_rej[k] = L > 0 ? L - n_acc : 0;                             // :57  (a later segment of the same path overwrites it)
+    if (sg.ial_state) {                                                         // hand the recurrence on to the next segment
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) { const int i = tid + HIST_NT * e; if (i < d) sg.ial_state[(size_t)k * d + i] = ial[e]; }
+        if (tid == 0) sg.nacc_state[k] = n_acc;
+    }
     // ---- hist_inds (:105) of every point from the accepted list: row l = the last min(n_acc(l), J) accepted steps, oldest first
     __threadfence_block();
     __syncthreads();
-    for (int q = 1 + tid; q <= L; q += HIST_NT) {
+    for (int q = b + 1 + tid; q <= L; q += HIST_NT) {
         int *row = hist_src + (size_t)(p0 + q) * J;
         const int na = row[0], re = na < J ? na : J;
         int first = 0;
@@ -182,12 +198,15 @@ template <int EPT>
 __global__ __launch_bounds__(1024) void pf_history_lean_kernel(
     int d, int J, double eps, const int64_t *__restrict__ off, const double *__restrict__ theta,
     const double *__restrict__ grad, double *__restrict__ alpha_all, int *__restrict__ hist_len,
-    int *__restrict__ hist_src, int *__restrict__ n_rej, int *__restrict__ acc_list) {
+    int *__restrict__ hist_src, int *__restrict__ n_rej, int *__restrict__ acc_list, HistSeg sg) {
     constexpr int HIST_NT = 1024;
     extern __shared__ double hl_ial[];                        // [EPT][1024]: 1 / alpha, element e of thread tid at e * 1024 + tid
     const int k = blockIdx.x, tid = threadIdx.x;
     const int64_t p0 = off[k];
-    const int L = (int)(off[k + 1] - p0 - 1);
+    const int Ltot = sg.npts ? sg.npts[k] - 1 : (int)(off[k + 1] - p0 - 1);
+    const int L = Ltot < sg.l_end - 1 ? Ltot : sg.l_end - 1;
+    const int b = sg.l_begin > 0 ? sg.l_begin - 1 : 0;      // (HistSeg: the steps of this launch are b + 1 .. L)
+    if (sg.l_begin > 0 && b >= L) return;
     __shared__ double red[2 * 4 * (HIST_NT / 64)];
     int flip = 0;
     int n_acc = 0;
@@ -200,12 +219,17 @@ __global__ __launch_bounds__(1024) void pf_history_lean_kernel(
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int i = tid + HIST_NT * e, ic = i < d ? i : d - 1;
-        al[e] = 1.0; hl_ial[e * HIST_NT + tid] = 1.0;                          // H0 = I  (:38-39)
-        if (i < d) alpha_all[(size_t)p0 * d + i] = 1.0;
-        if (!REREAD) { tc[REREAD ? 0 : e] = theta[(size_t)p0 * d + ic]; gc[REREAD ? 0 : e] = grad[(size_t)p0 * d + ic]; }
+        if (sg.l_begin > 0) {
+            al[e] = alpha_all[(size_t)(p0 + b) * d + ic]; hl_ial[e * HIST_NT + tid] = sg.ial_state[(size_t)k * d + ic];
+        } else {
+            al[e] = 1.0; hl_ial[e * HIST_NT + tid] = 1.0;                      // H0 = I  (:38-39)
+            if (i < d) alpha_all[(size_t)p0 * d + i] = 1.0;
+        }
+        if (!REREAD) { tc[REREAD ? 0 : e] = theta[(size_t)(p0 + b) * d + ic]; gc[REREAD ? 0 : e] = grad[(size_t)(p0 + b) * d + ic]; }
     }
-    if (tid == 0) hist_len[p0] = 0;
-    for (int l = 1; l <= L; ++l) {                                              // :43
+    if (sg.l_begin > 0) n_acc = sg.nacc_state[k];
+    else if (tid == 0) hist_len[p0] = 0;
+    for (int l = b + 1; l <= L; ++l) {                                          // :43
         const size_t row = (size_t)(p0 + l) * d;
         double v[4] = {0.0, 0.0, 0.0, 0.0};   // y.s, y.y, y'diag(a)y, s'diag(1/a)s
 #pragma unroll
@@ -257,9 +281,14 @@ __global__ __launch_bounds__(1024) void pf_history_lean_kernel(
         }
     }
     if (tid == 0) n_rej[k] = L > 0 ? L - n_acc : 0;                             // :57
+    if (sg.ial_state) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) { const int i = tid + HIST_NT * e; if (i < d) sg.ial_state[(size_t)k * d + i] = hl_ial[e * HIST_NT + tid]; }
+        if (tid == 0) sg.nacc_state[k] = n_acc;
+    }
     __threadfence_block();
     __syncthreads();
-    for (int q = 1 + tid; q <= L; q += HIST_NT) {                               // hist_inds (:105), as above
+    for (int q = b + 1 + tid; q <= L; q += HIST_NT) {                           // hist_inds (:105), as above
         int *row = hist_src + (size_t)(p0 + q) * J;
         const int na = row[0], re = na < J ? na : J;
         int first = 0;
@@ -278,18 +307,24 @@ __global__ __launch_bounds__(1024) void pf_history_lean_kernel(
 __global__ __launch_bounds__(1024) void pf_history_mem_kernel(
     int d, int J, double eps, const int64_t *__restrict__ off, const double *__restrict__ theta,
     const double *__restrict__ grad, double *__restrict__ alpha_all, int *__restrict__ hist_len,
-    int *__restrict__ hist_src, int *__restrict__ n_rej, int *__restrict__ acc_list) {
+    int *__restrict__ hist_src, int *__restrict__ n_rej, int *__restrict__ acc_list, HistSeg sg) {
     constexpr int HIST_NT = 1024;
     const int k = blockIdx.x, tid = threadIdx.x;
     const int64_t p0 = off[k];
-    const int L = (int)(off[k + 1] - p0 - 1);
+    const int Ltot = sg.npts ? sg.npts[k] - 1 : (int)(off[k + 1] - p0 - 1);
+    const int L = Ltot < sg.l_end - 1 ? Ltot : sg.l_end - 1;
+    const int b = sg.l_begin > 0 ? sg.l_begin - 1 : 0;      // (HistSeg: the steps of this launch are b + 1 .. L)
+    if (sg.l_begin > 0 && b >= L) return;
     __shared__ double red[2 * 4 * (HIST_NT / 64)];
     int flip = 0;
     int n_acc = 0;
     int *const acc = acc_list + p0;
-    for (int i = tid; i < d; i += HIST_NT) alpha_all[(size_t)p0 * d + i] = 1.0;      // H0 = I  (:38-39)
-    if (tid == 0) hist_len[p0] = 0;
-    for (int l = 1; l <= L; ++l) {                                                  // :43
+    if (sg.l_begin > 0) n_acc = sg.nacc_state[k];
+    else {
+        for (int i = tid; i < d; i += HIST_NT) alpha_all[(size_t)p0 * d + i] = 1.0;  // H0 = I  (:38-39)
+        if (tid == 0) hist_len[p0] = 0;
+    }
+    for (int l = b + 1; l <= L; ++l) {                                              // :43
         const size_t row = (size_t)(p0 + l) * d;
         double v[4] = {0.0, 0.0, 0.0, 0.0};   // y.s, y.y, y'diag(a)y, s'diag(1/a)s
         for (int i = tid; i < d; i += HIST_NT) {                                    // (a thread reads back only what it wrote itself: no barrier)
@@ -321,9 +356,10 @@ __global__ __launch_bounds__(1024) void pf_history_mem_kernel(
         }
     }
     if (tid == 0) n_rej[k] = L > 0 ? L - n_acc : 0;                                 // :57
+    if (sg.nacc_state && tid == 0) sg.nacc_state[k] = n_acc;
     __threadfence_block();
     __syncthreads();
-    for (int q = 1 + tid; q <= L; q += HIST_NT) {                                   // hist_inds (:105), as above
+    for (int q = b + 1 + tid; q <= L; q += HIST_NT) {                               // hist_inds (:105), as above
         int *rowp = hist_src + (size_t)(p0 + q) * J;
         const int na = rowp[0], re = na < J ? na : J;
         int first = 0;
@@ -368,7 +404,9 @@ __device__ __forceinline__ void pf_vec_dot(const double *M, int d, F f, double (
 
 template <int KPAD>
 __global__ __launch_bounds__(FIT_THREADS) void pf_fit_kernel(FitArgs A) {
-    const int p = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    int64_t p;
+    if (!pf_fit_point(A, blockIdx.x, p)) { if (tid == 0) A.status[p] = PFMI_FIT_ABSENT; return; }
     const int d = A.d, J = A.J;
     const int path = A.path_of[p];
     const int64_t p0 = A.off[path];
@@ -710,11 +748,12 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
     // of which its neighbours p - 1, p + 1, ... read as well: with p = b those neighbours sit on eight different L2s and the rows came from
     // HBM / MALL again and again (FETCH_SIZE 1.5 GB per launch for 0.18 GB of distinct rows; the row loads were a third of the kernel).  XCD x
     // now walks its own contiguous eighth of the points, so the ring's rows stay in that XCD's L2.
-    int p;
+    int64_t p;
     {
         const int P = (int)gridDim.x, x = blockIdx.x & 7, slot = blockIdx.x >> 3, q8 = P >> 3, r8 = P & 7;
-        p = x * q8 + (x < r8 ? x : r8) + slot;
-        if (FITREG_XCD == 0) p = blockIdx.x;
+        int idx = x * q8 + (x < r8 ? x : r8) + slot;
+        if (FITREG_XCD == 0) idx = blockIdx.x;
+        if (!pf_fit_point(A, idx, p)) { if (threadIdx.x == 0) A.status[p] = PFMI_FIT_ABSENT; return; }
     }
     const int tid = threadIdx.x;
     const int d = A.d, J = A.J;
@@ -1114,15 +1153,16 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
 }
 
 // ---------------------------------------------------------------------------------------------------
-int32_t pf_launch_history(pfmi_ctx *c, double eps) {
+int32_t pf_launch_history(pfmi_ctx *c, double eps, const HistSeg *seg) {
     PF_CHECK(c->J <= 64, PFMI_ERR_UNSUPPORTED, "history_length %d > 64 unsupported", c->J);
+    const HistSeg sg = seg ? *seg : HistSeg{nullptr, 0, INT_MAX, nullptr, nullptr};
     pf_kernel_begin(c);
     {
         const char *hk = pf_debug_get("PFMI_HISTORY_KERNEL");            // "mem": the memory-resident walk at every d (tests)
         if (c->d > 16 * 1024 || (hk && hk[0] == 'm')) {
             hipLaunchKernelGGL(pf_history_mem_kernel, dim3(c->K), dim3(1024), 0, c->stream, c->d, c->J, eps, c->d_off.as<int64_t>(),
-                               c->theta.as<double>(), c->grad.as<double>(), c->alpha_all.as<double>(), c->hist_len.as<int>(),
-                               c->hist_src.as<int>(), c->n_rej.as<int>(), c->hist_acc.as<int>());
+                               c->th(), c->gr(), c->alpha_all.as<double>(), c->hist_len.as<int>(),
+                               c->hist_src.as<int>(), c->n_rej.as<int>(), c->hist_acc.as<int>(), sg);
             pf_kernel_end(c, "history");
             PF_HIP(hipGetLastError());
             return PFMI_OK;
@@ -1130,9 +1170,9 @@ int32_t pf_launch_history(pfmi_ctx *c, double eps) {
     }
 #define PF_HIST(E, NT)                                                                                           \
     hipLaunchKernelGGL((pf_history_kernel<E, NT>), dim3(c->K), dim3(NT), 0, c->stream, c->d, c->J, eps,           \
-                       c->d_off.as<int64_t>(), c->theta.as<double>(), c->grad.as<double>(),                      \
+                       c->d_off.as<int64_t>(), c->th(), c->gr(),                      \
                        c->alpha_all.as<double>(), c->hist_len.as<int>(), c->hist_src.as<int>(), c->n_rej.as<int>(),          \
-                       c->hist_acc.as<int>())
+                       c->hist_acc.as<int>(), sg)
     // the walk is sequential in l: one block reduction per iteration, cheaper across 4 waves than across 16
     // (a single wave for d <= 256: no cross-wave exchange at all)
     if (c->d <= 64) PF_HIST(1, 64); else if (c->d <= 128) PF_HIST(2, 64); else if (c->d <= 256) PF_HIST(4, 64);
@@ -1145,8 +1185,8 @@ int32_t pf_launch_history(pfmi_ctx *c, double eps) {
         auto kern = pf_history_lean_kernel<E>;                                                                          \
         PF_TRY(pf_raise_lds_limit(c, reinterpret_cast<const void *>(kern), (int)(sizeof(double) * E * 1024)));           \
         hipLaunchKernelGGL(kern, dim3(c->K), dim3(1024), sizeof(double) * E * 1024, c->stream, c->d, c->J, eps,         \
-                           c->d_off.as<int64_t>(), c->theta.as<double>(), c->grad.as<double>(), c->alpha_all.as<double>(), \
-                           c->hist_len.as<int>(), c->hist_src.as<int>(), c->n_rej.as<int>(), c->hist_acc.as<int>());    \
+                           c->d_off.as<int64_t>(), c->th(), c->gr(), c->alpha_all.as<double>(), \
+                           c->hist_len.as<int>(), c->hist_src.as<int>(), c->n_rej.as<int>(), c->hist_acc.as<int>(), sg);  \
     } while (0)
            if (ept <= 2) PF_HIST(2, 1024);
            else if (ept <= 4) { if (lean) PF_HIST_LEAN(4); else PF_HIST(4, 1024); }
@@ -1165,7 +1205,7 @@ template <int KPAD>
 static void launch_fit_t(pfmi_ctx *c, const FitArgs &a) {
     const char *force = pf_debug_get("PFMI_FIT_KERNEL");            // "mem" forces the general (memory-resident) kernel
     const bool allow_reg = !(force && force[0] == 'm');
-    dim3 grid((unsigned)c->P), block(FIT_THREADS);
+    dim3 grid((unsigned)a.P), block(FIT_THREADS);
     if constexpr (KPAD <= 16) {
         // register-resident kernel: 256 threads x RPT rows (measured faster than 512 x 2: the kernel is bound by
         // block-reduction / serial O(m^3) latency, and 8-wave barriers cost more than the extra occupancy buys)
@@ -1178,16 +1218,18 @@ static void launch_fit_t(pfmi_ctx *c, const FitArgs &a) {
 
 int32_t pf_launch_fit_panel(pfmi_ctx *c, const FitArgs &a, bool *handled);   // fit_panel_kernel.hip
 
-int32_t pf_launch_fit(pfmi_ctx *c) {
+int32_t pf_launch_fit(pfmi_ctx *c, int seg_l0, int seg_len) {
     FitArgs a;
     a.d = c->d; a.J = c->J;
+    a.seg_l0 = seg_l0; a.seg_len = seg_len; a.vcap = c->vcap; a.npts = c->st_npts.as<int32_t>();
+    PF_CHECK(seg_len == 0 || c->virt, PFMI_ERR_STATE, "fit: segment launches need the streaming layout");
     a.off = c->d_off.as<int64_t>(); a.path_of = c->d_path_of.as<int32_t>();
-    a.theta = c->theta.as<double>(); a.grad = c->grad.as<double>(); a.alpha_all = c->alpha_all.as<double>();
+    a.theta = c->th(); a.grad = c->gr(); a.alpha_all = c->alpha_all.as<double>();
     a.hist_len = c->hist_len.as<int32_t>(); a.hist_src = c->hist_src.as<int32_t>();
     a.vh = c->vh.as<double>(); a.tmat = c->tmat.as<double>(); a.vchol = c->vchol.as<double>();
     a.rq = c->rq.as<double>(); a.dmat = c->dmat.as<double>(); a.sqrt_alpha = c->sqrt_alpha.as<double>();
     a.mu = c->mu.as<double>(); a.logdet = c->logdet.as<double>(); a.status = c->status.as<int32_t>();
-    a.P = c->P;
+    a.P = seg_len > 0 ? (int64_t)c->K * seg_len : c->P;        // work items of this launch
     pf_kernel_begin(c);
     {
         const char *force = pf_debug_get("PFMI_FIT_KERNEL");        // "mem": column-by-column memory-resident kernel also for d > 1024

@@ -97,8 +97,9 @@ __global__ __launch_bounds__(FP_NT, 1) void pf_fit_panel_kernel(FitArgs A, const
             sNext = next;
         }
         __syncthreads();
-        const int64_t p = sNext;
-        if (p < 0) break;
+        if (sNext < 0) break;
+        int64_t p;
+        if (!pf_fit_point(A, sNext, p)) { if (tid == 0) A.status[p] = PFMI_FIT_ABSENT; continue; }
         FP_STAMP(0);
 
         const int path = A.path_of[p];

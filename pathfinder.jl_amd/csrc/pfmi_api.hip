@@ -1,5 +1,7 @@
 // pfmi_api.hip -- the extern "C" boundary declared in include/pfmi.h (host side of libpfmi.so).
 #include "pfmi_common.h"
+#include "fit_args.h"
+#include <limits.h>
 
 #include <chrono>
 #include <map>
@@ -240,11 +242,11 @@ int32_t pfmi_destroy(pfmi_ctx *c) {
     DevBuf *bufs[] = {&c->theta, &c->grad, &c->d_off, &c->d_path_of, &c->target.mean, &c->target.a, &c->target.wd,
                       &c->target.g, &c->target.wd16, &c->alpha_all, &c->hist_len, &c->hist_src, &c->hist_acc, &c->n_rej, &c->vh, &c->tmat, &c->vchol,
                       &c->rq, &c->dmat, &c->sqrt_alpha, &c->mu, &c->logdet, &c->status, &c->seeds, &c->logp, &c->logq,
-                      &c->elbo, &c->se, &c->best_iter, &c->fit_list, &c->ubuf, &c->xbuf, &c->scratch, &c->qf_share, &c->fit_scratch, &c->pool,
+                      &c->elbo, &c->se, &c->best_iter, &c->fit_list, &c->ubuf, &c->xbuf, &c->scratch, &c->qf_share_s[0], &c->qf_share_s[1], &c->fit_scratch, &c->pool,
                       &c->pool_lr, &c->pool_lp, &c->pool_lq, &c->pool_points, &c->pool_seeds, &c->lw, &c->w,
                       &c->psis_out, &c->psis_aux, &c->tailbuf, &c->cdf, &c->idx, &c->gbuf, &c->trace_lp, &c->st_theta, &c->st_grad,
                       &c->st_lp, &c->st_npts, &c->lb_hs, &c->lb_hy, &c->lb_x0, &c->sortk, &c->sorti,
-                      &c->pool_ok, &c->fail_seeds, &c->rs_err};
+                      &c->pool_ok, &c->fail_seeds, &c->rs_err, &c->st_done, &c->hs_ial, &c->hs_nacc, &c->sg_err};
     for (DevBuf *b : bufs) b->release();
     for (int b = 0; b < 2; ++b) {
         c->cb_x[b].release(); c->cb_lp[b].release();
@@ -258,6 +260,8 @@ int32_t pfmi_destroy(pfmi_ctx *c) {
     (void)hipEventDestroy(c->kev0); (void)hipEventDestroy(c->kev1);
     pf_kernel_resolve(c, false);
     for (hipEvent_t e : c->kev_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->sg_ev) (void)hipEventDestroy(e);
+    for (hipStream_t s : {c->s_opt, c->s_fit, c->s_scan[0], c->s_scan[1]}) if (s) (void)hipStreamDestroy(s);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return PFMI_OK;
@@ -368,7 +372,7 @@ int32_t pfmi_set_traces(pfmi_ctx *c, int32_t K, const int64_t *npoints, int32_t 
     c->path_of.resize((size_t)P);
     for (int k = 0; k < K; ++k)
         for (int64_t p = c->off[k]; p < c->off[k + 1]; ++p) c->path_of[(size_t)p] = k;
-    c->K = K; c->d = d; c->P = P;
+    c->K = K; c->d = d; c->P = P; c->virt = false;
     c->fitted = false; c->elbo_done = false; c->pooled = false; c->have_trace_lp = false;
     const size_t bytes = sizeof(double) * (size_t)P * d;
     PF_TRY(c->theta.ensure(bytes));
@@ -427,7 +431,7 @@ int32_t pfmi_optimize_batch_wait(pfmi_ctx *c, int64_t *npoints) {
     c->path_of.resize((size_t)P);
     for (int k = 0; k < K; ++k)
         for (int64_t p = c->off[k]; p < c->off[k + 1]; ++p) c->path_of[(size_t)p] = k;
-    c->K = K; c->d = d; c->P = P;
+    c->K = K; c->d = d; c->P = P; c->virt = false;
     const size_t bytes = sizeof(double) * (size_t)P * d;
     PF_TRY(c->theta.ensure(bytes));
     PF_TRY(c->grad.ensure(bytes));
@@ -453,13 +457,228 @@ int32_t pfmi_optimize_batch(pfmi_ctx *c, int32_t K, const double *x0, int32_t J,
 int32_t pfmi_get_trace(pfmi_ctx *c, int32_t k, double *theta, double *logp, double *grad) {
     PF_CTX(c);
     PF_CHECK(c->P > 0 && k >= 0 && k < c->K, PFMI_ERR_ARG, "get_trace: bad path index");
-    const int64_t p0 = c->off[(size_t)k], n = c->off[(size_t)k + 1] - p0;
+    const int64_t p0 = c->off[(size_t)k], n = c->path_npts(k);
     const size_t bytes = sizeof(double) * (size_t)n * c->d;
-    if (theta) PF_TRY(d2h(c, theta, c->theta.as<double>() + (size_t)p0 * c->d, bytes));
-    if (grad) PF_TRY(d2h(c, grad, c->grad.as<double>() + (size_t)p0 * c->d, bytes));
+    if (theta) PF_TRY(d2h(c, theta, c->th() + (size_t)p0 * c->d, bytes));
+    if (grad) PF_TRY(d2h(c, grad, c->gr() + (size_t)p0 * c->d, bytes));
     if (logp) {
         PF_CHECK(c->have_trace_lp, PFMI_ERR_STATE, "get_trace: log densities exist only for pfmi_optimize_batch traces");
-        PF_TRY(d2h(c, logp, c->trace_lp.as<double>() + p0, sizeof(double) * n));
+        PF_TRY(d2h(c, logp, c->tlp() + p0, sizeof(double) * n));
+    }
+    return PFMI_OK;
+}
+
+// ---- streaming pipeline: optimise, fit and scan as ONE enqueued dataflow ------------------------------------------------------
+// (reference: src/multipath.jl:190-208 runs optimisation, fit and ELBO of a run back to back inside one task; here the K optimisations
+// run as one persistent kernel and the fits / scans of the trace points they have ALREADY produced run on the other CUs meanwhile)
+//
+//   stream s_opt   pf_lbfgs_kernel: one workgroup per path; publishes its point count every PF_STREAM_PUB points
+//   stream s_fit   per segment [l0, l1) of trace positions: gate (wait until every path has l1 points or has ended) -> history walk of
+//                  the segment (state carried from the previous segment) -> fits of the segment's points -> event F_i
+//   stream s_scan[i & 1]   wait F_i -> ELBO scan of the segment's fits (two streams alternate so that a segment's last, partly filled
+//                  round of CUs overlaps the next segment's first)
+//   ctx stream     waits for all of them -> mean / SE / argmax; then whatever the caller enqueues (pool, PSIS, resample)
+//
+// The trace points stay in the optimiser's fixed-stride staging buffers (point l of path k = slot k * (maxiters + 1) + l): nothing is
+// packed, no offset depends on another path's length, so no stage has to wait for the LAST path to end.  Same kernels, same arithmetic
+// as fit_batch + elbo_batch_enqueue on the packed trace: the results are bit-identical (tests/test_gpu_stream.py).
+#define PF_STREAM_PUB 16
+static std::vector<int> stream_bounds(int cap) {
+    static const int step[] = {16, 16, 32, 32, 32, 64, 64, 128, 128, 256};
+    std::vector<int> b{0};
+    for (int i = 0; b.back() < cap; ++i) {
+        const int st = step[i < 10 ? i : 9];
+        b.push_back(b.back() + st >= cap ? cap : b.back() + st);
+    }
+    return b;
+}
+struct StreamSwap {                       // the launch helpers enqueue on c->stream: point it at a side stream for the scope
+    pfmi_ctx *c; hipStream_t keep; int slot, ncu;
+    StreamSwap(pfmi_ctx *c_, hipStream_t s, int qf_slot = 0, int ncu_eff = 0) : c(c_), keep(c_->stream), slot(c_->qf_slot), ncu(c_->ncu_eff) {
+        c->stream = s; c->qf_slot = qf_slot; c->ncu_eff = ncu_eff;
+    }
+    ~StreamSwap() { c->stream = keep; c->qf_slot = slot; c->ncu_eff = ncu; }
+};
+static int32_t qf_share_reserve(pfmi_ctx *c, int slot, size_t bytes) {
+    DevBuf &b = c->qf_share_s[slot];
+    if (b.cap >= bytes) return PFMI_OK;
+    PF_TRY(b.ensure(bytes));
+    PF_HIP(hipMemsetAsync(b.p, 0, b.cap, c->stream));
+    c->qf_epoch_s[slot] = 0;
+    return PFMI_OK;
+}
+
+int32_t pfmi_stream_enqueue(pfmi_ctx *c, int32_t K, const double *x0, int32_t J, int32_t maxiters, double g_tol, double eps, int64_t N,
+                            const uint64_t *seeds) {
+    PF_CTX(c);
+    const TargetDev &T = c->target;
+    PF_CHECK(T.kind == PFMI_TARGET_GAUSS || T.kind == PFMI_TARGET_FUNNEL, PFMI_ERR_UNSUPPORTED,
+             "stream_enqueue: needs a built-in target (the optimiser runs on the device)");
+    PF_CHECK(K > 0 && x0 && seeds && maxiters >= 0 && N >= 1, PFMI_ERR_ARG, "stream_enqueue: bad arguments");
+    PF_CHECK(J >= 1 && J <= 16, PFMI_ERR_UNSUPPORTED, "stream_enqueue: history_length %d outside 1..16", J);
+    const int ncu = c->ncu > 0 ? c->ncu : 256;
+    PF_CHECK(2 * K <= ncu, PFMI_ERR_UNSUPPORTED, "stream_enqueue: %d paths on %d CUs -- the optimiser's workgroups must all be resident beside "
+             "their consumers (use pfmi_optimize_batch + pfmi_fit_batch + pfmi_elbo_batch)", K, ncu);
+    const int d = T.d;
+    const int64_t cap = (int64_t)maxiters + 1, P = (int64_t)K * cap;
+    PF_CHECK(P < (1ll << 31), PFMI_ERR_UNSUPPORTED, "stream_enqueue: too many trace slots");
+    int kpad = 0;
+    for (int o : {4, 8, 12, 16, 20, 32}) if (2 * J <= o) { kpad = o; break; }
+    {   // the fixed-stride layout sizes every per-point buffer for the LONGEST possible path: refuse what the device cannot hold
+        size_t free_b = 0, total_b = 0;
+        const double need = 8.0 * (double)P * ((double)d * (kpad + 5) + 2.0 * (double)N + 4.0 * kpad * kpad);
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            double have = (double)free_b;
+            for (const DevBuf *b : {&c->vh, &c->alpha_all, &c->sqrt_alpha, &c->mu, &c->logp, &c->logq, &c->st_theta, &c->st_grad}) have += (double)b->cap;
+            PF_CHECK(need < 0.8 * have, PFMI_ERR_UNSUPPORTED, "stream_enqueue: the fixed-stride layout needs %.1f GB for %d paths x %lld slots "
+                     "(%.1f GB available): use the packed route", need / 1e9, K, (long long)cap, have / 1e9);
+        }
+    }
+    // ---- every allocation BEFORE the first launch (a hipFree behind a grown buffer would synchronise the device in mid-flight)
+    const size_t Pz = (size_t)P, dz = (size_t)d, kk = (size_t)kpad * kpad;
+    PF_TRY(c->st_theta.ensure(sizeof(double) * Pz * dz));
+    PF_TRY(c->st_grad.ensure(sizeof(double) * Pz * dz));
+    PF_TRY(c->st_lp.ensure(sizeof(double) * Pz));
+    PF_TRY(c->st_npts.ensure(sizeof(int32_t) * K));
+    PF_TRY(c->st_done.ensure(sizeof(int32_t) * K));
+    PF_TRY(c->lb_x0.ensure(sizeof(double) * (size_t)K * dz));
+    PF_TRY(c->hs_ial.ensure(sizeof(double) * (size_t)K * dz));
+    PF_TRY(c->hs_nacc.ensure(sizeof(int32_t) * K));
+    PF_TRY(c->sg_err.ensure(sizeof(int32_t)));
+    PF_TRY(c->alpha_all.ensure(sizeof(double) * Pz * dz));
+    PF_TRY(c->hist_len.ensure(sizeof(int32_t) * Pz));
+    PF_TRY(c->hist_src.ensure(sizeof(int32_t) * Pz * J));
+    PF_TRY(c->hist_acc.ensure(sizeof(int32_t) * Pz));
+    PF_TRY(c->n_rej.ensure(sizeof(int32_t) * K));
+    PF_TRY(c->vh.ensure(sizeof(double) * Pz * dz * kpad));
+    PF_TRY(c->tmat.ensure(sizeof(double) * Pz * kk));
+    PF_TRY(c->vchol.ensure(sizeof(double) * Pz * kk));
+    PF_TRY(c->rq.ensure(sizeof(double) * Pz * kk));
+    PF_TRY(c->dmat.ensure(sizeof(double) * Pz * kk));
+    PF_TRY(c->sqrt_alpha.ensure(sizeof(double) * Pz * dz));
+    PF_TRY(c->mu.ensure(sizeof(double) * Pz * dz));
+    PF_TRY(c->logdet.ensure(sizeof(double) * Pz));
+    PF_TRY(c->status.ensure(sizeof(int32_t) * Pz));
+    PF_TRY(c->logp.ensure(sizeof(double) * Pz * N));
+    PF_TRY(c->logq.ensure(sizeof(double) * Pz * N));
+    PF_TRY(c->elbo.ensure(sizeof(double) * Pz));
+    PF_TRY(c->se.ensure(sizeof(double) * Pz));
+    PF_TRY(c->best_iter.ensure(sizeof(int64_t) * K));
+    PF_TRY(c->d_off.ensure(sizeof(int64_t) * (K + 1)));
+    PF_TRY(c->d_path_of.ensure(sizeof(int32_t) * Pz));
+    for (int q = 0; q < 2; ++q) PF_TRY(qf_share_reserve(c, q, (size_t)ncu * 1700 * sizeof(double) + ((size_t)ncu + 1) * sizeof(unsigned) + (64 << 10)));
+    if (!c->s_opt) {
+        PF_HIP(hipStreamCreateWithFlags(&c->s_opt, hipStreamNonBlocking));
+        PF_HIP(hipStreamCreateWithFlags(&c->s_fit, hipStreamNonBlocking));
+        PF_HIP(hipStreamCreateWithFlags(&c->s_scan[0], hipStreamNonBlocking));
+        PF_HIP(hipStreamCreateWithFlags(&c->s_scan[1], hipStreamNonBlocking));
+    }
+    const std::vector<int> bnd = stream_bounds((int)cap);
+    const int nseg = (int)bnd.size() - 1;
+    while ((int)c->sg_ev.size() < nseg + 6) {
+        hipEvent_t e = nullptr;
+        PF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->sg_ev.push_back(e);
+    }
+    // ---- host-side layout: slot offsets, and the scan's work lists of all segments (position-major inside a segment)
+    const bool same_layout = c->virt && c->K == K && c->vcap == cap && c->d == d && (int64_t)c->path_of.size() == P;
+    c->off.assign((size_t)K + 1, 0);
+    for (int k = 0; k <= K; ++k) c->off[(size_t)k] = (int64_t)k * cap;
+    if (!same_layout) {
+        c->path_of.resize(Pz);
+        for (int k = 0; k < K; ++k)
+            for (int64_t l = 0; l < cap; ++l) c->path_of[(size_t)(k * cap + l)] = k;
+    }
+    c->K = K; c->d = d; c->P = P; c->J = J; c->kpad = kpad; c->N_e = N; c->virt = true; c->vcap = cap;
+    c->npts_h.assign((size_t)K, 0);
+    c->fitted = false; c->elbo_done = false; c->pooled = false; c->have_trace_lp = false; c->opt_pending = false;
+    const int64_t nf = (int64_t)K * (cap - 1);
+    const size_t off_ls = sizeof(uint64_t) * Pz, off_li = off_ls + sizeof(uint64_t) * (size_t)(nf > 0 ? nf : 1);
+    const size_t up_bytes = off_li + sizeof(int32_t) * (size_t)(nf > 0 ? nf : 1);
+    PF_TRY(c->seeds.ensure(up_bytes + 16));
+    {
+        std::vector<char> stage(up_bytes);
+        memcpy(stage.data(), seeds, sizeof(uint64_t) * Pz);
+        uint64_t *ls = reinterpret_cast<uint64_t *>(stage.data() + off_ls);
+        int32_t *li = reinterpret_cast<int32_t *>(stage.data() + off_li);
+        int64_t t = 0;
+        for (int i = 0; i < nseg; ++i)
+            for (int l = bnd[(size_t)i] > 1 ? bnd[(size_t)i] : 1; l < bnd[(size_t)i + 1]; ++l)
+                for (int k = 0; k < K; ++k, ++t) { const int64_t pp = (int64_t)k * cap + l; li[t] = (int32_t)pp; ls[t] = seeds[pp]; }
+        PF_TRY(h2d(c, c->seeds.p, stage.data(), up_bytes));
+    }
+    uint64_t *d_lseeds = reinterpret_cast<uint64_t *>(c->seeds.as<char>() + off_ls);
+    int32_t *d_list = reinterpret_cast<int32_t *>(c->seeds.as<char>() + off_li);
+    PF_TRY(h2d(c, c->lb_x0.p, x0, sizeof(double) * (size_t)K * dz));
+    PF_TRY(h2d(c, c->d_off.p, c->off.data(), sizeof(int64_t) * (K + 1)));
+    if (!same_layout) PF_TRY(h2d(c, c->d_path_of.p, c->path_of.data(), sizeof(int32_t) * Pz));
+    PF_HIP(hipMemsetAsync(c->st_npts.p, 0, sizeof(int32_t) * K, c->stream));
+    PF_HIP(hipMemsetAsync(c->st_done.p, 0, sizeof(int32_t) * K, c->stream));
+    PF_HIP(hipMemsetAsync(c->sg_err.p, 0, sizeof(int32_t), c->stream));
+    PF_HIP(hipMemsetAsync(c->hist_src.p, 0, sizeof(int32_t) * Pz * J, c->stream));
+    c->stream_pending = true;
+    hipEvent_t ev0 = c->sg_ev[0], ev_opt = c->sg_ev[1], ev_fit = c->sg_ev[2], ev_s0 = c->sg_ev[3], ev_s1 = c->sg_ev[4];
+    PF_HIP(hipEventRecord(ev0, c->stream));
+    for (hipStream_t s : {c->s_opt, c->s_fit, c->s_scan[0], c->s_scan[1]}) PF_HIP(hipStreamWaitEvent(s, ev0, 0));
+    {   // ---- the producer
+        StreamSwap sw(c, c->s_opt);
+        pf_kernel_begin(c);
+        PF_TRY(pf_launch_lbfgs(c, K, J, maxiters, g_tol, c->lb_x0.as<double>(), PF_STREAM_PUB - 1));
+        pf_kernel_end(c, "optimize");
+        PF_HIP(hipEventRecord(ev_opt, c->s_opt));
+    }
+    // ---- the consumers, segment by segment
+    int64_t s0 = 0;
+    for (int i = 0; i < nseg; ++i) {
+        const int l0 = bnd[(size_t)i], l1 = bnd[(size_t)i + 1];
+        hipEvent_t ev_f = c->sg_ev[(size_t)6 + i];
+        {
+            StreamSwap sw(c, c->s_fit);
+            PF_TRY(pf_launch_stream_gate(c, c->s_fit, K, l1, c->sg_err.as<int32_t>()));
+            const HistSeg sg{c->st_npts.as<int32_t>(), l0, l1, c->hs_ial.as<double>(), c->hs_nacc.as<int32_t>()};
+            PF_TRY(pf_launch_history(c, eps, &sg));
+            PF_TRY(pf_launch_fit(c, l0, l1 - l0));
+            PF_HIP(hipEventRecord(ev_f, c->s_fit));
+        }
+        const int64_t ns = (int64_t)K * (l1 - (l0 > 1 ? l0 : 1));
+        if (ns > 0) {
+            // the scan's launch geometry counts the CUs it can have: while the optimiser runs, its K workgroups and the gate hold theirs
+            StreamSwap sw(c, c->s_scan[i & 1], i & 1, i + 1 < nseg ? ncu - K - 1 : 0);
+            PF_HIP(hipStreamWaitEvent(c->stream, ev_f, 0));
+            PF_TRY(pf_launch_elbo_draws(c, d_list + s0, d_lseeds + s0, ns, 0, N, nullptr, 0, nullptr, 0, c->logp.as<double>(),
+                                        c->logq.as<double>(), N, true, true));
+        }
+        s0 += ns;
+    }
+    PF_HIP(hipEventRecord(ev_fit, c->s_fit));
+    PF_HIP(hipEventRecord(ev_s0, c->s_scan[0]));
+    PF_HIP(hipEventRecord(ev_s1, c->s_scan[1]));
+    for (hipEvent_t e : {ev_opt, ev_fit, ev_s0, ev_s1}) PF_HIP(hipStreamWaitEvent(c->stream, e, 0));
+    c->stream_pending = false;
+    c->fitted = true;
+    PF_TRY(pf_launch_elbo_reduce(c));
+    c->elbo_done = true; c->elbo_pending = true; c->have_trace_lp = true;
+    return PFMI_OK;
+}
+
+int32_t pfmi_stream_wait(pfmi_ctx *c, int64_t *npoints) {
+    PF_CTX(c);
+    PF_CHECK(c->virt && c->elbo_done, PFMI_ERR_STATE, "stream_wait: no pfmi_stream_enqueue outstanding");
+    PF_CHECK(npoints != nullptr, PFMI_ERR_ARG, "stream_wait: null npoints");
+    int32_t gate_err = 0;
+    PF_TRY(d2h_async(c, c->npts_h.data(), c->st_npts.p, sizeof(int32_t) * c->K));
+    PF_TRY(d2h_async(c, &gate_err, c->sg_err.p, sizeof(int32_t)));
+    PF_TRY(stream_sync(c));
+    if (gate_err != 0) {
+        c->elbo_done = false; c->fitted = false;
+        pf_set_error("streaming pipeline: a gate saw no progress of the optimiser for seconds (GPU shared?); the step was discarded: enqueue it again "
+                     "or use the packed route");
+        return PFMI_ERR_RETRY;
+    }
+    for (int k = 0; k < c->K; ++k) {
+        PF_CHECK(c->npts_h[(size_t)k] >= 1 && c->npts_h[(size_t)k] <= c->vcap, PFMI_ERR_NUMERIC, "stream_wait: path %d produced %d points", k,
+                 c->npts_h[(size_t)k]);
+        npoints[k] = c->npts_h[(size_t)k];
     }
     return PFMI_OK;
 }
@@ -491,8 +710,14 @@ int32_t pfmi_fit_batch(pfmi_ctx *c, int32_t J, double eps) {
     PF_TRY(c->logdet.ensure(sizeof(double) * P));
     PF_TRY(c->status.ensure(sizeof(int32_t) * P));
     PF_HIP(hipMemsetAsync(c->hist_src.p, 0, sizeof(int32_t) * P * J, c->stream));
-    PF_TRY(pf_launch_history(c, eps));
-    PF_TRY(pf_launch_fit(c));
+    if (c->virt) {                                            // streaming layout: every path's slots, the absent ones marked as such
+        const HistSeg sg{c->st_npts.as<int32_t>(), 0, INT_MAX, nullptr, nullptr};
+        PF_TRY(pf_launch_history(c, eps, &sg));
+        PF_TRY(pf_launch_fit(c, 0, (int)c->vcap));
+    } else {
+        PF_TRY(pf_launch_history(c, eps));
+        PF_TRY(pf_launch_fit(c));
+    }
     c->fitted = true; c->elbo_done = false; c->pooled = false;
     return PFMI_OK;
 }
@@ -534,10 +759,10 @@ int32_t pfmi_get_fit(pfmi_ctx *c, int64_t p, double *alpha, double *B, double *D
         std::vector<double> t0((size_t)d), t1((size_t)d), g0((size_t)d), g1((size_t)d);
         for (int cidx = 0; cidx < j; ++cidx) {
             const size_t q0 = (size_t)(p0 + src[(size_t)cidx]) * d, q1 = q0 + d;
-            PF_TRY(d2h(c, t0.data(), c->theta.as<double>() + q0, sizeof(double) * d));
-            PF_TRY(d2h(c, t1.data(), c->theta.as<double>() + q1, sizeof(double) * d));
-            PF_TRY(d2h(c, g0.data(), c->grad.as<double>() + q0, sizeof(double) * d));
-            PF_TRY(d2h(c, g1.data(), c->grad.as<double>() + q1, sizeof(double) * d));
+            PF_TRY(d2h(c, t0.data(), c->th() + q0, sizeof(double) * d));
+            PF_TRY(d2h(c, t1.data(), c->th() + q1, sizeof(double) * d));
+            PF_TRY(d2h(c, g0.data(), c->gr() + q0, sizeof(double) * d));
+            PF_TRY(d2h(c, g1.data(), c->gr() + q1, sizeof(double) * d));
             for (int i = 0; i < d; ++i) {
                 B[i + (size_t)d * cidx] = al[(size_t)i] * (g0[(size_t)i] - g1[(size_t)i]);
                 B[i + (size_t)d * (j + cidx)] = t1[(size_t)i] - t0[(size_t)i];
@@ -646,7 +871,7 @@ int32_t pfmi_elbo_batch_enqueue(pfmi_ctx *c, int64_t N, const uint64_t *seeds, c
     // ONE upload (round 4; three copies in the stream cost three 12-us hand-overs between the fit and the scan): the per-point seeds, then
     // the list of fits = every point that is not the first of its path (fit_distributions[2:end]) -- their seeds, then their indices
     int64_t nf = 0;
-    for (int k = 0; k < c->K; ++k) nf += c->off[k + 1] - c->off[k] - 1;
+    for (int k = 0; k < c->K; ++k) nf += c->path_npts(k) - 1;
     const size_t off_ls = sizeof(uint64_t) * (size_t)P, off_li = off_ls + sizeof(uint64_t) * (size_t)(nf > 0 ? nf : 1);
     const size_t up_bytes = off_li + sizeof(int32_t) * (size_t)(nf > 0 ? nf : 1);
     std::vector<char> stage(up_bytes);
@@ -656,7 +881,7 @@ int32_t pfmi_elbo_batch_enqueue(pfmi_ctx *c, int64_t N, const uint64_t *seeds, c
         int32_t *li = reinterpret_cast<int32_t *>(stage.data() + off_li);
         int64_t t = 0;
         for (int k = 0; k < c->K; ++k)
-            for (int64_t p = c->off[k] + 1; p < c->off[k + 1]; ++p, ++t) { li[t] = (int32_t)p; ls[t] = seeds[p]; }
+            for (int64_t p = c->off[k] + 1; p < c->off[k] + c->path_npts(k); ++p, ++t) { li[t] = (int32_t)p; ls[t] = seeds[p]; }
     }
     PF_TRY(c->seeds.ensure(up_bytes + 16));
     PF_TRY(h2d(c, c->seeds.p, stage.data(), up_bytes));
@@ -742,11 +967,14 @@ int32_t pfmi_elbo_batch_wait(pfmi_ctx *c, double *elbo, double *se, int64_t *bes
     if (best_iter) PF_TRY(d2h_async(c, best_iter, c->best_iter.p, sizeof(int64_t) * c->K));
     // pieces of the scan that gave up waiting for their fit's constants (they poison their draws; elbo_qf_kernel.hip): the counter is
     // the last word of the hand-over buffer
-    uint32_t lost = 0;
-    if (c->qf_share.cap >= sizeof(uint32_t))
-        PF_TRY(d2h_async(c, &lost, c->qf_share.as<char>() + c->qf_share.cap - sizeof(uint32_t), sizeof(uint32_t)));
+    uint32_t lost2[2] = {0, 0};
+    for (int q = 0; q < 2; ++q)
+        if (c->qf_share_s[q].cap >= sizeof(uint32_t))
+            PF_TRY(d2h_async(c, &lost2[q], c->qf_share_s[q].as<char>() + c->qf_share_s[q].cap - sizeof(uint32_t), sizeof(uint32_t)));
     PF_TRY(stream_sync(c));
-    if (lost != 0) (void)hipMemsetAsync(c->qf_share.as<char>() + c->qf_share.cap - sizeof(uint32_t), 0, sizeof(uint32_t), c->stream);
+    uint32_t lost = lost2[0] + lost2[1];
+    for (int q = 0; q < 2; ++q)
+        if (lost2[q] != 0) (void)hipMemsetAsync(c->qf_share_s[q].as<char>() + c->qf_share_s[q].cap - sizeof(uint32_t), 0, sizeof(uint32_t), c->stream);
     {
         const char *fake = pf_debug_get("PFMI_QF_FAKE_LOST");       // test hook: the first wait of a ctx reports one lost piece (exercises the retry path)
         if (fake && fake[0] == '1' && !c->qf_no_share) lost = 1;
@@ -908,7 +1136,7 @@ int32_t pfmi_pool_build(pfmi_ctx *c, int64_t N_r, const int64_t *points, const u
     const int K = c->K;
     std::vector<int32_t> pts((size_t)K);
     for (int k = 0; k < K; ++k) {
-        PF_CHECK(points[k] >= c->off[k] && points[k] < c->off[k + 1], PFMI_ERR_ARG,
+        PF_CHECK(points[k] >= c->off[k] && points[k] < c->off[k] + c->path_npts(k), PFMI_ERR_ARG,
                  "pool_build: point %lld does not belong to path %d", (long long)points[k], k);
         pts[(size_t)k] = (int32_t)points[k];
     }

@@ -98,6 +98,24 @@ struct pfmi_ctx {
     bool have_trace_lp = false;
     DevBuf trace_lp;                          // [P]
     DevBuf st_theta, st_grad, st_lp, st_npts; // staging [K][maxiters+1][d]
+    DevBuf st_done;                           // int32 [K]: streaming -- path k has ended (st_npts[k] is final)
+    // streaming layout (pfmi_stream_enqueue): the trace points stay where the optimiser records them -- point l of path k is
+    // p = k * vcap + l, vcap = maxiters + 1 (theta / grad ARE st_theta / st_grad, nothing is packed), P = K * vcap slots of which path k fills
+    // st_npts[k]; off[k] = k * vcap.  Every per-point buffer is indexed by the slot.
+    bool virt = false;
+    int64_t vcap = 0;
+    std::vector<int32_t> npts_h;              // host copy of st_npts (valid after pfmi_stream_wait)
+    DevBuf hs_ial, hs_nacc;                   // state of the segmented history walk: carried 1 / alpha [K][d], accepted count [K]
+    DevBuf sg_err;                            // int32: a gate of the streaming pipeline timed out
+    hipStream_t s_opt = nullptr, s_fit = nullptr, s_scan[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> sg_ev;            // events of the last streaming call (reused)
+    bool stream_pending = false;
+    // the trace as the kernels see it: the packed buffers, or -- streaming layout -- the optimiser's staging buffers themselves
+    double *th() const { return virt ? st_theta.as<double>() : theta.as<double>(); }
+    double *gr() const { return virt ? st_grad.as<double>() : grad.as<double>(); }
+    double *tlp() const { return virt ? st_lp.as<double>() : trace_lp.as<double>(); }
+    int64_t path_npts(int k) const { return virt ? (int64_t)npts_h[(size_t)k] : off[(size_t)k + 1] - off[(size_t)k]; }
+    int ncu_eff = 0;                          // CUs the scan's launch geometry assumes (0: all) -- the streaming segments leave the producers' out
     DevBuf lb_hs, lb_hy, lb_x0;               // (s, y) ring scratch [K][J][d], x0 [K][d]
 
     // fit state
@@ -130,8 +148,10 @@ struct pfmi_ctx {
     DevBuf ubuf;        // parity-mode normals
     DevBuf xbuf;        // scratch draws (callback path / pfmi_draws)
     DevBuf scratch;     // misc
-    DevBuf qf_share;    // scan: per-fit constants handed from a tail fit's first piece to its other pieces, + one flag per tail fit
-    uint32_t qf_epoch = 0;   // launch counter of the shared-constants scan: a flag equal to it means "published in THIS launch"
+    DevBuf qf_share_s[2];   // scan: per-fit constants handed from a tail fit's first piece to its other pieces, + one flag per tail fit
+    uint32_t qf_epoch_s[2] = {0, 0};   // launch counter of the shared-constants scan: a flag equal to it means "published in THIS launch"
+                                       // (one hand-over buffer + counter per scan stream: launches on different streams overlap)
+    int qf_slot = 0;        // which of the two the next scan launch uses (0 outside the streaming pipeline)
     bool qf_no_share = false; // a hand-over of the shared-constants scan timed out on this ctx: later scans take the two-launch cut (no in-kernel wait)
     int64_t qf_lost_total = 0; // pieces that ever gave up waiting (pfmi_kernel_time("qf_handover_lost") reports it as `launches`)
 
@@ -185,8 +205,9 @@ int32_t pf_stream_sync(pfmi_ctx *c);
 void pf_download_forget(pfmi_ctx *c);
 
 // ---- launch helpers (implemented in the .hip files) ----------------------------------------------
-int32_t pf_launch_history(pfmi_ctx *c, double eps);
-int32_t pf_launch_fit(pfmi_ctx *c);
+struct HistSeg;
+int32_t pf_launch_history(pfmi_ctx *c, double eps, const HistSeg *seg = nullptr);
+int32_t pf_launch_fit(pfmi_ctx *c, int seg_l0 = 0, int seg_len = 0);
 int32_t pf_launch_elbo_draws(pfmi_ctx *c, const int32_t *d_points, const uint64_t *d_seeds, int64_t nfits,
                              int64_t n0, int64_t N, const double *d_u, int64_t u_stride,
                              double *d_x, int64_t x_stride, double *d_logp, double *d_logq,
@@ -213,7 +234,8 @@ int32_t pf_launch_resample_direct(pfmi_ctx *c, int64_t S, int64_t ndraws, const 
 int32_t pf_launch_gather(pfmi_ctx *c, int64_t ndraws, const int64_t *d_idx, int64_t col_offset, double *d_out);
 int32_t pf_launch_logratio(pfmi_ctx *c, int64_t n);
 int32_t pf_launch_scatter_rows(pfmi_ctx *c, int64_t ns, int64_t N, const int32_t *d_points, const double *d_src, double *d_dst);
-int32_t pf_launch_lbfgs(pfmi_ctx *c, int K, int J, int maxiters, double g_tol, const double *d_x0);
+int32_t pf_launch_lbfgs(pfmi_ctx *c, int K, int J, int maxiters, double g_tol, const double *d_x0, int pub_mask = -1);
+int32_t pf_launch_stream_gate(pfmi_ctx *c, hipStream_t s, int K, int need, int32_t *err);
 int32_t pf_launch_trace_pack(pfmi_ctx *c, int64_t cap);
 int32_t pf_launch_woodbury_prim(pfmi_ctx *c, int mode, int64_t p, int64_t N, const double *d_in, double *d_out);
 int32_t pf_launch_colsumsq(pfmi_ctx *c, int64_t N, const double *d_x, double *d_out);

@@ -225,7 +225,7 @@ int32_t pf_launch_woodbury_diag(pfmi_ctx *c, int64_t p, double *d_out) {
     dim3 grid((unsigned)((c->d + 255) / 256)), block(256);
 #define PF_WD(KP)                                                                                                   \
     hipLaunchKernelGGL(pf_woodbury_diag_kernel<KP>, grid, block, 0, c->stream, c->d, c->J, (int)p, p0,               \
-                       c->theta.as<double>(), c->grad.as<double>(), c->alpha_all.as<double>(),                       \
+                       c->th(), c->gr(), c->alpha_all.as<double>(),                       \
                        c->hist_len.as<int32_t>(), c->hist_src.as<int32_t>(), c->dmat.as<double>(), d_out)
     switch (c->kpad) {
         case 4: PF_WD(4); break;
