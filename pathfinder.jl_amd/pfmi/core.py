@@ -78,6 +78,7 @@ class Engine:
         self.target = None
         self.K = self.P = self.d = 0
         self.offsets = None
+        self.npoints = None
         self.J = 0
 
     def close(self):
@@ -154,6 +155,7 @@ class Engine:
         assert theta.shape == grad.shape and theta.ndim == 2
         self.K, self.P, self.d = len(npts), int(npts.sum()), theta.shape[1]
         self.offsets = np.concatenate([[0], np.cumsum(npts)]).astype(np.int64)
+        self.npoints = None
         self.gen_traces += 1
         check(self.L.pfmi_set_traces(self.ctx, C.c_int32(self.K), npts.ctypes.data_as(_i64p), C.c_int32(self.d),
                                      _d(theta), _d(grad)))
@@ -170,6 +172,7 @@ class Engine:
                                          C.c_double(g_tol), npts.ctypes.data_as(_i64p)))
         self.K, self.P, self.d = K, int(npts.sum()), d
         self.offsets = np.concatenate([[0], np.cumsum(npts)]).astype(np.int64)
+        self.npoints = None
         return npts
 
     def optimize_batch_enqueue(self, x0, history_length=6, maxiters=1000, g_tol=1e-8):
@@ -179,6 +182,7 @@ class Engine:
         assert self.target is not None and d == self.target.d
         self.gen_traces += 1
         self._opt_K, self.K, self.P, self.d, self.offsets = K, K, 0, d, None
+        self.npoints = None
         check(self.L.pfmi_optimize_batch_enqueue(self.ctx, C.c_int32(K), _d(x0), C.c_int32(history_length), C.c_int32(maxiters),
                                                  C.c_double(g_tol)))
 
@@ -189,8 +193,40 @@ class Engine:
         self.offsets = np.concatenate([[0], np.cumsum(npts)]).astype(np.int64)
         return npts
 
+    # ---- streaming pipeline (include/pfmi.h: pfmi_stream_enqueue) -------------------------------------------------------------
+    def stream_enqueue(self, x0, N, seeds, history_length=6, maxiters=1000, g_tol=1e-8, eps=1e-12):
+        """optimise + fit + ELBO scan of K runs as ONE enqueued dataflow (the fits and scans of the trace points a path has already
+        produced run while the paths are still being optimised).  Fixed-stride layout: trace point l of path k is slot
+        k * (maxiters + 1) + l of every per-point array; seeds (K * (maxiters + 1),) is laid out the same way.  Only enqueues."""
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        K, d = x0.shape
+        cap = int(maxiters) + 1
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        assert self.target is not None and d == self.target.d and seeds.size == K * cap
+        self.gen_traces += 1
+        self.gen_fit += 1
+        self.J = history_length
+        self.K, self.P, self.d = K, K * cap, d
+        self.offsets = np.arange(K + 1, dtype=np.int64) * cap
+        self.npoints = None
+        check(self.L.pfmi_stream_enqueue(self.ctx, C.c_int32(K), _d(x0), C.c_int32(history_length), C.c_int32(maxiters),
+                                         C.c_double(g_tol), C.c_double(eps), C.c_int64(N), seeds.ctypes.data_as(_u64p)))
+
+    def stream_wait(self):
+        """points per path of the last stream_enqueue (the first wait of that call)"""
+        npts = np.empty(self.K, dtype=np.int64)
+        check(self.L.pfmi_stream_wait(self.ctx, npts.ctypes.data_as(_i64p)))
+        self.npoints = npts
+        return npts
+
+    def path_len(self, k):
+        """trace points of path k (the streaming layout reserves maxiters + 1 slots per path and fills the first npoints[k])"""
+        if getattr(self, "npoints", None) is not None:
+            return int(self.npoints[k])
+        return int(self.offsets[k + 1] - self.offsets[k])
+
     def get_trace(self, k, logp=True):
-        n = int(self.offsets[k + 1] - self.offsets[k])
+        n = self.path_len(k)
         theta, grad = np.empty((n, self.d)), np.empty((n, self.d))
         lp = np.empty(n) if logp else None
         check(self.L.pfmi_get_trace(self.ctx, C.c_int32(k), _d(theta), _d(lp) if logp else None, _d(grad)))

@@ -1,0 +1,124 @@
+"""GPU tests of the streaming pipeline (pfmi_stream_enqueue / pfmi_stream_wait, round 5):
+
+optimise + fit + ELBO scan as ONE enqueued dataflow -- the fits and scans of the trace points a path has already produced run while
+the paths are still being optimised -- must be BIT-IDENTICAL to the packed route
+    pfmi_optimize_batch ; pfmi_fit_batch ; pfmi_elbo_batch_enqueue
+(reference src/singlepath.jl:285-325 per run, src/multipath.jl:190-208 over runs); only the layout differs: trace point l of path k is
+slot k * (maxiters + 1) + l.  All calls go through the C ABI of libpfmi.so.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pfmi_mod():
+    import pfmi
+    return pfmi
+
+
+def _packed(pfmi, tg, x0, J, maxiters, N, sd_stride, N_r, ndraws):
+    K = x0.shape[0]
+    cap = maxiters + 1
+    e = pfmi.Engine(0)
+    e.set_target(tg)
+    npts = e.optimize_batch(x0, J, maxiters)
+    e.fit_batch(J)
+    seeds = np.concatenate([sd_stride[k * cap:k * cap + int(npts[k])] for k in range(K)])
+    e.elbo_batch_enqueue(N, seeds)
+    fail = np.arange(K, dtype=np.uint64) + np.uint64(1000)
+    e.pool_build_best(N_r, fail)
+    comm = pfmi.Comm.init_all([e])
+    res, idx, draws = comm.psis_resample(ndraws, seed=9)
+    status, jeff, logdet, nrej = e.fit_status()
+    elbo, se, best = e.elbo_batch_wait()
+    traces = [e.get_trace(k) for k in range(K)]
+    fit = e.get_fit(int(e.offsets[0]) + int(best[0]), int(jeff[int(e.offsets[0]) + int(best[0])])) if best[0] > 0 else None
+    out = dict(npts=npts, off=e.offsets.copy(), status=status, jeff=jeff, logdet=logdet, nrej=nrej, elbo=elbo, se=se, best=best,
+               res=res, idx=idx, draws=draws, traces=traces, fit=fit)
+    comm.close(); e.close()
+    return out
+
+
+def _streamed(pfmi, tg, x0, J, maxiters, N, sd_stride, N_r, ndraws, repeat=1):
+    K = x0.shape[0]
+    e = pfmi.Engine(0)
+    e.set_target(tg)
+    outs = []
+    for _ in range(repeat):
+        e.stream_enqueue(x0, N, sd_stride, J, maxiters)
+        fail = np.arange(K, dtype=np.uint64) + np.uint64(1000)
+        e.pool_build_best(N_r, fail)
+        comm = pfmi.Comm.init_all([e])
+        res, idx, draws = comm.psis_resample(ndraws, seed=9)
+        npts = e.stream_wait()
+        status, jeff, logdet, nrej = e.fit_status()
+        elbo, se, best = e.elbo_batch_wait()
+        traces = [e.get_trace(k) for k in range(K)]
+        fit = e.get_fit(int(e.offsets[0]) + int(best[0]), int(jeff[int(e.offsets[0]) + int(best[0])])) if best[0] > 0 else None
+        outs.append(dict(npts=npts, off=e.offsets.copy(), status=status, jeff=jeff, logdet=logdet, nrej=nrej, elbo=elbo, se=se, best=best,
+                         res=res, idx=idx, draws=draws, traces=traces, fit=fit))
+        comm.close()
+    e.close()
+    return outs
+
+
+def _compare(a, s, K, cap):
+    """a: packed route, s: streamed (fixed stride)"""
+    np.testing.assert_array_equal(a["npts"], s["npts"])
+    np.testing.assert_array_equal(a["nrej"], s["nrej"])
+    np.testing.assert_array_equal(a["best"], s["best"])
+    for k in range(K):
+        n = int(a["npts"][k])
+        pa, ps = int(a["off"][k]), k * cap
+        for name in ("status", "jeff", "logdet", "elbo", "se"):
+            np.testing.assert_array_equal(a[name][pa:pa + n], s[name][ps:ps + n], err_msg=f"{name} path {k}")
+        assert np.all(s["status"][ps + n:ps + cap] == 4), "slots a path never reached carry PFMI_FIT_ABSENT"
+        assert np.all(np.isnan(s["elbo"][ps + n:ps + cap]))
+        for i in range(3):
+            np.testing.assert_array_equal(a["traces"][k][i], s["traces"][k][i])
+    np.testing.assert_array_equal(a["idx"], s["idx"])
+    np.testing.assert_array_equal(a["draws"], s["draws"])
+    assert a["res"]["pareto_shape"] == s["res"]["pareto_shape"] and a["res"]["tail_length"] == s["res"]["tail_length"]
+    if a["fit"] is not None:
+        for name in ("alpha", "B", "D", "qr_factors", "T", "V", "mu"):
+            np.testing.assert_array_equal(a["fit"][name], s["fit"][name], err_msg=name)
+        assert a["fit"]["logdet"] == s["fit"]["logdet"]
+
+
+CASES = [
+    # name, target, K, J, maxiters, N, init scale
+    ("lr64", lambda m: m.t_lowrank(64, r=8, seed=2), 4, 6, 60, 256, 2.0),
+    ("diag100", lambda m: m.t_diag(100, seed=1), 8, 6, 1000, 1000, 2.0),
+    ("lr1000", lambda m: m.t_lowrank(1000, r=8, seed=2), 8, 6, 1000, 1000, 2.0),
+    ("funnel50_j10", lambda m: m.t_funnel(50), 5, 10, 300, 200, 10.0),
+    ("iso10_short", lambda m: m.t_iso(10), 3, 6, 20, 64, 2.0),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_streamed_pipeline_is_bit_identical_to_the_packed_route(pfmi_mod, case):
+    name, mk, K, J, maxiters, N, scale = case
+    tg = mk(pfmi_mod)
+    d = tg.d
+    cap = maxiters + 1
+    x0 = pfmi_mod.HostRNG(31).rand(K * d).reshape(K, d) * 2 * scale - scale
+    sd = pfmi_mod.hostrng.rand_u64(77, np.arange(K * cap, dtype=np.uint64), 9)
+    a = _packed(pfmi_mod, tg, x0, J, maxiters, N, sd, N, 200)
+    assert int(a["npts"].min()) >= 1
+    s1, s2 = _streamed(pfmi_mod, tg, x0, J, maxiters, N, sd, N, 200, repeat=2)
+    _compare(a, s1, K, cap)
+    _compare(a, s2, K, cap)                     # the same context again: every buffer / event / flag is reusable
+
+
+def test_stream_refuses_what_it_cannot_run(pfmi_mod):
+    e = pfmi_mod.Engine(0)
+    tg = pfmi_mod.t_diag(16, seed=1)
+    e.set_target(tg)
+    x0 = np.zeros((200, 16))                    # 2 K > #CU: the optimiser's workgroups could not all be resident beside their consumers
+    with pytest.raises(pfmi_mod._lib.PfmiError):
+        e.stream_enqueue(x0, 16, np.zeros(200 * 11, dtype=np.uint64), 6, 10)
+    with pytest.raises(pfmi_mod._lib.PfmiError):  # history_length beyond the tuned kernels
+        e.stream_enqueue(np.zeros((2, 16)), 16, np.zeros(2 * 11, dtype=np.uint64), 20, 10)
+    e.close()
