@@ -142,9 +142,11 @@ int32_t pfmi_get_trace(pfmi_ctx *ctx, int32_t k, double *theta, double *logp, do
  *     pfmi_optimize_batch(K, x0, J, maxiters, g_tol) ; pfmi_fit_batch(J, eps) ; pfmi_elbo_batch_enqueue(N, seeds')
  * except for the LAYOUT: trace point l of path k is slot  p = k * (maxiters + 1) + l  in every per-point array of the context (status,
  * j_eff, logdet, elbo, se, ... have K * (maxiters + 1) entries; the slots a path did not reach carry status PFMI_FIT_ABSENT / NaN), and
- * `seeds` is laid out the same way: seeds[k * (maxiters + 1) + l] = the UInt64 seed of the ELBO estimate of fit l of run k
- * (src/elbo.jl:2; entries beyond a path's end are never used -- draw maxiters + 1 per run from a COPY of its rng, advance the rng by the
- * path's length afterwards).  Only enqueues; pfmi_stream_wait returns the points per path, pfmi_elbo_batch_wait the ELBO table, and
+ * `seeds` holds the runs' predrawn seed streams: seeds[k * (maxiters + 1) + i], i = 0 .. maxiters, = the (i + 1)-th UInt64 a COPY of run k's
+ * rng yields (src/elbo.jl:2 draws L of them AFTER the optimisation, when L is known; here maxiters + 1 are drawn up front and the host
+ * advances the run's rng by the L the path turned out to have).  The ELBO estimate of fit l (l = 1 .. L, slot k * (maxiters + 1) + l)
+ * uses value l - 1; a later pfmi_pool_build_best(ctx, N_r, NULL) gives a FAILED run the value behind the ones it consumed, index L (what
+ * rand(rng, fit_distribution, ndraws) would start from, src/singlepath.jl:231-233).  Only enqueues; pfmi_stream_wait returns the points per path, pfmi_elbo_batch_wait the ELBO table, and
  * pfmi_pool_build_best / pfmi_comm_psis_resample may be enqueued in between.  Built-in targets, history_length <= 16, 2 K <= #CU;
  * PFMI_ERR_UNSUPPORTED otherwise (use the three calls above). */
 int32_t pfmi_stream_enqueue(pfmi_ctx *ctx, int32_t K, const double *x0, int32_t history_length, int32_t maxiters, double g_tol,

@@ -280,11 +280,12 @@ __global__ void pf_nan_failed_kernel(int64_t ns, int64_t N, const int32_t *__res
 
 // Winners of the ELBO scan picked on the device (pfmi_pool_build_best): fit_distributions[fit_iteration + 1] (src/singlepath.jl:224),
 // success = L > 0 && ELBO finite and != -Inf (src/singlepath.jl:299, 309-314); a successful path reuses the seed of its winning
-// fit (src/singlepath.jl:226-230), a failed one takes fail_seeds[k] (rand(rng, fit_distribution, ndraws), :231-233).
+// fit (src/singlepath.jl:226-230), a failed one takes fail_seeds[k] (rand(rng, fit_distribution, ndraws), :231-233) -- or, streaming
+// layout without fail_seeds, the value its run's predrawn stream holds behind the L it consumed: stream_tab[k * vcap + L].
 __global__ void pf_pool_pick_kernel(int K, const int64_t *__restrict__ off, const int32_t *__restrict__ npts, const int64_t *__restrict__ best_iter,
                                     const double *__restrict__ elbo, const uint64_t *__restrict__ seeds,
-                                    const uint64_t *__restrict__ fail_seeds, int32_t *__restrict__ points, uint64_t *__restrict__ pseeds,
-                                    int32_t *__restrict__ ok) {
+                                    const uint64_t *__restrict__ fail_seeds, const uint64_t *__restrict__ stream_tab, int64_t vcap,
+                                    int32_t *__restrict__ points, uint64_t *__restrict__ pseeds, int32_t *__restrict__ ok) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
     const int64_t p0 = off[k], L = npts ? (int64_t)npts[k] - 1 : off[k + 1] - p0 - 1, b = best_iter[k];
@@ -292,7 +293,7 @@ __global__ void pf_pool_pick_kernel(int K, const int64_t *__restrict__ off, cons
     const double v = (b > 0) ? elbo[p] : NAN;
     const int good = (L > 0 && b > 0 && !isnan(v) && v != -INFINITY) ? 1 : 0;
     points[k] = (int32_t)p;
-    pseeds[k] = (good || fail_seeds == nullptr) ? seeds[p] : fail_seeds[k];
+    pseeds[k] = good ? seeds[p] : fail_seeds ? fail_seeds[k] : (stream_tab && L >= 0) ? stream_tab[(int64_t)k * vcap + L] : seeds[p];
     ok[k] = good;
 }
 
@@ -498,7 +499,8 @@ int32_t pf_launch_nan_failed(pfmi_ctx *c, int64_t ns, int64_t N, const int32_t *
 int32_t pf_launch_pool_pick(pfmi_ctx *c, int have_fail_seeds) {
     hipLaunchKernelGGL(pf_pool_pick_kernel, dim3((unsigned)((c->K + 63) / 64)), dim3(64), 0, c->stream, c->K, c->d_off.as<int64_t>(),
                        c->virt ? c->st_npts.as<int32_t>() : (const int32_t *)nullptr, c->best_iter.as<int64_t>(), c->elbo.as<double>(), c->seeds.as<uint64_t>(),
-                       have_fail_seeds ? c->fail_seeds.as<uint64_t>() : (const uint64_t *)nullptr, c->pool_points.as<int32_t>(),
+                       have_fail_seeds ? c->fail_seeds.as<uint64_t>() : (const uint64_t *)nullptr,
+                       c->virt ? c->d_stream_tab : (const uint64_t *)nullptr, c->vcap, c->pool_points.as<int32_t>(),
                        c->pool_seeds.as<uint64_t>(), c->pool_ok.as<int32_t>());
     PF_HIP(hipGetLastError());
     return PFMI_OK;

@@ -593,20 +593,28 @@ int32_t pfmi_stream_enqueue(pfmi_ctx *c, int32_t K, const double *x0, int32_t J,
     c->npts_h.assign((size_t)K, 0);
     c->fitted = false; c->elbo_done = false; c->pooled = false; c->have_trace_lp = false; c->opt_pending = false;
     const int64_t nf = (int64_t)K * (cap - 1);
-    const size_t off_ls = sizeof(uint64_t) * Pz, off_li = off_ls + sizeof(uint64_t) * (size_t)(nf > 0 ? nf : 1);
+    // ONE upload: the per-point seeds (slot k * cap + l holds stream value l - 1 of run k), the scan's work lists, the raw streams
+    const size_t off_ls = sizeof(uint64_t) * Pz, off_tab = off_ls + sizeof(uint64_t) * (size_t)(nf > 0 ? nf : 1);
+    const size_t off_li = off_tab + sizeof(uint64_t) * Pz;
     const size_t up_bytes = off_li + sizeof(int32_t) * (size_t)(nf > 0 ? nf : 1);
     PF_TRY(c->seeds.ensure(up_bytes + 16));
     {
         std::vector<char> stage(up_bytes);
-        memcpy(stage.data(), seeds, sizeof(uint64_t) * Pz);
+        uint64_t *pt = reinterpret_cast<uint64_t *>(stage.data());
+        for (int k = 0; k < K; ++k) {
+            pt[(size_t)k * cap] = 0;
+            if (cap > 1) memcpy(pt + (size_t)k * cap + 1, seeds + (size_t)k * cap, sizeof(uint64_t) * (size_t)(cap - 1));
+        }
+        memcpy(stage.data() + off_tab, seeds, sizeof(uint64_t) * Pz);
         uint64_t *ls = reinterpret_cast<uint64_t *>(stage.data() + off_ls);
         int32_t *li = reinterpret_cast<int32_t *>(stage.data() + off_li);
         int64_t t = 0;
         for (int i = 0; i < nseg; ++i)
             for (int l = bnd[(size_t)i] > 1 ? bnd[(size_t)i] : 1; l < bnd[(size_t)i + 1]; ++l)
-                for (int k = 0; k < K; ++k, ++t) { const int64_t pp = (int64_t)k * cap + l; li[t] = (int32_t)pp; ls[t] = seeds[pp]; }
+                for (int k = 0; k < K; ++k, ++t) { const int64_t pp = (int64_t)k * cap + l; li[t] = (int32_t)pp; ls[t] = pt[pp]; }
         PF_TRY(h2d(c, c->seeds.p, stage.data(), up_bytes));
     }
+    c->d_stream_tab = reinterpret_cast<const uint64_t *>(c->seeds.as<char>() + off_tab);
     uint64_t *d_lseeds = reinterpret_cast<uint64_t *>(c->seeds.as<char>() + off_ls);
     int32_t *d_list = reinterpret_cast<int32_t *>(c->seeds.as<char>() + off_li);
     PF_TRY(h2d(c, c->lb_x0.p, x0, sizeof(double) * (size_t)K * dz));
@@ -884,6 +892,7 @@ int32_t pfmi_elbo_batch_enqueue(pfmi_ctx *c, int64_t N, const uint64_t *seeds, c
             for (int64_t p = c->off[k] + 1; p < c->off[k] + c->path_npts(k); ++p, ++t) { li[t] = (int32_t)p; ls[t] = seeds[p]; }
     }
     PF_TRY(c->seeds.ensure(up_bytes + 16));
+    c->d_stream_tab = nullptr;                                  // (the streams of a streaming call lived in this buffer)
     PF_TRY(h2d(c, c->seeds.p, stage.data(), up_bytes));
     uint64_t *d_lseeds = reinterpret_cast<uint64_t *>(c->seeds.as<char>() + off_ls);
     int32_t *d_list = reinterpret_cast<int32_t *>(c->seeds.as<char>() + off_li);

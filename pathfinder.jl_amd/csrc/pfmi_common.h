@@ -105,6 +105,7 @@ struct pfmi_ctx {
     bool virt = false;
     int64_t vcap = 0;
     std::vector<int32_t> npts_h;              // host copy of st_npts (valid after pfmi_stream_wait)
+    const uint64_t *d_stream_tab = nullptr;   // device copy of the runs' predrawn seed streams [K][vcap] (inside `seeds`)
     DevBuf hs_ial, hs_nacc;                   // state of the segmented history walk: carried 1 / alpha [K][d], accepted count [K]
     DevBuf sg_err;                            // int32: a gate of the streaming pipeline timed out
     hipStream_t s_opt = nullptr, s_fit = nullptr, s_scan[2] = {nullptr, nullptr};

@@ -25,9 +25,10 @@ def _packed(pfmi, tg, x0, J, maxiters, N, sd_stride, N_r, ndraws):
     e.set_target(tg)
     npts = e.optimize_batch(x0, J, maxiters)
     e.fit_batch(J)
-    seeds = np.concatenate([sd_stride[k * cap:k * cap + int(npts[k])] for k in range(K)])
+    # fit l of run k uses value l - 1 of the run's predrawn stream; a failed run the value behind the L it consumed
+    seeds = np.concatenate([np.concatenate([[np.uint64(0)], sd_stride[k * cap:k * cap + int(npts[k]) - 1]]) for k in range(K)]).astype(np.uint64)
     e.elbo_batch_enqueue(N, seeds)
-    fail = np.arange(K, dtype=np.uint64) + np.uint64(1000)
+    fail = np.array([sd_stride[k * cap + int(npts[k]) - 1] for k in range(K)], dtype=np.uint64)
     e.pool_build_best(N_r, fail)
     comm = pfmi.Comm.init_all([e])
     res, idx, draws = comm.psis_resample(ndraws, seed=9)
@@ -48,8 +49,7 @@ def _streamed(pfmi, tg, x0, J, maxiters, N, sd_stride, N_r, ndraws, repeat=1):
     outs = []
     for _ in range(repeat):
         e.stream_enqueue(x0, N, sd_stride, J, maxiters)
-        fail = np.arange(K, dtype=np.uint64) + np.uint64(1000)
-        e.pool_build_best(N_r, fail)
+        e.pool_build_best(N_r, None)
         comm = pfmi.Comm.init_all([e])
         res, idx, draws = comm.psis_resample(ndraws, seed=9)
         npts = e.stream_wait()
@@ -80,7 +80,8 @@ def _compare(a, s, K, cap):
             np.testing.assert_array_equal(a["traces"][k][i], s["traces"][k][i])
     np.testing.assert_array_equal(a["idx"], s["idx"])
     np.testing.assert_array_equal(a["draws"], s["draws"])
-    assert a["res"]["pareto_shape"] == s["res"]["pareto_shape"] and a["res"]["tail_length"] == s["res"]["tail_length"]
+    np.testing.assert_equal(a["res"]["pareto_shape"], s["res"]["pareto_shape"])       # (NaN == NaN here: a pool of 64 draws has no tail to fit)
+    assert a["res"]["tail_length"] == s["res"]["tail_length"]
     if a["fit"] is not None:
         for name in ("alpha", "B", "D", "qr_factors", "T", "V", "mu"):
             np.testing.assert_array_equal(a["fit"][name], s["fit"][name], err_msg=name)
@@ -104,6 +105,8 @@ def test_streamed_pipeline_is_bit_identical_to_the_packed_route(pfmi_mod, case):
     d = tg.d
     cap = maxiters + 1
     x0 = pfmi_mod.HostRNG(31).rand(K * d).reshape(K, d) * 2 * scale - scale
+    if name.startswith("iso"):
+        x0[0] = 0.0                             # already at the optimum: one trace point, L = 0 -- a FAILED run (src/singlepath.jl:299)
     sd = pfmi_mod.hostrng.rand_u64(77, np.arange(K * cap, dtype=np.uint64), 9)
     a = _packed(pfmi_mod, tg, x0, J, maxiters, N, sd, N, 200)
     assert int(a["npts"].min()) >= 1
