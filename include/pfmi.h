@@ -151,6 +151,7 @@ int32_t pfmi_get_trace(pfmi_ctx *ctx, int32_t k, double *theta, double *logp, do
  * PFMI_ERR_UNSUPPORTED otherwise (use the three calls above). */
 int32_t pfmi_stream_enqueue(pfmi_ctx *ctx, int32_t K, const double *x0, int32_t history_length, int32_t maxiters, double g_tol,
                             double eps, int64_t N, const uint64_t *seeds);
+int32_t pfmi_stream_pump(pfmi_ctx *ctx, int32_t *finished);
 int32_t pfmi_stream_wait(pfmi_ctx *ctx, int64_t *npoints);
 
 /* ---- fit_mvnormals / lbfgs_inverse_hessians / pdfactorize --------------------------------------- */

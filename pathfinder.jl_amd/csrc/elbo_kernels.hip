@@ -200,8 +200,17 @@ __global__ __launch_bounds__(256) void pf_elbo_reduce_kernel(int64_t N, const in
                                                              const int32_t *__restrict__ status,
                                                              const double *__restrict__ logp,
                                                              const double *__restrict__ logq,
-                                                             double *__restrict__ elbo, double *__restrict__ se) {
-    const int p = blockIdx.x, tid = threadIdx.x;
+                                                             double *__restrict__ elbo, double *__restrict__ se,
+                                                             int64_t vcap, int seg_len, const int32_t *__restrict__ npts) {
+    // (seg_len > 0: the streaming layout -- block b is position b % seg_len of path b / seg_len, slot k * vcap + l; positions a path never
+    //  reached keep the NaN they were initialised with)
+    int p = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (seg_len > 0) {
+        const int k = blockIdx.x / seg_len, l = blockIdx.x - k * seg_len;
+        if (l >= npts[k]) return;
+        p = (int)((int64_t)k * vcap + l);
+    }
     __shared__ double red[8];
     const bool first = ((int64_t)p == off[path_of[p]]);
     if (first || status[p] != PFMI_FIT_OK || N <= 0) {
@@ -464,9 +473,12 @@ int32_t pf_launch_elbo_draws(pfmi_ctx *c, const int32_t *d_points, const uint64_
 
 int32_t pf_launch_elbo_reduce(pfmi_ctx *c) {
     pf_kernel_begin(c);
-    hipLaunchKernelGGL(pf_elbo_reduce_kernel, dim3((unsigned)c->P), dim3(256), 0, c->stream, c->N_e,
+    int seg_len = 0;
+    if (c->virt) for (int k = 0; k < c->K; ++k) if (c->npts_h[(size_t)k] > seg_len) seg_len = c->npts_h[(size_t)k];
+    hipLaunchKernelGGL(pf_elbo_reduce_kernel, dim3((unsigned)(c->virt ? (int64_t)c->K * seg_len : c->P)), dim3(256), 0, c->stream, c->N_e,
                        c->d_off.as<int64_t>(), c->d_path_of.as<int32_t>(), c->status.as<int32_t>(),
-                       c->logp.as<double>(), c->logq.as<double>(), c->elbo.as<double>(), c->se.as<double>());
+                       c->logp.as<double>(), c->logq.as<double>(), c->elbo.as<double>(), c->se.as<double>(),
+                       c->vcap, seg_len, c->st_npts.as<int32_t>());
     hipLaunchKernelGGL(pf_elbo_argmax_kernel, dim3((unsigned)c->K), dim3(64), 0, c->stream, c->K,
                        c->d_off.as<int64_t>(), c->virt ? c->st_npts.as<int32_t>() : (const int32_t *)nullptr, c->elbo.as<double>(),
                        c->best_iter.as<int64_t>());

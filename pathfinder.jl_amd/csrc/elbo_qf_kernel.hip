@@ -775,8 +775,9 @@ static int32_t launch_qf_ng(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
     constexpr int NPG = (TGT != 0) ? (KC + 1 + 15) / 16 : 0;
     // one workgroup per fit; a fit's groups are split over several workgroups only when there are few fits (every
     // workgroup recomputes the per-fit constants, so the pieces are kept to whole batches)
+    // (a segment of the streaming pipeline that is not the last: whole fits only -- the next segment's workgroups fill the CUs this one leaves)
     int split = 1;
-    while ((int64_t)split * nfits < 1024 && (ngroups + NPG) / (split * 2) >= QF_WAVES * NG) split *= 2;
+    while (!c->qf_seg_mode && (int64_t)split * nfits < 1024 && (ngroups + NPG) / (split * 2) >= QF_WAVES * NG) split *= 2;
     int gpw = (ngroups + split - 1) / split;
     if (split > 1) gpw = ((gpw + NPG + QF_WAVES * NG - 1) / (QF_WAVES * NG)) * (QF_WAVES * NG) - NPG;   // fill the last batch
     if (gpw < 1) gpw = 1;
@@ -803,7 +804,7 @@ static int32_t launch_qf_ng(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
     const char *no_tail = pf_debug_get("PFMI_QF_NO_TAIL");            // test hook: one workgroup per fit (geometry-invariance tests)
     const char *two = pf_debug_get("PFMI_QF_TWO_LAUNCHES");          // test hook: the round-3 cut
     const bool two_launches = (two && two[0] == '1') || c->qf_no_share;   // (qf_no_share: a hand-over timed out on this ctx before, pfmi_elbo_batch_wait)
-    if (split == 1 && TGT != 0 && !(no_tail && no_tail[0] == '1')) {
+    if (split == 1 && TGT != 0 && !(no_tail && no_tail[0] == '1') && !c->qf_seg_mode) {
         int ncu = 0;
         PF_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device));
         if (c->ncu_eff > 0 && c->ncu_eff < ncu) ncu = c->ncu_eff;           // streaming segments: the optimiser's workgroups hold some CUs

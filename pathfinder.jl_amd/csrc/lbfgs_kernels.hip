@@ -42,10 +42,11 @@ struct LbfgsArgs {
     double *hs, *hy;                        // [K][J][EPT * NT] scratch ring (used when !hist_in_lds)
     double *tr_theta, *tr_grad, *tr_lp;     // staging trace [K][maxiters+1][d], [K][maxiters+1]
     int32_t *npts;                          // [K]
-    // streaming (pfmi_stream_enqueue): npts[k] doubles as a PROGRESS counter -- published (release, agent scope) whenever the number of recorded
-    // points reaches a multiple of pub_mask + 1 -- and done[k] is raised behind the final count, so that the fits and scans of the first
-    // points of a path run on the other CUs while the path is still being optimised.  pub_mask < 0: no publication (the packed route).
-    int32_t *done;                          // [K] or null
+    // streaming (pfmi_stream_enqueue): the number of recorded points is PUBLISHED whenever it reaches a multiple of pub_mask + 1 -- to npts[k]
+    // (device) and to h_prog[k] (page-locked HOST memory the calling thread polls: it launches the fits and scans of the points every path
+    // has produced so far on the other CUs while the paths are still being optimised) -- and h_prog[K + k] is raised behind the final count.
+    // Nobody on the device ever waits for these: the host is the scheduler.  pub_mask < 0: no publication (the packed route).
+    int32_t *h_prog;                        // [2 K] host-visible (hipHostMalloc, coherent), or null
     int pub_mask;
 };
 
@@ -352,11 +353,14 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
         S.grow = tr_grad + (size_t)n * d;                                      // (XGM: every thread re-reads only what it wrote)
         ++n;
         if (A.pub_mask >= 0 && (n & A.pub_mask) == 0) {
-            // rows 0 .. n - 1 become visible to the consumers on other CUs / XCDs: every wave writes its own stores back (agent-scope
-            // fence), the barrier orders all of them before thread 0 releases the counter (the hand-over pattern of elbo_qf_kernel.hip)
+            // rows 0 .. n - 1 reach memory: every wave writes its own stores back (agent-scope fence), the barrier orders all of them before
+            // thread 0 publishes the count.  The consumers are kernels the host launches AFTER it has read the count (a launch acquires).
             __threadfence();
             __syncthreads();
-            if (tid == 0) __hip_atomic_store(A.npts + k, n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) {
+                __hip_atomic_store(A.npts + k, n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(A.h_prog + k, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     };
     record();
@@ -618,39 +622,10 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
         __syncthreads();
         if (tid == 0) {
             __hip_atomic_store(A.npts + k, n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(A.done + k, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(A.h_prog + k, n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(A.h_prog + gridDim.x + k, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);      // final: behind the count
         }
     } else if (tid == 0) A.npts[k] = n;
-}
-
-// Gate of the streaming pipeline: ONE wave that returns once every path has recorded `need` points or has ended -- the kernels behind it in
-// the stream (history walk, fits and, through an event, the scan of the segment [.., need)) then find their inputs complete.  The producer
-// (pf_lbfgs_kernel, launched earlier on its own stream, K <= #CU / 2 workgroups: all resident) never waits for anybody, so this wave
-// cannot starve it; it occupies one wave slot.  A gate that sees no progress for ~`spins` x 2 us raises *err (the host then discards the
-// step: PFMI_ERR_RETRY) instead of hanging the stream.
-__global__ __launch_bounds__(64) void pf_stream_gate_kernel(int K, int need, const int32_t *__restrict__ npts, const int32_t *__restrict__ done,
-                                                           int spins, int32_t *__restrict__ err) {
-    const int lane = threadIdx.x;
-    for (int k0 = 0; k0 < K; k0 += 64) {
-        const int k = k0 + lane;
-        bool ok = k >= K;
-        int last = -1, idle = 0;
-        while (true) {
-            if (!ok) {
-                const int n = __hip_atomic_load(npts + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                ok = n >= need || __hip_atomic_load(done + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0;
-                if (n != last) { last = n; idle = 0; } else ++idle;
-            }
-            if (__all(ok)) break;
-            if (__any(!ok && idle > spins)) { if (lane == 0) atomicAdd(err, 1); return; }
-            __builtin_amdgcn_s_sleep(64);
-        }
-    }
-}
-int32_t pf_launch_stream_gate(pfmi_ctx *c, hipStream_t s, int K, int need, int32_t *err) {
-    hipLaunchKernelGGL(pf_stream_gate_kernel, dim3(1), dim3(64), 0, s, K, need, c->st_npts.as<int32_t>(), c->st_done.as<int32_t>(), 4000000, err);
-    PF_HIP(hipGetLastError());
-    return PFMI_OK;
 }
 
 // compaction: staging [K][cap][d] -> packed [P][d] (the layout pfmi_set_traces uploads)
@@ -676,7 +651,7 @@ static int32_t launch_lb(pfmi_ctx *c, const LbfgsArgs &A, int K, size_t dyn) {
     return PFMI_OK;
 }
 
-int32_t pf_launch_lbfgs(pfmi_ctx *c, int K, int J, int maxiters, double g_tol, const double *d_x0, int pub_mask) {
+int32_t pf_launch_lbfgs(pfmi_ctx *c, int K, int J, int maxiters, double g_tol, const double *d_x0, int pub_mask, int32_t *h_prog) {
     const TargetDev &T = c->target;
     const int d = T.d;
     LbfgsArgs A;
@@ -695,7 +670,7 @@ int32_t pf_launch_lbfgs(pfmi_ctx *c, int K, int J, int maxiters, double g_tol, c
     A.hs = c->lb_hs.as<double>(); A.hy = c->lb_hy.as<double>();
     A.tr_theta = c->st_theta.as<double>(); A.tr_grad = c->st_grad.as<double>(); A.tr_lp = c->st_lp.as<double>();
     A.npts = c->st_npts.as<int32_t>();
-    A.done = c->st_done.as<int32_t>(); A.pub_mask = pub_mask;
+    A.h_prog = h_prog; A.pub_mask = h_prog ? pub_mask : -1;
     const size_t dyn = gram_bytes + (A.hist_in_lds ? hist_bytes : 0);
     const int rp = T.kind == PFMI_TARGET_GAUSS ? T.rpad : 0;
 #define PF_LB(EPT, NT)                                                                    \

@@ -246,7 +246,7 @@ int32_t pfmi_destroy(pfmi_ctx *c) {
                       &c->pool_lr, &c->pool_lp, &c->pool_lq, &c->pool_points, &c->pool_seeds, &c->lw, &c->w,
                       &c->psis_out, &c->psis_aux, &c->tailbuf, &c->cdf, &c->idx, &c->gbuf, &c->trace_lp, &c->st_theta, &c->st_grad,
                       &c->st_lp, &c->st_npts, &c->lb_hs, &c->lb_hy, &c->lb_x0, &c->sortk, &c->sorti,
-                      &c->pool_ok, &c->fail_seeds, &c->rs_err, &c->st_done, &c->hs_ial, &c->hs_nacc, &c->sg_err};
+                      &c->pool_ok, &c->fail_seeds, &c->rs_err, &c->hs_ial, &c->hs_nacc};
     for (DevBuf *b : bufs) b->release();
     for (int b = 0; b < 2; ++b) {
         c->cb_x[b].release(); c->cb_lp[b].release();
@@ -260,8 +260,10 @@ int32_t pfmi_destroy(pfmi_ctx *c) {
     (void)hipEventDestroy(c->kev0); (void)hipEventDestroy(c->kev1);
     pf_kernel_resolve(c, false);
     for (hipEvent_t e : c->kev_pool) (void)hipEventDestroy(e);
-    for (hipEvent_t e : c->sg_ev) (void)hipEventDestroy(e);
-    for (hipStream_t s : {c->s_opt, c->s_fit, c->s_scan[0], c->s_scan[1]}) if (s) (void)hipStreamDestroy(s);
+    for (hipEvent_t e : {c->sg_fit, c->sg_opt, c->sg_scan[0], c->sg_scan[1], c->sg_start}) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t s : {c->s_opt, c->s_fit, c->s_scan1}) if (s) (void)hipStreamDestroy(s);
+    if (c->h_prog) (void)hipHostFree(c->h_prog);
+    if (c->h_list) (void)hipHostFree(c->h_list);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return PFMI_OK;
@@ -468,36 +470,29 @@ int32_t pfmi_get_trace(pfmi_ctx *c, int32_t k, double *theta, double *logp, doub
     return PFMI_OK;
 }
 
-// ---- streaming pipeline: optimise, fit and scan as ONE enqueued dataflow ------------------------------------------------------
+// ---- streaming pipeline: optimise, fit and scan as ONE dataflow the calling thread schedules -----------------------------------------
 // (reference: src/multipath.jl:190-208 runs optimisation, fit and ELBO of a run back to back inside one task; here the K optimisations
 // run as one persistent kernel and the fits / scans of the trace points they have ALREADY produced run on the other CUs meanwhile)
 //
-//   stream s_opt   pf_lbfgs_kernel: one workgroup per path; publishes its point count every PF_STREAM_PUB points
-//   stream s_fit   per segment [l0, l1) of trace positions: gate (wait until every path has l1 points or has ended) -> history walk of
-//                  the segment (state carried from the previous segment) -> fits of the segment's points -> event F_i
-//   stream s_scan[i & 1]   wait F_i -> ELBO scan of the segment's fits (two streams alternate so that a segment's last, partly filled
-//                  round of CUs overlaps the next segment's first)
-//   ctx stream     waits for all of them -> mean / SE / argmax; then whatever the caller enqueues (pool, PSIS, resample)
+//   stream s_opt   pf_lbfgs_kernel: one workgroup per path; publishes its point count every PF_STREAM_PUB points into page-locked HOST memory
+//   host           pfmi_stream_pump (called by pfmi_stream_wait until the pipeline is drained): reads the counts; once every path that is still
+//                  running has recorded l1 points, the segment [l0, l1) of trace positions is complete and its work is launched:
+//   stream s_fit   history walk of the segment (state carried from the previous segment) -> fits of the segment's points -> event
+//   ctx stream / s_scan1 (alternating)   upload of the segment's work list -> wait for the fits -> ELBO scan of the segment's fits
+//   ctx stream     at the end: waits for all of them -> mean / SE / argmax; then whatever the caller enqueues (pool, PSIS, resample)
 //
-// The trace points stay in the optimiser's fixed-stride staging buffers (point l of path k = slot k * (maxiters + 1) + l): nothing is
-// packed, no offset depends on another path's length, so no stage has to wait for the LAST path to end.  Same kernels, same arithmetic
-// as fit_batch + elbo_batch_enqueue on the packed trace: the results are bit-identical (tests/test_gpu_stream.py).
+// No kernel waits for another kernel: a consumer is only launched when its inputs are complete (the host saw the count; a kernel launch
+// acquires what was released before it), so nothing depends on dispatch order, residency or the number of CUs.  The trace points stay in
+// the optimiser's fixed-stride staging buffers (point l of path k = slot k * (maxiters + 1) + l): nothing is packed, no offset depends on
+// another path's length.  Same kernels, same arithmetic as fit_batch + elbo_batch_enqueue on the packed trace: bit-identical results
+// (tests/test_gpu_stream.py).  Four streams in all -- the default number of hardware queues, so none of them shares a queue.
 #define PF_STREAM_PUB 16
-static std::vector<int> stream_bounds(int cap) {
-    static const int step[] = {16, 16, 32, 32, 32, 64, 64, 128, 128, 256};
-    std::vector<int> b{0};
-    for (int i = 0; b.back() < cap; ++i) {
-        const int st = step[i < 10 ? i : 9];
-        b.push_back(b.back() + st >= cap ? cap : b.back() + st);
-    }
-    return b;
-}
 struct StreamSwap {                       // the launch helpers enqueue on c->stream: point it at a side stream for the scope
-    pfmi_ctx *c; hipStream_t keep; int slot, ncu;
-    StreamSwap(pfmi_ctx *c_, hipStream_t s, int qf_slot = 0, int ncu_eff = 0) : c(c_), keep(c_->stream), slot(c_->qf_slot), ncu(c_->ncu_eff) {
-        c->stream = s; c->qf_slot = qf_slot; c->ncu_eff = ncu_eff;
+    pfmi_ctx *c; hipStream_t keep; int slot; bool seg;
+    StreamSwap(pfmi_ctx *c_, hipStream_t s, int qf_slot = 0, bool seg_mode = false) : c(c_), keep(c_->stream), slot(c_->qf_slot), seg(c_->qf_seg_mode) {
+        c->stream = s; c->qf_slot = qf_slot; c->qf_seg_mode = seg_mode;
     }
-    ~StreamSwap() { c->stream = keep; c->qf_slot = slot; c->ncu_eff = ncu; }
+    ~StreamSwap() { c->stream = keep; c->qf_slot = slot; c->qf_seg_mode = seg; }
 };
 static int32_t qf_share_reserve(pfmi_ctx *c, int slot, size_t bytes) {
     DevBuf &b = c->qf_share_s[slot];
@@ -516,10 +511,11 @@ int32_t pfmi_stream_enqueue(pfmi_ctx *c, int32_t K, const double *x0, int32_t J,
              "stream_enqueue: needs a built-in target (the optimiser runs on the device)");
     PF_CHECK(K > 0 && x0 && seeds && maxiters >= 0 && N >= 1, PFMI_ERR_ARG, "stream_enqueue: bad arguments");
     PF_CHECK(J >= 1 && J <= 16, PFMI_ERR_UNSUPPORTED, "stream_enqueue: history_length %d outside 1..16", J);
+    PF_CHECK(!c->sr.active, PFMI_ERR_STATE, "stream_enqueue: the previous streaming call has not been waited for (pfmi_stream_wait)");
+    if (c->s_opt) PF_TRY(stream_sync(c));      // the page-locked progress words and work lists are reused: the previous call's copies must have landed
     const int ncu = c->ncu > 0 ? c->ncu : 256;
-    PF_CHECK(2 * K <= ncu, PFMI_ERR_UNSUPPORTED, "stream_enqueue: %d paths on %d CUs -- the optimiser's workgroups must all be resident beside "
-             "their consumers (use pfmi_optimize_batch + pfmi_fit_batch + pfmi_elbo_batch)", K, ncu);
     const int d = T.d;
+    PF_CHECK(d <= 16384, PFMI_ERR_UNSUPPORTED, "stream_enqueue: the device optimiser takes d <= 16384");
     const int64_t cap = (int64_t)maxiters + 1, P = (int64_t)K * cap;
     PF_CHECK(P < (1ll << 31), PFMI_ERR_UNSUPPORTED, "stream_enqueue: too many trace slots");
     int kpad = 0;
@@ -540,11 +536,9 @@ int32_t pfmi_stream_enqueue(pfmi_ctx *c, int32_t K, const double *x0, int32_t J,
     PF_TRY(c->st_grad.ensure(sizeof(double) * Pz * dz));
     PF_TRY(c->st_lp.ensure(sizeof(double) * Pz));
     PF_TRY(c->st_npts.ensure(sizeof(int32_t) * K));
-    PF_TRY(c->st_done.ensure(sizeof(int32_t) * K));
     PF_TRY(c->lb_x0.ensure(sizeof(double) * (size_t)K * dz));
     PF_TRY(c->hs_ial.ensure(sizeof(double) * (size_t)K * dz));
     PF_TRY(c->hs_nacc.ensure(sizeof(int32_t) * K));
-    PF_TRY(c->sg_err.ensure(sizeof(int32_t)));
     PF_TRY(c->alpha_all.ensure(sizeof(double) * Pz * dz));
     PF_TRY(c->hist_len.ensure(sizeof(int32_t) * Pz));
     PF_TRY(c->hist_src.ensure(sizeof(int32_t) * Pz * J));
@@ -568,19 +562,28 @@ int32_t pfmi_stream_enqueue(pfmi_ctx *c, int32_t K, const double *x0, int32_t J,
     PF_TRY(c->d_path_of.ensure(sizeof(int32_t) * Pz));
     for (int q = 0; q < 2; ++q) PF_TRY(qf_share_reserve(c, q, (size_t)ncu * 1700 * sizeof(double) + ((size_t)ncu + 1) * sizeof(unsigned) + (64 << 10)));
     if (!c->s_opt) {
-        PF_HIP(hipStreamCreateWithFlags(&c->s_opt, hipStreamNonBlocking));
-        PF_HIP(hipStreamCreateWithFlags(&c->s_fit, hipStreamNonBlocking));
-        PF_HIP(hipStreamCreateWithFlags(&c->s_scan[0], hipStreamNonBlocking));
-        PF_HIP(hipStreamCreateWithFlags(&c->s_scan[1], hipStreamNonBlocking));
+        int lo = 0, hi = 0;
+        PF_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));              // (hi is the numerically smaller = more urgent one)
+        PF_HIP(hipStreamCreateWithPriority(&c->s_opt, hipStreamNonBlocking, hi));     // the producer and the fits go in front of queued scan workgroups
+        PF_HIP(hipStreamCreateWithPriority(&c->s_fit, hipStreamNonBlocking, hi));
+        PF_HIP(hipStreamCreateWithFlags(&c->s_scan1, hipStreamNonBlocking));
+        for (hipEvent_t *e : {&c->sg_fit, &c->sg_opt, &c->sg_scan[0], &c->sg_scan[1], &c->sg_start}) PF_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
-    const std::vector<int> bnd = stream_bounds((int)cap);
-    const int nseg = (int)bnd.size() - 1;
-    while ((int)c->sg_ev.size() < nseg + 6) {
-        hipEvent_t e = nullptr;
-        PF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        c->sg_ev.push_back(e);
+    if (c->h_prog_cap < 2 * K) {
+        if (c->h_prog) (void)hipHostFree(c->h_prog);
+        c->h_prog = nullptr; c->h_prog_cap = 0;
+        PF_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_prog), sizeof(int32_t) * 2 * (size_t)K, hipHostMallocCoherent | hipHostMallocMapped));
+        c->h_prog_cap = 2 * K;
     }
-    // ---- host-side layout: slot offsets, and the scan's work lists of all segments (position-major inside a segment)
+    const int64_t nf = (int64_t)K * (cap - 1);
+    const size_t list_bytes = (size_t)(nf > 0 ? nf : 1) * (sizeof(uint64_t) + sizeof(int32_t));
+    if (c->h_list_cap < list_bytes) {
+        if (c->h_list) (void)hipHostFree(c->h_list);
+        c->h_list = nullptr; c->h_list_cap = 0;
+        PF_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_list), list_bytes, hipHostMallocDefault));
+        c->h_list_cap = list_bytes;
+    }
+    // ---- host-side layout: slot offsets
     const bool same_layout = c->virt && c->K == K && c->vcap == cap && c->d == d && (int64_t)c->path_of.size() == P;
     c->off.assign((size_t)K + 1, 0);
     for (int k = 0; k <= K; ++k) c->off[(size_t)k] = (int64_t)k * cap;
@@ -592,102 +595,170 @@ int32_t pfmi_stream_enqueue(pfmi_ctx *c, int32_t K, const double *x0, int32_t J,
     c->K = K; c->d = d; c->P = P; c->J = J; c->kpad = kpad; c->N_e = N; c->virt = true; c->vcap = cap;
     c->npts_h.assign((size_t)K, 0);
     c->fitted = false; c->elbo_done = false; c->pooled = false; c->have_trace_lp = false; c->opt_pending = false;
-    const int64_t nf = (int64_t)K * (cap - 1);
-    // ONE upload: the per-point seeds (slot k * cap + l holds stream value l - 1 of run k), the scan's work lists, the raw streams
-    const size_t off_ls = sizeof(uint64_t) * Pz, off_tab = off_ls + sizeof(uint64_t) * (size_t)(nf > 0 ? nf : 1);
-    const size_t off_li = off_tab + sizeof(uint64_t) * Pz;
-    const size_t up_bytes = off_li + sizeof(int32_t) * (size_t)(nf > 0 ? nf : 1);
-    PF_TRY(c->seeds.ensure(up_bytes + 16));
+    // ONE upload: the per-point seeds (slot k * cap + l holds stream value l - 1 of run k), then the raw streams; behind them the room of the
+    // scan's work lists (filled segment by segment from h_list)
+    const size_t off_tab = sizeof(uint64_t) * Pz, off_ls = off_tab + sizeof(uint64_t) * Pz;
+    const size_t off_li = off_ls + sizeof(uint64_t) * (size_t)(nf > 0 ? nf : 1);
+    const size_t all_bytes = off_li + sizeof(int32_t) * (size_t)(nf > 0 ? nf : 1);
+    PF_TRY(c->seeds.ensure(all_bytes + 16));
     {
-        std::vector<char> stage(up_bytes);
-        uint64_t *pt = reinterpret_cast<uint64_t *>(stage.data());
+        std::vector<uint64_t> stage(2 * Pz);
         for (int k = 0; k < K; ++k) {
-            pt[(size_t)k * cap] = 0;
-            if (cap > 1) memcpy(pt + (size_t)k * cap + 1, seeds + (size_t)k * cap, sizeof(uint64_t) * (size_t)(cap - 1));
+            stage[(size_t)k * cap] = 0;
+            if (cap > 1) memcpy(stage.data() + (size_t)k * cap + 1, seeds + (size_t)k * cap, sizeof(uint64_t) * (size_t)(cap - 1));
         }
-        memcpy(stage.data() + off_tab, seeds, sizeof(uint64_t) * Pz);
-        uint64_t *ls = reinterpret_cast<uint64_t *>(stage.data() + off_ls);
-        int32_t *li = reinterpret_cast<int32_t *>(stage.data() + off_li);
-        int64_t t = 0;
-        for (int i = 0; i < nseg; ++i)
-            for (int l = bnd[(size_t)i] > 1 ? bnd[(size_t)i] : 1; l < bnd[(size_t)i + 1]; ++l)
-                for (int k = 0; k < K; ++k, ++t) { const int64_t pp = (int64_t)k * cap + l; li[t] = (int32_t)pp; ls[t] = pt[pp]; }
-        PF_TRY(h2d(c, c->seeds.p, stage.data(), up_bytes));
+        memcpy(stage.data() + Pz, seeds, sizeof(uint64_t) * Pz);
+        PF_TRY(h2d(c, c->seeds.p, stage.data(), sizeof(uint64_t) * 2 * Pz));
+        stage.resize(Pz);
+        c->sr.seeds_pt.swap(stage);
     }
     c->d_stream_tab = reinterpret_cast<const uint64_t *>(c->seeds.as<char>() + off_tab);
-    uint64_t *d_lseeds = reinterpret_cast<uint64_t *>(c->seeds.as<char>() + off_ls);
-    int32_t *d_list = reinterpret_cast<int32_t *>(c->seeds.as<char>() + off_li);
     PF_TRY(h2d(c, c->lb_x0.p, x0, sizeof(double) * (size_t)K * dz));
     PF_TRY(h2d(c, c->d_off.p, c->off.data(), sizeof(int64_t) * (K + 1)));
     if (!same_layout) PF_TRY(h2d(c, c->d_path_of.p, c->path_of.data(), sizeof(int32_t) * Pz));
+    // slots no path reaches: PFMI_FIT_ABSENT, j_eff 0, NaN ELBO (0xFF.. is a NaN) -- nothing is ever launched for them
+    PF_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->status.p), PFMI_FIT_ABSENT, Pz, c->stream));
+    PF_HIP(hipMemsetAsync(c->hist_len.p, 0, sizeof(int32_t) * Pz, c->stream));
+    PF_HIP(hipMemsetAsync(c->elbo.p, 0xFF, sizeof(double) * Pz, c->stream));
+    PF_HIP(hipMemsetAsync(c->se.p, 0xFF, sizeof(double) * Pz, c->stream));
     PF_HIP(hipMemsetAsync(c->st_npts.p, 0, sizeof(int32_t) * K, c->stream));
-    PF_HIP(hipMemsetAsync(c->st_done.p, 0, sizeof(int32_t) * K, c->stream));
-    PF_HIP(hipMemsetAsync(c->sg_err.p, 0, sizeof(int32_t), c->stream));
     PF_HIP(hipMemsetAsync(c->hist_src.p, 0, sizeof(int32_t) * Pz * J, c->stream));
+    for (int i = 0; i < 2 * K; ++i) __atomic_store_n(c->h_prog + i, 0, __ATOMIC_RELAXED);
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    pfmi_ctx::StreamRun &R = c->sr;
+    {
+        std::vector<uint64_t> keep;
+        keep.swap(R.seeds_pt);
+        R = pfmi_ctx::StreamRun();
+        R.seeds_pt.swap(keep);
+    }
+    R.K = K; R.J = J; R.cap = (int)cap; R.N = N; R.eps = eps;
+    R.d_lseeds = reinterpret_cast<uint64_t *>(c->seeds.as<char>() + off_ls);
+    R.d_list = reinterpret_cast<int32_t *>(c->seeds.as<char>() + off_li);
+    // a segment should fill at least half the CUs with one workgroup per fit
+    R.minlen = ((ncu / 2 + K - 1) / K + PF_STREAM_PUB - 1) / PF_STREAM_PUB * PF_STREAM_PUB;
+    if (R.minlen < PF_STREAM_PUB) R.minlen = PF_STREAM_PUB;
+    { const char *ml = pf_debug_get("PFMI_STREAM_MINLEN"); if (ml && atoi(ml) > 0) R.minlen = (atoi(ml) + PF_STREAM_PUB - 1) / PF_STREAM_PUB * PF_STREAM_PUB; }
     c->stream_pending = true;
-    hipEvent_t ev0 = c->sg_ev[0], ev_opt = c->sg_ev[1], ev_fit = c->sg_ev[2], ev_s0 = c->sg_ev[3], ev_s1 = c->sg_ev[4];
-    PF_HIP(hipEventRecord(ev0, c->stream));
-    for (hipStream_t s : {c->s_opt, c->s_fit, c->s_scan[0], c->s_scan[1]}) PF_HIP(hipStreamWaitEvent(s, ev0, 0));
+    PF_HIP(hipEventRecord(c->sg_start, c->stream));
+    for (hipStream_t s : {c->s_opt, c->s_fit, c->s_scan1}) PF_HIP(hipStreamWaitEvent(s, c->sg_start, 0));
     {   // ---- the producer
         StreamSwap sw(c, c->s_opt);
         pf_kernel_begin(c);
-        PF_TRY(pf_launch_lbfgs(c, K, J, maxiters, g_tol, c->lb_x0.as<double>(), PF_STREAM_PUB - 1));
+        PF_TRY(pf_launch_lbfgs(c, K, J, maxiters, g_tol, c->lb_x0.as<double>(), PF_STREAM_PUB - 1, c->h_prog));
         pf_kernel_end(c, "optimize");
-        PF_HIP(hipEventRecord(ev_opt, c->s_opt));
+        PF_HIP(hipEventRecord(c->sg_opt, c->s_opt));
     }
-    // ---- the consumers, segment by segment
-    int64_t s0 = 0;
-    for (int i = 0; i < nseg; ++i) {
-        const int l0 = bnd[(size_t)i], l1 = bnd[(size_t)i + 1];
-        hipEvent_t ev_f = c->sg_ev[(size_t)6 + i];
+    R.active = true;
+    R.t_progress = std::chrono::steady_clock::now();
+    return PFMI_OK;
+}
+
+// One scheduling pass: launches the next segment when its inputs are complete (and a scan stream is free), finishes the call when the last
+// one is out.  *finished = 1: everything is enqueued (pfmi_stream_wait then returns at once).  Never blocks.
+int32_t pfmi_stream_pump(pfmi_ctx *c, int32_t *finished) {
+    PF_CTX(c);
+    pfmi_ctx::StreamRun &R = c->sr;
+    if (finished) *finished = R.active ? 0 : 1;
+    if (!R.active) return PFMI_OK;
+    const int K = R.K;
+    bool all_done = true;
+    int avail = INT_MAX, lmax = 0;
+    for (int k = 0; k < K; ++k) {
+        const int dn = __atomic_load_n(c->h_prog + K + k, __ATOMIC_ACQUIRE);         // flag first: a raised flag means the count is final
+        const int n = __atomic_load_n(c->h_prog + k, __ATOMIC_ACQUIRE);
+        c->npts_h[(size_t)k] = dn ? n : -n;                                           // (negative: still running, at least that many points)
+        if (!dn) { all_done = false; if (n < avail) avail = n; }
+        if (n > lmax) lmax = n;
+    }
+    const auto now = std::chrono::steady_clock::now();
+    if (!all_done) {
+        if (avail != R.last_min) { R.last_min = avail; R.t_progress = now; }
+        else if (std::chrono::duration<double>(now - R.t_progress).count() > 20.0) {
+            // the producer is a plain kernel: it either runs or has failed
+            const hipError_t q = hipStreamQuery(c->s_opt);
+            R.active = false; c->stream_pending = false;
+            (void)hipDeviceSynchronize();
+            PF_CHECK(false, PFMI_ERR_HIP, "stream_pump: the optimiser made no progress for 20 s (stream state: %s)", hipGetErrorString(q));
+        }
+    }
+    int l1 = all_done ? lmax : avail / PF_STREAM_PUB * PF_STREAM_PUB;
+    if (l1 > R.cap) l1 = R.cap;
+    const int l0 = R.l_next;
+    // at most one scan launch queued per scan stream: the next segment then takes everything that has arrived meanwhile
+    int q_free = -1;
+    for (int q = 0; q < 2 && q_free < 0; ++q) {
+        const int qq = (R.nseg + q) & 1;
+        if (!R.scan_used[qq] || hipEventQuery(c->sg_scan[qq]) == hipSuccess) q_free = qq;
+    }
+    if (!all_done && (l1 - l0 < R.minlen || q_free < 0)) return PFMI_OK;
+    if (q_free < 0) q_free = R.nseg & 1;
+    if (l1 > l0) {
+        // ---- the segment's walk and fits
         {
             StreamSwap sw(c, c->s_fit);
-            PF_TRY(pf_launch_stream_gate(c, c->s_fit, K, l1, c->sg_err.as<int32_t>()));
             const HistSeg sg{c->st_npts.as<int32_t>(), l0, l1, c->hs_ial.as<double>(), c->hs_nacc.as<int32_t>()};
-            PF_TRY(pf_launch_history(c, eps, &sg));
+            PF_TRY(pf_launch_history(c, R.eps, &sg));
             PF_TRY(pf_launch_fit(c, l0, l1 - l0));
-            PF_HIP(hipEventRecord(ev_f, c->s_fit));
+            PF_HIP(hipEventRecord(c->sg_fit, c->s_fit));
         }
-        const int64_t ns = (int64_t)K * (l1 - (l0 > 1 ? l0 : 1));
+        // ---- its scan: the fits that exist, position-major
+        uint64_t *hs = reinterpret_cast<uint64_t *>(c->h_list);
+        int32_t *hl = reinterpret_cast<int32_t *>(c->h_list + sizeof(uint64_t) * (size_t)((int64_t)K * (R.cap - 1) > 0 ? (int64_t)K * (R.cap - 1) : 1));
+        int64_t t = R.s0;
+        for (int l = l0 > 1 ? l0 : 1; l < l1; ++l)
+            for (int k = 0; k < K; ++k) {
+                const int n = c->npts_h[(size_t)k];
+                if (n >= 0 && l >= n) continue;                                       // the path ended before this position
+                const int64_t pp = (int64_t)k * R.cap + l;
+                hl[t] = (int32_t)pp; hs[t] = R.seeds_pt[(size_t)pp]; ++t;
+            }
+        const int64_t ns = t - R.s0;
         if (ns > 0) {
-            // the scan's launch geometry counts the CUs it can have: while the optimiser runs, its K workgroups and the gate hold theirs
-            StreamSwap sw(c, c->s_scan[i & 1], i & 1, i + 1 < nseg ? ncu - K - 1 : 0);
-            PF_HIP(hipStreamWaitEvent(c->stream, ev_f, 0));
-            PF_TRY(pf_launch_elbo_draws(c, d_list + s0, d_lseeds + s0, ns, 0, N, nullptr, 0, nullptr, 0, c->logp.as<double>(),
-                                        c->logq.as<double>(), N, true, true));
+            const int qq = q_free;
+            hipStream_t ss = qq == 0 ? c->stream : c->s_scan1;
+            StreamSwap sw(c, ss, qq, !all_done);
+            PF_HIP(hipMemcpyAsync(R.d_lseeds + R.s0, hs + R.s0, sizeof(uint64_t) * (size_t)ns, hipMemcpyHostToDevice, ss));
+            PF_HIP(hipMemcpyAsync(R.d_list + R.s0, hl + R.s0, sizeof(int32_t) * (size_t)ns, hipMemcpyHostToDevice, ss));
+            PF_HIP(hipStreamWaitEvent(ss, c->sg_fit, 0));
+            PF_TRY(pf_launch_elbo_draws(c, R.d_list + R.s0, R.d_lseeds + R.s0, ns, 0, R.N, nullptr, 0, nullptr, 0, c->logp.as<double>(),
+                                        c->logq.as<double>(), R.N, true, true));
+            PF_HIP(hipEventRecord(c->sg_scan[qq], ss));
+            R.scan_used[qq] = true;
+            ++R.nseg;
         }
-        s0 += ns;
+        R.s0 = t;
+        R.l_next = l1;
     }
-    PF_HIP(hipEventRecord(ev_fit, c->s_fit));
-    PF_HIP(hipEventRecord(ev_s0, c->s_scan[0]));
-    PF_HIP(hipEventRecord(ev_s1, c->s_scan[1]));
-    for (hipEvent_t e : {ev_opt, ev_fit, ev_s0, ev_s1}) PF_HIP(hipStreamWaitEvent(c->stream, e, 0));
+    if (!all_done) return PFMI_OK;
+    // ---- drained: join the side streams, reduce
+    for (int k = 0; k < K; ++k) {
+        PF_CHECK(c->npts_h[(size_t)k] >= 1 && c->npts_h[(size_t)k] <= R.cap, PFMI_ERR_NUMERIC, "stream: path %d produced %d points", k, c->npts_h[(size_t)k]);
+    }
+    PF_HIP(hipEventRecord(c->sg_fit, c->s_fit));
+    PF_HIP(hipStreamWaitEvent(c->stream, c->sg_opt, 0));
+    PF_HIP(hipStreamWaitEvent(c->stream, c->sg_fit, 0));
+    if (R.scan_used[1]) PF_HIP(hipStreamWaitEvent(c->stream, c->sg_scan[1], 0));
+    R.active = false;
     c->stream_pending = false;
     c->fitted = true;
     PF_TRY(pf_launch_elbo_reduce(c));
     c->elbo_done = true; c->elbo_pending = true; c->have_trace_lp = true;
+    if (finished) *finished = 1;
     return PFMI_OK;
 }
 
 int32_t pfmi_stream_wait(pfmi_ctx *c, int64_t *npoints) {
     PF_CTX(c);
-    PF_CHECK(c->virt && c->elbo_done, PFMI_ERR_STATE, "stream_wait: no pfmi_stream_enqueue outstanding");
+    PF_CHECK(c->virt && (c->sr.active || c->elbo_done), PFMI_ERR_STATE, "stream_wait: no pfmi_stream_enqueue outstanding");
     PF_CHECK(npoints != nullptr, PFMI_ERR_ARG, "stream_wait: null npoints");
-    int32_t gate_err = 0;
-    PF_TRY(d2h_async(c, c->npts_h.data(), c->st_npts.p, sizeof(int32_t) * c->K));
-    PF_TRY(d2h_async(c, &gate_err, c->sg_err.p, sizeof(int32_t)));
-    PF_TRY(stream_sync(c));
-    if (gate_err != 0) {
-        c->elbo_done = false; c->fitted = false;
-        pf_set_error("streaming pipeline: a gate saw no progress of the optimiser for seconds (GPU shared?); the step was discarded: enqueue it again "
-                     "or use the packed route");
-        return PFMI_ERR_RETRY;
+    int32_t fin = 0;
+    while (true) {
+        PF_TRY(pfmi_stream_pump(c, &fin));
+        if (fin) break;
+        for (int i = 0; i < 64; ++i) __builtin_ia32_pause();
     }
-    for (int k = 0; k < c->K; ++k) {
-        PF_CHECK(c->npts_h[(size_t)k] >= 1 && c->npts_h[(size_t)k] <= c->vcap, PFMI_ERR_NUMERIC, "stream_wait: path %d produced %d points", k,
-                 c->npts_h[(size_t)k]);
-        npoints[k] = c->npts_h[(size_t)k];
-    }
+    for (int k = 0; k < c->K; ++k) npoints[k] = c->npts_h[(size_t)k];
     return PFMI_OK;
 }
 

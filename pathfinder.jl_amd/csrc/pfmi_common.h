@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <chrono>
 #include <string>
 #include <map>
 #include <set>
@@ -98,7 +99,6 @@ struct pfmi_ctx {
     bool have_trace_lp = false;
     DevBuf trace_lp;                          // [P]
     DevBuf st_theta, st_grad, st_lp, st_npts; // staging [K][maxiters+1][d]
-    DevBuf st_done;                           // int32 [K]: streaming -- path k has ended (st_npts[k] is final)
     // streaming layout (pfmi_stream_enqueue): the trace points stay where the optimiser records them -- point l of path k is
     // p = k * vcap + l, vcap = maxiters + 1 (theta / grad ARE st_theta / st_grad, nothing is packed), P = K * vcap slots of which path k fills
     // st_npts[k]; off[k] = k * vcap.  Every per-point buffer is indexed by the slot.
@@ -107,10 +107,26 @@ struct pfmi_ctx {
     std::vector<int32_t> npts_h;              // host copy of st_npts (valid after pfmi_stream_wait)
     const uint64_t *d_stream_tab = nullptr;   // device copy of the runs' predrawn seed streams [K][vcap] (inside `seeds`)
     DevBuf hs_ial, hs_nacc;                   // state of the segmented history walk: carried 1 / alpha [K][d], accepted count [K]
-    DevBuf sg_err;                            // int32: a gate of the streaming pipeline timed out
-    hipStream_t s_opt = nullptr, s_fit = nullptr, s_scan[2] = {nullptr, nullptr};
-    std::vector<hipEvent_t> sg_ev;            // events of the last streaming call (reused)
+    // The HOST schedules the pipeline (pfmi_stream_pump): the optimiser publishes its progress into page-locked memory, the calling thread
+    // launches the walk / fits / scan of every segment of trace positions whose inputs are complete.  No kernel ever waits for another.
+    int32_t *h_prog = nullptr;                // page-locked, coherent: [2 K] point counts, then "ended" flags -- written by pf_lbfgs_kernel
+    int h_prog_cap = 0;
+    char *h_list = nullptr;                   // page-locked staging of the scan's work lists (seeds, then points, of every fit slot)
+    size_t h_list_cap = 0;
+    hipStream_t s_opt = nullptr, s_fit = nullptr, s_scan1 = nullptr;    // producer; walk + fits; the second scan stream (the first is `stream`)
+    hipEvent_t sg_fit = nullptr, sg_opt = nullptr, sg_scan[2] = {nullptr, nullptr}, sg_start = nullptr;
+    struct StreamRun {
+        bool active = false;                  // a pfmi_stream_enqueue is being pumped
+        int K = 0, J = 0, cap = 0, l_next = 0, nseg = 0, minlen = 16, last_min = -1;
+        int64_t N = 0, s0 = 0;                // s0: fit slots handed to the scan so far (offset into the work lists)
+        double eps = 0.0;
+        uint64_t *d_lseeds = nullptr; int32_t *d_list = nullptr;
+        bool scan_used[2] = {false, false};
+        std::vector<uint64_t> seeds_pt;       // host copy of the per-point seeds (the scan's work lists are cut from it)
+        std::chrono::steady_clock::time_point t_progress;
+    } sr;
     bool stream_pending = false;
+    bool qf_seg_mode = false;                 // scan launches of a segment that is not the last: one workgroup per fit, no tail cut (they overlap)
     // the trace as the kernels see it: the packed buffers, or -- streaming layout -- the optimiser's staging buffers themselves
     double *th() const { return virt ? st_theta.as<double>() : theta.as<double>(); }
     double *gr() const { return virt ? st_grad.as<double>() : grad.as<double>(); }
@@ -235,8 +251,7 @@ int32_t pf_launch_resample_direct(pfmi_ctx *c, int64_t S, int64_t ndraws, const 
 int32_t pf_launch_gather(pfmi_ctx *c, int64_t ndraws, const int64_t *d_idx, int64_t col_offset, double *d_out);
 int32_t pf_launch_logratio(pfmi_ctx *c, int64_t n);
 int32_t pf_launch_scatter_rows(pfmi_ctx *c, int64_t ns, int64_t N, const int32_t *d_points, const double *d_src, double *d_dst);
-int32_t pf_launch_lbfgs(pfmi_ctx *c, int K, int J, int maxiters, double g_tol, const double *d_x0, int pub_mask = -1);
-int32_t pf_launch_stream_gate(pfmi_ctx *c, hipStream_t s, int K, int need, int32_t *err);
+int32_t pf_launch_lbfgs(pfmi_ctx *c, int K, int J, int maxiters, double g_tol, const double *d_x0, int pub_mask = -1, int32_t *h_prog = nullptr);
 int32_t pf_launch_trace_pack(pfmi_ctx *c, int64_t cap);
 int32_t pf_launch_woodbury_prim(pfmi_ctx *c, int mode, int64_t p, int64_t N, const double *d_in, double *d_out);
 int32_t pf_launch_colsumsq(pfmi_ctx *c, int64_t N, const double *d_x, double *d_out);

@@ -49,10 +49,10 @@ def _streamed(pfmi, tg, x0, J, maxiters, N, sd_stride, N_r, ndraws, repeat=1):
     outs = []
     for _ in range(repeat):
         e.stream_enqueue(x0, N, sd_stride, J, maxiters)
+        npts = e.stream_wait()                 # schedules the pipeline until the last segment is out; does not wait for the GPU
         e.pool_build_best(N_r, None)
         comm = pfmi.Comm.init_all([e])
         res, idx, draws = comm.psis_resample(ndraws, seed=9)
-        npts = e.stream_wait()
         status, jeff, logdet, nrej = e.fit_status()
         elbo, se, best = e.elbo_batch_wait()
         traces = [e.get_trace(k) for k in range(K)]
@@ -95,6 +95,7 @@ CASES = [
     ("lr1000", lambda m: m.t_lowrank(1000, r=8, seed=2), 8, 6, 1000, 1000, 2.0),
     ("funnel50_j10", lambda m: m.t_funnel(50), 5, 10, 300, 200, 10.0),
     ("iso10_short", lambda m: m.t_iso(10), 3, 6, 20, 64, 2.0),
+    ("diag16_many", lambda m: m.t_diag(16, seed=1), 300, 6, 40, 64, 2.0),      # more paths than CUs: nothing on the device waits for anything
 ]
 
 
@@ -119,9 +120,10 @@ def test_stream_refuses_what_it_cannot_run(pfmi_mod):
     e = pfmi_mod.Engine(0)
     tg = pfmi_mod.t_diag(16, seed=1)
     e.set_target(tg)
-    x0 = np.zeros((200, 16))                    # 2 K > #CU: the optimiser's workgroups could not all be resident beside their consumers
-    with pytest.raises(pfmi_mod._lib.PfmiError):
-        e.stream_enqueue(x0, 16, np.zeros(200 * 11, dtype=np.uint64), 6, 10)
     with pytest.raises(pfmi_mod._lib.PfmiError):  # history_length beyond the tuned kernels
         e.stream_enqueue(np.zeros((2, 16)), 16, np.zeros(2 * 11, dtype=np.uint64), 20, 10)
+    cb = pfmi_mod.CallbackTarget(16, lambda x: float(-0.5 * (x @ x)))
+    e.set_target(cb)
+    with pytest.raises(pfmi_mod._lib.PfmiError):  # a host closure cannot be optimised on the device
+        e.stream_enqueue(np.zeros((2, 16)), 16, np.zeros(2 * 11, dtype=np.uint64), 6, 10)
     e.close()
