@@ -365,10 +365,21 @@ def main():
 
     state = {}
 
-    def step():
+    # the streaming pipeline (pfmi_stream_enqueue) draws maxiters + 1 seeds per run up front; fit l of a run takes value l - 1 of that stream:
+    # the same seeds as `seeds` above (whose entry l of a run is counter l)
+    cap = args.maxiters + 1
+    seed_tab = np.concatenate([rand_u64(int(run_seeds[k0 + i]), np.arange(1, cap + 1, dtype=np.uint64), 10) for i in range(Kl)])
+
+    def step(streamed=False):
         # everything up to the last line of the `comm` branch only ENQUEUES work on the engine's stream
-        eng.fit_batch(J)
-        eng.elbo_batch_enqueue(N_e, seeds)
+        if streamed:
+            # optimise + fit + scan as one dataflow: the calling thread launches each segment of trace positions as soon as every path has
+            # produced it (csrc/pfmi_api.hip: pfmi_stream_pump); stream_wait returns when the last segment is OUT, not when it is done
+            eng.stream_enqueue(x0s, N_e, seed_tab, J, args.maxiters)
+            eng.stream_wait()
+        else:
+            eng.fit_batch(J)
+            eng.elbo_batch_enqueue(N_e, seeds)
         eng.pool_build_best(N_r)                                    # winners (fit_iteration per path) picked on the device
         if comm is not None:
             # [ONE RCCL all-gather of the log-ratio shards] + replicated PSIS + replicated indices + owner gather [+ sum all-reduce],
@@ -471,7 +482,8 @@ def main():
             vnote = (vnote or "") + f"; rank {rank} MISMATCH in {bad}"
 
     # ---- metric (ii): end-to-end wall-clock incl. trajectory generation (x0 on the host -> resampled draws on the host)
-    wall_e2e = None
+    wall_e2e = wall_e2e_packed = None
+    streamed_equal, stream_note = None, None
     if not args.host_traces and not args.minimal:
         barrier()
         t0 = time.perf_counter()
@@ -479,12 +491,32 @@ def main():
             eng.optimize_batch(x0s, J, args.maxiters)
             step()
         barrier()
-        wall_e2e = (time.perf_counter() - t0) / args.steps * 1e3
+        wall_e2e_packed = (time.perf_counter() - t0) / args.steps * 1e3
+        wall_e2e = wall_e2e_packed
         if timed_stages:
             for name in ("optimize", "trace_pack"):
                 ms_, n_ = eng.kernel_time(name)
                 stages[name] = {"ms": round(ms_ / max(n_, 1), 4), "launches": int(n_)}
             eng.profile(0)
+        ref_fp = (state["pareto_k"], state["idx"].copy(), np.array(state["draws"], copy=True) if isinstance(state["draws"], np.ndarray) else None,
+                  state["best"].copy())
+        # the same job as ONE dataflow: fits and scans of the points a path has already produced run while the paths are still being optimised
+        if comm is not None or not use_dist:
+            try:
+                for _ in range(2):
+                    step(streamed=True)
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    step(streamed=True)
+                barrier()
+                wall_e2e = (time.perf_counter() - t0) / args.steps * 1e3
+                streamed_equal = bool(state["pareto_k"] == ref_fp[0] and np.array_equal(state["idx"], ref_fp[1]) and np.array_equal(state["best"], ref_fp[3])
+                                      and (ref_fp[2] is None or np.array_equal(state["draws"], ref_fp[2])))
+                stream_note = "pfmi_stream_enqueue / pfmi_stream_wait"
+            except Exception as ex:                                     # (e.g. PFMI_ERR_UNSUPPORTED: no room for the fixed-stride layout)
+                stream_note = f"streaming pipeline not used: {ex!r}"
+            npts = eng.optimize_batch(x0s, J, args.maxiters)           # back to the packed layout for what follows
 
     # ---- the same job through the public host API (pfmi.multipathfinder: x0 sampling, device L-BFGS, fit, ELBO, pool, PSIS,
     #      resample, result objects), single GPU only
@@ -743,6 +775,8 @@ def main():
                        "collective_backend": comm_note if use_dist else None},
             "multipathfinder_hot_path_ms": round(ms_per_step, 3),
             "multipathfinder_wall_ms_incl_device_lbfgs": None if wall_e2e is None else round(wall_e2e, 3),
+            "multipathfinder_wall_ms_incl_device_lbfgs_packed_route": None if wall_e2e_packed is None else round(wall_e2e_packed, 3),
+            "streamed_equals_packed": streamed_equal, "streaming_note": stream_note,
             "multipathfinder_api_wall_ms": None if api_wall is None else round(api_wall, 3),
             "traces": "host numpy L-BFGS driver" if args.host_traces else "device L-BFGS (pfmi_optimize_batch)",
             "pareto_k": state.get("pareto_k"),

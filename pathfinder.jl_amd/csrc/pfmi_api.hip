@@ -486,7 +486,7 @@ int32_t pfmi_get_trace(pfmi_ctx *c, int32_t k, double *theta, double *logp, doub
 // the optimiser's fixed-stride staging buffers (point l of path k = slot k * (maxiters + 1) + l): nothing is packed, no offset depends on
 // another path's length.  Same kernels, same arithmetic as fit_batch + elbo_batch_enqueue on the packed trace: bit-identical results
 // (tests/test_gpu_stream.py).  Four streams in all -- the default number of hardware queues, so none of them shares a queue.
-#define PF_STREAM_PUB 16
+#define PF_STREAM_PUB 16                   // points between two publications of the optimiser's progress (a power of two; hook PFMI_STREAM_PUB)
 struct StreamSwap {                       // the launch helpers enqueue on c->stream: point it at a side stream for the scope
     pfmi_ctx *c; hipStream_t keep; int slot; bool seg;
     StreamSwap(pfmi_ctx *c_, hipStream_t s, int qf_slot = 0, bool seg_mode = false) : c(c_), keep(c_->stream), slot(c_->qf_slot), seg(c_->qf_seg_mode) {
@@ -636,21 +636,23 @@ int32_t pfmi_stream_enqueue(pfmi_ctx *c, int32_t K, const double *x0, int32_t J,
     R.d_lseeds = reinterpret_cast<uint64_t *>(c->seeds.as<char>() + off_ls);
     R.d_list = reinterpret_cast<int32_t *>(c->seeds.as<char>() + off_li);
     // a segment should fill at least half the CUs with one workgroup per fit
-    R.minlen = ((ncu / 2 + K - 1) / K + PF_STREAM_PUB - 1) / PF_STREAM_PUB * PF_STREAM_PUB;
-    if (R.minlen < PF_STREAM_PUB) R.minlen = PF_STREAM_PUB;
-    { const char *ml = pf_debug_get("PFMI_STREAM_MINLEN"); if (ml && atoi(ml) > 0) R.minlen = (atoi(ml) + PF_STREAM_PUB - 1) / PF_STREAM_PUB * PF_STREAM_PUB; }
+    R.pub = PF_STREAM_PUB;
+    { const char *pb = pf_debug_get("PFMI_STREAM_PUB"); if (pb && (atoi(pb) == 4 || atoi(pb) == 8 || atoi(pb) == 32)) R.pub = atoi(pb); }
+    R.minlen = ((ncu / 2 + K - 1) / K + R.pub - 1) / R.pub * R.pub;
+    if (R.minlen < R.pub) R.minlen = R.pub;
+    { const char *ml = pf_debug_get("PFMI_STREAM_MINLEN"); if (ml && atoi(ml) > 0) R.minlen = (atoi(ml) + R.pub - 1) / R.pub * R.pub; }
     c->stream_pending = true;
     PF_HIP(hipEventRecord(c->sg_start, c->stream));
     for (hipStream_t s : {c->s_opt, c->s_fit, c->s_scan1}) PF_HIP(hipStreamWaitEvent(s, c->sg_start, 0));
     {   // ---- the producer
         StreamSwap sw(c, c->s_opt);
         pf_kernel_begin(c);
-        PF_TRY(pf_launch_lbfgs(c, K, J, maxiters, g_tol, c->lb_x0.as<double>(), PF_STREAM_PUB - 1, c->h_prog));
+        PF_TRY(pf_launch_lbfgs(c, K, J, maxiters, g_tol, c->lb_x0.as<double>(), R.pub - 1, c->h_prog));
         pf_kernel_end(c, "optimize");
         PF_HIP(hipEventRecord(c->sg_opt, c->s_opt));
     }
     R.active = true;
-    R.t_progress = std::chrono::steady_clock::now();
+    R.t_progress = R.t_start = std::chrono::steady_clock::now();
     return PFMI_OK;
 }
 
@@ -682,7 +684,7 @@ int32_t pfmi_stream_pump(pfmi_ctx *c, int32_t *finished) {
             PF_CHECK(false, PFMI_ERR_HIP, "stream_pump: the optimiser made no progress for 20 s (stream state: %s)", hipGetErrorString(q));
         }
     }
-    int l1 = all_done ? lmax : avail / PF_STREAM_PUB * PF_STREAM_PUB;
+    int l1 = all_done ? lmax : avail / R.pub * R.pub;
     if (l1 > R.cap) l1 = R.cap;
     const int l0 = R.l_next;
     // at most one scan launch queued per scan stream: the next segment then takes everything that has arrived meanwhile
@@ -727,6 +729,7 @@ int32_t pfmi_stream_pump(pfmi_ctx *c, int32_t *finished) {
             R.scan_used[qq] = true;
             ++R.nseg;
         }
+        R.trace.insert(R.trace.end(), {std::chrono::duration<double>(now - R.t_start).count() * 1e6, (double)l0, (double)l1, (double)ns, (double)q_free});
         R.s0 = t;
         R.l_next = l1;
     }
@@ -742,6 +745,14 @@ int32_t pfmi_stream_pump(pfmi_ctx *c, int32_t *finished) {
     R.active = false;
     c->stream_pending = false;
     c->fitted = true;
+    if (const char *tr = pf_debug_get("PFMI_STREAM_TRACE")) {         // test / tuning hook: what was launched when
+        if (tr[0] == '1') {
+            fprintf(stderr, "stream: %d segments, drained at %.0f us:", R.nseg, std::chrono::duration<double>(std::chrono::steady_clock::now() - R.t_start).count() * 1e6);
+            for (size_t i = 0; i + 4 < R.trace.size() + 1; i += 5)
+                fprintf(stderr, "  [%.0f us: %d..%d, %d fits, q%d]", R.trace[i], (int)R.trace[i + 1], (int)R.trace[i + 2], (int)R.trace[i + 3], (int)R.trace[i + 4]);
+            fprintf(stderr, "\n");
+        }
+    }
     PF_TRY(pf_launch_elbo_reduce(c));
     c->elbo_done = true; c->elbo_pending = true; c->have_trace_lp = true;
     if (finished) *finished = 1;

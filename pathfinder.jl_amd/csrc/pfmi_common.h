@@ -117,13 +117,14 @@ struct pfmi_ctx {
     hipEvent_t sg_fit = nullptr, sg_opt = nullptr, sg_scan[2] = {nullptr, nullptr}, sg_start = nullptr;
     struct StreamRun {
         bool active = false;                  // a pfmi_stream_enqueue is being pumped
-        int K = 0, J = 0, cap = 0, l_next = 0, nseg = 0, minlen = 16, last_min = -1;
+        int K = 0, J = 0, cap = 0, l_next = 0, nseg = 0, minlen = 16, last_min = -1, pub = 16;
         int64_t N = 0, s0 = 0;                // s0: fit slots handed to the scan so far (offset into the work lists)
         double eps = 0.0;
         uint64_t *d_lseeds = nullptr; int32_t *d_list = nullptr;
         bool scan_used[2] = {false, false};
         std::vector<uint64_t> seeds_pt;       // host copy of the per-point seeds (the scan's work lists are cut from it)
-        std::chrono::steady_clock::time_point t_progress;
+        std::chrono::steady_clock::time_point t_progress, t_start;
+        std::vector<double> trace;            // PFMI_STREAM_TRACE: (t_us, l0, l1, fits, scan stream) per segment
     } sr;
     bool stream_pending = false;
     bool qf_seg_mode = false;                 // scan launches of a segment that is not the last: one workgroup per fit, no tail cut (they overlap)

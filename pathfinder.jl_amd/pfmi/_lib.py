@@ -86,4 +86,6 @@ def check(rc):
     if rc == -7:
         raise PfmiRetry(f"libpfmi: {lib().pfmi_last_error().decode()}")
     if rc != 0:
-        raise PfmiError(f"libpfmi error {rc}: {lib().pfmi_last_error().decode()}")
+        ex = PfmiError(f"libpfmi error {rc}: {lib().pfmi_last_error().decode()}")
+        ex.code = rc
+        raise ex

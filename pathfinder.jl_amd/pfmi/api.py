@@ -13,6 +13,7 @@ src/multipath.jl:190-193), then ONE fit_batch / elbo_batch / pool_build covers e
 (The north-star host language is Julia; no Julia toolchain exists in this image, so the host mirror
 is Python and the Julia `ccall` wrapper lives, untested, in pathfinder.jl_amd/julia/ -- INTEGRATION.md.)
 """
+import os
 import warnings
 from collections.abc import Sequence
 from dataclasses import dataclass, field
@@ -20,7 +21,7 @@ from typing import Any, List, Optional
 
 import numpy as np
 
-from ._lib import PfmiRetry
+from ._lib import PfmiError, PfmiRetry
 from .core import Engine, StaleHandleError  # noqa: F401
 from .hostrng import HostRNG, rand_u64_multi
 from .optimize import OptimizationTrace, optimize_with_trace
@@ -436,6 +437,7 @@ def _run_paths(engs, target, inits, run_rngs, *, dim, history_length, ndraws_elb
             state[k].update(eng=engs[g], g=g, kl=k - k0)
     pending = list(range(K))
     on_device = _use_device_optimizer(target, optimizer)
+    stream_ok = on_device and history_length <= 16 and os.environ.get("PFMI_NO_STREAM") != "1"
     okw = {k: v for k, v in optimizer_kwargs.items() if k in ("maxiters", "g_tol")}
     pooled = None
     while pending:
@@ -456,7 +458,35 @@ def _run_paths(engs, target, inits, run_rngs, *, dim, history_length, ndraws_elb
             for k in need:
                 state[k]["x0"] = init_sampler(run_rngs[k], np.empty(dim))
         predrawn = None
-        if on_device:     # every path in one launch per engine; finished paths are recomputed identically from their x0
+        streamed = False
+        if on_device and stream_ok:
+            # ONE dataflow per engine (pfmi_stream_enqueue): the fits and ELBO scans of the trace points a path has already produced run
+            # while the paths are still being optimised.  The per-fit seeds of every run for the LONGEST possible trace are drawn up front
+            # from copies of the runs' rngs (a run that was finished in an earlier try keeps the stream it had).
+            cap = int(okw.get("maxiters", 1000)) + 1
+            for k, sd in zip(pending, rand_u64_multi([run_rngs[k].copy() for k in pending], [cap] * len(pending))):
+                state[k]["stream_tab"] = sd
+            predrawn = {k: state[k]["stream_tab"] for k in pending}
+            try:
+                for eng, (k0, k1) in zip(engs, blocks):
+                    eng.stream_enqueue(np.stack([s["x0"] for s in state[k0:k1]]), ndraws_elbo,
+                                       np.concatenate([s["stream_tab"] for s in state[k0:k1]]), history_length, **okw)
+                streamed = True
+            except PfmiError as ex:
+                if getattr(ex, "code", 0) != -4 or eng is not engs[0]:    # PFMI_ERR_UNSUPPORTED on the first engine: the packed route below
+                    raise
+                stream_ok = False
+        if streamed:
+            active = list(zip(engs, blocks))
+            while active:                                           # the calling thread schedules every engine's pipeline
+                active = [(eng, b) for eng, b in active if not eng.stream_pump()]
+            for eng, (k0, k1) in zip(engs, blocks):
+                npts = eng.stream_wait()
+                for k in range(k0, k1):
+                    state[k]["trace"] = DeviceOptimizationTrace(eng, k - k0, int(npts[k - k0]))
+                    if materialise:
+                        state[k]["trace"].materialise()
+        elif on_device:     # every path in one launch per engine; finished paths are recomputed identically from their x0
             for eng, (k0, k1) in zip(engs, blocks):
                 eng.optimize_batch_enqueue(np.stack([s["x0"] for s in state[k0:k1]]), history_length, **okw)
             # while the optimisations run: the per-fit seeds of every pending run for the LONGEST possible trace, drawn from copies of
@@ -477,8 +507,9 @@ def _run_paths(engs, target, inits, run_rngs, *, dim, history_length, ndraws_elb
                 eng.set_traces([s["trace"].points for s in state[k0:k1]], [s["trace"].gradients for s in state[k0:k1]])
         # one batched fit + ELBO over every path (finished paths are recomputed identically from their seeds).  fit_batch only
         # ENQUEUES the history walk and the fits; the per-fit seeds are drawn on the host while they run
-        for eng in engs:
-            eng.fit_batch(history_length)
+        if not streamed:
+            for eng in engs:
+                eng.fit_batch(history_length)
         if predrawn is not None:
             for k in pending:
                 L = len(state[k]["trace"]) - 1
@@ -492,8 +523,9 @@ def _run_paths(engs, target, inits, run_rngs, *, dim, history_length, ndraws_elb
                 # what rand(rng_k, fit_distribution, ndraws) would use if this try ends in failure (src/singlepath.jl:231-233): peeked
                 # from a copy, the run's rng only advances when the path really fails (_assemble_path)
                 state[k]["fail_seed"] = np.uint64(run_rngs[k].copy().rand_u64(1)[0])
-        for eng, (k0, k1) in zip(engs, blocks):
-            eng.elbo_batch_enqueue(ndraws_elbo, np.concatenate([s["seeds"] for s in state[k0:k1]]))
+        if not streamed:
+            for eng, (k0, k1) in zip(engs, blocks):
+                eng.elbo_batch_enqueue(ndraws_elbo, np.concatenate([s["seeds"] for s in state[k0:k1]]))
         if pool is not None:                                        # optimistic: right behind the scan, no host round trip
             for eng, (k0, k1) in zip(engs, blocks):
                 eng.pool_build_best(pool["N_r"], np.array([s["fail_seed"] for s in state[k0:k1]], dtype=np.uint64))
@@ -510,7 +542,7 @@ def _run_paths(engs, target, inits, run_rngs, *, dim, history_length, ndraws_elb
         for eng, (k0, k1) in zip(engs, blocks):
             status, jeff, logdet, nrej = eng.fit_status()
             all_status.append(status); all_jeff.append(jeff)
-            bad = np.flatnonzero(status)
+            bad = np.flatnonzero((status != 0) & (status != 4))      # (4 = PFMI_FIT_ABSENT: a slot of the streaming layout no path reached)
             if len(bad) and strict:
                 # WoodburyPDMat's constructor throws inside fit_mvnormals (src/woodbury.jl:202,205) and nothing in
                 # _pathfinder / the retry loop catches it (src/singlepath.jl:259-314): the reference's call fails as a whole
@@ -522,7 +554,8 @@ def _run_paths(engs, target, inits, run_rngs, *, dim, history_length, ndraws_elb
             for k in range(k0, k1):
                 st = state[k]
                 kl = k - k0
-                p0, p1 = int(eng.offsets[kl]), int(eng.offsets[kl + 1])
+                p0 = int(eng.offsets[kl])
+                p1 = p0 + eng.path_len(kl)
                 L = p1 - p0 - 1
                 fit_it = int(best[kl])
                 ok = L > 0                                           # src/singlepath.jl:299

@@ -212,6 +212,12 @@ class Engine:
         check(self.L.pfmi_stream_enqueue(self.ctx, C.c_int32(K), _d(x0), C.c_int32(history_length), C.c_int32(maxiters),
                                          C.c_double(g_tol), C.c_double(eps), C.c_int64(N), seeds.ctypes.data_as(_u64p)))
 
+    def stream_pump(self):
+        """one scheduling pass of the pipeline (never blocks); True once its last segment has been launched"""
+        fin = C.c_int32()
+        check(self.L.pfmi_stream_pump(self.ctx, C.byref(fin)))
+        return bool(fin.value)
+
     def stream_wait(self):
         """points per path of the last stream_enqueue (the first wait of that call)"""
         npts = np.empty(self.K, dtype=np.int64)
