@@ -146,11 +146,20 @@ int32_t pfmi_get_trace(pfmi_ctx *ctx, int32_t k, double *theta, double *logp, do
  * rng yields (src/elbo.jl:2 draws L of them AFTER the optimisation, when L is known; here maxiters + 1 are drawn up front and the host
  * advances the run's rng by the L the path turned out to have).  The ELBO estimate of fit l (l = 1 .. L, slot k * (maxiters + 1) + l)
  * uses value l - 1; a later pfmi_pool_build_best(ctx, N_r, NULL) gives a FAILED run the value behind the ones it consumed, index L (what
- * rand(rng, fit_distribution, ndraws) would start from, src/singlepath.jl:231-233).  Only enqueues; pfmi_stream_wait returns the points per path, pfmi_elbo_batch_wait the ELBO table, and
- * pfmi_pool_build_best / pfmi_comm_psis_resample may be enqueued in between.  Built-in targets, history_length <= 16, 2 K <= #CU;
+ * rand(rng, fit_distribution, ndraws) would start from, src/singlepath.jl:231-233).
+ * The calling thread SCHEDULES the dataflow: the optimiser (one workgroup per path) publishes its progress into page-locked host memory,
+ * pfmi_stream_pump / pfmi_stream_wait launch the walk, fits and scan of each segment of trace positions once every path has produced it -- no
+ * kernel ever waits for another.  After pfmi_stream_wait: pfmi_pool_build_best / pfmi_comm_psis_resample as usual, pfmi_get_fit_status and
+ * pfmi_elbo_batch_wait return the slot arrays.  Built-in targets, history_length <= 16, d <= 16384, room for the fixed-stride layout;
  * PFMI_ERR_UNSUPPORTED otherwise (use the three calls above). */
 int32_t pfmi_stream_enqueue(pfmi_ctx *ctx, int32_t K, const double *x0, int32_t history_length, int32_t maxiters, double g_tol,
                             double eps, int64_t N, const uint64_t *seeds);
+/* seeds may be NULL in pfmi_stream_enqueue: the optimiser starts at once and the host draws the streams while it runs; pfmi_stream_seeds
+ * hands them over before the first pfmi_stream_pump / pfmi_stream_wait (nothing but the optimiser is launched until then). */
+int32_t pfmi_stream_seeds(pfmi_ctx *ctx, const uint64_t *seeds);
+/* pfmi_stream_pump: ONE scheduling pass of the calling thread (never blocks): launches the walk, fits and scan of the trace positions every
+ * path has produced since the last pass; *finished = 1 once the last segment and the reduction are enqueued.  pfmi_stream_wait pumps until
+ * then and returns the points per path -- it does NOT wait for the GPU.  A host that drives several contexts pumps them in turn. */
 int32_t pfmi_stream_pump(pfmi_ctx *ctx, int32_t *finished);
 int32_t pfmi_stream_wait(pfmi_ctx *ctx, int64_t *npoints);
 
@@ -309,6 +318,16 @@ int32_t pfmi_comm_resample(pfmi_comm *comm, int64_t ndraws, int32_t importance, 
  * or a size mismatch is reported on EVERY rank instead of leaving the others blocked in a collective. */
 int32_t pfmi_comm_psis_resample(pfmi_comm *comm, int64_t ndraws, int32_t importance, int32_t replace, uint64_t seed,
                                 const double *uniforms, double *pareto_k, int64_t *tail_len, int64_t *idx, double *draws);
+/* The same in two halves: _enqueue launches everything (all-gather, PSIS, index selection, owner gather, all-reduce), _wait is the one host
+ * round trip.  Between the two the caller may queue downloads on the member contexts with pfmi_defer_downloads: _wait delivers them too. */
+int32_t pfmi_comm_psis_resample_enqueue(pfmi_comm *comm, int64_t ndraws, int32_t importance, int32_t replace, uint64_t seed, const double *uniforms);
+int32_t pfmi_comm_psis_resample_wait(pfmi_comm *comm, double *pareto_k, int64_t *tail_len, int64_t *idx, double *draws);
+/* pfmi_defer_downloads(ctx, 1): from now on the download-only entry points -- pfmi_get_fit_status, pfmi_elbo_batch_wait, pfmi_psis_weights --
+ * queue their copies behind whatever is enqueued and return at once; the destination arrays are filled (and a PFMI_ERR_RETRY of the scan
+ * is reported) by the NEXT entry point that waits on this context (pfmi_sync, pfmi_comm_psis_resample_wait, ...): one host round trip for
+ * all of them.  The arrays must stay valid until then.  (ctx, 0): back to normal, what is queued stays queued.  (ctx, -1): drop everything
+ * queued (after a failure between queueing and waiting). */
+int32_t pfmi_defer_downloads(pfmi_ctx *ctx, int32_t mode);
 
 /* ---- host utility --------------------------------------------------------------------------------------------------- */
 /* The counter-based generator the Python / C host mirrors use for the reference's seed hierarchy (run_seeds =

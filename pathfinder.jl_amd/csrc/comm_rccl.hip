@@ -128,6 +128,8 @@ struct pfmi_comm {
     bool psis_pending = false;
     int64_t rs_ndraws = 0;               // draws of the enqueued resample stage
     bool rs_local_error = false;
+    bool pr_pending = false, pr_importance = false;   // pfmi_comm_psis_resample_enqueue is waiting for its pfmi_comm_psis_resample_wait
+    int32_t pr_rc = 0;
     bool dead = false;                   // a member context was destroyed: the group is torn down, every call reports PFMI_ERR_STATE
 };
 
@@ -602,6 +604,39 @@ int32_t pfmi_comm_psis_resample(pfmi_comm *c, int64_t ndraws, int32_t importance
     if (pareto_k) *pareto_k = k;
     if (tail_len) *tail_len = m;
     return rc != PFMI_OK ? rc : (rp != PFMI_OK ? rp : rf);
+}
+
+// the same in two halves: everything enqueued / the one wait.  Between the two the caller may queue downloads on the member contexts
+// (pfmi_defer_downloads): the wait delivers them in the same host round trip.
+int32_t pfmi_comm_psis_resample_enqueue(pfmi_comm *c, int64_t ndraws, int32_t importance, int32_t replace, uint64_t seed, const double *uniforms) {
+    if (c) for (pfmi_ctx *x : c->ctx) pf_download_forget(x);
+    PF_COMM(c);
+    PF_CHECK(ndraws >= 1, PFMI_ERR_ARG, "comm_psis_resample: ndraws must be positive");
+    const int64_t out_doubles = (int64_t)c->ctx[0]->d * ndraws + 1;
+    if (importance) PF_TRY(enqueue_pool_psis(c, out_doubles));
+    else {
+        int64_t shard = 0;
+        PF_TRY(agree_on_shard(c, &shard, false, out_doubles));
+        c->shard = shard;
+    }
+    c->pr_importance = importance != 0;
+    c->pr_rc = enqueue_resample(c, ndraws, importance, replace, seed, uniforms);
+    c->pr_pending = true;
+    return PFMI_OK;
+}
+
+int32_t pfmi_comm_psis_resample_wait(pfmi_comm *c, double *pareto_k, int64_t *tail_len, int64_t *idx, double *draws) {
+    PF_COMM(c);
+    PF_CHECK(c->pr_pending, PFMI_ERR_STATE, "comm_psis_resample_wait: nothing enqueued");
+    c->pr_pending = false;
+    double k = NAN;
+    int64_t m = 0;
+    int32_t rp = PFMI_OK;
+    if (c->pr_importance) rp = finish_pool_psis(c, &k, &m);
+    const int32_t rf = finish_resample(c, idx, draws);
+    if (pareto_k) *pareto_k = k;
+    if (tail_len) *tail_len = m;
+    return c->pr_rc != PFMI_OK ? c->pr_rc : (rp != PFMI_OK ? rp : rf);
 }
 
 }  // extern "C"

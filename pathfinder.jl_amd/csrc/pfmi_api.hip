@@ -3,6 +3,7 @@
 #include "fit_args.h"
 #include <limits.h>
 
+#include <array>
 #include <chrono>
 #include <map>
 #include <mutex>
@@ -116,7 +117,7 @@ int32_t pf_download(pfmi_ctx *c, void *dst, const void *src, size_t bytes) {
         }
         if (a.off + bytes <= a.cap) {
             PF_HIP(hipMemcpyAsync(a.base + a.off, src, bytes, hipMemcpyDeviceToHost, c->stream));
-            c->dl_pending.push_back(DlPending{dst, a.base + a.off, bytes});
+            c->dl_pending.push_back(DlPending{dst, a.base + a.off, bytes, c->defer});
             a.off += (bytes + 255) & ~(size_t)255;
             return PFMI_OK;
         }
@@ -124,18 +125,30 @@ int32_t pf_download(pfmi_ctx *c, void *dst, const void *src, size_t bytes) {
     PF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));    // pageable destination: blocks until the copy is done
     return PFMI_OK;
 }
+static void pf_deferred_drop(pfmi_ctx *c) { c->dl_pending.clear(); c->post_sync.clear(); c->dl.off = 0; }
 int32_t pf_stream_sync(pfmi_ctx *c) {
     const hipError_t e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) { pf_download_forget(c); PF_HIP(e); }      // nothing is delivered after a failed wait
+    if (e != hipSuccess) { pf_deferred_drop(c); PF_HIP(e); }        // nothing is delivered after a failed wait
     for (const DlPending &q : c->dl_pending) memcpy(q.dst, q.slot, q.bytes);
     c->dl_pending.clear();
     c->dl.off = 0;
     pf_arena_reset(c);
-    return PFMI_OK;
+    // what deferred entry points would have done behind their own wait (pfmi_defer_downloads): the first failure is this wait's result
+    int32_t rc = PFMI_OK;
+    std::vector<std::function<int32_t()>> hooks;
+    hooks.swap(c->post_sync);
+    for (auto &h : hooks) { const int32_t r = h(); if (rc == PFMI_OK) rc = r; }
+    return rc;
 }
 // Staged downloads are delivered by the pf_stream_sync of the entry point that queued them.  An entry point that FAILED between queuing and
 // waiting leaves entries whose destinations (stack variables, a caller's array) may be gone: every public entry point forgets them first.
-void pf_download_forget(pfmi_ctx *c) { c->dl_pending.clear(); c->dl.off = 0; }
+// (entries queued under pfmi_defer_downloads stay: their destinations are the caller's until the next wait)
+void pf_download_forget(pfmi_ctx *c) {
+    size_t w = 0;
+    for (size_t i = 0; i < c->dl_pending.size(); ++i) if (c->dl_pending[i].keep) c->dl_pending[w++] = c->dl_pending[i];
+    c->dl_pending.resize(w);
+    if (w == 0) c->dl.off = 0;
+}
 static int32_t d2h_async(pfmi_ctx *c, void *dst, const void *src, size_t bytes) { return pf_download(c, dst, src, bytes); }
 static int32_t stream_sync(pfmi_ctx *c) { return pf_stream_sync(c); }
 static int32_t d2h(pfmi_ctx *c, void *dst, const void *src, size_t bytes) {
@@ -503,13 +516,30 @@ static int32_t qf_share_reserve(pfmi_ctx *c, int slot, size_t bytes) {
     return PFMI_OK;
 }
 
+// the runs' predrawn seed streams [K][cap]: host copy of the per-point seeds (the scan's work lists are cut from it) + ONE upload of the
+// per-point seeds (slot k * cap + l holds stream value l - 1 of run k) and the raw streams (pfmi_pool_build_best: a failed run's draw seed)
+static int32_t stream_set_seeds(pfmi_ctx *c, const uint64_t *seeds) {
+    const size_t K = (size_t)c->K, cap = (size_t)c->vcap, Pz = K * cap;
+    std::vector<uint64_t> stage(2 * Pz);
+    for (size_t k = 0; k < K; ++k) {
+        stage[k * cap] = 0;
+        if (cap > 1) memcpy(stage.data() + k * cap + 1, seeds + k * cap, sizeof(uint64_t) * (cap - 1));
+    }
+    memcpy(stage.data() + Pz, seeds, sizeof(uint64_t) * Pz);
+    PF_TRY(h2d(c, c->seeds.p, stage.data(), sizeof(uint64_t) * 2 * Pz));     // on the ctx stream: in front of everything that reads them
+    stage.resize(Pz);
+    c->sr.seeds_pt.swap(stage);
+    c->sr.have_seeds = true;
+    return PFMI_OK;
+}
+
 int32_t pfmi_stream_enqueue(pfmi_ctx *c, int32_t K, const double *x0, int32_t J, int32_t maxiters, double g_tol, double eps, int64_t N,
                             const uint64_t *seeds) {
     PF_CTX(c);
     const TargetDev &T = c->target;
     PF_CHECK(T.kind == PFMI_TARGET_GAUSS || T.kind == PFMI_TARGET_FUNNEL, PFMI_ERR_UNSUPPORTED,
              "stream_enqueue: needs a built-in target (the optimiser runs on the device)");
-    PF_CHECK(K > 0 && x0 && seeds && maxiters >= 0 && N >= 1, PFMI_ERR_ARG, "stream_enqueue: bad arguments");
+    PF_CHECK(K > 0 && x0 && maxiters >= 0 && N >= 1, PFMI_ERR_ARG, "stream_enqueue: bad arguments");
     PF_CHECK(J >= 1 && J <= 16, PFMI_ERR_UNSUPPORTED, "stream_enqueue: history_length %d outside 1..16", J);
     PF_CHECK(!c->sr.active, PFMI_ERR_STATE, "stream_enqueue: the previous streaming call has not been waited for (pfmi_stream_wait)");
     if (c->s_opt) PF_TRY(stream_sync(c));      // the page-locked progress words and work lists are reused: the previous call's copies must have landed
@@ -601,17 +631,6 @@ int32_t pfmi_stream_enqueue(pfmi_ctx *c, int32_t K, const double *x0, int32_t J,
     const size_t off_li = off_ls + sizeof(uint64_t) * (size_t)(nf > 0 ? nf : 1);
     const size_t all_bytes = off_li + sizeof(int32_t) * (size_t)(nf > 0 ? nf : 1);
     PF_TRY(c->seeds.ensure(all_bytes + 16));
-    {
-        std::vector<uint64_t> stage(2 * Pz);
-        for (int k = 0; k < K; ++k) {
-            stage[(size_t)k * cap] = 0;
-            if (cap > 1) memcpy(stage.data() + (size_t)k * cap + 1, seeds + (size_t)k * cap, sizeof(uint64_t) * (size_t)(cap - 1));
-        }
-        memcpy(stage.data() + Pz, seeds, sizeof(uint64_t) * Pz);
-        PF_TRY(h2d(c, c->seeds.p, stage.data(), sizeof(uint64_t) * 2 * Pz));
-        stage.resize(Pz);
-        c->sr.seeds_pt.swap(stage);
-    }
     c->d_stream_tab = reinterpret_cast<const uint64_t *>(c->seeds.as<char>() + off_tab);
     PF_TRY(h2d(c, c->lb_x0.p, x0, sizeof(double) * (size_t)K * dz));
     PF_TRY(h2d(c, c->d_off.p, c->off.data(), sizeof(int64_t) * (K + 1)));
@@ -641,6 +660,7 @@ int32_t pfmi_stream_enqueue(pfmi_ctx *c, int32_t K, const double *x0, int32_t J,
     R.minlen = ((ncu / 2 + K - 1) / K + R.pub - 1) / R.pub * R.pub;
     if (R.minlen < R.pub) R.minlen = R.pub;
     { const char *ml = pf_debug_get("PFMI_STREAM_MINLEN"); if (ml && atoi(ml) > 0) R.minlen = (atoi(ml) + R.pub - 1) / R.pub * R.pub; }
+    if (seeds) PF_TRY(stream_set_seeds(c, seeds));
     c->stream_pending = true;
     PF_HIP(hipEventRecord(c->sg_start, c->stream));
     for (hipStream_t s : {c->s_opt, c->s_fit, c->s_scan1}) PF_HIP(hipStreamWaitEvent(s, c->sg_start, 0));
@@ -654,6 +674,13 @@ int32_t pfmi_stream_enqueue(pfmi_ctx *c, int32_t K, const double *x0, int32_t J,
     R.active = true;
     R.t_progress = R.t_start = std::chrono::steady_clock::now();
     return PFMI_OK;
+}
+
+int32_t pfmi_stream_seeds(pfmi_ctx *c, const uint64_t *seeds) {
+    PF_CTX(c);
+    PF_CHECK(c->sr.active && !c->sr.have_seeds, PFMI_ERR_STATE, "stream_seeds: no pfmi_stream_enqueue(..., seeds = NULL) outstanding");
+    PF_CHECK(seeds != nullptr, PFMI_ERR_ARG, "stream_seeds: null seeds");
+    return stream_set_seeds(c, seeds);
 }
 
 // One scheduling pass: launches the next segment when its inputs are complete (and a scan stream is free), finishes the call when the last
@@ -673,6 +700,7 @@ int32_t pfmi_stream_pump(pfmi_ctx *c, int32_t *finished) {
         if (!dn) { all_done = false; if (n < avail) avail = n; }
         if (n > lmax) lmax = n;
     }
+    if (!R.have_seeds) return PFMI_OK;                                              // pfmi_stream_seeds has not been called yet
     const auto now = std::chrono::steady_clock::now();
     if (!all_done) {
         if (avail != R.last_min) { R.last_min = avail; R.t_progress = now; }
@@ -763,6 +791,7 @@ int32_t pfmi_stream_wait(pfmi_ctx *c, int64_t *npoints) {
     PF_CTX(c);
     PF_CHECK(c->virt && (c->sr.active || c->elbo_done), PFMI_ERR_STATE, "stream_wait: no pfmi_stream_enqueue outstanding");
     PF_CHECK(npoints != nullptr, PFMI_ERR_ARG, "stream_wait: null npoints");
+    PF_CHECK(!c->sr.active || c->sr.have_seeds, PFMI_ERR_STATE, "stream_wait: pfmi_stream_enqueue was given no seeds: call pfmi_stream_seeds first");
     int32_t fin = 0;
     while (true) {
         PF_TRY(pfmi_stream_pump(c, &fin));
@@ -815,15 +844,20 @@ int32_t pfmi_fit_batch(pfmi_ctx *c, int32_t J, double eps) {
 int32_t pfmi_get_fit_status(pfmi_ctx *c, int32_t *status, int32_t *j_eff, double *logdet, int64_t *n_rejected) {
     PF_CTX(c);
     PF_CHECK(c->fitted, PFMI_ERR_STATE, "get_fit_status: call pfmi_fit_batch first");
-    std::vector<int32_t> r((size_t)c->K);
+    auto r = std::make_shared<std::vector<int32_t>>((size_t)c->K);
     if (status) PF_TRY(d2h_async(c, status, c->status.p, sizeof(int32_t) * c->P));
     if (j_eff) PF_TRY(d2h_async(c, j_eff, c->hist_len.p, sizeof(int32_t) * c->P));
     if (logdet) PF_TRY(d2h_async(c, logdet, c->logdet.p, sizeof(double) * c->P));
-    if (n_rejected) PF_TRY(d2h_async(c, r.data(), c->n_rej.p, sizeof(int32_t) * c->K));
+    if (n_rejected) PF_TRY(d2h_async(c, r->data(), c->n_rej.p, sizeof(int32_t) * c->K));
+    const int K = c->K;
+    auto widen = [r, n_rejected, K]() -> int32_t {
+        if (n_rejected)
+            for (int k = 0; k < K; ++k) n_rejected[k] = (*r)[(size_t)k];
+        return PFMI_OK;
+    };
+    if (c->defer) { c->post_sync.push_back(widen); return PFMI_OK; }
     PF_TRY(stream_sync(c));
-    if (n_rejected)
-        for (int k = 0; k < c->K; ++k) n_rejected[k] = r[(size_t)k];
-    return PFMI_OK;
+    return widen();
 }
 
 int32_t pfmi_get_fit(pfmi_ctx *c, int64_t p, double *alpha, double *B, double *D, double *qr_factors, double *T,
@@ -1058,30 +1092,35 @@ int32_t pfmi_elbo_batch_wait(pfmi_ctx *c, double *elbo, double *se, int64_t *bes
     if (best_iter) PF_TRY(d2h_async(c, best_iter, c->best_iter.p, sizeof(int64_t) * c->K));
     // pieces of the scan that gave up waiting for their fit's constants (they poison their draws; elbo_qf_kernel.hip): the counter is
     // the last word of the hand-over buffer
-    uint32_t lost2[2] = {0, 0};
+    auto lost2 = std::make_shared<std::array<uint32_t, 2>>();
+    (*lost2)[0] = (*lost2)[1] = 0;
     for (int q = 0; q < 2; ++q)
         if (c->qf_share_s[q].cap >= sizeof(uint32_t))
-            PF_TRY(d2h_async(c, &lost2[q], c->qf_share_s[q].as<char>() + c->qf_share_s[q].cap - sizeof(uint32_t), sizeof(uint32_t)));
+            PF_TRY(d2h_async(c, &(*lost2)[(size_t)q], c->qf_share_s[q].as<char>() + c->qf_share_s[q].cap - sizeof(uint32_t), sizeof(uint32_t)));
+    auto after = [c, lost2]() -> int32_t {
+        uint32_t lost = (*lost2)[0] + (*lost2)[1];
+        for (int q = 0; q < 2; ++q)
+            if ((*lost2)[(size_t)q] != 0) (void)hipMemsetAsync(c->qf_share_s[q].as<char>() + c->qf_share_s[q].cap - sizeof(uint32_t), 0, sizeof(uint32_t), c->stream);
+        {
+            const char *fake = pf_debug_get("PFMI_QF_FAKE_LOST");       // test hook: the first wait of a ctx reports one lost piece (exercises the retry path)
+            if (fake && fake[0] == '1' && !c->qf_no_share) lost = 1;
+        }
+        if (lost != 0) {
+            // plain contention (another process on the GPU, CU masking, a profiler serialising dispatch) must not turn into wrong
+            // results or a hard failure.  The poisoned scan (and whatever was enqueued behind it) is void; this ctx takes the two-launch cut --
+            // no in-kernel wait -- from now on, and the caller is told to enqueue the step again.
+            c->qf_no_share = true;
+            c->qf_lost_total += lost;
+            c->elbo_done = false; c->pooled = false;
+            pf_set_error("ELBO scan: %u workgroup(s) gave up waiting for their fit's constants (GPU shared or dispatch serialised?); results discarded, "
+                         "later scans on this context use the two-launch cut: enqueue the step again", lost);
+            return PFMI_ERR_RETRY;
+        }
+        return PFMI_OK;
+    };
+    if (c->defer) { c->post_sync.push_back(after); return PFMI_OK; }
     PF_TRY(stream_sync(c));
-    uint32_t lost = lost2[0] + lost2[1];
-    for (int q = 0; q < 2; ++q)
-        if (lost2[q] != 0) (void)hipMemsetAsync(c->qf_share_s[q].as<char>() + c->qf_share_s[q].cap - sizeof(uint32_t), 0, sizeof(uint32_t), c->stream);
-    {
-        const char *fake = pf_debug_get("PFMI_QF_FAKE_LOST");       // test hook: the first wait of a ctx reports one lost piece (exercises the retry path)
-        if (fake && fake[0] == '1' && !c->qf_no_share) lost = 1;
-    }
-    if (lost != 0) {
-        // plain contention (another process on the GPU, CU masking, a profiler serialising dispatch) must not turn into wrong
-        // results or a hard failure.  The poisoned scan (and whatever was enqueued behind it) is void; this ctx takes the two-launch cut --
-        // no in-kernel wait -- from now on, and the caller is told to enqueue the step again.
-        c->qf_no_share = true;
-        c->qf_lost_total += lost;
-        c->elbo_done = false; c->pooled = false;
-        pf_set_error("ELBO scan: %u workgroup(s) gave up waiting for their fit's constants (GPU shared or dispatch serialised?); results discarded, "
-                     "later scans on this context use the two-launch cut: enqueue the step again", lost);
-        return PFMI_ERR_RETRY;
-    }
-    return PFMI_OK;
+    return after();
 }
 
 int32_t pfmi_elbo_batch(pfmi_ctx *c, int64_t N, const uint64_t *seeds, const double *u_host, double *elbo,
@@ -1322,7 +1361,15 @@ int32_t pfmi_psis_weights(pfmi_ctx *c, int64_t S, double *weights, double *log_w
     PF_CHECK(S > 0 && c->S_w == S, PFMI_ERR_STATE, "psis_weights: no PSIS result for S=%lld on this ctx", (long long)S);
     if (weights) PF_TRY(d2h_async(c, weights, c->w.p, sizeof(double) * S));
     if (log_weights) PF_TRY(d2h_async(c, log_weights, c->lw.p, sizeof(double) * S));
+    if (c->defer) return PFMI_OK;
     return stream_sync(c);
+}
+
+int32_t pfmi_defer_downloads(pfmi_ctx *c, int32_t mode) {
+    PF_CHECK(c != nullptr, PFMI_ERR_ARG, "null pfmi_ctx");
+    if (mode < 0) { pf_deferred_drop(c); c->defer = false; return PFMI_OK; }       // cancel: nothing queued is ever delivered
+    c->defer = mode != 0;
+    return PFMI_OK;
 }
 
 int32_t pfmi_psis(pfmi_ctx *c, const double *lr, int64_t S, double *weights, double *log_weights, double *pareto_k,

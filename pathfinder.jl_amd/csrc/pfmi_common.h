@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <chrono>
+#include <functional>
+#include <memory>
 #include <string>
 #include <map>
 #include <set>
@@ -59,7 +61,7 @@ struct KernelStat { double ms = 0.0; int64_t launches = 0; };
 // rewound whenever the stream is known to be idle (pf_arena_reset after a full synchronisation).
 struct PinArena { char *base = nullptr; size_t cap = 0, off = 0; };
 // a small device -> host download staged in the ctx's pinned download arena: delivered to `dst` by pf_stream_sync
-struct DlPending { void *dst; const char *slot; size_t bytes; };
+struct DlPending { void *dst; const char *slot; size_t bytes; bool keep; };   // keep: queued under pfmi_defer_downloads (survives the next entry points)
 
 // device-resident target description (Gaussian family rows are stored row-major for scalar loads)
 struct TargetDev {
@@ -86,6 +88,10 @@ struct pfmi_ctx {
     PinArena arena;                         // staging of small uploads (pf_upload)
     PinArena dl;                            // staging of small downloads (pf_download)
     std::vector<DlPending> dl_pending;
+    // pfmi_defer_downloads: the download-only entry points queue their copies (and what they would do after their wait) and return at once;
+    // the next wait on this ctx delivers everything in one host round trip
+    bool defer = false;
+    std::vector<std::function<int32_t()>> post_sync;
     int ncu = 0;                            // compute units of the device
 
     // traces
@@ -122,6 +128,7 @@ struct pfmi_ctx {
         double eps = 0.0;
         uint64_t *d_lseeds = nullptr; int32_t *d_list = nullptr;
         bool scan_used[2] = {false, false};
+        bool have_seeds = false;              // the runs' seed streams have arrived (pfmi_stream_enqueue or, later, pfmi_stream_seeds)
         std::vector<uint64_t> seeds_pt;       // host copy of the per-point seeds (the scan's work lists are cut from it)
         std::chrono::steady_clock::time_point t_progress, t_start;
         std::vector<double> trace;            // PFMI_STREAM_TRACE: (t_us, l0, l1, fits, scan stream) per segment

@@ -442,6 +442,7 @@ def _run_paths(engs, target, inits, run_rngs, *, dim, history_length, ndraws_elb
     pooled = None
     while pending:
         pooled_error = None
+        tables = None                                               # per engine: (fit_status, elbo_batch_wait, psis_weights) delivered by the pooled wait
         need = []
         for k in pending:
             st = state[k]
@@ -451,9 +452,10 @@ def _run_paths(engs, target, inits, run_rngs, *, dim, history_length, ndraws_elb
             else:
                 need.append(k)
         if need and type(init_sampler) is UniformSampler:          # src/singlepath.jl:167-168, 277 -- all runs in one Philox batch
-            for k, u in zip(need, rand_u64_multi([run_rngs[k] for k in need], [dim] * len(need))):
-                state[k]["x0"] = ((u >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)) * 2 * init_sampler.scale \
-                    - init_sampler.scale
+            u = np.stack(rand_u64_multi([run_rngs[k] for k in need], [dim] * len(need)))
+            x0s = ((u >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)) * 2 * init_sampler.scale - init_sampler.scale
+            for i, k in enumerate(need):
+                state[k]["x0"] = x0s[i]
         else:
             for k in need:
                 state[k]["x0"] = init_sampler(run_rngs[k], np.empty(dim))
@@ -464,18 +466,20 @@ def _run_paths(engs, target, inits, run_rngs, *, dim, history_length, ndraws_elb
             # while the paths are still being optimised.  The per-fit seeds of every run for the LONGEST possible trace are drawn up front
             # from copies of the runs' rngs (a run that was finished in an earlier try keeps the stream it had).
             cap = int(okw.get("maxiters", 1000)) + 1
-            for k, sd in zip(pending, rand_u64_multi([run_rngs[k].copy() for k in pending], [cap] * len(pending))):
-                state[k]["stream_tab"] = sd
-            predrawn = {k: state[k]["stream_tab"] for k in pending}
             try:
-                for eng, (k0, k1) in zip(engs, blocks):
-                    eng.stream_enqueue(np.stack([s["x0"] for s in state[k0:k1]]), ndraws_elbo,
-                                       np.concatenate([s["stream_tab"] for s in state[k0:k1]]), history_length, **okw)
+                for eng, (k0, k1) in zip(engs, blocks):             # the optimiser starts at once; the seed streams follow while it runs
+                    eng.stream_enqueue(np.stack([s["x0"] for s in state[k0:k1]]), ndraws_elbo, None, history_length, **okw)
                 streamed = True
             except PfmiError as ex:
                 if getattr(ex, "code", 0) != -4 or eng is not engs[0]:    # PFMI_ERR_UNSUPPORTED on the first engine: the packed route below
                     raise
                 stream_ok = False
+            if streamed:
+                for k, sd in zip(pending, rand_u64_multi([run_rngs[k].copy() for k in pending], [cap] * len(pending))):
+                    state[k]["stream_tab"] = sd
+                predrawn = {k: state[k]["stream_tab"] for k in pending}
+                for eng, (k0, k1) in zip(engs, blocks):
+                    eng.stream_seeds(np.concatenate([s["stream_tab"] for s in state[k0:k1]]))
         if streamed:
             active = list(zip(engs, blocks))
             while active:                                           # the calling thread schedules every engine's pipeline
@@ -530,17 +534,52 @@ def _run_paths(engs, target, inits, run_rngs, *, dim, history_length, ndraws_elb
             for eng, (k0, k1) in zip(engs, blocks):
                 eng.pool_build_best(pool["N_r"], np.array([s["fail_seed"] for s in state[k0:k1]], dtype=np.uint64))
             comm = _comm_for(engs)
+            # the pooled stage is ENQUEUED; the tables of this try (fit statuses, ELBO table, PSIS weights) are queued behind it and the one
+            # wait below delivers everything: a single host round trip per try
             try:
-                res, idx, draws = comm.psis_resample(pool["ndraws"], importance=pool["importance"], replace=pool.get("replace", True),
-                                                     seed=pool["seed"])
-                pooled = dict(psis=res, idx=idx, draws=draws, comm=comm)
+                comm.psis_resample_enqueue(pool["ndraws"], importance=pool["importance"], replace=pool.get("replace", True), seed=pool["seed"])
+                queued = []
+                try:
+                    for eng in engs:
+                        eng.defer(1)
+                    for g, eng in enumerate(engs):
+                        queued.append((eng.fit_status(), eng.elbo_batch_wait(),
+                                       eng.psis_weights(len(inits) * pool["N_r"]) if (g == 0 and pool["importance"]) else None))
+                except BaseException:
+                    for eng in engs:
+                        eng.defer(-1)                               # nothing queued may be delivered into arrays that are going away
+                    raise
+                for eng in engs:
+                    eng.defer(0)
+            except PfmiRetry:
+                raise
             except Exception as ex:                                 # surfaced AFTER the fit statuses: the reference would have thrown
                 pooled_error = ex                                   # PosDefException from fit_mvnormals before it ever pooled
+            else:
+                try:
+                    res, idx, draws = comm.psis_resample_wait()
+                    pooled = dict(psis=res, idx=idx, draws=draws, comm=comm, weights=queued[0][2])
+                    tables = queued
+                except PfmiRetry:
+                    for eng in engs:
+                        eng.defer(-1)
+                    raise
+                except Exception as ex:
+                    pooled_error = ex
+                    try:                                            # whatever the failed wait did not deliver
+                        for eng in engs:
+                            eng.sync()
+                        tables = queued
+                    except PfmiRetry:
+                        raise
+                    except Exception:
+                        for eng in engs:
+                            eng.defer(-1)
         # ---- first wait of this try: everything above is in flight on every engine
         new_pending = []
         all_status, all_jeff = [], []
-        for eng, (k0, k1) in zip(engs, blocks):
-            status, jeff, logdet, nrej = eng.fit_status()
+        for g, (eng, (k0, k1)) in enumerate(zip(engs, blocks)):
+            status, jeff, logdet, nrej = tables[g][0] if tables is not None else eng.fit_status()
             all_status.append(status); all_jeff.append(jeff)
             bad = np.flatnonzero((status != 0) & (status != 4))      # (4 = PFMI_FIT_ABSENT: a slot of the streaming layout no path reached)
             if len(bad) and strict:
@@ -550,7 +589,7 @@ def _run_paths(engs, target, inits, run_rngs, *, dim, history_length, ndraws_elb
                 kl = int(np.searchsorted(eng.offsets, p, side="right") - 1)
                 raise PosDefException(f"run {k0 + kl + 1}, fit {p - int(eng.offsets[kl]) + 1}: {_STATUS_MSG.get(int(status[p]), 'failed')} "
                                       f"({len(bad)} of {len(status)} fits failed; strict=False keeps them as NaN ELBOs instead)")
-            elbo, se, best = eng.elbo_batch_wait()
+            elbo, se, best = tables[g][1] if tables is not None else eng.elbo_batch_wait()
             for k in range(k0, k1):
                 st = state[k]
                 kl = k - k0
@@ -710,7 +749,7 @@ def multipathfinder(target, ndraws, *, init=None, nruns=-1, ndraws_elbo=DEFAULT_
     S = nruns * ndraws_per_run
     psis_result = None
     if importance:                                                                               # :220-224
-        w, lw = engs[0].psis_weights(S)
+        w, lw = pooled["weights"] if pooled.get("weights") is not None else engs[0].psis_weights(S)
         psis_result = PSISResult(w, lw, pooled["psis"]["pareto_shape"], pooled["psis"]["tail_length"])
     ids = pooled["idx"] // ndraws_per_run + 1                                                   # cld.(inds, N) with 1-based inds
     return MultiPathfinderResult(input if input is not None else target, rng, target.logp,

@@ -141,6 +141,11 @@ class Engine:
         check(self.L.pfmi_kernel_time(self.ctx, name.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def defer(self, mode):
+        """1: fit_status / elbo_batch_wait / psis_weights only QUEUE their downloads -- the arrays they return are filled by the next call
+        that waits on this engine (sync, Comm.psis_resample_wait); 0: back to normal; -1: drop what is queued (after an error)"""
+        check(self.L.pfmi_defer_downloads(self.ctx, C.c_int32(int(mode))))
+
     # ---- inputs -------------------------------------------------------------------------------------
     def set_target(self, target):
         self.target = target                      # keep parameter arrays / callbacks alive
@@ -201,8 +206,10 @@ class Engine:
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
         K, d = x0.shape
         cap = int(maxiters) + 1
-        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
-        assert self.target is not None and d == self.target.d and seeds.size == K * cap
+        if seeds is not None:
+            seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+            assert seeds.size == K * cap
+        assert self.target is not None and d == self.target.d
         self.gen_traces += 1
         self.gen_fit += 1
         self.J = history_length
@@ -210,7 +217,14 @@ class Engine:
         self.offsets = np.arange(K + 1, dtype=np.int64) * cap
         self.npoints = None
         check(self.L.pfmi_stream_enqueue(self.ctx, C.c_int32(K), _d(x0), C.c_int32(history_length), C.c_int32(maxiters),
-                                         C.c_double(g_tol), C.c_double(eps), C.c_int64(N), seeds.ctypes.data_as(_u64p)))
+                                         C.c_double(g_tol), C.c_double(eps), C.c_int64(N),
+                                         seeds.ctypes.data_as(_u64p) if seeds is not None else None))
+
+    def stream_seeds(self, seeds):
+        """the runs' predrawn seed streams (K * (maxiters + 1),) of a stream_enqueue(..., seeds=None): drawn while the optimiser already runs"""
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        assert seeds.size == self.P
+        check(self.L.pfmi_stream_seeds(self.ctx, seeds.ctypes.data_as(_u64p)))
 
     def stream_pump(self):
         """one scheduling pass of the pipeline (never blocks); True once its last segment has been launched"""
@@ -520,6 +534,25 @@ class Comm:
         check(self.L.pfmi_comm_psis_resample(self.h, C.c_int64(ndraws), C.c_int32(int(importance)), C.c_int32(int(replace)),
                                              C.c_uint64(int(seed)), _d(uniforms), C.byref(k), C.byref(M),
                                              idx.ctypes.data_as(_i64p), _d(out)))
+        return dict(pareto_shape=k.value, tail_length=M.value), idx, out
+
+    def psis_resample_enqueue(self, ndraws, importance=True, replace=True, seed=0, uniforms=None):
+        """first half of psis_resample: everything launched on every local context, no wait"""
+        if uniforms is not None:
+            uniforms = np.ascontiguousarray(uniforms, dtype=np.float64)
+        self._pr = (ndraws, uniforms)                   # (keeps the uniforms alive until the wait)
+        check(self.L.pfmi_comm_psis_resample_enqueue(self.h, C.c_int64(ndraws), C.c_int32(int(importance)), C.c_int32(int(replace)),
+                                                     C.c_uint64(int(seed)), _d(uniforms)))
+
+    def psis_resample_wait(self, want_draws=True):
+        """second half: the ONE host round trip (also delivers what the member engines queued under Engine.deferred())"""
+        ndraws = self._pr[0]
+        d = self.engines[0].d
+        idx = np.empty(ndraws, dtype=np.int64)
+        out = result_empty((d, ndraws)) if want_draws else None
+        k, M = C.c_double(), C.c_int64()
+        check(self.L.pfmi_comm_psis_resample_wait(self.h, C.byref(k), C.byref(M), idx.ctypes.data_as(_i64p), _d(out)))
+        self._pr = None
         return dict(pareto_shape=k.value, tail_length=M.value), idx, out
 
     def close(self):

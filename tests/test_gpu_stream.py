@@ -127,3 +127,50 @@ def test_stream_refuses_what_it_cannot_run(pfmi_mod):
     with pytest.raises(pfmi_mod._lib.PfmiError):  # a host closure cannot be optimised on the device
         e.stream_enqueue(np.zeros((2, 16)), 16, np.zeros(2 * 11, dtype=np.uint64), 6, 10)
     e.close()
+
+
+def test_seeds_handed_over_later_and_deferred_downloads_equal_the_plain_calls(pfmi_mod):
+    """pfmi_stream_enqueue(seeds = NULL) + pfmi_stream_seeds: the optimiser starts before the host has drawn the streams;
+    pfmi_comm_psis_resample_enqueue / _wait with pfmi_defer_downloads in between: fit statuses, ELBO table and PSIS weights arrive with the ONE
+    wait of the pooled stage.  Same bits as the plain sequence."""
+    tg = pfmi_mod.t_lowrank(200, r=8, seed=2)
+    K, J, maxiters, N = 6, 6, 80, 512
+    cap = maxiters + 1
+    x0 = pfmi_mod.HostRNG(5).rand(K * 200).reshape(K, 200) * 4 - 2
+    sd = pfmi_mod.hostrng.rand_u64(78, np.arange(K * cap, dtype=np.uint64), 9)
+    a = _streamed(pfmi_mod, tg, x0, J, maxiters, N, sd, N, 300)[0]          # (np.empty arrays: a cancelled deferral leaves them as they were)
+    e = pfmi_mod.Engine(0)
+    e.set_target(tg)
+    comm = pfmi_mod.Comm.init_all([e])
+    for rep in range(2):
+        e.stream_enqueue(x0, N, None, J, maxiters)
+        assert not e.stream_pump()                  # nothing but the optimiser runs before the seeds are there
+        with pytest.raises(pfmi_mod._lib.PfmiError):
+            e.stream_wait()
+        e.stream_seeds(sd)
+        npts = e.stream_wait()
+        e.pool_build_best(N, None)
+        comm.psis_resample_enqueue(300, seed=9)
+        e.defer(1)
+        st = e.fit_status()
+        el = e.elbo_batch_wait()
+        ws = e.psis_weights(K * N)
+        e.defer(0)
+        res, idx, draws = comm.psis_resample_wait()
+        np.testing.assert_array_equal(npts, a["npts"])
+        for i in range(4):
+            np.testing.assert_array_equal(st[i], [a["status"], a["jeff"], a["logdet"], a["nrej"]][i])
+        np.testing.assert_array_equal(el[0], a["elbo"]); np.testing.assert_array_equal(el[1], a["se"]); np.testing.assert_array_equal(el[2], a["best"])
+        np.testing.assert_array_equal(idx, a["idx"]); np.testing.assert_array_equal(draws, a["draws"])
+        w, lw = e.psis_weights(K * N)
+        np.testing.assert_array_equal(ws[0], w); np.testing.assert_array_equal(ws[1], lw)
+        assert abs(w.sum() - 1) < 1e-12
+    # cancelled deferral: nothing is delivered later
+    e.defer(1)
+    junk = e.fit_status()
+    before = [x.copy() for x in junk]
+    e.defer(-1)
+    e.sync()
+    for x, y in zip(junk, before):
+        np.testing.assert_array_equal(x, y)
+    comm.close(); e.close()
