@@ -109,6 +109,7 @@ template <int KC, int TGT, int RPAD, int NG, bool PERSIST = false>
 __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int ch_blocks, int nchunks, int groups_per_wg, int ngroups, int n_whole,
                                                                   int n_tail, int ndep, double *, unsigned *, unsigned) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ int s_next;
 #if QF_PROF
     const long long qf_t0 = wall_clock64();
     long long qf_tb = 0, qf_te = 0, qf_tp = 0, qf_last = 0;
@@ -132,12 +133,11 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
             unsigned *const counter = *reinterpret_cast<unsigned *const *>(ka + offsetof(QfKernArgs, cflag));
             const unsigned total = *reinterpret_cast<const unsigned *>(ka + offsetof(QfKernArgs, epoch));
             const unsigned t = atomicAdd(counter, 1u);
-            reinterpret_cast<int *>(lds)[0] = t < total ? (int)t : -1;      // (the dynamic block is all the LDS there is: 160 KB at d = 1000)
+            s_next = t < total ? (int)t : -1;
         }
         __syncthreads();
-        slot = reinterpret_cast<const int *>(lds)[0];
+        slot = s_next;
         if (slot < 0) return;
-        __syncthreads();                                               // everybody has read it: the staging below may overwrite it
     }
     int g_begin = blockIdx.x * groups_per_wg, g_cap = groups_per_wg;
     if (!PERSIST && n_tail > 0 && slot >= n_whole) {
