@@ -100,16 +100,10 @@ struct QfKernArgs { ElboArgs A; int ch_blocks, nchunks, groups_per_wg, ngroups, 
 #ifndef QF_SHARE_SPINS
 #define QF_SHARE_SPINS 2000000          // x ~1 us: how long a dependent piece waits for its fit's constants before it gives up
 #endif
-// PERSIST (the segments of the streaming pipeline, pfmi_stream_pump): the launch has fewer workgroups than fits; a workgroup takes the next
-// fit of the launch's list from a counter (`cflag` = the counter, `epoch` = the number of fits) until the list is exhausted.  Every
-// workgroup of the scan takes the same time per fit, so the launch ends within one fit's time of its last workgroup's start however its
-// workgroups were spread over the XCDs and whenever each of them got its CU -- concurrent launches of whole-fit workgroups do not have that
-// property (profiles/r05_experiments.md).  Nobody waits for anybody; the arithmetic of a fit is untouched.
-template <int KC, int TGT, int RPAD, int NG, bool PERSIST = false>
+template <int KC, int TGT, int RPAD, int NG>
 __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int ch_blocks, int nchunks, int groups_per_wg, int ngroups, int n_whole,
                                                                   int n_tail, int ndep, double *, unsigned *, unsigned) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    __shared__ int s_next;
 #if QF_PROF
     const long long qf_t0 = wall_clock64();
     long long qf_tb = 0, qf_te = 0, qf_tp = 0, qf_last = 0;
@@ -124,23 +118,9 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
     // leaves idle: first the n_tail PUBLISHERS (role 1: the pseudo groups + the first groups of the fit; they hand the per-fit
     // constants over through `cshare` / `cflag`), then the ndep DEPENDENTS of each fit (role 2: a full batch of real groups, the
     // constants fetched before the first draw is finished).  A workgroup that waits was dispatched after every publisher.
-  for (;;) {                                                         // (one trip unless PERSIST)
     int slot = blockIdx.y, role = 0;
-    if constexpr (PERSIST) {
-        __syncthreads();                                               // the previous fit's LDS is no longer read
-        if (tid == 0) {
-            const char *ka = (const char *)__builtin_amdgcn_kernarg_segment_ptr();
-            unsigned *const counter = *reinterpret_cast<unsigned *const *>(ka + offsetof(QfKernArgs, cflag));
-            const unsigned total = *reinterpret_cast<const unsigned *>(ka + offsetof(QfKernArgs, epoch));
-            const unsigned t = atomicAdd(counter, 1u);
-            s_next = t < total ? (int)t : -1;
-        }
-        __syncthreads();
-        slot = s_next;
-        if (slot < 0) return;
-    }
     int g_begin = blockIdx.x * groups_per_wg, g_cap = groups_per_wg;
-    if (!PERSIST && n_tail > 0 && slot >= n_whole) {
+    if (n_tail > 0 && slot >= n_whole) {
         constexpr int SL = QF_WAVES * NG, NPG_ = (TGT != 0) ? (KC + 1 + 15) / 16 : 0;
         int tail_f;
         if (slot < n_whole + n_tail) { role = 1; tail_f = slot - n_whole; g_begin = 0; g_cap = SL - NPG_; }
@@ -166,7 +146,7 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
         for (int64_t n = (int64_t)g_begin * 16 + tid; n < (int64_t)g_end * 16 && n < A.N; n += QF_THREADS) {
             out_lp[n] = NAN; out_lq[n] = NAN;
         }
-        if constexpr (PERSIST) continue; else return;
+        return;
     }
     // ---- LDS carve-up (offsets in doubles from `lds`; plain offsets keep every access a ds_ instruction)
     const int vh_sz = ch_blocks * 16 * KC, rs_sz = ch_blocks * 48;
@@ -771,8 +751,6 @@ __global__ __launch_bounds__(QF_THREADS) void pf_elbo_qf_kernel(ElboArgs A, int 
         printf("QF_PROF fit %d wave %d (10 ns ticks): prologue %lld blocks %lld epilogue+publish %lld total %lld batches %d\n", slot, wv, qf_tp, qf_tb,
                qf_te, (long long)(wall_clock64() - qf_t0), nlb);
 #endif
-    if constexpr (!PERSIST) break;
-  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -795,27 +773,6 @@ static int32_t launch_qf_ng(pfmi_ctx *c, const ElboArgs &a, int64_t nfits) {
     PF_TRY(pf_raise_lds_limit(c, reinterpret_cast<const void *>(kern), 160 * 1024));
     const int ngroups = (int)((a.N + 15) / 16);
     constexpr int NPG = (TGT != 0) ? (KC + 1 + 15) / 16 : 0;
-    if (const char *fp = pf_debug_get("PFMI_QF_PERSIST")) {          // test / tuning hook: an ordinary scan as ONE work-queue launch of n workgroups
-        if (atoi(fp) > 0 && c->qf_persist_counter == nullptr && TGT != 0) {
-            PF_TRY(c->qf_counters.ensure(sizeof(unsigned) * 4096));
-            PF_HIP(hipMemsetAsync(c->qf_counters.p, 0, sizeof(unsigned), c->stream));
-            auto pk = pf_elbo_qf_kernel<KC, TGT, RPAD, NG, true>;
-            PF_TRY(pf_raise_lds_limit(c, reinterpret_cast<const void *>(pk), 160 * 1024));
-            const unsigned nwg = (unsigned)(nfits < atoi(fp) ? nfits : atoi(fp));
-            hipLaunchKernelGGL(pk, dim3(1, nwg), dim3(QF_THREADS), lds_bytes, c->stream, a, ch_blocks, nchunks, ngroups, ngroups, 0, 0, 0,
-                               (double *)nullptr, c->qf_counters.as<unsigned>(), (unsigned)nfits);
-            return PFMI_OK;
-        }
-    }
-    if (c->qf_persist_counter != nullptr && c->qf_persist_wgs > 0 && nfits < (1ll << 31)) {
-        // a segment of the streaming pipeline: at most qf_persist_wgs workgroups, each takes whole fits from the list until it is exhausted
-        auto pk = pf_elbo_qf_kernel<KC, TGT, RPAD, NG, true>;
-        PF_TRY(pf_raise_lds_limit(c, reinterpret_cast<const void *>(pk), 160 * 1024));
-        const unsigned nwg = (unsigned)(nfits < c->qf_persist_wgs ? nfits : c->qf_persist_wgs);
-        hipLaunchKernelGGL(pk, dim3(1, nwg), dim3(QF_THREADS), lds_bytes, c->stream, a, ch_blocks, nchunks, ngroups, ngroups, 0, 0, 0,
-                           (double *)nullptr, c->qf_persist_counter, (unsigned)nfits);
-        return PFMI_OK;
-    }
     // one workgroup per fit; a fit's groups are split over several workgroups only when there are few fits (every
     // workgroup recomputes the per-fit constants, so the pieces are kept to whole batches)
     // (a segment of the streaming pipeline that is not the last: whole fits only -- the next segment's workgroups fill the CUs this one leaves)

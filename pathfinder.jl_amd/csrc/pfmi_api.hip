@@ -259,7 +259,7 @@ int32_t pfmi_destroy(pfmi_ctx *c) {
                       &c->pool_lr, &c->pool_lp, &c->pool_lq, &c->pool_points, &c->pool_seeds, &c->lw, &c->w,
                       &c->psis_out, &c->psis_aux, &c->tailbuf, &c->cdf, &c->idx, &c->gbuf, &c->trace_lp, &c->st_theta, &c->st_grad,
                       &c->st_lp, &c->st_npts, &c->lb_hs, &c->lb_hy, &c->lb_x0, &c->sortk, &c->sorti,
-                      &c->pool_ok, &c->fail_seeds, &c->rs_err, &c->hs_ial, &c->hs_nacc, &c->qf_counters};
+                      &c->pool_ok, &c->fail_seeds, &c->rs_err, &c->hs_ial, &c->hs_nacc};
     for (DevBuf *b : bufs) b->release();
     for (int b = 0; b < 2; ++b) {
         c->cb_x[b].release(); c->cb_lp[b].release();

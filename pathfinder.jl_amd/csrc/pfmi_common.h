@@ -177,9 +177,6 @@ struct pfmi_ctx {
     uint32_t qf_epoch_s[2] = {0, 0};   // launch counter of the shared-constants scan: a flag equal to it means "published in THIS launch"
                                        // (one hand-over buffer + counter per scan stream: launches on different streams overlap)
     int qf_slot = 0;        // which of the two the next scan launch uses (0 outside the streaming pipeline)
-    DevBuf qf_counters;                       // work-queue counters of the scan's work-queue launches (one per launch of a streaming call)
-    unsigned *qf_persist_counter = nullptr;   // != null: the next scan launch is a work-queue launch of at most qf_persist_wgs workgroups (streaming segments)
-    int qf_persist_wgs = 0;
     bool qf_no_share = false; // a hand-over of the shared-constants scan timed out on this ctx: later scans take the two-launch cut (no in-kernel wait)
     int64_t qf_lost_total = 0; // pieces that ever gave up waiting (pfmi_kernel_time("qf_handover_lost") reports it as `launches`)
 

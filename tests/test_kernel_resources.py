@@ -18,9 +18,9 @@ sys.path.insert(0, os.path.join(ROOT, "pathfinder.jl_amd", "tools"))
 
 # kernel (demangled prefix) -> (max VGPRs incl. AGPRs, max scratch bytes per work-item, why)
 PINS = {
-    "pf_elbo_qf_kernel<12, 1, 8, 2, false>(": (256, 64, "config 3/4 scan: 2 waves per SIMD; only the per-batch epilogue may spill (round 4: 140 B -> 56 B)"),
-    "pf_elbo_qf_kernel<12, 1, 0, 2, false>(": (256, 0, "config 2 scan (diagonal Gaussian)"),
-    "pf_elbo_qf_kernel<20, 2, 0, 2, false>(": (256, 64, "config 5 scan (funnel, J = 10): register-lean body of round 3, no spill inside the block loop"),
+    "pf_elbo_qf_kernel<12, 1, 8, 2>(": (256, 64, "config 3/4 scan: 2 waves per SIMD; only the per-batch epilogue may spill (round 4: 140 B -> 56 B)"),
+    "pf_elbo_qf_kernel<12, 1, 0, 2>(": (256, 0, "config 2 scan (diagonal Gaussian)"),
+    "pf_elbo_qf_kernel<20, 2, 0, 2>(": (256, 64, "config 5 scan (funnel, J = 10): register-lean body of round 3, no spill inside the block loop"),
     "pf_elbo_xw_kernel<12>(": (216, 0, "draw writer at J = 6: 207 - 209 VGPRs, no scratch (round 4: opaque lane indices)"),
     "pf_elbo_xw_kernel<20>(": (256, 128, "draw writer at J = 10 (round 4: 264 -> 96-104 B of scratch)"),
     "pf_fit_reg_kernel<12, 4, 256>(": (168, 0, "fit at d <= 1024, J = 6: 3 workgroups per CU need <= 168 VGPRs, no spill (round 4: 163)"),
