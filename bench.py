@@ -28,6 +28,11 @@ import subprocess
 import sys
 import time
 
+# The engine's streaming pipeline runs the optimiser, the fits and two scan launches on four streams beside the context's own; torch and
+# RCCL create streams too.  With the runtime's default of 4 hardware queues they share queues and serialise one another (measured in the
+# one-rank-per-GPU mode: packed route 5.0 -> 6.1 ms per step at 8 paths); 8 queues keep them apart.  Must be set before HIP initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "pathfinder.jl_amd"), os.path.join(ROOT, "tests")):
     if _p not in sys.path:
@@ -384,7 +389,13 @@ def main():
         if comm is not None:
             # [ONE RCCL all-gather of the log-ratio shards] + replicated PSIS + replicated indices + owner gather [+ sum all-reduce],
             # one synchronisation, D2H of k-hat / indices / draws
-            res, idx, state["draws"] = comm.psis_resample(ndraws, seed=master)
+            comm.psis_resample_enqueue(ndraws, seed=master)
+            eng.defer(1)                                            # the ELBO tables' downloads are queued behind the pooled stage ...
+            elbo, se, best = eng.elbo_batch_wait()
+            eng.defer(0)
+            res, idx, state["draws"] = comm.psis_resample_wait()    # ... and this ONE wait delivers everything
+            state.update(elbo=elbo, best=best, pareto_k=res["pareto_shape"], tail=res["tail_length"], idx=idx)
+            return
         elif use_dist:                                              # fallback: the same orchestration through torch.distributed
             import torch
             from pfmi.distributed import pooled_psis_resample

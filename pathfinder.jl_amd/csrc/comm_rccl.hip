@@ -318,18 +318,19 @@ int32_t enqueue_pool_psis(pfmi_comm *c, int64_t out_doubles) {
     return PFMI_OK;
 }
 
-int32_t finish_pool_psis(pfmi_comm *c, double *pareto_k, int64_t *tail_len) {
+// the pooled PSIS' scalars (k-hat, tail length, ...) of every local replica: queued for download / checked after the wait
+int32_t queue_pool_psis(pfmi_comm *c, std::vector<double> &out) {
     const size_t nl = c->ctx.size();
-    std::vector<double> out(4 * nl);
+    out.assign(4 * nl, 0.0);
     for (size_t i = 0; i < nl; ++i) {
         pfmi_ctx *x = c->ctx[i];
         PF_HIP(hipSetDevice(x->device));
         PF_TRY(pf_download(x, &out[4 * i], x->psis_out.p, 4 * sizeof(double)));
     }
-    for (size_t i = 0; i < nl; ++i) {
-        PF_HIP(hipSetDevice(c->ctx[i]->device));
-        PF_TRY(pf_stream_sync(c->ctx[i]));
-    }
+    return PFMI_OK;
+}
+int32_t check_pool_psis(pfmi_comm *c, const std::vector<double> &out, double *pareto_k, int64_t *tail_len) {
+    const size_t nl = c->ctx.size();
     c->psis_pending = false;
     const double k0 = out[0];
     const int64_t m0 = (int64_t)out[1];
@@ -341,6 +342,15 @@ int32_t finish_pool_psis(pfmi_comm *c, double *pareto_k, int64_t *tail_len) {
     if (pareto_k) *pareto_k = k0;
     if (tail_len) *tail_len = m0;
     return PFMI_OK;
+}
+int32_t finish_pool_psis(pfmi_comm *c, double *pareto_k, int64_t *tail_len) {
+    std::vector<double> out;
+    PF_TRY(queue_pool_psis(c, out));
+    for (size_t i = 0; i < c->ctx.size(); ++i) {
+        PF_HIP(hipSetDevice(c->ctx[i]->device));
+        PF_TRY(pf_stream_sync(c->ctx[i]));
+    }
+    return check_pool_psis(c, out, pareto_k, tail_len);
 }
 
 // replicated index selection -> owner gather (zeros elsewhere) -> sum all-reduce, enqueued on every local context.  The result buffers
@@ -599,8 +609,11 @@ int32_t pfmi_comm_psis_resample(pfmi_comm *c, int64_t ndraws, int32_t importance
     double k = NAN;
     int64_t m = 0;
     int32_t rp = PFMI_OK;
-    if (importance) rp = finish_pool_psis(c, &k, &m);                   // first wait: everything above is already in flight
-    const int32_t rf = finish_resample(c, idx, draws);
+    std::vector<double> pout;
+    if (importance) rp = queue_pool_psis(c, pout);                      // the PSIS scalars ride in front of the resample stage's results:
+    const int32_t rf = finish_resample(c, idx, draws);                  // ONE wait for both stages
+    c->psis_pending = false;
+    if (importance && rp == PFMI_OK && rf == PFMI_OK) rp = check_pool_psis(c, pout, &k, &m);     // (a failed wait delivered nothing)
     if (pareto_k) *pareto_k = k;
     if (tail_len) *tail_len = m;
     return rc != PFMI_OK ? rc : (rp != PFMI_OK ? rp : rf);
@@ -632,8 +645,11 @@ int32_t pfmi_comm_psis_resample_wait(pfmi_comm *c, double *pareto_k, int64_t *ta
     double k = NAN;
     int64_t m = 0;
     int32_t rp = PFMI_OK;
-    if (c->pr_importance) rp = finish_pool_psis(c, &k, &m);
-    const int32_t rf = finish_resample(c, idx, draws);
+    std::vector<double> pout;
+    if (c->pr_importance) rp = queue_pool_psis(c, pout);
+    const int32_t rf = finish_resample(c, idx, draws);                  // ONE wait for both stages (and whatever the contexts queued)
+    c->psis_pending = false;
+    if (c->pr_importance && rp == PFMI_OK && rf == PFMI_OK) rp = check_pool_psis(c, pout, &k, &m);
     if (pareto_k) *pareto_k = k;
     if (tail_len) *tail_len = m;
     return c->pr_rc != PFMI_OK ? c->pr_rc : (rp != PFMI_OK ? rp : rf);

@@ -656,6 +656,12 @@ int32_t pfmi_stream_enqueue(pfmi_ctx *c, int32_t K, const double *x0, int32_t J,
     R.d_list = reinterpret_cast<int32_t *>(c->seeds.as<char>() + off_li);
     // a segment should fill at least half the CUs with one workgroup per fit
     R.pub = PF_STREAM_PUB;
+    // when are the segments cut?  Few paths (one publication step = at most one round of CUs): at FIXED, geometrically growing positions, as soon
+    // as a segment's inputs are complete.  Many paths: whenever a scan stream is free, with everything that has arrived meanwhile
+    // (profiles/r05_experiments.md section 4: 8 / 16 paths 3.94 / 6.84 against 4.01 / 6.93 ms, and far less sensitive to what else
+    // shares the hardware queues; 32 / 64 paths 12.66 / 24.29 against 12.46 / 24.03 ms)
+    R.policy = (K * PF_STREAM_PUB <= ncu) ? 1 : 0;
+    { const char *po = pf_debug_get("PFMI_STREAM_POLICY"); if (po) R.policy = atoi(po); }
     { const char *pb = pf_debug_get("PFMI_STREAM_PUB"); if (pb && (atoi(pb) == 4 || atoi(pb) == 8 || atoi(pb) == 32)) R.pub = atoi(pb); }
     R.minlen = ((ncu / 2 + K - 1) / K + R.pub - 1) / R.pub * R.pub;
     if (R.minlen < R.pub) R.minlen = R.pub;
@@ -721,8 +727,26 @@ int32_t pfmi_stream_pump(pfmi_ctx *c, int32_t *finished) {
         const int qq = (R.nseg + q) & 1;
         if (!R.scan_used[qq] || hipEventQuery(c->sg_scan[qq]) == hipSuccess) q_free = qq;
     }
-    if (!all_done && (l1 - l0 < R.minlen || q_free < 0)) return PFMI_OK;
-    if (q_free < 0) q_free = R.nseg & 1;
+    if (R.policy == 1) {
+        // fixed boundaries (geometric): a segment goes out as soon as its positions are complete, whatever the scan streams are doing
+        static const int step[] = {16, 16, 32, 32, 32, 64, 64, 128, 128, 256};
+        int bnd = 0, i = 0;
+        while (bnd <= l0) { bnd += step[i < 10 ? i : 9]; ++i; }
+        if (!all_done) {
+            if (l1 < bnd) return PFMI_OK;
+            l1 = bnd;
+        }
+        q_free = R.nseg & 1;
+    } else {
+        if (!all_done && (l1 - l0 < R.minlen || q_free < 0)) return PFMI_OK;
+        if (R.policy == 2 && !all_done) {
+            // not behind a much larger launch that has just started: a small segment's fits would wait a round for CUs and its scan would
+            // block its stream for the work that arrives meanwhile
+            const int other = q_free ^ 1;
+            if (R.scan_used[other] && hipEventQuery(c->sg_scan[other]) != hipSuccess && (int64_t)K * (l1 - l0) * 2 < R.scan_ns[other]) return PFMI_OK;
+        }
+        if (q_free < 0) q_free = R.nseg & 1;
+    }
     if (l1 > l0) {
         // ---- the segment's walk and fits
         {
@@ -755,6 +779,7 @@ int32_t pfmi_stream_pump(pfmi_ctx *c, int32_t *finished) {
                                         c->logq.as<double>(), R.N, true, true));
             PF_HIP(hipEventRecord(c->sg_scan[qq], ss));
             R.scan_used[qq] = true;
+            R.scan_ns[qq] = ns;
             ++R.nseg;
         }
         R.trace.insert(R.trace.end(), {std::chrono::duration<double>(now - R.t_start).count() * 1e6, (double)l0, (double)l1, (double)ns, (double)q_free});

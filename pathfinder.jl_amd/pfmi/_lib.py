@@ -67,6 +67,9 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # the streaming pipeline uses four streams beside the context's own: give the runtime enough hardware queues that they (and torch's /
+    # RCCL's) do not share one (only effective when HIP has not been initialised yet)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if not os.environ.get("PFMI_NO_TORCH") and "torch" not in sys.modules:
         try:
             import torch  # noqa: F401

@@ -24,7 +24,7 @@ x0 = np.stack([pfmi.HostRNG(int(s)).rand(d) * 4 - 2 for s in run_seeds])
 tab = np.concatenate([rand_u64(int(s), np.arange(1, cap + 1, dtype=np.uint64), 10) for s in run_seeds])
 eng = pfmi.Engine(0)
 eng.set_target(tg)
-comm = pfmi.Comm.init_all([eng])
+comm = pfmi.Comm.init_rank(eng, 1, 0, pfmi.Comm.unique_id()) if os.environ.get("STREAM_RCCL") else pfmi.Comm.init_all([eng])    # STREAM_RCCL=1: a world of one rank THROUGH RCCL
 npts = eng.optimize_batch(x0, J, maxiters)
 seeds = np.concatenate([rand_u64(int(s), np.arange(n, dtype=np.uint64), 10) for s, n in zip(run_seeds, npts)])
 out = {}
