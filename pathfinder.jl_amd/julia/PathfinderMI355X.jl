@@ -773,6 +773,43 @@ function optimize_batch!(eng::Engine, x0::Matrix{Float64}; history_length::Int=6
                 eng.ptr, K, x0, history_length, maxiters, g_tol, npts))
     return npts
 end
+# ---- streaming pipeline (round 5): optimise + fit + ELBO scan as ONE dataflow the calling task schedules (include/pfmi.h: pfmi_stream_*).
+# What src/singlepath.jl:285-325 does per run, for K runs at once, with the fits and scans of the trace points a path has already produced
+# running while the paths are still being optimised.  Slot layout: trace point l of run k is slot k * (maxiters + 1) + l (0-based) of every
+# per-point table; `seeds` = the runs' predrawn streams, `maxiters + 1` values per run (`rand!(copy(rng_k), Vector{UInt64}(undef, maxiters + 1))`).
+#   stream_enqueue!(eng, x0; ...)  ->  stream_seeds!(eng, seeds)  ->  npts = stream_wait!(eng, K)  ->  _pool_build_best! / psis_resample ...
+# stream_wait! only schedules (it returns when the last segment is enqueued); several engines: call stream_pump! on each in turn.
+function stream_enqueue!(eng::Engine, x0::Matrix{Float64}, ndraws_elbo::Int; history_length::Int=6, maxiters::Int=1000, g_tol::Float64=1e-8,
+                         ϵ::Float64=1e-12, seeds::Union{Nothing,Vector{UInt64}}=nothing)
+    K = size(x0, 2)
+    eng.generation += 1
+    check(ccall((:pfmi_stream_enqueue, libpfmi), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Int32, Int32, Float64, Float64, Int64, Ptr{UInt64}),
+                eng.ptr, K, x0, history_length, maxiters, g_tol, ϵ, ndraws_elbo, seeds === nothing ? C_NULL : seeds))
+    return nothing
+end
+stream_seeds!(eng::Engine, seeds::Vector{UInt64}) = check(ccall((:pfmi_stream_seeds, libpfmi), Int32, (Ptr{Cvoid}, Ptr{UInt64}), eng.ptr, seeds))
+function stream_pump!(eng::Engine)
+    fin = Ref{Int32}(0)
+    check(ccall((:pfmi_stream_pump, libpfmi), Int32, (Ptr{Cvoid}, Ref{Int32}), eng.ptr, fin))
+    return fin[] != 0
+end
+function stream_wait!(eng::Engine, K::Integer)
+    npts = Vector{Int64}(undef, K)
+    check(ccall((:pfmi_stream_wait, libpfmi), Int32, (Ptr{Cvoid}, Ptr{Int64}), eng.ptr, npts))
+    return npts
+end
+"1: pfmi_get_fit_status / pfmi_elbo_batch_wait / pfmi_psis_weights only queue their downloads (delivered by the next wait); 0: normal; -1: drop"
+defer_downloads!(eng::Engine, mode::Integer) = check(ccall((:pfmi_defer_downloads, libpfmi), Int32, (Ptr{Cvoid}, Int32), eng.ptr, mode))
+function psis_resample_enqueue!(c::Comm, ndraws::Int; importance::Bool=true, replace::Bool=true, seed::UInt64)
+    check(ccall((:pfmi_comm_psis_resample_enqueue, libpfmi), Int32, (Ptr{Cvoid}, Int64, Int32, Int32, UInt64, Ptr{Float64}),
+                c.ptr, ndraws, importance, replace, seed, C_NULL))
+end
+function psis_resample_wait!(c::Comm, dim::Int, ndraws::Int)
+    idx = Vector{Int64}(undef, ndraws); X = Matrix{Float64}(undef, dim, ndraws)
+    k̂ = Ref{Float64}(NaN); M = Ref{Int64}(0)
+    check(ccall((:pfmi_comm_psis_resample_wait, libpfmi), Int32, (Ptr{Cvoid}, Ref{Float64}, Ref{Int64}, Ptr{Int64}, Ptr{Float64}), c.ptr, k̂, M, idx, X))
+    return k̂[], Int(M[]), idx, X
+end
 function get_trace(eng::Engine, k::Integer, npoints::Integer, d::Integer)   # OptimizationTrace, src/optimize.jl:94-100
     θ = Matrix{Float64}(undef, d, npoints); g = similar(θ); lp = Vector{Float64}(undef, npoints)
     check(ccall((:pfmi_get_trace, libpfmi), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), eng.ptr, k, θ, lp, g))
