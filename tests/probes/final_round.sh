@@ -8,7 +8,7 @@ bash tests/probes/profile_round.sh $TAG > $O/${TAG}_profile_round.log 2>&1
 python bench.py --npaths 8 --no-cpu-baseline --no-pmc > $O/${TAG}_c4_share_bench_line.json 2>> $O/${TAG}_bench.err
 python bench.py --npaths 8 --dim 100 --target diag --no-cpu-baseline --no-pmc > $O/${TAG}_c2_bench_line.json 2>> $O/${TAG}_bench.err
 python bench.py --npaths 8 --dim 10000 --target funnel --history 10 --ndraws-elbo 2000 --ndraws 2000 --init-scale 10 --maxiters 200 --steps 3 --warmup 1 --no-cpu-baseline --no-pmc > $O/${TAG}_c5_shape_bench_line.json 2>> $O/${TAG}_bench.err
-bash tests/probes/c5_share_profile.sh > $O/${TAG}_c5_share.log 2>&1
+TAG=$TAG bash tests/probes/c5_share_profile.sh > $O/${TAG}_c5_share.log 2>&1
 grep -n "passed\|failed" $O/${TAG}_pytest.log | tail -2; tail -2 $O/${TAG}_smoke.log
 for f in bench_line c4_share_bench_line c2_bench_line c5_shape_bench_line c5_share_bench_line; do python - <<PY
 import json
