@@ -462,6 +462,7 @@ int32_t pf_launch_elbo_draws(pfmi_ctx *c, const int32_t *d_points, const uint64_
             case 16: rc = launch_draws_k<16>(b, grid, c->stream, mem, tgt, rpad); break;
             case 20: rc = launch_draws_k<20>(b, grid, c->stream, mem, tgt, rpad); break;
             case 32: rc = launch_draws_k<32>(b, grid, c->stream, mem, tgt, rpad); break;
+            case 64: rc = launch_draws_k<64>(b, grid, c->stream, mem, tgt, rpad); break;     // history_length 17 .. 32: this kernel only
             default: pf_set_error("unsupported kpad %d", c->kpad); rc = PFMI_ERR_UNSUPPORTED;
         }
         pf_kernel_end(c, d_x ? "elbo_draws_x" : "elbo_draws");
@@ -541,6 +542,7 @@ int32_t pf_launch_logpdf(pfmi_ctx *c, int64_t point, int64_t N, const double *d_
         case 16: PF_LPDF(16); break;
         case 20: PF_LPDF(20); break;
         case 32: PF_LPDF(32); break;
+        case 64: PF_LPDF(64); break;
         default: PF_CHECK(false, PFMI_ERR_UNSUPPORTED, "unsupported kpad %d", c->kpad);
     }
 #undef PF_LPDF

@@ -17,6 +17,7 @@ struct FitArgs {
     double *vh, *tmat, *vchol, *rq, *dmat, *sqrt_alpha, *mu, *logdet;
     int32_t *status;
     int64_t P;
+    double *big;                   // KPAD = 64 only: per-workgroup scratch [P][64][64] (the Gram block; the other small matrices live in the outputs)
 };
 #ifdef __HIPCC__
 // work item idx of a fit launch -> trace point p; false: the path never reached that point (the caller marks it PFMI_FIT_ABSENT)

@@ -419,7 +419,17 @@ __global__ __launch_bounds__(FIT_THREADS) void pf_fit_kernel(FitArgs A) {
 
     __shared__ double red[(FIT_THREADS / 64) * KPAD];
     __shared__ double sP[KPAD], sW[KPAD], sHead[KPAD], sTau[KPAD];
-    __shared__ double sD[KPAD * KPAD], sR[KPAD * KPAD], sT[KPAD * KPAD], sV[KPAD * KPAD], sG[KPAD * KPAD];
+    // the five small matrices: LDS up to KPAD = 32; KPAD = 64 (history_length 17 .. 32, the slow-but-correct route): 5 x 32 KB do not fit, the
+    // kernel works directly in the fit's OUTPUT blocks (T, V, R, D of this point in global memory) and a per-workgroup scratch for G
+    constexpr bool BIG = KPAD > 32;
+    constexpr int MSZ = BIG ? 1 : KPAD * KPAD;
+    __shared__ double sD_[MSZ], sR_[MSZ], sT_[MSZ], sV_[MSZ], sG_[MSZ];
+    double *sD = sD_, *sR = sR_, *sT = sT_, *sV = sV_, *sG = sG_;
+    if constexpr (BIG) {
+        const size_t sm0 = (size_t)p * KPAD * KPAD;
+        sD = A.dmat + sm0; sR = A.rq + sm0; sT = A.tmat + sm0; sV = A.vchol + sm0;
+        sG = A.big + (size_t)blockIdx.x * KPAD * KPAD;
+    }
     __shared__ double sScal, sBeta, sLogdetV;
     __shared__ int sStatus;
 
@@ -663,9 +673,11 @@ __global__ __launch_bounds__(FIT_THREADS) void pf_fit_kernel(FitArgs A) {
     }
     __syncthreads();
     const size_t sm = (size_t)p * KPAD * KPAD;
-    for (int t = tid; t < KPAD * KPAD; t += nt) {
-        A.tmat[sm + t] = sT[t]; A.vchol[sm + t] = sV[t]; A.rq[sm + t] = sR[t]; A.dmat[sm + t] = sD[t];
-    }
+    if constexpr (!BIG) {
+        for (int t = tid; t < KPAD * KPAD; t += nt) {
+            A.tmat[sm + t] = sT[t]; A.vchol[sm + t] = sV[t]; A.rq[sm + t] = sR[t]; A.dmat[sm + t] = sD[t];
+        }
+    } else { (void)sm; __threadfence_block(); }
     if (sStatus != PFMI_FIT_OK) {
         for (int i = tid; i < d; i += nt) mu[i] = NAN;
         if (tid == 0) { A.status[p] = sStatus; A.logdet[p] = NAN; }
@@ -1230,6 +1242,7 @@ int32_t pf_launch_fit(pfmi_ctx *c, int seg_l0, int seg_len) {
     a.rq = c->rq.as<double>(); a.dmat = c->dmat.as<double>(); a.sqrt_alpha = c->sqrt_alpha.as<double>();
     a.mu = c->mu.as<double>(); a.logdet = c->logdet.as<double>(); a.status = c->status.as<int32_t>();
     a.P = seg_len > 0 ? (int64_t)c->K * seg_len : c->P;        // work items of this launch
+    a.big = nullptr;
     pf_kernel_begin(c);
     {
         const char *force = pf_debug_get("PFMI_FIT_KERNEL");        // "mem": column-by-column memory-resident kernel also for d > 1024
@@ -1248,6 +1261,11 @@ int32_t pf_launch_fit(pfmi_ctx *c, int seg_l0, int seg_len) {
         case 16: launch_fit_t<16>(c, a); break;
         case 20: launch_fit_t<20>(c, a); break;
         case 32: launch_fit_t<32>(c, a); break;
+        case 64:
+            PF_TRY(c->fit_scratch.ensure(sizeof(double) * (size_t)a.P * 64 * 64));
+            a.big = c->fit_scratch.as<double>();
+            launch_fit_t<64>(c, a);
+            break;
         default: PF_CHECK(false, PFMI_ERR_UNSUPPORTED, "unsupported kpad %d", c->kpad);
     }
     pf_kernel_end(c, "fit");

@@ -207,6 +207,7 @@ int32_t pf_launch_woodbury_prim(pfmi_ctx *c, int mode, int64_t p, int64_t N, con
         case 16: launch_wb<16>(c, mode, p, N, d_in, d_out); break;
         case 20: launch_wb<20>(c, mode, p, N, d_in, d_out); break;
         case 32: launch_wb<32>(c, mode, p, N, d_in, d_out); break;
+        case 64: launch_wb<64>(c, mode, p, N, d_in, d_out); break;
         default: PF_CHECK(false, PFMI_ERR_UNSUPPORTED, "unsupported kpad %d", c->kpad);
     }
     PF_HIP(hipGetLastError());
@@ -234,6 +235,7 @@ int32_t pf_launch_woodbury_diag(pfmi_ctx *c, int64_t p, double *d_out) {
         case 16: PF_WD(16); break;
         case 20: PF_WD(20); break;
         case 32: PF_WD(32); break;
+        case 64: PF_WD(64); break;
         default: PF_CHECK(false, PFMI_ERR_UNSUPPORTED, "unsupported kpad %d", c->kpad);
     }
 #undef PF_WD
