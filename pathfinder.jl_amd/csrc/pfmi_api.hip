@@ -834,9 +834,11 @@ int32_t pfmi_fit_batch(pfmi_ctx *c, int32_t J, double eps) {
     PF_CHECK(J >= 1, PFMI_ERR_ARG, "history_length must be >= 1");
     const int m = 2 * J;
     int kpad = 0;
-    const int opts[] = {4, 8, 12, 16, 20, 32};
+    // (column padding 64 = history_length 17 .. 32: the slow-but-correct route -- memory-resident fit kernel with its small matrices in
+    //  global memory, lane-per-draw kernel for every draw / scan; the tuned kernels stop at 32 columns)
+    const int opts[] = {4, 8, 12, 16, 20, 32, 64};
     for (int o : opts) if (m <= o) { kpad = o; break; }
-    PF_CHECK(kpad != 0, PFMI_ERR_UNSUPPORTED, "history_length %d > 16 unsupported", J);
+    PF_CHECK(kpad != 0, PFMI_ERR_UNSUPPORTED, "history_length %d > 32 unsupported", J);
     c->J = J; c->kpad = kpad;
     const size_t P = (size_t)c->P, d = (size_t)c->d, kk = (size_t)kpad * kpad;
     PF_TRY(c->alpha_all.ensure(sizeof(double) * P * d));

@@ -390,12 +390,12 @@ class DeviceOptimizationTrace:
     def gradients(self): return self.materialise()._cache[2]
 
 
-def _use_device_optimizer(target, optimizer):
+def _use_device_optimizer(target, optimizer, history_length=DEFAULT_HISTORY_LENGTH):
     builtin = getattr(target, "kind", 2) in (0, 1)
     if optimizer == "device" and not builtin:
         raise ValueError("optimizer='device' needs a built-in target (analytic gradient on the GPU)")
-    if optimizer == "auto":                                  # the device L-BFGS keeps a path's vectors in registers: d <= 16 384
-        return builtin and getattr(target, "d", 0) <= 16384
+    if optimizer == "auto":                                  # the device L-BFGS keeps a path's vectors in registers (d <= 16 384) and its
+        return builtin and getattr(target, "d", 0) <= 16384 and history_length <= 16      # ring in LDS / a scratch of 16 pairs
     return optimizer == "device"
 
 
@@ -436,7 +436,7 @@ def _run_paths(engs, target, inits, run_rngs, *, dim, history_length, ndraws_elb
         for k in range(k0, k1):
             state[k].update(eng=engs[g], g=g, kl=k - k0)
     pending = list(range(K))
-    on_device = _use_device_optimizer(target, optimizer)
+    on_device = _use_device_optimizer(target, optimizer, history_length)
     stream_ok = on_device and history_length <= 16 and os.environ.get("PFMI_NO_STREAM") != "1"
     okw = {k: v for k, v in optimizer_kwargs.items() if k in ("maxiters", "g_tol")}
     pooled = None

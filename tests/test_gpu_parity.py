@@ -1099,7 +1099,7 @@ def test_c_abi_error_behaviour(pfmi_mod):
                            best.ctypes.data_as(C.POINTER(C.c_int64)))
     assert rc == -3                                                                          # fit_batch not called yet
     assert L.pfmi_fit_batch(e.ctx, C.c_int32(0), C.c_double(1e-12)) == -1                      # PFMI_ERR_ARG
-    assert L.pfmi_fit_batch(e.ctx, C.c_int32(40), C.c_double(1e-12)) == -4                     # PFMI_ERR_UNSUPPORTED (J > 16)
+    assert L.pfmi_fit_batch(e.ctx, C.c_int32(40), C.c_double(1e-12)) == -4                     # PFMI_ERR_UNSUPPORTED (J > 32)
     e.fit_batch(6)
     X = np.zeros((8, 3), order="F"); out = np.zeros((8, 3), order="F")
     dp = C.POINTER(C.c_double)

@@ -135,3 +135,90 @@ def test_all_runs_failing_their_first_try_are_retried_before_the_pooled_stage_co
         warnings.simplefilter("ignore")
         with pytest.raises(Exception):
             pfmi_mod.multipathfinder(tgt, 60, init=inits, ndraws_elbo=40, ntries=1, rng=pfmi_mod.HostRNG(2))
+
+
+# ---- history_length 17 .. 32 (VERDICT r4 missing #5 / next #8): the reference's keyword is unbounded (src/inverse_hessian.jl:25) -------------
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("d,J,K,maxit,N", [(50, 20, 3, 60, 256), (50, 32, 3, 80, 256), (3000, 20, 2, 45, 200), (3000, 32, 2, 50, 200)])
+def test_history_length_17_to_32_against_the_oracle(pfmi_mod, d, J, K, maxit, N):
+    """Column padding 64 (2 J <= 64): the memory-resident fit kernel with its small matrices in global memory and the lane-per-draw
+    kernel -- slow but correct.  Walk (status, j_eff, rejections), factor (dense W, logdet, mu), ELBO / SE, per-draw logq / logp / x on the
+    GPU's own factor, pool + PSIS + indices: all against the oracle within SURVEY 8(d)."""
+    import margins as mg
+    from helpers import fit_seeds, oracle_factor_from_gpu, oracle_target
+    from oracle import pf_oracle as po
+    from test_gpu_parity_r2 import _factor, _wc
+    tg = pfmi_mod.t_diag(d, seed=1)
+    otg = oracle_target(tg)
+    rng = pfmi_mod.HostRNG(17)
+    traces = [pfmi_mod.optimize_with_trace(tg, rng.rand(d) * 4 - 2, history_length=J, maxiters=maxit) for _ in range(K)]
+    eng = pfmi_mod.Engine(0)
+    eng.set_target(tg)
+    eng.set_traces([t.points for t in traces], [t.gradients for t in traces])
+    eng.fit_batch(J)
+    status, jeff, logdet, nrej = eng.fit_status()
+    seeds = fit_seeds(eng.P, 4)
+    elbo, se, best = eng.elbo_batch(N, seeds)
+    th = np.concatenate([t.points for t in traces]); gr = np.concatenate([t.gradients for t in traces])
+    ref = po.multipath_fit_elbo(eng.offsets, th, gr, J, otg, N, seeds, nthreads=K)
+    np.testing.assert_array_equal(status, ref["status"])
+    np.testing.assert_array_equal(jeff, ref["j_eff"])
+    np.testing.assert_array_equal(nrej, ref["n_rejected"])
+    assert int(jeff.max()) > 16, "the traces must fill more than 16 history pairs"
+    cfg = f"J{J}:diag{d}"
+    n_strict = 0
+    for k in range(K):
+        p0, p1 = int(eng.offsets[k]), int(eng.offsets[k + 1])
+        alpha_all, hl, hs, _ = po.lbfgs_history(th[p0:p1], gr[p0:p1], J)
+        for l in sorted({1, min(18, p1 - p0 - 1), (p1 - p0) // 2, p1 - p0 - 1}):
+            if ref["status"][p0 + l] != 0:
+                assert np.isnan(elbo[p0 + l])
+                continue
+            F = _factor(th[p0:p1], gr[p0:p1], alpha_all, hl, hs, l, d)
+            f = eng.get_fit(p0 + l, int(jeff[p0 + l]))
+            mg.check(cfg, "logdet", mg.rel(logdet[p0 + l], ref["logdet"][p0 + l]))
+            mg.check(cfg, "mu", np.max(np.abs(f["mu"] - F.fit_mean(th[p0 + l], gr[p0 + l]))) / (1 + np.abs(f["mu"]).max()))
+            if d <= 200:
+                Wg = np.diag(f["alpha"]) + f["B"] @ f["D"] @ f["B"].T
+                Wo = np.diag(F.alpha) + F.B @ F.D @ F.B.T
+                mg.check(cfg, "W", np.max(np.abs(Wg - Wo)) / np.max(np.abs(Wo)))
+            if _wc(F):
+                n_strict += 1
+                mg.check(cfg, "elbo", mg.rel(elbo[p0 + l], ref["elbo"][p0 + l]))
+                mg.check(cfg, "se", mg.rel(se[p0 + l], ref["se"][p0 + l]))
+            # per-draw quantities through the oracle's reflector-by-reflector apply on the GPU's OWN factor
+            Fg = oracle_factor_from_gpu(f)
+            Xg, lqg = Fg.rand_and_logpdf(f["mu"], po.randn_fill(int(seeds[p0 + l]), d, N))
+            lp, lq = eng.elbo_logs(p0 + l, N)
+            mg.check(cfg, "logq@scan_vs_oracle_on_gpu_factor", mg.rel(lq, lqg))
+            mg.check(cfg, "logp@scan_vs_oracle_on_gpu_factor", mg.rel(lp, otg.logp(Xg)))
+            Xd, lpd, lqd = eng.draws(p0 + l, int(seeds[p0 + l]), 24, n0=3)
+            mg.check(cfg, "draws@writer_vs_oracle_on_gpu_factor", np.abs(Xd - Xg[:, 3:27]) / (1 + np.abs(Xg[:, 3:27]).max(axis=0)))
+            np.testing.assert_array_equal(lqd, lq[3:27])
+            # logpdf of arbitrary points through the factor (src/resample.jl:85-89)
+            mg.check(cfg, "logq@logpdf", mg.rel(eng.logpdf(p0 + l, Xd), lqg[3:27]))
+    assert n_strict >= K, n_strict
+    np.testing.assert_array_equal(best, ref["best_iter"])
+    # pooled stage on the winners
+    pts = [int(eng.offsets[k]) + int(best[k]) for k in range(K)]
+    eng.pool_build(N, pts, seeds[pts])
+    _, lr = eng.pool_get(draws=False)
+    res = eng.psis(lr)
+    lw, w, kk, M = po.psis(lr)
+    mg.check(cfg, "psis_logw", np.abs(res["log_weights"] - lw) / (1 + np.abs(lw)))
+    idx = eng.resample_indices(len(lr), 50, seed=3)
+    np.testing.assert_array_equal(idx, po.sample_weighted(res["weights"], 50, seed=3))
+    # the operator surface of a fitted covariance
+    p = pts[0]
+    f = eng.get_fit(p, int(jeff[p]))
+    W = np.diag(f["alpha"]) + f["B"] @ f["D"] @ f["B"].T if d <= 200 else None
+    x = pfmi_mod.HostRNG(2).randn(d)
+    if W is not None:
+        np.testing.assert_allclose(eng.woodbury_apply(p, "mul", x), W @ x, rtol=1e-9, atol=1e-9 * np.abs(W @ x).max())
+        np.testing.assert_allclose(eng.woodbury_apply(p, "solve", W @ x), x, rtol=1e-7, atol=1e-8 * np.abs(x).max())
+        np.testing.assert_allclose(eng.woodbury_diag(p), np.diag(W), rtol=1e-9)
+    assert np.isclose(eng.woodbury_apply(p, "quad", x), x @ eng.woodbury_apply(p, "mul", x), rtol=1e-9)
+    # and the public call takes the host optimiser + this route on its own
+    r = pfmi_mod.multipathfinder(tg, 40, nruns=2, ndraws_elbo=64, history_length=J, rng=pfmi_mod.HostRNG(3), engine=eng, maxiters=maxit)
+    assert r.draws.shape == (d, 40) and np.all(np.isfinite(r.draws))
+    eng.close()
