@@ -174,3 +174,33 @@ def test_seeds_handed_over_later_and_deferred_downloads_equal_the_plain_calls(pf
     for x, y in zip(junk, before):
         np.testing.assert_array_equal(x, y)
     comm.close(); e.close()
+
+
+def test_results_do_not_depend_on_where_the_segments_are_cut(pfmi_mod):
+    """PFMI_STREAM_POLICY / _PUB / _MINLEN move the segment boundaries and the publication rate; the results are the same bits."""
+    L = pfmi_mod.lib()
+    tg = pfmi_mod.t_lowrank(300, r=8, seed=2)
+    K, J, maxiters, N = 5, 6, 150, 512
+    cap = maxiters + 1
+    x0 = pfmi_mod.HostRNG(8).rand(K * 300).reshape(K, 300) * 4 - 2
+    sd = pfmi_mod.hostrng.rand_u64(79, np.arange(K * cap, dtype=np.uint64), 9)
+    ref = _streamed(pfmi_mod, tg, x0, J, maxiters, N, sd, N, 200)[0]
+    hooks = [(b"PFMI_STREAM_POLICY", b"0"), (b"PFMI_STREAM_POLICY", b"1"), (b"PFMI_STREAM_POLICY", b"2"), (b"PFMI_STREAM_PUB", b"4"),
+             (b"PFMI_STREAM_PUB", b"32"), (b"PFMI_STREAM_MINLEN", b"64")]
+    for key, val in hooks:
+        assert L.pfmi_debug_set(key, val) == 0
+        try:
+            got = _streamed(pfmi_mod, tg, x0, J, maxiters, N, sd, N, 200)[0]
+        finally:
+            assert L.pfmi_debug_set(key, None) == 0
+        _compare_streamed(ref, got, K, cap)
+
+
+def _compare_streamed(a, s, K, cap):
+    for name in ("npts", "nrej", "best", "status", "jeff", "idx", "draws"):
+        np.testing.assert_array_equal(a[name], s[name], err_msg=name)
+    for k in range(K):
+        n = int(a["npts"][k])
+        for name in ("logdet", "elbo", "se"):
+            np.testing.assert_array_equal(a[name][k * cap:k * cap + n], s[name][k * cap:k * cap + n], err_msg=f"{name} path {k}")
+    np.testing.assert_equal(a["res"]["pareto_shape"], s["res"]["pareto_shape"])
