@@ -129,7 +129,8 @@ struct pfmi_ctx {
         uint64_t *d_lseeds = nullptr; int32_t *d_list = nullptr;
         bool scan_used[2] = {false, false};
         int64_t scan_ns[2] = {0, 0};          // fits of the launch in flight on each scan stream
-        int policy = 0;
+        int policy = 0, fit_eager = 1;
+        int l_fit = 0;                        // positions whose walk + fits have been launched (>= l_next: the fits run ahead of the scans)
         bool have_seeds = false;              // the runs' seed streams have arrived (pfmi_stream_enqueue or, later, pfmi_stream_seeds)
         std::vector<uint64_t> seeds_pt;       // host copy of the per-point seeds (the scan's work lists are cut from it)
         std::chrono::steady_clock::time_point t_progress, t_start;
