@@ -334,6 +334,8 @@ int32_t pfmi_defer_downloads(pfmi_ctx *ctx, int32_t mode);
  * rand!(rng, UInt64[nruns]) src/multipath.jl:162; seeds = rand!(rng, UInt64[L]) src/elbo.jl:2): out[i] = low 64 bits of
  * Philox4x32-10(counter (t0 + i, stream), key seed).  Host code only (a Julia host uses its own rng instead). */
 int32_t pfmi_host_rand_u64(uint64_t seed, uint64_t t0, int64_t n, uint32_t stream, uint64_t *out);
+/* m generators in one call: out[j * n + i] = value i of generator (seeds[j], first counter t0[j]) */
+int32_t pfmi_host_rand_u64_multi(int32_t m, const uint64_t *seeds, const uint64_t *t0, int64_t n, uint32_t stream, uint64_t *out);
 
 /* ---- device utilities for hosts that keep buffers on the GPU (bench, multi-GPU) ---------------- */
 int32_t pfmi_malloc_dev(pfmi_ctx *ctx, int64_t bytes, void **dev_ptr);

@@ -1496,6 +1496,12 @@ int32_t pfmi_host_rand_u64(uint64_t seed, uint64_t t0, int64_t n, uint32_t strea
     }
     return PFMI_OK;
 }
+// the same for m generators in one call (out is [m][n] row-major): a host that seeds every run of a batch pays one call, not m
+int32_t pfmi_host_rand_u64_multi(int32_t m, const uint64_t *seeds, const uint64_t *t0, int64_t n, uint32_t stream, uint64_t *out) {
+    PF_CHECK(m >= 0 && n >= 0 && (m == 0 || (seeds && t0)) && (out != nullptr || (int64_t)m * n == 0), PFMI_ERR_ARG, "host_rand_u64_multi: bad arguments");
+    for (int32_t j = 0; j < m; ++j) PF_TRY(pfmi_host_rand_u64(seeds[j], t0[j], n, stream, out + (size_t)j * (size_t)n));
+    return PFMI_OK;
+}
 
 // ---- device utilities ----------------------------------------------------------------------------------
 int32_t pfmi_malloc_dev(pfmi_ctx *c, int64_t bytes, void **dev_ptr) {

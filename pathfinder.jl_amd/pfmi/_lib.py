@@ -41,7 +41,7 @@ SYMBOLS = [
     "pfmi_pool_log_ratios_dev", "pfmi_psis_dev", "pfmi_psis", "pfmi_resample_indices", "pfmi_resample_indices_direct", "pfmi_pool_gather",
     "pfmi_pool_gather_dev", "pfmi_malloc_dev", "pfmi_free_dev", "pfmi_memcpy_h2d", "pfmi_memcpy_d2h",
     "pfmi_comm_unique_id", "pfmi_comm_init_all", "pfmi_comm_init_rank", "pfmi_comm_destroy", "pfmi_comm_info",
-    "pfmi_comm_pool_psis", "pfmi_comm_resample", "pfmi_host_rand_u64",
+    "pfmi_comm_pool_psis", "pfmi_comm_resample", "pfmi_host_rand_u64", "pfmi_host_rand_u64_multi",
     "pfmi_optimize_batch_enqueue", "pfmi_optimize_batch_wait", "pfmi_elbo_batch_enqueue", "pfmi_elbo_batch_wait",
     "pfmi_callback_stats_dev", "pfmi_pool_build_best", "pfmi_pool_winners", "pfmi_psis_weights", "pfmi_comm_psis_resample", "pfmi_debug_set",
     "pfmi_host_alloc", "pfmi_host_free", "pfmi_comm_psis_resample_enqueue", "pfmi_comm_psis_resample_wait", "pfmi_defer_downloads",

@@ -56,6 +56,21 @@ def rand_u64_multi(rngs, counts):
     if tot == 0:
         return [np.zeros(0, dtype=np.uint64) for _ in counts]
     f = _native()
+    if f is not None and len(counts) > 1 and min(counts) == max(counts):
+        # every generator the same number of values (the runs' starting points, their seed streams): ONE native call
+        import ctypes as C
+        from . import _lib
+        n, m = counts[0], len(counts)
+        sd = np.array([r.seed for r in rngs], dtype=np.uint64)
+        t0 = np.array([r.counter for r in rngs], dtype=np.uint64)
+        out = np.empty((m, n), dtype=np.uint64)
+        u64p = C.POINTER(C.c_uint64)
+        rc = _lib.lib().pfmi_host_rand_u64_multi(C.c_int32(m), sd.ctypes.data_as(u64p), t0.ctypes.data_as(u64p), C.c_int64(n),
+                                                 C.c_uint32(HostRNG.STREAM), out.ctypes.data_as(u64p))
+        if rc == 0:
+            for r in rngs:
+                r.counter += n
+            return list(out)
     if f is not None:
         import ctypes as C
         res = []

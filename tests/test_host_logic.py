@@ -148,3 +148,19 @@ def test_uniform_sampler_and_argument_errors_like_reference_testsets():
         pfmi.pathfinder(pfmi.CallbackTarget(0, lambda x: 0.0))
     with pytest.raises(ValueError):                              # multipathfinder(l, 10; nruns = 0)
         pfmi.multipathfinder(pfmi.t_iso(5), 10, nruns=0)
+
+
+def test_rand_u64_multi_one_native_call_equals_the_per_generator_calls():
+    import numpy as np
+    import pfmi
+    from pfmi.hostrng import HostRNG, rand_u64_multi
+    a = [HostRNG(s) for s in (11, 12, 13, 14)]
+    b = [HostRNG(s) for s in (11, 12, 13, 14)]
+    for r in a + b:
+        r.counter = 9
+    x = rand_u64_multi(a, [33] * 4)                      # equal counts: pfmi_host_rand_u64_multi
+    y = [r.rand_u64(33) for r in b]
+    assert all(np.array_equal(p, q) for p, q in zip(x, y)) and [r.counter for r in a] == [42] * 4
+    x = rand_u64_multi(a, [3, 0, 5, 1])                  # ragged: one call per generator
+    y = [r.rand_u64(n) for r, n in zip(b, [3, 0, 5, 1])]
+    assert all(np.array_equal(p, q) for p, q in zip(x, y))
