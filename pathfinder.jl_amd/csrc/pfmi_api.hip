@@ -247,10 +247,19 @@ int32_t pfmi_create(int32_t device, pfmi_ctx **out) {
     return PFMI_OK;
 }
 
+// a streaming call that was never waited for (pfmi_stream_wait): let what is in flight on the side streams finish -- the optimiser still writes the
+// staging trace -- and forget the call.  Called by whatever is about to reuse or free that memory.
+static void stream_abandon(pfmi_ctx *c) {
+    for (hipStream_t s : {c->s_opt, c->s_fit, c->s_scan1}) if (s) (void)hipStreamSynchronize(s);
+    c->sr.active = false;
+    c->stream_pending = false;
+}
+
 int32_t pfmi_destroy(pfmi_ctx *c) {
     if (!c) return PFMI_OK;
     pf_comm_ctx_dying(c);                   // communicators that borrow this context close themselves first (any finaliser order is safe)
     (void)hipSetDevice(c->device);
+    stream_abandon(c);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->theta, &c->grad, &c->d_off, &c->d_path_of, &c->target.mean, &c->target.a, &c->target.wd,
                       &c->target.g, &c->target.wd16, &c->alpha_all, &c->hist_len, &c->hist_src, &c->hist_acc, &c->n_rej, &c->vh, &c->tmat, &c->vchol,
@@ -376,6 +385,7 @@ int32_t pfmi_set_target(pfmi_ctx *c, const pfmi_target *t) {
 int32_t pfmi_set_traces(pfmi_ctx *c, int32_t K, const int64_t *npoints, int32_t d, const double *theta,
                         const double *grad) {
     PF_CTX(c);
+    if (c->sr.active) stream_abandon(c);
     PF_CHECK(K > 0 && d > 0 && npoints && theta && grad, PFMI_ERR_ARG, "set_traces: bad arguments");
     c->off.assign((size_t)K + 1, 0);
     for (int k = 0; k < K; ++k) {
@@ -404,6 +414,7 @@ int32_t pfmi_set_traces(pfmi_ctx *c, int32_t K, const int64_t *npoints, int32_t 
 // ---- device trajectory generation ------------------------------------------------------------------------
 int32_t pfmi_optimize_batch_enqueue(pfmi_ctx *c, int32_t K, const double *x0, int32_t J, int32_t maxiters, double g_tol) {
     PF_CTX(c);
+    if (c->sr.active) stream_abandon(c);
     const TargetDev &T = c->target;
     PF_CHECK(T.kind == PFMI_TARGET_GAUSS || T.kind == PFMI_TARGET_FUNNEL, PFMI_ERR_UNSUPPORTED,
              "optimize_batch: needs a built-in target (optimise callback targets on the host, then pfmi_set_traces)");

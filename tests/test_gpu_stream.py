@@ -204,3 +204,32 @@ def _compare_streamed(a, s, K, cap):
         for name in ("logdet", "elbo", "se"):
             np.testing.assert_array_equal(a[name][k * cap:k * cap + n], s[name][k * cap:k * cap + n], err_msg=f"{name} path {k}")
     np.testing.assert_equal(a["res"]["pareto_shape"], s["res"]["pareto_shape"])
+
+
+def test_an_abandoned_streaming_call_is_drained_before_its_memory_is_reused(pfmi_mod):
+    """pfmi_stream_enqueue without its pfmi_stream_wait, then the packed route / pfmi_destroy on the same context: what is in flight finishes
+    first (the optimiser still writes the staging trace), nothing is corrupted, nothing hangs."""
+    tg = pfmi_mod.t_lowrank(500, r=8, seed=2)
+    K, J, maxiters, N = 6, 6, 200, 256
+    x0 = pfmi_mod.HostRNG(12).rand(K * 500).reshape(K, 500) * 4 - 2
+    sd = pfmi_mod.hostrng.rand_u64(80, np.arange(K * (maxiters + 1), dtype=np.uint64), 9)
+
+    def packed(e):
+        npts = e.optimize_batch(x0, J, maxiters)
+        e.fit_batch(J)
+        seeds = pfmi_mod.hostrng.rand_u64(81, np.arange(e.P, dtype=np.uint64), 9)
+        return npts, e.elbo_batch(N, seeds)
+
+    e0 = pfmi_mod.Engine(0)
+    e0.set_target(tg)
+    ref = packed(e0)
+    e0.close()
+    e = pfmi_mod.Engine(0)
+    e.set_target(tg)
+    e.stream_enqueue(x0, N, sd, J, maxiters)                # ... and never waited for
+    got = packed(e)
+    np.testing.assert_array_equal(got[0], ref[0])
+    for a, b in zip(got[1], ref[1]):
+        np.testing.assert_array_equal(a, b)
+    e.stream_enqueue(x0, N, None, J, maxiters)              # (not even its seeds have arrived)
+    e.close()                                               # pfmi_destroy with the optimiser in flight
