@@ -56,7 +56,9 @@ for _ in range(10):
     runs.append((tot, order, agg))
 runs.sort(key=lambda r: r[0])
 tot, order, agg = runs[len(runs) // 2]
-print(f"K={K}: wall {tot * 1e3:.3f} ms (median of 10)")
+res = pfmi.multipathfinder(tg, 1000, rng=pfmi.HostRNG(20260928), **kw)
+nfit = sum(len(r.optim_trace) - 1 for r in res.pathfinder_results)
+print(f"K={K}: wall {tot * 1e3:.3f} ms (median of 10); this call's instance: {nfit} fits, longest path {max(len(r.optim_trace) for r in res.pathfinder_results)} points")
 for name in order:
     st, du, n = agg[name]
     print(f"  {st * 1e3:8.3f} ms  {name:24s} {du * 1e3:8.3f} ms  x{n}")

@@ -95,6 +95,7 @@ CASES = [
     ("lr1000", lambda m: m.t_lowrank(1000, r=8, seed=2), 8, 6, 1000, 1000, 2.0),
     ("funnel50_j10", lambda m: m.t_funnel(50), 5, 10, 300, 200, 10.0),
     ("iso10_short", lambda m: m.t_iso(10), 3, 6, 20, 64, 2.0),
+    ("funnel3000_j10", lambda m: m.t_funnel(3000), 4, 10, 80, 256, 10.0),         # d > 1024: panel fit, streamed factor blocks (KC = 20)
     ("diag16_many", lambda m: m.t_diag(16, seed=1), 300, 6, 40, 64, 2.0),      # more paths than CUs: nothing on the device waits for anything
 ]
 
