@@ -703,8 +703,14 @@ int32_t pfmi_stream_seeds(pfmi_ctx *c, const uint64_t *seeds) {
 
 // One scheduling pass: launches the next segment when its inputs are complete (and a scan stream is free), finishes the call when the last
 // one is out.  *finished = 1: everything is enqueued (pfmi_stream_wait then returns at once).  Never blocks.
+static int32_t stream_pump_pass(pfmi_ctx *c, int32_t *finished);
 int32_t pfmi_stream_pump(pfmi_ctx *c, int32_t *finished) {
     PF_CTX(c);
+    const int32_t rc = stream_pump_pass(c, finished);
+    if (rc != PFMI_OK && c->sr.active) stream_abandon(c);          // a failed pass ends the call: what is in flight is drained, the context is usable again
+    return rc;
+}
+static int32_t stream_pump_pass(pfmi_ctx *c, int32_t *finished) {
     pfmi_ctx::StreamRun &R = c->sr;
     if (finished) *finished = R.active ? 0 : 1;
     if (!R.active) return PFMI_OK;

@@ -234,3 +234,35 @@ def test_an_abandoned_streaming_call_is_drained_before_its_memory_is_reused(pfmi
         np.testing.assert_array_equal(a, b)
     e.stream_enqueue(x0, N, None, J, maxiters)              # (not even its seeds have arrived)
     e.close()                                               # pfmi_destroy with the optimiser in flight
+
+
+def test_the_packed_entry_points_work_on_the_streaming_layout(pfmi_mod):
+    """After a streamed call the context holds the fixed-stride layout; pfmi_fit_batch / pfmi_elbo_batch (a refit, a rescan with other draws)
+    take slots there: the same numbers as the streamed call produced, absent slots left alone."""
+    tg = pfmi_mod.t_lowrank(200, r=8, seed=2)
+    K, J, maxiters, N = 4, 6, 90, 256
+    cap = maxiters + 1
+    x0 = pfmi_mod.HostRNG(15).rand(K * 200).reshape(K, 200) * 4 - 2
+    tab = pfmi_mod.hostrng.rand_u64(83, np.arange(K * cap, dtype=np.uint64), 9)
+    e = pfmi_mod.Engine(0)
+    e.set_target(tg)
+    e.stream_enqueue(x0, N, tab, J, maxiters)
+    npts = e.stream_wait()
+    st0 = e.fit_status()
+    el0 = e.elbo_batch_wait()
+    slot_seeds = np.zeros(K * cap, dtype=np.uint64)
+    for k in range(K):
+        slot_seeds[k * cap + 1:(k + 1) * cap] = tab[k * cap:(k + 1) * cap - 1]
+    e.fit_batch(J)
+    st1 = e.fit_status()
+    el1 = e.elbo_batch(N, slot_seeds)
+    for k in range(K):
+        sl = slice(k * cap, k * cap + int(npts[k]))
+        for a, b in zip(st0[:3], st1[:3]):
+            np.testing.assert_array_equal(a[sl], b[sl])
+        np.testing.assert_array_equal(el0[0][sl], el1[0][sl]); np.testing.assert_array_equal(el0[1][sl], el1[1][sl])
+        assert np.all(st1[0][k * cap + int(npts[k]):(k + 1) * cap] == 4)
+    np.testing.assert_array_equal(st0[3], st1[3]); np.testing.assert_array_equal(el0[2], el1[2])
+    X, lp, lq = e.draws(int(el1[2][0]), int(slot_seeds[int(el1[2][0])]), 16)          # slot of run 0's winner (offset 0)
+    assert np.all(np.isfinite(X)) and np.all(np.isfinite(lq))
+    e.close()
