@@ -747,9 +747,9 @@ static int32_t stream_pump_pass(pfmi_ctx *c, int32_t *finished) {
     }
     if (R.policy == 1) {
         // fixed boundaries (geometric): a segment goes out as soon as its positions are complete, whatever the scan streams are doing
-        static const int step[] = {16, 16, 32, 32, 32, 64, 64, 128, 128, 256};
+        static const int step[] = {1, 1, 2, 2, 2, 4, 4, 8, 8, 16};               // in publication steps: 16, 32, 64, 96, 128, 192, 256, 384, ... at 16 points
         int bnd = 0, i = 0;
-        while (bnd <= l0) { bnd += step[i < 10 ? i : 9]; ++i; }
+        while (bnd <= l0) { bnd += R.pub * step[i < 10 ? i : 9]; ++i; }
         if (!all_done) {
             if (l1 < bnd) return PFMI_OK;
             l1 = bnd;
