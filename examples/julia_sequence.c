@@ -392,6 +392,69 @@ int main(int argc, char **argv) {
         REQUIRE(memcmp(wg, w1, sizeof(w1)) == 0, "PSIS weights depend on the sharding");
         CHECK(pfmi_comm_destroy(cm));
 
+        /* ---- round 5: the streaming pipeline (PathfinderMI355X.jl: stream_enqueue!, stream_seeds!, stream_pump!, stream_wait!,
+         *      psis_resample_enqueue!, defer_downloads!, psis_resample_wait!) -- the optimisations, the fits and the scans as ONE dataflow per
+         *      engine, the calling thread scheduling all of them; fixed-stride slots; ONE wait for every result.  Same bits as above. */
+        {
+            const int64_t cap = MAXIT + 1;
+            for (int g = 0; g < G; ++g)                      /* the optimisers start at once; the seed streams are drawn while they run */
+                CHECK(pfmi_stream_enqueue(eg[g], Kl, x0 + (size_t)g * Kl * D, 6, MAXIT, 1e-8, 1e-12, N_ELBO, NULL));
+            uint64_t *tab = calloc((size_t)K3 * cap, sizeof(uint64_t));
+            memcpy(r3, run3, sizeof(r3));
+            for (int k = 0; k < K3; ++k)                     /* rand!(copy(rng_k), UInt64[maxiters + 1]): value l - 1 seeds fit l, value L a failed run */
+                for (int64_t i = 0; i < cap; ++i) tab[k * cap + i] = splitmix(&r3[k]);
+            for (int g = 0; g < G; ++g) CHECK(pfmi_stream_seeds(eg[g], tab + (size_t)g * Kl * cap));
+            int left = G, done5[K3];
+            memset(done5, 0, sizeof(done5));
+            while (left > 0)                                 /* one scheduling pass per engine in turn, never blocking */
+                for (int g = 0; g < G; ++g) {
+                    if (done5[g]) continue;
+                    int32_t fin = 0;
+                    CHECK(pfmi_stream_pump(eg[g], &fin));
+                    if (fin) { done5[g] = 1; --left; }
+                }
+            int64_t np5[K3];
+            for (int g = 0; g < G; ++g) CHECK(pfmi_stream_wait(eg[g], np5 + g * Kl));
+            for (int k = 0; k < K3; ++k) REQUIRE(np5[k] == np1[k], "streamed trace length of run %d", k);
+            for (int g = 0; g < G; ++g) CHECK(pfmi_pool_build_best(eg[g], N_R, NULL));      /* failed runs: value L of their stream, looked up on the device */
+            pfmi_comm *cm5 = NULL;
+            CHECK(pfmi_comm_init_all(G, eg, &cm5));
+            CHECK(pfmi_comm_psis_resample_enqueue(cm5, NDRAWS, 1, 1, rs3, NULL));
+            double *el5[K3], *se5[K3];
+            int32_t *st5[K3];
+            int64_t b5[K3];
+            for (int g = 0; g < G; ++g) {                    /* queued behind the pooled stage, delivered by its ONE wait */
+                const int64_t Pg = Kl * cap;
+                el5[g] = malloc(sizeof(double) * Pg); se5[g] = malloc(sizeof(double) * Pg); st5[g] = malloc(sizeof(int32_t) * Pg);
+                CHECK(pfmi_defer_downloads(eg[g], 1));
+                CHECK(pfmi_get_fit_status(eg[g], st5[g], NULL, NULL, NULL));
+                CHECK(pfmi_elbo_batch_wait(eg[g], el5[g], se5[g], b5 + g * Kl));
+                CHECK(pfmi_defer_downloads(eg[g], 0));
+            }
+            double k5 = NAN;
+            int64_t M5 = 0, idx5[NDRAWS];
+            static double dr5[D * NDRAWS];
+            CHECK(pfmi_comm_psis_resample_wait(cm5, &k5, &M5, idx5, dr5));
+            REQUIRE(k5 == k1 && M5 == M1, "streamed pooled PSIS: k %.17g vs %.17g", k5, k1);
+            REQUIRE(memcmp(idx5, idx1, sizeof(idx1)) == 0 && memcmp(dr5, dr1, sizeof(dr1)) == 0, "streamed resampled draws (G = %d)", G);
+            for (int k = 0; k < K3; ++k) {
+                const int g = k / Kl, j = k % Kl;
+                REQUIRE(b5[k] == best1[k], "streamed winner of run %d", k);
+                for (int64_t l = 0; l < cap; ++l) {
+                    const int64_t slot = (int64_t)j * cap + l;
+                    if (l < np1[k]) {
+                        REQUIRE(st5[g][slot] == PFMI_FIT_OK, "status of run %d point %lld", k, (long long)l);
+                        if (l >= 1) REQUIRE(memcmp(&el5[g][slot], &el1[off1[k] + l], sizeof(double)) == 0 &&
+                                            memcmp(&se5[g][slot], &se1[off1[k] + l], sizeof(double)) == 0, "streamed ELBO of run %d fit %lld", k, (long long)l);
+                    } else REQUIRE(st5[g][slot] == PFMI_FIT_ABSENT && isnan(el5[g][slot]), "slot %lld of run %d is not marked absent", (long long)l, k);
+                }
+            }
+            for (int g = 0; g < G; ++g) { free(el5[g]); free(se5[g]); free(st5[g]); }
+            CHECK(pfmi_comm_destroy(cm5));
+            free(tab);
+            printf("round-5 streaming sequence ok: G=%d engines\n", G);
+        }
+
         /* ---- DeviceClosureTarget (kind 3): the closure is a kernel launcher from a user library; same draws, logp evaluated in HBM */
         const char *demo = getenv("PFMI_DEMO_LIB");
         if (demo && demo[0]) {

@@ -564,6 +564,7 @@ def test_julia_call_sequence_in_c(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert r.stdout.strip().splitlines()[-1].startswith("OK julia_sequence") and "device closure ok" in r.stdout
+    assert "round-5 streaming sequence ok: G=1 engines" in r.stdout
     # round 3: multipathfinder(engines::Vector{Engine}, ...) -- the same program with the runs sharded over G engines (all on GPU 0,
     # the in-process RCCL stand-in of tests/rccl_standin) must reproduce the single-engine result bit for bit
     for G in (2, 4):
@@ -571,6 +572,7 @@ def test_julia_call_sequence_in_c(tmp_path):
         r = subprocess.run([exe, str(G)], capture_output=True, text=True, timeout=300, env=envg)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
         assert f"round-3 sequence ok: G={G} engines, rccl_version=99999" in r.stdout
+        assert f"round-5 streaming sequence ok: G={G} engines" in r.stdout
 
 
 # ---- bench.py contract on the GPU box ---------------------------------------------------------------------------
