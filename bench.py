@@ -418,6 +418,12 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
+    # Like timeit: no cyclic garbage collection inside the timed loops.  A full collection of this process (~50 ms: every ~120 steps at 8 paths)
+    # stops the host, and in the streamed call the host is the scheduler of the pipeline: one such step took 46.5 ms instead of 3.9
+    # (profiles/r05_experiments.md section 5).  Nothing here creates reference cycles; memory is reclaimed by reference counting as before.
+    import gc
+    gc.collect()
+    gc.disable()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -518,10 +524,15 @@ def main():
                     step(streamed=True)
                 barrier()
                 t0 = time.perf_counter()
+                per_step = []
                 for _ in range(args.steps):
+                    t1 = time.perf_counter()
                     step(streamed=True)
+                    per_step.append((time.perf_counter() - t1) * 1e3)
                 barrier()
                 wall_e2e = (time.perf_counter() - t0) / args.steps * 1e3
+                if os.environ.get("BENCH_STEP_TIMES"):
+                    print("streamed steps (ms):", " ".join(f"{t:.2f}" for t in per_step), file=sys.stderr)
                 streamed_equal = bool(state["pareto_k"] == ref_fp[0] and np.array_equal(state["idx"], ref_fp[1]) and np.array_equal(state["best"], ref_fp[3])
                                       and (ref_fp[2] is None or np.array_equal(state["draws"], ref_fp[2])))
                 stream_note = "pfmi_stream_enqueue / pfmi_stream_wait"

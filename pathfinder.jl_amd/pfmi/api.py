@@ -13,6 +13,7 @@ src/multipath.jl:190-193), then ONE fit_batch / elbo_batch / pool_build covers e
 (The north-star host language is Julia; no Julia toolchain exists in this image, so the host mirror
 is Python and the Julia `ccall` wrapper lives, untested, in pathfinder.jl_amd/julia/ -- INTEGRATION.md.)
 """
+import gc
 import os
 import warnings
 from collections.abc import Sequence
@@ -482,8 +483,14 @@ def _run_paths(engs, target, inits, run_rngs, *, dim, history_length, ndraws_elb
                     eng.stream_seeds(np.concatenate([s["stream_tab"] for s in state[k0:k1]]))
         if streamed:
             active = list(zip(engs, blocks))
-            while active:                                           # the calling thread schedules every engine's pipeline
-                active = [(eng, b) for eng, b in active if not eng.stream_pump()]
+            gc_was_on = gc.isenabled()
+            gc.disable()                    # this thread IS the pipeline's scheduler for the next millisecond or two: a full collection (tens of
+            try:                            # milliseconds) in here would starve every GPU it drives (profiles/r05_experiments.md section 5)
+                while active:                                       # the calling thread schedules every engine's pipeline
+                    active = [(eng, b) for eng, b in active if not eng.stream_pump()]
+            finally:
+                if gc_was_on:
+                    gc.enable()
             for eng, (k0, k1) in zip(engs, blocks):
                 npts = eng.stream_wait()
                 for k in range(k0, k1):
