@@ -1,3 +1,5 @@
+"""usage: python tests/probes/stream_steps.py -- 120 streamed end-to-end steps at 8 paths (d = 1000): mean / median / max and the outliers (a host pause -- e.g. a full
+garbage collection -- shows as ONE step of tens of milliseconds: the calling thread schedules the pipeline)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "pathfinder.jl_amd")]
