@@ -266,3 +266,41 @@ def test_the_packed_entry_points_work_on_the_streaming_layout(pfmi_mod):
     X, lp, lq = e.draws(int(el1[2][0]), int(slot_seeds[int(el1[2][0])]), 16)          # slot of run 0's winner (offset 0)
     assert np.all(np.isfinite(X)) and np.all(np.isfinite(lq))
     e.close()
+
+
+def test_public_call_retries_and_failed_runs_are_the_same_streamed_or_packed(pfmi_mod, monkeypatch):
+    """pfmi.multipathfinder on a built-in target takes the streaming pipeline; PFMI_NO_STREAM=1 forces the packed route.  A run that starts AT the
+    optimum has no fit (L = 0: a failed try, src/singlepath.jl:299): with ntries = 3 it is retried from a sampled point (the other runs keep the
+    streams they had), with ntries = 1 it stays failed and draws from fit_distributions[1] with the seed its rng yields next (:231-233).  Same
+    draws, component ids, k-hat, tries and fit iterations on both routes."""
+    import warnings
+    d = 40
+    tg = pfmi_mod.t_diag(d, seed=3)
+    rng0 = pfmi_mod.HostRNG(4)
+    inits = [tg.mean.copy(), rng0.rand(d) * 4 - 2, rng0.rand(d) * 4 - 2, rng0.rand(d) * 4 - 2]
+
+    def run(ntries):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            e = pfmi_mod.Engine(0)
+            r = pfmi_mod.multipathfinder(tg, 300, init=[x.copy() for x in inits], ndraws_elbo=128, ntries=ntries, rng=pfmi_mod.HostRNG(6), engine=e,
+                                         maxiters=80)
+            out = (r.draws.copy(), r.draw_component_ids.copy(), r.psis_result.pareto_shape, [p.num_tries for p in r.pathfinder_results],
+                   [p.fit_iteration for p in r.pathfinder_results], [p.success for p in r.pathfinder_results],
+                   [len(p.optim_trace) for p in r.pathfinder_results], r.pathfinder_results[1].draws.copy())
+            e.close()
+            return out
+
+    for ntries in (3, 1):
+        monkeypatch.delenv("PFMI_NO_STREAM", raising=False)
+        s = run(ntries)
+        monkeypatch.setenv("PFMI_NO_STREAM", "1")
+        p = run(ntries)
+        monkeypatch.delenv("PFMI_NO_STREAM", raising=False)
+        np.testing.assert_array_equal(s[0], p[0]); np.testing.assert_array_equal(s[1], p[1]); np.testing.assert_array_equal(s[7], p[7])
+        np.testing.assert_equal(s[2], p[2])
+        assert s[3:7] == p[3:7], (s[3:7], p[3:7])
+        if ntries == 3:
+            assert s[3][0] == 2 and all(s[5]), s[3:6]                 # the run that started at the optimum needed its second try
+        else:
+            assert s[3][0] == 1 and not s[5][0] and s[4][0] == 0 and all(s[5][1:]), s[3:6]
