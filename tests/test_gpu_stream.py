@@ -304,3 +304,27 @@ def test_public_call_retries_and_failed_runs_are_the_same_streamed_or_packed(pfm
             assert s[3][0] == 2 and all(s[5]), s[3:6]                 # the run that started at the optimum needed its second try
         else:
             assert s[3][0] == 1 and not s[5][0] and s[4][0] == 0 and all(s[5][1:]), s[3:6]
+
+
+def test_streamed_pipeline_random_shapes(pfmi_mod):
+    """a dozen random (target, K, d, J, maxiters, N) shapes -- register / panel fit kernels, resident / streamed factor blocks, every padding of the
+    history block up to 32 columns, paths that stop at maxiters -- streamed against packed, bit for bit"""
+    rs = np.random.RandomState(20260929)
+    for it in range(12):
+        d = int(rs.choice([7, 33, 64, 130, 257, 700, 1024, 1500, 2300]))
+        J = int(rs.choice([1, 2, 3, 5, 6, 8, 10, 13, 16]))
+        K = int(rs.choice([1, 2, 3, 7, 12]))
+        maxiters = int(rs.choice([5, 17, 40, 100]))
+        N = int(rs.choice([16, 64, 100, 300]))
+        kind = int(rs.randint(3))
+        tg = pfmi_mod.t_diag(d, seed=1 + it) if kind == 0 else pfmi_mod.t_lowrank(d, r=int(rs.choice([1, 4, 8, 16])), seed=2 + it) if kind == 1 else pfmi_mod.t_funnel(d)
+        scale = 10.0 if kind == 2 else 2.0
+        cap = maxiters + 1
+        x0 = pfmi_mod.HostRNG(100 + it).rand(K * d).reshape(K, d) * 2 * scale - scale
+        sd = pfmi_mod.hostrng.rand_u64(200 + it, np.arange(K * cap, dtype=np.uint64), 9)
+        a = _packed(pfmi_mod, tg, x0, J, maxiters, N, sd, N, 50)
+        s = _streamed(pfmi_mod, tg, x0, J, maxiters, N, sd, N, 50)[0]
+        try:
+            _compare(a, s, K, cap)
+        except AssertionError as ex:
+            raise AssertionError(f"shape {it}: kind {kind} d {d} J {J} K {K} maxiters {maxiters} N {N}: {ex}") from ex
