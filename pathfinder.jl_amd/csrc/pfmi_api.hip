@@ -112,12 +112,16 @@ int32_t pf_download(pfmi_ctx *c, void *dst, const void *src, size_t bytes) {
     if (bytes <= PF_DL_MAX) {
         if (!a.base) {
             void *pp = nullptr;
-            PF_HIP(hipHostMalloc(&pp, PF_DL_BYTES, hipHostMallocDefault));
+            PF_HIP(hipHostMalloc(&pp, PF_DL_BYTES, hipHostMallocMapped));          // (the gather kernel of pf_dl_flush writes into it)
             a.base = reinterpret_cast<char *>(pp); a.cap = PF_DL_BYTES; a.off = 0;
         }
         if (a.off + bytes <= a.cap) {
-            PF_HIP(hipMemcpyAsync(a.base + a.off, src, bytes, hipMemcpyDeviceToHost, c->stream));
-            c->dl_pending.push_back(DlPending{dst, a.base + a.off, bytes, c->defer});
+            // (round 5) the copy itself is NOT issued here: every small result of an entry point used to be its own blit kernel in the stream
+            // (eight of them, 5 us each, behind the last kernel of a step); pf_dl_flush -- called by the wait -- moves all of them with ONE
+            // kernel that writes straight into the page-locked arena.  The sources are result buffers nothing rewrites before the wait.
+            static const bool immediate = [] { const char *e = getenv("PFMI_DL_IMMEDIATE"); return e && e[0] == '1'; }();      // A/B: one blit copy per result, at once
+            if (immediate) PF_HIP(hipMemcpyAsync(a.base + a.off, src, bytes, hipMemcpyDeviceToHost, c->stream));
+            c->dl_pending.push_back(DlPending{dst, a.base + a.off, bytes, c->defer, immediate ? nullptr : static_cast<const char *>(src), immediate});
             a.off += (bytes + 255) & ~(size_t)255;
             return PFMI_OK;
         }
@@ -126,7 +130,48 @@ int32_t pf_download(pfmi_ctx *c, void *dst, const void *src, size_t bytes) {
     return PFMI_OK;
 }
 static void pf_deferred_drop(pfmi_ctx *c) { c->dl_pending.clear(); c->post_sync.clear(); c->dl.off = 0; }
+// ---- one kernel for all staged downloads of a wait: block (x, y) copies slice x of segment y into the page-locked arena (zero copy)
+#define PF_DL_NSEG 24
+struct DlSegs { const char *src[PF_DL_NSEG]; char *dst[PF_DL_NSEG]; uint32_t bytes[PF_DL_NSEG]; };
+__global__ __launch_bounds__(256) void pf_dl_gather_kernel(DlSegs S) {
+    const int y = blockIdx.y;
+    const char *src = S.src[y];
+    char *dst = S.dst[y];
+    const uint32_t n = S.bytes[y];
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | n) & 7u) == 0) {
+        const uint32_t n8 = n >> 3;
+        for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n8; i += gridDim.x * 256)
+            reinterpret_cast<uint64_t *>(dst)[i] = reinterpret_cast<const uint64_t *>(src)[i];
+    } else {
+        for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) dst[i] = src[i];
+    }
+}
+static int32_t pf_dl_flush(pfmi_ctx *c) {
+    DlSegs S;
+    int n = 0;
+    uint32_t big = 0;
+    auto launch = [&]() -> int32_t {
+        if (n == 0) return PFMI_OK;
+        const unsigned gx = big > (64u << 10) ? 32 : big > (4u << 10) ? 4 : 1;
+        hipLaunchKernelGGL(pf_dl_gather_kernel, dim3(gx, (unsigned)n), dim3(256), 0, c->stream, S);
+        PF_HIP(hipGetLastError());
+        n = 0; big = 0;
+        return PFMI_OK;
+    };
+    for (DlPending &q : c->dl_pending) {
+        if (q.issued || q.src == nullptr) continue;
+        S.src[n] = q.src; S.dst[n] = const_cast<char *>(q.slot); S.bytes[n] = (uint32_t)q.bytes;
+        if ((uint32_t)q.bytes > big) big = (uint32_t)q.bytes;
+        q.issued = true;
+        if (++n == PF_DL_NSEG) PF_TRY(launch());
+    }
+    return launch();
+}
 int32_t pf_stream_sync(pfmi_ctx *c) {
+    {
+        const int32_t rf = pf_dl_flush(c);
+        if (rf != PFMI_OK) { pf_deferred_drop(c); return rf; }
+    }
     const hipError_t e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { pf_deferred_drop(c); PF_HIP(e); }        // nothing is delivered after a failed wait
     for (const DlPending &q : c->dl_pending) memcpy(q.dst, q.slot, q.bytes);

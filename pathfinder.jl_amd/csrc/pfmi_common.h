@@ -61,7 +61,7 @@ struct KernelStat { double ms = 0.0; int64_t launches = 0; };
 // rewound whenever the stream is known to be idle (pf_arena_reset after a full synchronisation).
 struct PinArena { char *base = nullptr; size_t cap = 0, off = 0; };
 // a small device -> host download staged in the ctx's pinned download arena: delivered to `dst` by pf_stream_sync
-struct DlPending { void *dst; const char *slot; size_t bytes; bool keep; };   // keep: queued under pfmi_defer_downloads (survives the next entry points)
+struct DlPending { void *dst; const char *slot; size_t bytes; bool keep; const char *src; bool issued; };   // keep: queued under pfmi_defer_downloads (survives the next entry points)
 
 // device-resident target description (Gaussian family rows are stored row-major for scalar loads)
 struct TargetDev {
