@@ -162,12 +162,29 @@ int32_t pfmi_stream_seeds(pfmi_ctx *ctx, const uint64_t *seeds);
  * then and returns the points per path -- it does NOT wait for the GPU.  A host that drives several contexts pumps them in turn. */
 int32_t pfmi_stream_pump(pfmi_ctx *ctx, int32_t *finished);
 int32_t pfmi_stream_wait(pfmi_ctx *ctx, int64_t *npoints);
+/* Give up an outstanding streaming call -- for a host that failed between pfmi_stream_enqueue and pfmi_stream_wait (an exception while it
+ * drew the seed streams or pumped another context; the reference's task-based fan-out simply propagates the exception, src/multipath.jl:190-208).
+ * Drains what is in flight, forgets the half-made results; the context is usable again.  No call outstanding: no-op.  (pfmi_stream_enqueue,
+ * pfmi_set_traces and pfmi_optimize_batch_enqueue do the same implicitly when they find a stale call.) */
+int32_t pfmi_stream_cancel(pfmi_ctx *ctx);
 
 /* ---- fit_mvnormals / lbfgs_inverse_hessians / pdfactorize --------------------------------------- */
 /* replaces fit_mvnormals (src/mvnormal.jl:14-21) = lbfgs_inverse_hessians (src/inverse_hessian.jl:25-66)
  * + lbfgs_inverse_hessian (:98-133) + WoodburyPDMat/pdfactorize (src/woodbury.jl:259-263, 201-207)
  * + mu = theta + Sigma*grad, for every point of every trace, batched on the GPU. */
 int32_t pfmi_fit_batch(pfmi_ctx *ctx, int32_t history_length, double eps);
+/* The `Hinit` keyword of lbfgs_inverse_hessians (src/inverse_hessian.jl:25, forwarded by fit_mvnormals, src/mvnormal.jl:14-16): how the
+ * diagonal H0 is updated at every ACCEPTED step (:55).  A Julia closure cannot cross the boundary; the two the reference itself uses can:
+ *   PFMI_HINIT_GILBERT            gilbert_init (src/inverse_hessian.jl:5-10), the default;
+ *   PFMI_HINIT_SCALAR_YS_OVER_YY  (alpha, s, y) -> fill(y's / y'y): the Nocedal-Wright scaling Optim.LBFGS starts from, which the
+ *                                 reference's own test passes as Hinit (test/inverse_hessian.jl:49, :62-66: H * grad is then the step
+ *                                 the optimiser took).
+ * pfmi_fit_batch_ex = pfmi_fit_batch with Hinit for THIS call; pfmi_set_hinit sets the context's default (pfmi_fit_batch and the
+ * streaming pipeline use it). */
+#define PFMI_HINIT_GILBERT 0
+#define PFMI_HINIT_SCALAR_YS_OVER_YY 1
+int32_t pfmi_fit_batch_ex(pfmi_ctx *ctx, int32_t history_length, double eps, int32_t hinit);
+int32_t pfmi_set_hinit(pfmi_ctx *ctx, int32_t hinit);
 
 /* status[P], j_eff[P] (effective history length), logdet[P], n_rejected[K]; any may be NULL */
 int32_t pfmi_get_fit_status(pfmi_ctx *ctx, int32_t *status, int32_t *j_eff, double *logdet,

@@ -158,6 +158,10 @@ void pfo_lbfgs_inverse_hessian(int d, int j, const double *alpha, const double *
 /*                          c-th oldest history column, c < hist_len[l]  (order of :105)       */
 /* returns num_bfgs_updates_rejected.                                                          */
 /* ------------------------------------------------------------------------------------------ */
+/* Hinit (src/inverse_hessian.jl:25 keyword): 0 = gilbert_init (the default), 1 = (alpha, s, y) -> fill(y's / y'y), the Nocedal-Wright
+ * scaling the reference's own test passes (test/inverse_hessian.jl:49).  A process-wide setting of this TEST oracle (pfo_set_hinit). */
+static int g_pfo_hinit = 0;
+void pfo_set_hinit(int hinit) { g_pfo_hinit = hinit; }
 int pfo_lbfgs_history(int d, int L, const double *theta, const double *grad, int J, double eps,
                       double *alpha_all, int *hist_len, int *hist_src) {
     int history_ind = 0;      /* 1-based slot of last set entry, 0 = none   :32 */
@@ -185,7 +189,8 @@ int pfo_lbfgs_history(int d, int L, const double *theta, const double *grad, int
             history_ind = (history_ind % J) + 1;                    /* mod1(ind+1, J) :49 */
             if (history_ind > history_len_eff) history_len_eff = history_ind; /* :50 */
             slot_src[history_ind - 1] = l - 1;                      /* :51-52 */
-            pfo_gilbert_init(d, alpha, s, y, anew);                 /* :55 */
+            if (g_pfo_hinit == 1) { for (int i = 0; i < d; ++i) anew[i] = ys / yy; }   /* fill!(similar(α), dot(y, s) / sum(abs2, y)), test/inverse_hessian.jl:49 */
+            else pfo_gilbert_init(d, alpha, s, y, anew);             /* :55 */
             memcpy(alpha, anew, sizeof(double) * d);
         } else {
             rejected += 1;                                          /* :57 */

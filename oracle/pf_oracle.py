@@ -62,6 +62,11 @@ def gilbert_init(alpha, s, y):
     return out
 
 
+def set_hinit(hinit):
+    """Hinit of the history walk: 0 / "gilbert" (default) or 1 / "nocedal_wright" (test/inverse_hessian.jl:49).  Process-wide; reset it."""
+    lib().pfo_set_hinit({"gilbert": 0, "nocedal_wright": 1, 0: 0, 1: 1}[hinit])
+
+
 def lbfgs_inverse_hessian(alpha, S, Y):
     """S, Y ordered oldest->newest, shape (d, j).  Returns (B (d,2j), D (2j,2j))."""
     alpha, S, Y = _f(alpha), _f(S), _f(Y)

@@ -34,4 +34,6 @@ __device__ __forceinline__ bool pf_fit_point(const FitArgs &A, int64_t idx, int6
 // [K][d] (it is x * (1 / b), not 1 / alpha: it must travel bit for bit), the number of accepted updates in nacc_state[K], the accepted
 // list in acc_list.  npts[k] (device) = points of path k recorded so far (>= l_end, or final).  The packed route passes
 // {nullptr, 0, INT_MAX, nullptr, nullptr}: one launch walks the whole path, exactly as before.
-struct HistSeg { const int32_t *npts; int l_begin, l_end; double *ial_state; int *nacc_state; };
+// hinit: the `Hinit` keyword of lbfgs_inverse_hessians (src/inverse_hessian.jl:25): PFMI_HINIT_GILBERT (0, the default, :5-10) or
+// PFMI_HINIT_SCALAR_YS_OVER_YY (1: alpha = fill(y's / y'y), the Nocedal-Wright scaling of test/inverse_hessian.jl:49).
+struct HistSeg { const int32_t *npts; int l_begin, l_end; double *ial_state; int *nacc_state; int hinit; };

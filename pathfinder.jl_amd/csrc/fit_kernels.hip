@@ -125,7 +125,12 @@ __global__ __launch_bounds__(HIST_NT) void pf_history_kernel(
         pf_block_sum_mv<4, 4, (HIST_NT <= 256 ? HIST_NT / 64 : 0)>(v, red, flip);   // static wave count only for <= 4 waves (16 waves: register pressure)
         HP_STAMP(1);
         const bool accept = v[0] > eps * v[1];                                  // :47
-        if (accept) {                                                           // gilbert_init :5-10
+        if (accept && sg.hinit == 1) {                                          // Hinit = (alpha, s, y) -> fill(y's / y'y)  (test/inverse_hessian.jl:49)
+            const double an = v[0] / v[1], ian = 1.0 / an;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) { al[e] = an; ial[e] = ian; }
+            n_acc += 1;
+        } else if (accept) {                                                    // gilbert_init :5-10
             const double a = v[2], b = v[0], c = v[3], aoc = a / c, rb = 1.0 / b;
 #pragma unroll
             for (int e = 0; e < EPT; ++e) {
@@ -257,7 +262,12 @@ __global__ __launch_bounds__(1024) void pf_history_lean_kernel(
         }
         pf_block_sum_mv<4, 4, 0>(v, red, flip);
         const bool accept = v[0] > eps * v[1];                                  // :47
-        if (accept) {                                                           // gilbert_init :5-10
+        if (accept && sg.hinit == 1) {                                          // Hinit = fill(y's / y'y)  (test/inverse_hessian.jl:49)
+            const double an = v[0] / v[1], ian = 1.0 / an;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) { al[e] = an; hl_ial[e * HIST_NT + tid] = ian; }
+            n_acc += 1;
+        } else if (accept) {                                                    // gilbert_init :5-10
             const double a = v[2], b = v[0], c = v[3], aoc = a / c, rb = 1.0 / b;
 #pragma unroll
             for (int e = 0; e < EPT; ++e) {
@@ -344,7 +354,7 @@ __global__ __launch_bounds__(1024) void pf_history_mem_kernel(
             if (accept) {                                                           // gilbert_init :5-10
                 const double s = theta[row + i] - theta[row - d + i], y = grad[row - d + i] - grad[row + i];
                 const double sa = s / al;
-                an = b / (a / al + y * y - aoc * sa * sa);
+                an = sg.hinit == 1 ? v[0] / v[1] : b / (a / al + y * y - aoc * sa * sa);       // (hinit 1: fill(y's / y'y), test/inverse_hessian.jl:49)
             }
             alpha_all[row + i] = an;
         }
@@ -1167,7 +1177,8 @@ __global__ __launch_bounds__(NT, (KPAD <= 8 ? 4 : KPAD <= 12 ? 3 : 2)) void pf_f
 // ---------------------------------------------------------------------------------------------------
 int32_t pf_launch_history(pfmi_ctx *c, double eps, const HistSeg *seg) {
     PF_CHECK(c->J <= 64, PFMI_ERR_UNSUPPORTED, "history_length %d > 64 unsupported", c->J);
-    const HistSeg sg = seg ? *seg : HistSeg{nullptr, 0, INT_MAX, nullptr, nullptr};
+    HistSeg sg = seg ? *seg : HistSeg{nullptr, 0, INT_MAX, nullptr, nullptr, 0};
+    sg.hinit = c->hinit;
     pf_kernel_begin(c);
     {
         const char *hk = pf_debug_get("PFMI_HISTORY_KERNEL");            // "mem": the memory-resident walk at every d (tests)

@@ -359,7 +359,9 @@ __global__ __launch_bounds__(NT) void pf_lbfgs_kernel(LbfgsArgs A) {
             __syncthreads();
             if (tid == 0) {
                 __hip_atomic_store(A.npts + k, n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(A.h_prog + k, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                // RELEASE at system scope: the host must not see count n before npts[k] and the rows behind it are visible to the
+                // kernels it then launches -- a relaxed store is not ordered after a release store to another address
+                __hip_atomic_store(A.h_prog + k, n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     };

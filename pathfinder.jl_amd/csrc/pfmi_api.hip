@@ -104,6 +104,7 @@ int32_t pf_upload(pfmi_ctx *c, void *dst, const void *src, size_t bytes) {
     return PFMI_OK;
 }
 static int32_t h2d(pfmi_ctx *c, void *dst, const void *src, size_t bytes) { return pf_upload(c, dst, src, bytes); }
+int32_t pf_dl_flush(pfmi_ctx *c);
 #define PF_DL_BYTES (4u << 20)
 #define PF_DL_MAX (1u << 20)
 int32_t pf_download(pfmi_ctx *c, void *dst, const void *src, size_t bytes) {
@@ -126,7 +127,10 @@ int32_t pf_download(pfmi_ctx *c, void *dst, const void *src, size_t bytes) {
             return PFMI_OK;
         }
     }
-    PF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));    // pageable destination: blocks until the copy is done
+    // a large result: its own copy (pageable destination: blocks until the copy is done).  The staged small results go out FIRST, as their one
+    // gather kernel, so that the wait behind this copy finds them delivered instead of paying a launch + a second round trip
+    PF_TRY(pf_dl_flush(c));
+    PF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     return PFMI_OK;
 }
 static void pf_deferred_drop(pfmi_ctx *c) { c->dl_pending.clear(); c->post_sync.clear(); c->dl.off = 0; }
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(256) void pf_dl_gather_kernel(DlSegs S) {
         for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) dst[i] = src[i];
     }
 }
-static int32_t pf_dl_flush(pfmi_ctx *c) {
+int32_t pf_dl_flush(pfmi_ctx *c) {
     DlSegs S;
     int n = 0;
     uint32_t big = 0;
@@ -225,6 +229,15 @@ static int32_t ensure_pinned(pfmi_ctx *c, size_t x_bytes, size_t lp_bytes) {
         PF_CHECK((c) != nullptr, PFMI_ERR_ARG, "null pfmi_ctx");           \
         PF_HIP(hipSetDevice((c)->device));                                 \
         pf_download_forget(c);                                             \
+    } while (0)
+// Entry points that enqueue work which REWRITES (or may reallocate) result buffers: the staged downloads still pending -- entries queued under
+// pfmi_defer_downloads survive several entry points, and their copy is only issued by the gather kernel of the next wait -- are issued NOW, in
+// stream order in front of the new work, so that they deliver the values of the call they were queued for (a source must be a
+// snapshot at queueing time, as it was when every download was its own stream-ordered copy).  No pending entry: no launch.
+#define PF_CTX_MUT(c)                                                      \
+    do {                                                                   \
+        PF_CTX(c);                                                         \
+        PF_TRY(pf_dl_flush(c));                                            \
     } while (0)
 
 // ---- test / tuning hooks (pfmi_common.h: pf_debug_get) ---------------------------------------------------------------------
@@ -380,7 +393,7 @@ int32_t pfmi_kernel_time(pfmi_ctx *c, const char *name, double *ms, int64_t *lau
 
 // ---- inputs ------------------------------------------------------------------------------------------
 int32_t pfmi_set_target(pfmi_ctx *c, const pfmi_target *t) {
-    PF_CTX(c);
+    PF_CTX_MUT(c);
     PF_CHECK(t != nullptr, PFMI_ERR_ARG, "null target");
     PF_CHECK(t->d > 0, PFMI_ERR_ARG, "target dimension must be positive");
     TargetDev &T = c->target;
@@ -429,7 +442,7 @@ int32_t pfmi_set_target(pfmi_ctx *c, const pfmi_target *t) {
 
 int32_t pfmi_set_traces(pfmi_ctx *c, int32_t K, const int64_t *npoints, int32_t d, const double *theta,
                         const double *grad) {
-    PF_CTX(c);
+    PF_CTX_MUT(c);
     if (c->sr.active) stream_abandon(c);
     PF_CHECK(K > 0 && d > 0 && npoints && theta && grad, PFMI_ERR_ARG, "set_traces: bad arguments");
     c->off.assign((size_t)K + 1, 0);
@@ -458,7 +471,7 @@ int32_t pfmi_set_traces(pfmi_ctx *c, int32_t K, const int64_t *npoints, int32_t 
 
 // ---- device trajectory generation ------------------------------------------------------------------------
 int32_t pfmi_optimize_batch_enqueue(pfmi_ctx *c, int32_t K, const double *x0, int32_t J, int32_t maxiters, double g_tol) {
-    PF_CTX(c);
+    PF_CTX_MUT(c);
     if (c->sr.active) stream_abandon(c);
     const TargetDev &T = c->target;
     PF_CHECK(T.kind == PFMI_TARGET_GAUSS || T.kind == PFMI_TARGET_FUNNEL, PFMI_ERR_UNSUPPORTED,
@@ -482,7 +495,7 @@ int32_t pfmi_optimize_batch_enqueue(pfmi_ctx *c, int32_t K, const double *x0, in
 }
 
 int32_t pfmi_optimize_batch_wait(pfmi_ctx *c, int64_t *npoints) {
-    PF_CTX(c);
+    PF_CTX_MUT(c);
     PF_CHECK(c->opt_pending, PFMI_ERR_STATE, "optimize_batch_wait: no pfmi_optimize_batch_enqueue outstanding");
     PF_CHECK(npoints != nullptr, PFMI_ERR_ARG, "optimize_batch_wait: null npoints");
     c->opt_pending = false;
@@ -589,15 +602,30 @@ static int32_t stream_set_seeds(pfmi_ctx *c, const uint64_t *seeds) {
     return PFMI_OK;
 }
 
+static int32_t stream_enqueue_impl(pfmi_ctx *c, int32_t K, const double *x0, int32_t J, int32_t maxiters, double g_tol, double eps, int64_t N,
+                                   const uint64_t *seeds);
 int32_t pfmi_stream_enqueue(pfmi_ctx *c, int32_t K, const double *x0, int32_t J, int32_t maxiters, double g_tol, double eps, int64_t N,
                             const uint64_t *seeds) {
-    PF_CTX(c);
+    PF_CTX_MUT(c);
+    const int32_t rc = stream_enqueue_impl(c, K, x0, J, maxiters, g_tol, eps, N, seeds);
+    if (rc != PFMI_OK && rc != PFMI_ERR_ARG && rc != PFMI_ERR_UNSUPPORTED) {
+        // failed half-way (an allocation, an upload, the producer's launch): nothing of the call survives -- the side streams are drained and the
+        // context forgets the half-built layout, so that later calls see "no traces" instead of a layout whose producer never ran
+        stream_abandon(c);
+        c->virt = false; c->P = 0; c->K = 0; c->fitted = false; c->elbo_done = false; c->pooled = false; c->opt_pending = false;
+    }
+    return rc;
+}
+static int32_t stream_enqueue_impl(pfmi_ctx *c, int32_t K, const double *x0, int32_t J, int32_t maxiters, double g_tol, double eps, int64_t N,
+                                   const uint64_t *seeds) {
     const TargetDev &T = c->target;
     PF_CHECK(T.kind == PFMI_TARGET_GAUSS || T.kind == PFMI_TARGET_FUNNEL, PFMI_ERR_UNSUPPORTED,
              "stream_enqueue: needs a built-in target (the optimiser runs on the device)");
     PF_CHECK(K > 0 && x0 && maxiters >= 0 && N >= 1, PFMI_ERR_ARG, "stream_enqueue: bad arguments");
     PF_CHECK(J >= 1 && J <= 16, PFMI_ERR_UNSUPPORTED, "stream_enqueue: history_length %d outside 1..16", J);
-    PF_CHECK(!c->sr.active, PFMI_ERR_STATE, "stream_enqueue: the previous streaming call has not been waited for (pfmi_stream_wait)");
+    // a previous streaming call that was never waited for (a host exception between enqueue and wait): drain and forget it, like
+    // pfmi_set_traces / pfmi_optimize_batch_enqueue do -- a persistent context must stay usable
+    if (c->sr.active) stream_abandon(c);
     if (c->s_opt) PF_TRY(stream_sync(c));      // the page-locked progress words and work lists are reused: the previous call's copies must have landed
     const int ncu = c->ncu > 0 ? c->ncu : 256;
     const int d = T.d;
@@ -739,6 +767,17 @@ int32_t pfmi_stream_enqueue(pfmi_ctx *c, int32_t K, const double *x0, int32_t J,
     return PFMI_OK;
 }
 
+// Give up an outstanding streaming call (a host that failed between pfmi_stream_enqueue and pfmi_stream_wait): what is in flight is drained, the
+// half-made results are forgotten, the context is usable again.  No call outstanding: no-op.
+int32_t pfmi_stream_cancel(pfmi_ctx *c) {
+    PF_CTX(c);
+    if (!c->sr.active && !c->stream_pending) return PFMI_OK;
+    stream_abandon(c);
+    (void)hipStreamSynchronize(c->stream);
+    c->fitted = false; c->elbo_done = false; c->elbo_pending = false; c->pooled = false;
+    return PFMI_OK;
+}
+
 int32_t pfmi_stream_seeds(pfmi_ctx *c, const uint64_t *seeds) {
     PF_CTX(c);
     PF_CHECK(c->sr.active && !c->sr.have_seeds, PFMI_ERR_STATE, "stream_seeds: no pfmi_stream_enqueue(..., seeds = NULL) outstanding");
@@ -750,7 +789,7 @@ int32_t pfmi_stream_seeds(pfmi_ctx *c, const uint64_t *seeds) {
 // one is out.  *finished = 1: everything is enqueued (pfmi_stream_wait then returns at once).  Never blocks.
 static int32_t stream_pump_pass(pfmi_ctx *c, int32_t *finished);
 int32_t pfmi_stream_pump(pfmi_ctx *c, int32_t *finished) {
-    PF_CTX(c);
+    PF_CTX_MUT(c);
     const int32_t rc = stream_pump_pass(c, finished);
     if (rc != PFMI_OK && c->sr.active) stream_abandon(c);          // a failed pass ends the call: what is in flight is drained, the context is usable again
     return rc;
@@ -772,13 +811,23 @@ static int32_t stream_pump_pass(pfmi_ctx *c, int32_t *finished) {
     if (!R.have_seeds) return PFMI_OK;                                              // pfmi_stream_seeds has not been called yet
     const auto now = std::chrono::steady_clock::now();
     if (!all_done) {
-        if (avail != R.last_min) { R.last_min = avail; R.t_progress = now; }
-        else if (std::chrono::duration<double>(now - R.t_progress).count() > 20.0) {
-            // the producer is a plain kernel: it either runs or has failed
-            const hipError_t q = hipStreamQuery(c->s_opt);
+        // Watchdog.  The producer is a plain kernel: it runs, or its stream carries an error.  An ERROR ends the call at once; no
+        // progress alone ends it only after PFMI_STREAM_TIMEOUT_S seconds (default 60: a host that pumps rarely or a GPU shared with another
+        // process must not trip it), and never with a device-wide synchronise -- that would block for ever behind a hung kernel and stall
+        // every other context of the device.  The context's own side streams are drained by the next entry point that reuses its memory.
+        const hipError_t q = hipStreamQuery(c->s_opt);
+        if (q != hipSuccess && q != hipErrorNotReady) {
             R.active = false; c->stream_pending = false;
-            (void)hipDeviceSynchronize();
-            PF_CHECK(false, PFMI_ERR_HIP, "stream_pump: the optimiser made no progress for 20 s (stream state: %s)", hipGetErrorString(q));
+            PF_CHECK(false, PFMI_ERR_HIP, "stream_pump: the optimiser's stream reports %s", hipGetErrorString(q));
+        }
+        if (avail != R.last_min) { R.last_min = avail; R.t_progress = now; }
+        else {
+            double limit = 60.0;
+            if (const char *tl = pf_debug_get("PFMI_STREAM_TIMEOUT_S")) { const double v = atof(tl); if (v > 0) limit = v; }
+            if (std::chrono::duration<double>(now - R.t_progress).count() > limit) {
+                R.active = false; c->stream_pending = false;
+                PF_CHECK(false, PFMI_ERR_HIP, "stream_pump: the optimiser made no progress for %.0f s (stream state: %s)", limit, hipGetErrorString(q));
+            }
         }
     }
     int l1 = all_done ? lmax : avail / R.pub * R.pub;
@@ -821,7 +870,7 @@ static int32_t stream_pump_pass(pfmi_ctx *c, int32_t *finished) {
             if (lf < l1) lf = l1;
             if (R.fit_eager == 0) lf = l1;
             StreamSwap sw(c, c->s_fit);
-            const HistSeg sg{c->st_npts.as<int32_t>(), R.l_fit, lf, c->hs_ial.as<double>(), c->hs_nacc.as<int32_t>()};
+            const HistSeg sg{c->st_npts.as<int32_t>(), R.l_fit, lf, c->hs_ial.as<double>(), c->hs_nacc.as<int32_t>(), c->hinit};
             PF_TRY(pf_launch_history(c, R.eps, &sg));
             PF_TRY(pf_launch_fit(c, R.l_fit, lf - R.l_fit));
             PF_HIP(hipEventRecord(c->sg_fit, c->s_fit));
@@ -899,8 +948,27 @@ int32_t pfmi_stream_wait(pfmi_ctx *c, int64_t *npoints) {
 }
 
 // ---- fit ----------------------------------------------------------------------------------------------
-int32_t pfmi_fit_batch(pfmi_ctx *c, int32_t J, double eps) {
+static int32_t fit_batch_impl(pfmi_ctx *c, int32_t J, double eps);
+int32_t pfmi_set_hinit(pfmi_ctx *c, int32_t hinit) {
     PF_CTX(c);
+    PF_CHECK(hinit == PFMI_HINIT_GILBERT || hinit == PFMI_HINIT_SCALAR_YS_OVER_YY, PFMI_ERR_ARG, "set_hinit: unknown Hinit %d", hinit);
+    c->hinit = hinit;
+    return PFMI_OK;
+}
+int32_t pfmi_fit_batch(pfmi_ctx *c, int32_t J, double eps) {
+    PF_CTX_MUT(c);
+    return fit_batch_impl(c, J, eps);
+}
+int32_t pfmi_fit_batch_ex(pfmi_ctx *c, int32_t J, double eps, int32_t hinit) {
+    PF_CTX_MUT(c);
+    PF_CHECK(hinit == PFMI_HINIT_GILBERT || hinit == PFMI_HINIT_SCALAR_YS_OVER_YY, PFMI_ERR_ARG, "fit_batch_ex: unknown Hinit %d", hinit);
+    const int keep = c->hinit;
+    c->hinit = hinit;                                       // for THIS call (pfmi_set_hinit is the persistent setting)
+    const int32_t rc = fit_batch_impl(c, J, eps);
+    c->hinit = keep;
+    return rc;
+}
+static int32_t fit_batch_impl(pfmi_ctx *c, int32_t J, double eps) {
     PF_CHECK(c->P > 0, PFMI_ERR_STATE, "fit_batch: no traces set");
     PF_CHECK(J >= 1, PFMI_ERR_ARG, "history_length must be >= 1");
     const int m = 2 * J;
@@ -928,7 +996,7 @@ int32_t pfmi_fit_batch(pfmi_ctx *c, int32_t J, double eps) {
     PF_TRY(c->status.ensure(sizeof(int32_t) * P));
     PF_HIP(hipMemsetAsync(c->hist_src.p, 0, sizeof(int32_t) * P * J, c->stream));
     if (c->virt) {                                            // streaming layout: every path's slots, the absent ones marked as such
-        const HistSeg sg{c->st_npts.as<int32_t>(), 0, INT_MAX, nullptr, nullptr};
+        const HistSeg sg{c->st_npts.as<int32_t>(), 0, INT_MAX, nullptr, nullptr, c->hinit};
         PF_TRY(pf_launch_history(c, eps, &sg));
         PF_TRY(pf_launch_fit(c, 0, (int)c->vcap));
     } else {
@@ -1077,7 +1145,7 @@ static int32_t devcb_logp(pfmi_ctx *c, const double *d_x, int64_t n, double *d_l
 }
 
 int32_t pfmi_elbo_batch_enqueue(pfmi_ctx *c, int64_t N, const uint64_t *seeds, const double *u_host) {
-    PF_CTX(c);
+    PF_CTX_MUT(c);
     PF_CHECK(c->fitted, PFMI_ERR_STATE, "elbo_batch: call pfmi_fit_batch first");
     PF_CHECK(c->target.kind >= 0, PFMI_ERR_STATE, "elbo_batch: call pfmi_set_target first");
     PF_CHECK(c->target.d == c->d, PFMI_ERR_ARG, "target dimension %d != trace dimension %d", c->target.d, c->d);
@@ -1251,7 +1319,7 @@ int32_t pfmi_get_elbo_logs(pfmi_ctx *c, int64_t p, double *logp, double *logq) {
 
 int32_t pfmi_draws(pfmi_ctx *c, int64_t p, uint64_t seed, int64_t n0, int64_t N, const double *u_host, double *X,
                    double *logp, double *logq) {
-    PF_CTX(c);
+    PF_CTX_MUT(c);
     PF_CHECK(c->fitted, PFMI_ERR_STATE, "draws: call pfmi_fit_batch first");
     PF_CHECK(p >= 0 && p < c->P && N >= 1 && n0 >= 0, PFMI_ERR_ARG, "draws: bad arguments");
     const int d = c->d;
@@ -1357,7 +1425,7 @@ static int32_t pool_alloc(pfmi_ctx *c, int64_t N_r) {
 }
 
 int32_t pfmi_pool_build(pfmi_ctx *c, int64_t N_r, const int64_t *points, const uint64_t *seeds) {
-    PF_CTX(c);
+    PF_CTX_MUT(c);
     PF_CHECK(c->fitted, PFMI_ERR_STATE, "pool_build: call pfmi_fit_batch first");
     PF_CHECK(c->target.kind >= 0, PFMI_ERR_STATE, "pool_build: call pfmi_set_target first");
     PF_CHECK(N_r >= 1 && points && seeds, PFMI_ERR_ARG, "pool_build: bad arguments");
@@ -1392,7 +1460,7 @@ static int32_t pool_fill(pfmi_ctx *c) {
 }
 
 int32_t pfmi_pool_build_best(pfmi_ctx *c, int64_t N_r, const uint64_t *fail_seeds) {
-    PF_CTX(c);
+    PF_CTX_MUT(c);
     PF_CHECK(c->elbo_done, PFMI_ERR_STATE, "pool_build_best: call pfmi_elbo_batch[_enqueue] first");
     PF_CHECK(N_r >= 1, PFMI_ERR_ARG, "pool_build_best: bad arguments");
     PF_TRY(pool_alloc(c, N_r));
@@ -1442,7 +1510,7 @@ int32_t pfmi_pool_log_ratios_dev(pfmi_ctx *c, void **dev_ptr, int64_t *count) {
 
 int32_t pfmi_psis_dev(pfmi_ctx *c, const void *lr_dev, int64_t S, double *weights, double *log_weights,
                       double *pareto_k, int64_t *tail_len) {
-    PF_CTX(c);
+    PF_CTX_MUT(c);
     PF_CHECK(lr_dev != nullptr && S > 0, PFMI_ERR_ARG, "psis: bad arguments");
     PF_TRY(pf_launch_psis(c, reinterpret_cast<const double *>(lr_dev), S));
     double out[4];
@@ -1472,7 +1540,7 @@ int32_t pfmi_defer_downloads(pfmi_ctx *c, int32_t mode) {
 
 int32_t pfmi_psis(pfmi_ctx *c, const double *lr, int64_t S, double *weights, double *log_weights, double *pareto_k,
                   int64_t *tail_len) {
-    PF_CTX(c);
+    PF_CTX_MUT(c);
     PF_CHECK(lr != nullptr && S > 0, PFMI_ERR_ARG, "psis: bad arguments");
     PF_TRY(c->gbuf.ensure(sizeof(double) * S));
     PF_TRY(h2d(c, c->gbuf.p, lr, sizeof(double) * S));
@@ -1481,7 +1549,7 @@ int32_t pfmi_psis(pfmi_ctx *c, const double *lr, int64_t S, double *weights, dou
 
 int32_t pfmi_resample_indices(pfmi_ctx *c, int64_t S, int64_t ndraws, int32_t importance, int32_t replace,
                               uint64_t seed, const double *uniforms, int64_t *idx) {
-    PF_CTX(c);
+    PF_CTX_MUT(c);
     PF_CHECK(S > 0 && ndraws >= 0, PFMI_ERR_ARG, "resample: bad arguments");
     PF_CHECK(!importance || c->S_w == S, PFMI_ERR_STATE,
              "resample: importance weights for S=%lld not available (run pfmi_psis first)", (long long)S);
@@ -1497,7 +1565,7 @@ int32_t pfmi_resample_indices(pfmi_ctx *c, int64_t S, int64_t ndraws, int32_t im
 }
 
 int32_t pfmi_resample_indices_direct(pfmi_ctx *c, int64_t S, int64_t ndraws, const double *uniforms, int64_t *idx) {
-    PF_CTX(c);
+    PF_CTX_MUT(c);
     PF_CHECK(S > 0 && ndraws >= 0 && (uniforms != nullptr || ndraws == 0), PFMI_ERR_ARG, "resample_direct: bad arguments");
     PF_CHECK(c->S_w == S, PFMI_ERR_STATE, "resample_direct: importance weights for S=%lld not available (run pfmi_psis first)",
              (long long)S);

@@ -86,6 +86,7 @@ struct pfmi_ctx {
     hipEvent_t kcur = nullptr;
     std::set<const void *> lds_attr_done;   // kernels whose dynamic-LDS limit was raised on THIS ctx's device (see pf_raise_lds_limit)
     PinArena arena;                         // staging of small uploads (pf_upload)
+    int hinit = 0;                          // Hinit of the history walk (PFMI_HINIT_*; pfmi_set_hinit / pfmi_fit_batch_ex)
     PinArena dl;                            // staging of small downloads (pf_download)
     std::vector<DlPending> dl_pending;
     // pfmi_defer_downloads: the download-only entry points queue their copies (and what they would do after their wait) and return at once;
@@ -229,6 +230,7 @@ void pf_arena_reset(pfmi_ctx *c);
 int32_t pf_download(pfmi_ctx *c, void *dst, const void *src, size_t bytes);
 // hipStreamSynchronize + delivery of the staged downloads + arena rewind
 int32_t pf_stream_sync(pfmi_ctx *c);
+int32_t pf_dl_flush(pfmi_ctx *c);         // issue the staged downloads still pending as ONE gather kernel on the ctx stream (no wait)
 // drops staged downloads that were never delivered (an entry point failed between queuing and waiting); called on entry by every public call
 void pf_download_forget(pfmi_ctx *c);
 

@@ -229,7 +229,12 @@ All runs at once (`strict`: see below).  `traces[k]` is the `OptimizationTrace` 
 src/optimize.jl:94-114).  Replaces `fit_mvnormals` (src/mvnormal.jl:14-21) = `lbfgs_inverse_hessians` + `WoodburyPDMat` +
 `muladd(Σ, ∇logp, θ)` for every trace point.
 """
-function fit_mvnormals(eng::Engine, traces; history_length::Int=Pathfinder.DEFAULT_HISTORY_LENGTH, ϵ::Float64=1e-12, strict::Bool=true)
+# `Hinit` (src/inverse_hessian.jl:25) as a name: a Julia closure cannot cross the C boundary; the two the reference itself uses can
+const HINIT = (gilbert_init=Int32(0), nocedal_wright_scaling=Int32(1))
+_hinit_code(h::Symbol) = getproperty(HINIT, h)
+_hinit_code(::typeof(Pathfinder.gilbert_init)) = HINIT.gilbert_init
+function fit_mvnormals(eng::Engine, traces; history_length::Int=Pathfinder.DEFAULT_HISTORY_LENGTH, ϵ::Float64=1e-12, strict::Bool=true,
+                       Hinit=Pathfinder.gilbert_init)
     K = length(traces)
     npts = Int64[length(t.points) for t in traces]
     d = length(first(first(traces).points))
@@ -238,7 +243,7 @@ function fit_mvnormals(eng::Engine, traces; history_length::Int=Pathfinder.DEFAU
     eng.generation += 1
     check(ccall((:pfmi_set_traces, libpfmi), Int32, (Ptr{Cvoid}, Int32, Ptr{Int64}, Int32, Ptr{Float64}, Ptr{Float64}),
                 eng.ptr, K, npts, d, theta, grad))
-    check(ccall((:pfmi_fit_batch, libpfmi), Int32, (Ptr{Cvoid}, Int32, Float64), eng.ptr, history_length, ϵ))
+    check(ccall((:pfmi_fit_batch_ex, libpfmi), Int32, (Ptr{Cvoid}, Int32, Float64, Int32), eng.ptr, history_length, ϵ, _hinit_code(Hinit)))
     P = sum(npts)
     status = Vector{Int32}(undef, P); jeff = Vector{Int32}(undef, P); nrej = Vector{Int64}(undef, K)
     check(ccall((:pfmi_get_fit_status, libpfmi), Int32, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ptr{Int64}),
@@ -798,6 +803,10 @@ function stream_wait!(eng::Engine, K::Integer)
     check(ccall((:pfmi_stream_wait, libpfmi), Int32, (Ptr{Cvoid}, Ptr{Int64}), eng.ptr, npts))
     return npts
 end
+"the engine's default `Hinit` (`:gilbert_init` or `:nocedal_wright_scaling`): what `pfmi_fit_batch` and the streaming pipeline use"
+set_hinit!(eng::Engine, h) = check(ccall((:pfmi_set_hinit, libpfmi), Int32, (Ptr{Cvoid}, Int32), eng.ptr, _hinit_code(h)))
+"give up an outstanding stream_enqueue! (an exception between enqueue and wait); no-op otherwise"
+stream_cancel!(eng::Engine) = check(ccall((:pfmi_stream_cancel, libpfmi), Int32, (Ptr{Cvoid},), eng.ptr))
 "1: pfmi_get_fit_status / pfmi_elbo_batch_wait / pfmi_psis_weights only queue their downloads (delivered by the next wait); 0: normal; -1: drop"
 defer_downloads!(eng::Engine, mode::Integer) = check(ccall((:pfmi_defer_downloads, libpfmi), Int32, (Ptr{Cvoid}, Int32), eng.ptr, mode))
 function psis_resample_enqueue!(c::Comm, ndraws::Int; importance::Bool=true, replace::Bool=true, seed::UInt64)

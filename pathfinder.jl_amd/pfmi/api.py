@@ -311,12 +311,14 @@ def _make_dists(eng, p0, npts, status, jeff, materialise=True):
     return [_make_dist(eng, p0 + l, jeff, True) for l in range(npts)]
 
 
-def fit_mvnormals(points, gradients, history_length=5, engine=None, eps=1e-12):
-    """fit_mvnormals(θs, ∇logpθs; history_length) -> (dists, num_bfgs_updates_rejected)
-    reference src/mvnormal.jl:14-21.  Raises PosDefException like WoodburyPDMat's constructor."""
+def fit_mvnormals(points, gradients, history_length=5, engine=None, eps=1e-12, Hinit="gilbert"):
+    """fit_mvnormals(θs, ∇logpθs; history_length, Hinit, ϵ) -> (dists, num_bfgs_updates_rejected)
+    reference src/mvnormal.jl:14-21 (keywords forwarded to lbfgs_inverse_hessians, src/inverse_hessian.jl:25).  Hinit: "gilbert" (the
+    reference's default gilbert_init) or "nocedal_wright" ((α, s, y) -> fill(y's / y'y), test/inverse_hessian.jl:49).  Raises
+    PosDefException like WoodburyPDMat's constructor."""
     eng = engine or Engine()
     eng.set_traces([np.asarray(points)], [np.asarray(gradients)])
-    eng.fit_batch(history_length, eps)
+    eng.fit_batch(history_length, eps, hinit=Hinit)
     status, jeff, _, nrej = eng.fit_status()
     bad = np.nonzero(status)[0]
     if len(bad):
@@ -472,31 +474,44 @@ def _run_paths(engs, target, inits, run_rngs, *, dim, history_length, ndraws_elb
                     eng.stream_enqueue(np.stack([s["x0"] for s in state[k0:k1]]), ndraws_elbo, None, history_length, **okw)
                 streamed = True
             except PfmiError as ex:
-                if getattr(ex, "code", 0) != -4 or eng is not engs[0]:    # PFMI_ERR_UNSUPPORTED on the first engine: the packed route below
+                for e2 in engs:                                     # engines enqueued before the refusal / failure are released
+                    e2.stream_cancel()
+                if getattr(ex, "code", 0) != -4:                    # PFMI_ERR_UNSUPPORTED: the packed route below (on every engine)
                     raise
                 stream_ok = False
-            if streamed:
+            except BaseException:
+                for e2 in engs:                                     #  an engine enqueued before the failure must not stay "active":
+                    e2.stream_cancel()                              # a caller's persistent Engine has to survive a failed call
+                raise
+        if streamed:
+            try:
                 for k, sd in zip(pending, rand_u64_multi([run_rngs[k].copy() for k in pending], [cap] * len(pending))):
                     state[k]["stream_tab"] = sd
                 predrawn = {k: state[k]["stream_tab"] for k in pending}
                 for eng, (k0, k1) in zip(engs, blocks):
                     eng.stream_seeds(np.concatenate([s["stream_tab"] for s in state[k0:k1]]))
-        if streamed:
-            active = list(zip(engs, blocks))
-            gc_was_on = gc.isenabled()
-            gc.disable()                    # this thread IS the pipeline's scheduler for the next millisecond or two: a full collection (tens of
-            try:                            # milliseconds) in here would starve every GPU it drives (profiles/r05_experiments.md section 5)
-                while active:                                       # the calling thread schedules every engine's pipeline
-                    active = [(eng, b) for eng, b in active if not eng.stream_pump()]
-            finally:
-                if gc_was_on:
-                    gc.enable()
-            for eng, (k0, k1) in zip(engs, blocks):
-                npts = eng.stream_wait()
-                for k in range(k0, k1):
-                    state[k]["trace"] = DeviceOptimizationTrace(eng, k - k0, int(npts[k - k0]))
-                    if materialise:
-                        state[k]["trace"].materialise()
+                active = list(zip(engs, blocks))
+                gc_was_on = gc.isenabled()
+                gc.disable()                # this thread IS the pipeline's scheduler for the next millisecond or two: a full collection (tens of
+                try:                        # milliseconds) in here would starve every GPU it drives (profiles/r05_experiments.md section 5)
+                    while active:                                   # the calling thread schedules every engine's pipeline
+                        active = [(eng, b) for eng, b in active if not eng.stream_pump()]
+                finally:
+                    if gc_was_on:
+                        gc.enable()
+                for eng, (k0, k1) in zip(engs, blocks):
+                    npts = eng.stream_wait()
+                    for k in range(k0, k1):
+                        state[k]["trace"] = DeviceOptimizationTrace(eng, k - k0, int(npts[k - k0]))
+                        if materialise:
+                            state[k]["trace"].materialise()
+            except BaseException:           # KeyboardInterrupt while pumping, a failure in the seed draw, an engine's pump error: no engine
+                for e2 in engs:             # may be left with a streaming call outstanding
+                    try:
+                        e2.stream_cancel()
+                    except Exception:
+                        pass
+                raise
         elif on_device:     # every path in one launch per engine; finished paths are recomputed identically from their x0
             for eng, (k0, k1) in zip(engs, blocks):
                 eng.optimize_batch_enqueue(np.stack([s["x0"] for s in state[k0:k1]]), history_length, **okw)

@@ -68,6 +68,10 @@ class StaleHandleError(RuntimeError):
     given new traces / refitted: the reference's results own their data, these handles only index device buffers."""
 
 
+# Hinit of lbfgs_inverse_hessians (src/inverse_hessian.jl:25): the reference's default and the scaling its own test passes (test/inverse_hessian.jl:49)
+HINIT = {"gilbert": 0, "gilbert_init": 0, 0: 0, "nocedal_wright": 1, "nocedal_wright_scaling": 1, 1: 1}
+
+
 class Engine:
     def __init__(self, device=0):
         self.gen_traces = self.gen_fit = self.gen_pool = 0   # bumped by set_traces/optimize_batch, fit_batch, pool_build
@@ -239,6 +243,10 @@ class Engine:
         self.npoints = npts
         return npts
 
+    def stream_cancel(self):
+        """give up an outstanding stream_enqueue (a host failure between enqueue and wait): drains what is in flight; no-op otherwise"""
+        check(self.L.pfmi_stream_cancel(self.ctx))
+
     def path_len(self, k):
         """trace points of path k (the streaming layout reserves maxiters + 1 slots per path and fills the first npoints[k])"""
         if getattr(self, "npoints", None) is not None:
@@ -253,10 +261,19 @@ class Engine:
         return theta, lp, grad
 
     # ---- fit -------------------------------------------------------------------------------------------
-    def fit_batch(self, history_length=6, eps=1e-12):
+    def fit_batch(self, history_length=6, eps=1e-12, hinit=None):
+        """hinit: None (the context's default, gilbert_init unless set_hinit changed it), "gilbert" or "nocedal_wright" -- the `Hinit`
+        keyword of lbfgs_inverse_hessians (src/inverse_hessian.jl:25)"""
         self.J = history_length
         self.gen_fit += 1
-        check(self.L.pfmi_fit_batch(self.ctx, C.c_int32(history_length), C.c_double(eps)))
+        if hinit is None:
+            check(self.L.pfmi_fit_batch(self.ctx, C.c_int32(history_length), C.c_double(eps)))
+        else:
+            check(self.L.pfmi_fit_batch_ex(self.ctx, C.c_int32(history_length), C.c_double(eps), C.c_int32(HINIT[hinit])))
+
+    def set_hinit(self, hinit):
+        """the context's default Hinit (pfmi_fit_batch and the streaming pipeline use it)"""
+        check(self.L.pfmi_set_hinit(self.ctx, C.c_int32(HINIT[hinit])))
 
     def fit_status(self):
         status = np.empty(self.P, dtype=np.int32)

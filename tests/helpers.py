@@ -69,3 +69,19 @@ def oracle_factor_from_gpu(f):
     F.V = np.asfortranarray(f["V"]) if k else np.zeros((1, 1), order="F")
     F.status, F.logdet = 0, float(f["logdet"])
     return F
+
+
+class Banana:
+    """the reference's banana density with its gradient (test/test_utils.jl:29-36: y = [x1; x2 + b (x1^2 - 100); x3..], Sigma =
+    diag(100, 1, ..), logp = -y' Sigma^-1 y / 2, b = 0.03) -- the target of test/inverse_hessian.jl:46-76"""
+    def __init__(self, n=10, b=0.03):
+        self.d, self.b = n, b
+        self.sig = np.r_[100.0, np.ones(n - 1)]
+
+    def logp_and_grad(self, x):
+        y = x.copy()
+        y[1] = x[1] + self.b * (x[0] ** 2 - 100.0)
+        w = y / self.sig
+        g = -w.copy()
+        g[0] += -w[1] * 2 * self.b * x[0]
+        return float(-0.5 * (y @ w)), g

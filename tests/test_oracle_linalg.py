@@ -235,25 +235,52 @@ def test_inverse_hessian_reproduces_the_lbfgs_direction_on_the_banana():
     took: dot(p, s) / (|p| |s|) = 1, and no update is rejected.  The trace comes from this repo's host driver (two-loop recursion,
     the same initialisation); the inverse Hessian from the oracle's restatement of src/inverse_hessian.jl:98-133."""
     from pfmi.optimize import optimize_with_trace
-    n, J, b = 10, 5, 0.03
-    sig = np.r_[100.0, np.ones(n - 1)]
-
-    class Banana:                                           # test/test_utils.jl:29-36
-        def logp_and_grad(self, x):
-            y = x.copy()
-            y[1] = x[1] + b * (x[0] ** 2 - 100.0)
-            w = y / sig
-            g = -w.copy()
-            g[0] += -w[1] * 2 * b * x[0]
-            return float(-0.5 * (y @ w)), g
-
+    from helpers import Banana
+    n, J = 10, 5
     rng = np.random.default_rng(7)
     total = 0
     for _ in range(4):
-        tr = optimize_with_trace(Banana(), 10 * rng.normal(size=n), J, 1000)
+        tr = optimize_with_trace(Banana(n), 10 * rng.normal(size=n), J, 1000)
         total += len(tr)
         _check_directions(tr, n, J)
     assert total > 40
+
+
+def test_oracle_hinit_switch_is_the_nocedal_wright_walk():
+    """The oracle's `Hinit` switch (pfo_set_hinit(1): alpha = fill(y's / y'y) at every accepted step, test/inverse_hessian.jl:49) against
+    a literal NumPy walk of src/inverse_hessian.jl:25-66 with that Hinit, on banana traces; and the reference's property itself through the
+    oracle's own walk + compact form + factor: H_l * grad_l is parallel to the step the optimiser took (test/inverse_hessian.jl:62-76)."""
+    from helpers import Banana
+    from pfmi.optimize import optimize_with_trace
+    n, J = 10, 5
+    rng = np.random.default_rng(11)
+    try:
+        po.set_hinit("nocedal_wright")
+        for _ in range(3):
+            tr = optimize_with_trace(Banana(n), 10 * rng.normal(size=n), J, 1000)
+            P, G = tr.points, tr.gradients
+            alpha_all, hist_len, hist_src, rej = po.lbfgs_history(P, G, J)
+            assert rej == 0
+            alpha = np.ones(n)
+            for l in range(1, len(tr)):
+                s, y = P[l] - P[l - 1], G[l - 1] - G[l]
+                if y @ s > 1e-12 * (y @ y):
+                    alpha = np.full(n, (y @ s) / (y @ y))
+                np.testing.assert_allclose(alpha_all[l], alpha, rtol=1e-15)
+            for l in range(1, len(tr) - 1):
+                j = hist_len[l]
+                src = hist_src[l, :j]
+                S = np.stack([P[q + 1] - P[q] for q in src], axis=1)
+                Y = np.stack([G[q] - G[q + 1] for q in src], axis=1)
+                B, D = po.lbfgs_inverse_hessian(alpha_all[l], S, Y)
+                F = po.Factor(alpha_all[l], B, D)
+                p = F.mul_W(G[l][:, None])[:, 0]
+                step = P[l + 1] - P[l]
+                assert abs((p @ step) / np.linalg.norm(p) / np.linalg.norm(step) - 1) < 1e-8
+    finally:
+        po.set_hinit("gilbert")
+    a0 = po.lbfgs_history(P, G, J)[0]                      # back to gilbert_init: a different diagonal
+    assert not np.allclose(a0[-1], alpha_all[-1])
 
 
 def _check_directions(tr, n, J):
