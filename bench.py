@@ -41,10 +41,16 @@ for _p in (ROOT, os.path.join(ROOT, "pathfinder.jl_amd"), os.path.join(ROOT, "te
 import numpy as np  # noqa: E402
 
 
-class _DevArray:
-    """zero-copy view of a libpfmi device buffer for torch (CUDA array interface); fallback collective path only"""
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+def _blocks(K, G):
+    """contiguous blocks of paths, one per GPU, the first K % G one path longer (any npaths over any GPU count, like the reference's
+    nruns over tasks, src/multipath.jl:131-146); returns the G + 1 block boundaries"""
+    if K < G:
+        sys.exit(f"bench.py: npaths={K} is smaller than the number of GPUs {G}")
+    base, rem = divmod(K, G)
+    b = [0]
+    for g in range(G):
+        b.append(b[-1] + base + (1 if g < rem else 0))
+    return b
 
 
 def _self_launch(ngpus):
@@ -176,8 +182,7 @@ def main_single_process(args):
     import pfmi
     from pfmi.hostrng import rand_u64
     K, d, N_e, J, ndraws, G = args.npaths, args.dim, args.ndraws_elbo, args.history, args.ndraws, args.gpus
-    assert K % G == 0, "npaths must be divisible by the number of GPUs"
-    Kl = K // G
+    bk = _blocks(K, G)
     N_r = max(N_e, -(-ndraws // K))
     master = 20260928
     tg = {"lowrank": lambda: pfmi.t_lowrank(d, r=8, seed=2), "diag": lambda: pfmi.t_diag(d, seed=1), "iso": lambda: pfmi.t_iso(d),
@@ -192,14 +197,14 @@ def main_single_process(args):
     for e in engs:
         e.set_target(tg)
     for g, e in enumerate(engs):
-        e.optimize_batch_enqueue(x0[g * Kl:(g + 1) * Kl], J, args.maxiters)
+        e.optimize_batch_enqueue(x0[bk[g]:bk[g + 1]], J, args.maxiters)
     seeds = []
     for g, e in enumerate(engs):
         npts = e.optimize_batch_wait()
-        seeds.append(np.concatenate([rand_u64(int(run_seeds[g * Kl + i]), np.arange(n, dtype=np.uint64), 10) for i, n in enumerate(npts)]))
+        seeds.append(np.concatenate([rand_u64(int(run_seeds[bk[g] + i]), np.arange(n, dtype=np.uint64), 10) for i, n in enumerate(npts)]))
     comm = pfmi.Comm.init_all(engs)
     info = comm.info()
-    total_draws = float(sum((e.P - Kl) * N_e for e in engs))
+    total_draws = float(sum((e.P - (bk[g + 1] - bk[g])) * N_e for g, e in enumerate(engs)))
     state = {}
 
     def step():
@@ -233,7 +238,8 @@ def main_single_process(args):
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"multipathfinder npaths={K} d={d} target={args.target}, history_length={J}, ndraws_elbo={N_e}, ndraws={ndraws}",
-                       "npaths": K, "paths_per_gpu": Kl, "fits_total": int(total_draws // N_e), "elbo_draws_per_step": int(total_draws),
+                       "npaths": K, "paths_per_gpu": [bk[g + 1] - bk[g] for g in range(G)], "fits_total": int(total_draws // N_e),
+                       "elbo_draws_per_step": int(total_draws),
                        "parallelism": f"paths sharded x{G}, ONE host process / thread (pfmi_comm_init_all)",
                        "ranks_in_collective": info["world"], "rccl_version": info["rccl_version"]},
             "pareto_k": state.get("pareto_k"), "sharded_equals_single": verdict, "sharded_equals_single_note": vnote,
@@ -305,9 +311,8 @@ def main():
 
     K, d, N_e, J, ndraws = args.npaths, args.dim, args.ndraws_elbo, args.history, args.ndraws
     G = world
-    assert K % G == 0, "npaths must be divisible by the number of GPUs"
-    Kl = K // G
-    k0 = rank * Kl
+    bk = _blocks(K, G)
+    k0, Kl = bk[rank], bk[rank + 1] - bk[rank]
     N_r = max(N_e, -(-ndraws // K))                                 # reference src/multipath.jl:138
     master = 20260928
 
@@ -336,37 +341,22 @@ def main():
     if not use_dist:
         comm = pfmi.Comm.init_all([eng])                            # a world of one context: same entry points, no RCCL involved
     if use_dist:
-        # the data-path collectives go through the C ABI (pfmi_comm_*: ncclAllGather / ncclAllReduce on the engine's stream,
-        # csrc/comm_rccl.hip); torch.distributed only ships the 128-byte RCCL id, the barrier and the timing reduction
+        # the data-path collectives go through the C ABI (pfmi_comm_*: ncclAllGather of the log-ratio shards, ncclSend / ncclRecv of the selected
+        # columns to rank 0, on the engine's stream, csrc/comm_rccl.hip); torch.distributed only ships the 128-byte RCCL id, the barrier and
+        # the timing reduction.  There is no second data path: if the group cannot be formed the run fails on every rank.
         comm_note = "RCCL through the C ABI (pfmi_comm_*), torch nccl group for barrier / timing"
-        try:
-            if os.environ.get("PFMI_BENCH_COMM") == "torch":        # test hook: exercise the fallback branch
-                raise RuntimeError("PFMI_BENCH_COMM=torch")
-            uid = [None]
-            if rank == 0:
-                try:
-                    uid = [pfmi.Comm.unique_id()]
-                except Exception as ex0:                            # every rank must still reach the broadcast
-                    uid = [("error", repr(ex0))]
-            dist.broadcast_object_list(uid, src=0)
-            if not isinstance(uid[0], (bytes, bytearray)):
-                raise RuntimeError(f"rank 0 could not create an RCCL id: {uid[0]}")
-            comm = pfmi.Comm.init_rank(eng, world, rank, uid[0])
-            info = comm.info()
-            assert info["world"] == world, info
-            ok = 1.0
-        except Exception as ex:                                     # reported in the JSON line, never silent
-            comm, ok, comm_note = None, 0.0, f"torch.distributed nccl collectives on engine memory (pfmi_comm_init_rank failed: {ex!r})"
-        import torch
-        flag = torch.tensor([ok], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)                 # all ranks take the same path
-        if float(flag[0]) < 1.0:
-            if comm is not None:
-                comm.close()
-                comm = None
-                comm_note = "torch.distributed nccl collectives on engine memory (pfmi_comm_init_rank failed on another rank)"
-            lr_all = torch.empty(K * N_r, dtype=torch.float64, device=f"cuda:{local_rank}")
-            out_dev = torch.zeros(ndraws * d, dtype=torch.float64, device=f"cuda:{local_rank}")
+        uid = [None]
+        if rank == 0:
+            try:
+                uid = [pfmi.Comm.unique_id()]
+            except Exception as ex0:                            # every rank must still reach the broadcast
+                uid = [("error", repr(ex0))]
+        dist.broadcast_object_list(uid, src=0)
+        if not isinstance(uid[0], (bytes, bytearray)):
+            sys.exit(f"bench.py: rank 0 could not create an RCCL id: {uid[0]}")
+        comm = pfmi.Comm.init_rank(eng, world, rank, uid[0])
+        info = comm.info()
+        assert info["world"] == world, info
 
     state = {}
     self_check_failures = []
@@ -388,29 +378,16 @@ def main():
             eng.elbo_batch_enqueue(N_e, seeds)
         eng.pool_build_best(N_r)                                    # winners (fit_iteration per path) picked on the device
         if comm is not None:
-            # [ONE RCCL all-gather of the log-ratio shards] + replicated PSIS + replicated indices + owner gather [+ sum all-reduce],
-            # one synchronisation, D2H of k-hat / indices / draws
+            # [ONE RCCL all-gather of the log-ratio shards] + replicated PSIS + replicated indices + owner-only transfer of the selected
+            # columns (one process per GPU: ncclSend / ncclRecv to rank 0, which alone holds the d x ndraws result), D2H of k-hat / indices / draws
             comm.psis_resample_enqueue(ndraws, seed=master)
             eng.defer(1)                                            # the ELBO tables' downloads are queued behind the pooled stage ...
             elbo, se, best = eng.elbo_batch_wait()
             eng.defer(0)
-            res, idx, state["draws"] = comm.psis_resample_wait()    # ... and this ONE wait delivers everything
+            res, idx, state["draws"] = comm.psis_resample_wait(want_draws=(rank == 0))    # ... and this ONE wait delivers everything
             state.update(elbo=elbo, best=best, pareto_k=res["pareto_shape"], tail=res["tail_length"], idx=idx)
             return
-        elif use_dist:                                              # fallback: the same orchestration through torch.distributed
-            import torch
-            from pfmi.distributed import pooled_psis_resample
-            ptr, cnt = eng.pool_log_ratios_dev()
-            shard = torch.as_tensor(_DevArray(ptr, cnt), device=f"cuda:{local_rank}")
-            res, idx = pooled_psis_resample(
-                dist, shard, lr_all, out_dev,
-                psis_fn=lambda t: eng.psis_dev(t.data_ptr(), t.numel(), want_weights=False),
-                sample_fn=lambda S: eng.resample_indices(S, ndraws, seed=master),
-                gather_fn=lambda ix, o: eng.pool_gather_dev(ix, k0 * N_r, o.data_ptr()),
-                sync_fn=torch.cuda.synchronize, min_world=1)
-            state["draws"] = out_dev
-        elbo, se, best = eng.elbo_batch_wait()                      # already complete: plain downloads
-        state.update(elbo=elbo, best=best, pareto_k=res["pareto_shape"], tail=res["tail_length"], idx=idx)
+        raise RuntimeError("no communicator")
 
     def barrier():
         eng.sync()
@@ -441,7 +418,7 @@ def main():
     stages, scan_ms, scan_n = {}, 0.0, 0
     if timed_stages:
         for name in ("history", "fit", "elbo_draws", "elbo_draws_x", "elbo_reduce", "psis", "resample", "comm_handshake_host", "comm_allgather",
-                     "comm_allreduce"):
+                     "comm_sendrecv"):
             ms_, n_ = eng.kernel_time(name)
             stages[name] = {"ms": round(ms_ / max(n_, 1), 4), "launches": int(n_),      # average per launch
                             "ms_per_step": round(ms_ / max(args.steps, 1), 4)}
@@ -474,10 +451,7 @@ def main():
             pass
     if (args.verify_sharding or (world > 1 and not args.no_verify_sharding)) and not args.minimal and not args.host_traces:
         from pfmi.distributed import result_fingerprint, sharded_equals_single
-        dr = state["draws"]
-        if not isinstance(dr, np.ndarray):                              # fallback collective path: a flat device tensor, draw-major
-            dr = np.asfortranarray(dr.cpu().numpy().reshape(ndraws, d).T)
-        mine = result_fingerprint(state["pareto_k"], state["tail"], state["idx"], dr)
+        mine = result_fingerprint(state["pareto_k"], state["tail"], state["idx"], state["draws"])    # (draws: rank 0 only, the result lives there)
         ref = None
         if rank == 0:
             x0_all = np.stack([pfmi.HostRNG(int(run_seeds[k])).rand(d) * 2 * sc - sc for k in range(K)])
@@ -783,7 +757,7 @@ def main():
         shard_ms = ps("fit") + ps("elbo_draws") + ps("elbo_draws_x") + ps("elbo_reduce")
         fixed = {"history_walk": ps("history"), "psis_replicated": ps("psis"), "index_selection_and_owner_gather": ps("resample"),
                  "collective_handshake_host": ps("comm_handshake_host"), "all_gather_log_ratios": ps("comm_allgather"),
-                 "result_all_reduce": ps("comm_allreduce")}
+                 "owned_columns_to_rank0": ps("comm_sendrecv")}
         fixed["host_launch_gaps_and_result_download"] = round(ms_per_step - shard_ms - sum(fixed.values()), 4)
         non_sharding = {"per_step_ms": fixed, "sharding_stages_ms": round(shard_ms, 4), "step_ms": round(ms_per_step, 4),
                         "non_sharding_total_ms": round(ms_per_step - shard_ms, 4),

@@ -164,6 +164,10 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
     const uint32_t icdf_adj = pf_icdf_adj<XW_NB>(icdf);
     // every draw of this launch starts on a 32-byte boundary: the 16-byte stores are aligned
     const bool x_aligned = ((d & 3) == 0) && ((A.x_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(A.x) & 31) == 0);
+    // the priority hand-over between the two waves of a SIMD pays when the factor block is resident (config 3: 4.93 -> 4.71 ms); with a streamed
+    // block every chunk ends in a barrier that re-aligns the waves anyway, and the hand-over only costs (config-5 shape: 34.1 -> 33.0 ms
+    // without it; profiles/r06_experiments.md)
+    const bool fair = nchunks == 1;
     __syncthreads();
 
     int cur = 0;
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
                         for (int bl = 0; bl < ((XW_ABLATE & 4) ? 1 : nb); ++bl) {
                             const int blk = blk0 + bl;
 #if XW_PRIO_FAIR
-                            if ((blk & (XW_PRIO_FAIR - 1)) == 0) {           // the two waves of a SIMD take turns at the higher issue priority (see elbo_qf_kernel.hip)
+                            if (fair && (blk & (XW_PRIO_FAIR - 1)) == 0) {   // the two waves of a SIMD take turns at the higher issue priority (see elbo_qf_kernel.hip)
                                 if (((blk / XW_PRIO_FAIR) ^ (wv >> 2) ^ lb ^ pass) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
                             }
 #endif
@@ -330,9 +334,14 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
                         }
                     } else {
                         // ---- pass 2: the same normals again, x~ = z - Vh tv, x = mu + sqrt(alpha) x~, full-line stores
-                        auto body2 = [&](const int bl, auto special_tag, auto nga_tag) {
+                        // FAST (round 6): every group of this wave is a full, 32-byte-aligned block of 16 draws (decided once per batch, wave-uniform):
+                        // the interior body then holds no store predicate and no branch at all; the MFMA chains of the groups are issued
+                        // INTERLEAVED (s outer, g inner: a group's chain order is unchanged -- same bits), so that a chain's result latency is
+                        // covered by the other group's MFMAs instead of s_nop, and the fma + store tails follow the last MFMA
+                        auto body2 = [&](const int bl, auto special_tag, auto nga_tag, auto fast_tag) {
                             constexpr bool SPECIAL = decltype(special_tag)::value;
                             constexpr int NGA = decltype(nga_tag)::value;
+                            constexpr bool FAST = decltype(fast_tag)::value;
                             const int blk = blk0 + bl;
                             // A[i' = c][k = q] = Vh[16 blk + rho(c)][4 s + q]
                             const double *a2p = vs + ((bl * 4 + (c >> 2)) * NT << 4) + (c & 3) * 4 + q;
@@ -353,17 +362,21 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
                                 normals(g, blk, z[g], std::false_type{}, special_tag);
 #endif
                             }
+                            xw_d4 xa[NGA];
+#pragma unroll
+                            for (int g = 0; g < NGA; ++g) xa[g] = xw_d4{z[g][0], z[g][1], z[g][2], z[g][3]};
+#pragma unroll
+                            for (int s = 0; s < ((XW_ABLATE & 64) ? 0 : NT); ++s)
+#pragma unroll
+                                for (int g = 0; g < NGA; ++g) xa[g] = xw_mfma16(a2v[s], ntv[g][s], xa[g]);
 #pragma unroll
                             for (int g = 0; g < NGA; ++g) {
-                                xw_d4 xa = {z[g][0], z[g][1], z[g][2], z[g][3]};
-#pragma unroll
-                                for (int s = 0; s < ((XW_ABLATE & 64) ? 0 : NT); ++s) xa = xw_mfma16(a2v[s], ntv[g][s], xa);
                                 double xv[4];
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) xv[r] = fma(s4[r], xa[r], m4[r]);       // x = mu + sqrt(alpha) x~
+                                for (int r = 0; r < 4; ++r) xv[r] = fma(s4[r], xa[g][r], m4[r]);    // x = mu + sqrt(alpha) x~
                                 double *xo = xg[g] + (size_t)c * d + blk * 16 + 4 * q;              // rows 4q .. 4q+3 of draw c: 32 contiguous bytes
                                 if ((XW_ABLATE & 1) && xv[0] != 1.2345e301) continue;
-                                if (!SPECIAL && fullc[g] && x_aligned) {
+                                if (FAST || (!SPECIAL && fullc[g] && x_aligned)) {
                                     typedef double xw_d2 __attribute__((ext_vector_type(2)));
                                     xw_d2 lo = {xv[0], xv[1]}, hi = {xv[2], xv[3]};
                                     *reinterpret_cast<xw_d2 *>(xo) = lo;
@@ -375,17 +388,22 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
                                 }
                             }
                         };
+                        bool fast_all = x_aligned;
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) fast_all = fast_all && fullc[g];
+                        fast_all = __builtin_amdgcn_readfirstlane((int)fast_all) != 0;      // wave-uniform (groups are per wave): a scalar branch, no exec masking
                         for (int bl = 0; bl < nb; ++bl) {
                             const int blk = blk0 + bl;
 #if XW_PRIO_FAIR
-                            if ((blk & (XW_PRIO_FAIR - 1)) == 0) {           // the two waves of a SIMD take turns at the higher issue priority (see elbo_qf_kernel.hip)
+                            if (fair && (blk & (XW_PRIO_FAIR - 1)) == 0) {   // the two waves of a SIMD take turns at the higher issue priority (see elbo_qf_kernel.hip)
                                 if (((blk / XW_PRIO_FAIR) ^ (wv >> 2) ^ lb ^ pass) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
                             }
 #endif
                             const bool special = (blk == 0) | (blk == nblk - 1) | (KC > 16 && blk == 1);
                             // (the groups of a wave that lie beyond the last one are computed too -- their stores are predicated off)
-                            if (__builtin_expect(special, 0)) body2(bl, std::true_type{}, std::integral_constant<int, NG>{});
-                            else body2(bl, std::false_type{}, std::integral_constant<int, NG>{});
+                            if (__builtin_expect(special, 0)) body2(bl, std::true_type{}, std::integral_constant<int, NG>{}, std::false_type{});
+                            else if (fast_all) body2(bl, std::false_type{}, std::integral_constant<int, NG>{}, std::true_type{});
+                            else body2(bl, std::false_type{}, std::integral_constant<int, NG>{}, std::false_type{});
                         }
                     }
                 }

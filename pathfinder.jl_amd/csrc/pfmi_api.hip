@@ -1648,7 +1648,7 @@ int32_t pfmi_free_dev(pfmi_ctx *c, void *dev_ptr) {
 int32_t pfmi_host_alloc(int64_t bytes, void **host_ptr) {
     PF_CHECK(bytes > 0 && host_ptr, PFMI_ERR_ARG, "host_alloc: bad arguments");
     *host_ptr = nullptr;
-    PF_HIP(hipHostMalloc(host_ptr, (size_t)bytes, hipHostMallocPortable));
+    PF_HIP(hipHostMalloc(host_ptr, (size_t)bytes, hipHostMallocPortable | hipHostMallocMapped));   // (mapped: the owner-only assembly of a multi-GPU result writes into it from every GPU)
     return PFMI_OK;
 }
 int32_t pfmi_host_free(void *host_ptr) {

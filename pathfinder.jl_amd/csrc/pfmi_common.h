@@ -261,7 +261,10 @@ int32_t pf_launch_pool_pick(pfmi_ctx *c, int have_fail_seeds);
 // d_lp[s * N + n] = NaN for every slot s whose fit d_points[s] failed
 int32_t pf_launch_nan_failed(pfmi_ctx *c, int64_t npts, int64_t N, const int32_t *d_points, double *d_lp);
 int32_t pf_launch_resample_direct(pfmi_ctx *c, int64_t S, int64_t ndraws, const double *d_uniforms);
-int32_t pf_launch_gather(pfmi_ctx *c, int64_t ndraws, const int64_t *d_idx, int64_t col_offset, double *d_out);
+int32_t pf_launch_gather(pfmi_ctx *c, int64_t ndraws, const int64_t *d_idx, int64_t col_offset, double *d_out, bool skip_unowned = false);
+int32_t pf_launch_gather_pos(pfmi_ctx *c, int64_t n, const int64_t *d_idx, const int64_t *d_pos, int64_t col_offset, double *d_out);
+int32_t pf_launch_scatter_cols(pfmi_ctx *c, int64_t n, const int64_t *d_pos, const double *d_in, double *d_out);
+int32_t pf_launch_idx_digest(pfmi_ctx *c, int64_t ndraws, const int64_t *d_idx, double *d_out4, double local_err);
 int32_t pf_launch_logratio(pfmi_ctx *c, int64_t n);
 int32_t pf_launch_scatter_rows(pfmi_ctx *c, int64_t ns, int64_t N, const int32_t *d_points, const double *d_src, double *d_dst);
 int32_t pf_launch_lbfgs(pfmi_ctx *c, int K, int J, int maxiters, double g_tol, const double *d_x0, int pub_mask = -1, int32_t *h_prog = nullptr);

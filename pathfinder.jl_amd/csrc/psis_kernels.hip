@@ -676,17 +676,50 @@ __global__ void pf_direct_sample_kernel(long long S, long long ndraws, const dou
     idx[t] = lo;
 }
 
-// out[:, t] = owned(idx[t]) ? pool[:, idx[t] - col_offset] : 0
+// out[:, t] = owned(idx[t]) ? pool[:, idx[t] - col_offset] : 0     (skip_unowned: columns of other ranks are left untouched -- the owner-only
+// assembly of the multi-GPU result, csrc/comm_rccl.hip: every rank writes ITS columns of one shared, host-resident result)
 __global__ void pf_gather_kernel(int d, long long ndraws, long long ncols_local, long long col_offset,
                                  const int64_t *__restrict__ idx, const double *__restrict__ pool,
-                                 double *__restrict__ out) {
+                                 double *__restrict__ out, int skip_unowned) {
     const long long t = blockIdx.x;
     const long long g = idx[t] - col_offset;
     const bool own = (g >= 0 && g < ncols_local);
+    if (!own && skip_unowned) return;
     for (int i = threadIdx.x; i < d; i += blockDim.x)
         out[(size_t)t * d + i] = own ? pool[(size_t)g * d + i] : 0.0;
 }
-
+// compact owner gather: out[:, j] = pool[:, idx[pos[j]] - col_offset], j < n   (the columns a rank SENDS to the root, in selection order)
+__global__ void pf_gather_pos_kernel(int d, long long ncols_local, long long col_offset, const int64_t *__restrict__ idx,
+                                     const int64_t *__restrict__ pos, const double *__restrict__ pool, double *__restrict__ out) {
+    const long long j = blockIdx.x;
+    const long long g = idx[pos[j]] - col_offset;
+    const bool own = (g >= 0 && g < ncols_local);                      // (always true by construction; a foreign column would be NaN, never stale)
+    for (int i = threadIdx.x; i < d; i += blockDim.x)
+        out[(size_t)j * d + i] = own ? pool[(size_t)g * d + i] : __longlong_as_double(0x7FF8000000000000ll);
+}
+// out[:, pos[j]] = in[:, j]   (the root places the columns it received, rank by rank, at their selection positions)
+__global__ void pf_scatter_cols_kernel(int d, const int64_t *__restrict__ pos, const double *__restrict__ in, double *__restrict__ out) {
+    const long long j = blockIdx.x;
+    const long long t = pos[j];
+    for (int i = threadIdx.x; i < d; i += blockDim.x) out[(size_t)t * d + i] = in[(size_t)j * d + i];
+}
+// order-independent 52-bit digest of the selected indices (exact in a double): the ranks of a process-per-GPU group compare it
+__global__ void pf_idx_digest_kernel(long long ndraws, const int64_t *__restrict__ idx, double *__restrict__ out4, double local_err) {
+    __shared__ unsigned long long sh[256];
+    unsigned long long h = 0;
+    for (long long t = threadIdx.x; t < ndraws; t += blockDim.x) {
+        unsigned long long v = (unsigned long long)idx[t] * 0x9E3779B97F4A7C15ull + (unsigned long long)t * 0xC2B2AE3D27D4EB4Full;
+        v ^= v >> 29; v *= 0xBF58476D1CE4E5B9ull; v ^= v >> 32;
+        h += v;
+    }
+    sh[threadIdx.x] = h;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) {
+        const double hv = (double)(sh[0] >> 12);                        // 52 bits: exactly representable
+        out4[0] = local_err; out4[1] = hv; out4[2] = -hv; out4[3] = 0.0;
+    }
+}
 
 // ---- PSIS with a tail beyond the LDS capacity (M + 1 > TAILCAP, i.e. pools of more than 1 863 225 draws; round 4) -----------------
 // The (key, index) pairs of ALL log ratios are sorted in global memory (the bitonic kernels above; padding keys 0 sort to the front),
@@ -928,12 +961,34 @@ int32_t pf_launch_resample_direct(pfmi_ctx *c, int64_t S, int64_t ndraws, const 
     return PFMI_OK;
 }
 
-int32_t pf_launch_gather(pfmi_ctx *c, int64_t ndraws, const int64_t *d_idx, int64_t col_offset, double *d_out) {
+int32_t pf_launch_gather(pfmi_ctx *c, int64_t ndraws, const int64_t *d_idx, int64_t col_offset, double *d_out, bool skip_unowned) {
     if (ndraws <= 0) return PFMI_OK;
     pf_kernel_begin(c);
     hipLaunchKernelGGL(pf_gather_kernel, dim3((unsigned)ndraws), dim3(256), 0, c->stream, c->d, (long long)ndraws,
-                       (long long)(c->K * c->N_r), (long long)col_offset, d_idx, c->pool.as<double>(), d_out);
+                       (long long)(c->K * c->N_r), (long long)col_offset, d_idx, c->pool.as<double>(), d_out, skip_unowned ? 1 : 0);
     pf_kernel_end(c, "resample");
+    PF_HIP(hipGetLastError());
+    return PFMI_OK;
+}
+int32_t pf_launch_gather_pos(pfmi_ctx *c, int64_t n, const int64_t *d_idx, const int64_t *d_pos, int64_t col_offset, double *d_out) {
+    if (n <= 0) return PFMI_OK;
+    pf_kernel_begin(c);
+    hipLaunchKernelGGL(pf_gather_pos_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, c->d, (long long)(c->K * c->N_r), (long long)col_offset,
+                       d_idx, d_pos, c->pool.as<double>(), d_out);
+    pf_kernel_end(c, "resample");
+    PF_HIP(hipGetLastError());
+    return PFMI_OK;
+}
+int32_t pf_launch_scatter_cols(pfmi_ctx *c, int64_t n, const int64_t *d_pos, const double *d_in, double *d_out) {
+    if (n <= 0) return PFMI_OK;
+    pf_kernel_begin(c);
+    hipLaunchKernelGGL(pf_scatter_cols_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, c->d, d_pos, d_in, d_out);
+    pf_kernel_end(c, "resample");
+    PF_HIP(hipGetLastError());
+    return PFMI_OK;
+}
+int32_t pf_launch_idx_digest(pfmi_ctx *c, int64_t ndraws, const int64_t *d_idx, double *d_out4, double local_err) {
+    hipLaunchKernelGGL(pf_idx_digest_kernel, dim3(1), dim3(256), 0, c->stream, (long long)ndraws, d_idx, d_out4, local_err);
     PF_HIP(hipGetLastError());
     return PFMI_OK;
 }

@@ -538,9 +538,10 @@ end
 # per-engine downloads (status, ELBO table, winners) come last, when everything is already in flight.
 "contiguous blocks of runs, one per engine (pool order stays k-major, src/resample.jl:93)"
 function _blocks(K::Int, G::Int)
-    K % G == 0 || throw(ArgumentError("nruns = $K must be divisible by the number of engines $G (equal log-ratio shards keep the result independent of the GPU count)"))
-    per = K ÷ G
-    return [((g - 1) * per + 1):(g * per) for g in 1:G]
+    K >= G || throw(ArgumentError("nruns = $K is smaller than the number of engines $G: every engine needs at least one run"))
+    base, rem = divrem(K, G)                      # any nruns (src/multipath.jl:131-146): the first K % G blocks are one run longer
+    stops = cumsum([base + (g <= rem ? 1 : 0) for g in 1:G])
+    return [(g == 1 ? 1 : stops[g - 1] + 1):stops[g] for g in 1:G]
 end
 
 function _fit_enqueue!(eng::Engine, history_length::Int, ϵ::Float64)

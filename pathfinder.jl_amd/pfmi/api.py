@@ -414,12 +414,17 @@ def _comm_for(engs):
 
 
 def _blocks(K, G):
-    """contiguous blocks of paths, one per engine (pool order stays k-major, src/resample.jl:93)"""
-    if K % G != 0:
-        raise ValueError(f"nruns={K} must be divisible by the number of engines {G} "
-                         "(equal log-ratio shards keep the result independent of the GPU count)")
-    per = K // G
-    return [(g * per, (g + 1) * per) for g in range(G)]
+    """contiguous blocks of paths, one per engine, the first K % G one path longer (pool order stays k-major, src/resample.jl:93; any
+    nruns over any number of engines, like the reference's nruns over ntasks, src/multipath.jl:131-146, 190-208)"""
+    if K < G:
+        raise ValueError(f"nruns={K} is smaller than the number of engines {G}: every engine needs at least one run")
+    base, rem = divmod(K, G)
+    out, k0 = [], 0
+    for g in range(G):
+        k1 = k0 + base + (1 if g < rem else 0)
+        out.append((k0, k1))
+        k0 = k1
+    return out
 
 
 def _run_paths(engs, target, inits, run_rngs, *, dim, history_length, ndraws_elbo, ntries, init_sampler,

@@ -1,7 +1,7 @@
 // rccl_standin.hip -- TEST INFRASTRUCTURE, never shipped or linked into libpfmi.so.
 //
-// An in-process stand-in for the 11 RCCL entry points csrc/comm_rccl.hip resolves with dlsym (ncclGetUniqueId, ncclCommInitAll,
-// ncclCommInitRank, ncclCommDestroy, ncclCommCount, ncclAllGather, ncclAllReduce, ncclGroupStart, ncclGroupEnd,
+// An in-process stand-in for the 13 RCCL entry points csrc/comm_rccl.hip resolves with dlsym (ncclGetUniqueId, ncclCommInitAll,
+// ncclCommInitRank, ncclCommDestroy, ncclCommCount, ncclAllGather, ncclAllReduce, ncclSend, ncclRecv, ncclGroupStart, ncclGroupEnd,
 // ncclGetErrorString, ncclGetVersion), loaded through PFMI_RCCL_LIB.  RCCL itself refuses two ranks on one GPU, so a 1-GPU box can
 // only ever form a world of ONE rank -- where every shard offset is 0 and every pool column is owned.  With this library the ranks
 // are contexts (streams) of one process, possibly all on the same GPU, and the collectives are done with hipMemcpyAsync / a
@@ -12,7 +12,11 @@
 //   * ncclCommInitRank         one rank per caller (threads of this process): blocks until all `nranks` callers with the same id
 //                              have arrived; a collective completes when every rank has posted it (the last one enqueues the
 //                              whole exchange on all streams, the others wait for that to have happened);
-//   * element counts / kinds must agree across ranks (ncclInvalidArgument otherwise), in-place all-reduce is supported;
+//   * element counts / kinds must agree across ranks (ncclInvalidArgument otherwise), in-place all-reduce and in-place all-gather
+//     (sendbuff == recvbuff + rank * count) are supported;
+//   * ncclSend / ncclRecv (round 6: the owners send their selected columns to rank 0): a send matches the receive the peer posts for
+//     it (same count, FIFO per ordered pair); the copy is enqueued on the receiver's stream behind an event of the sender's stream,
+//     the sender's stream waits for the copy; a rank whose peer never posts times out like a collective;
 //   * a rank that never arrives makes the others time out after PFMI_STANDIN_TIMEOUT_S (default 20 s) with ncclInternalError
 //     instead of hanging the test run.
 // ncclGetVersion reports 99999 so that a test can tell which library libpfmi actually loaded.
@@ -31,7 +35,7 @@
 
 namespace {
 
-enum Kind { NONE = 0, ALLGATHER = 1, ALLREDUCE = 2 };
+enum Kind { NONE = 0, ALLGATHER = 1, ALLREDUCE = 2, SEND = 3, RECV = 4 };
 
 struct Op {
     Kind kind = NONE;
@@ -41,7 +45,10 @@ struct Op {
     ncclDataType_t dtype = ncclDouble;
     ncclRedOp_t op = ncclSum;
     hipStream_t stream = nullptr;
+    int peer = -1;                         // SEND / RECV
 };
+
+struct P2P { Op op; int rank; unsigned long long ticket; };
 
 struct World {
     int n = 0;
@@ -55,6 +62,10 @@ struct World {
     std::vector<hipEvent_t> ready, mid, done;
     std::vector<void *> tmp;               // per-rank reduction scratch
     std::vector<size_t> tmp_cap;
+    std::vector<P2P> p2p;                  // posted, not yet matched sends / receives
+    unsigned long long p2p_next = 1;
+    std::vector<unsigned long long> p2p_matched;   // tickets matched by a peer (the poster is waiting for them)
+    std::vector<hipEvent_t> p2p_events;    // freed with the world
     std::mutex mu;
     std::condition_variable cv;
 };
@@ -129,8 +140,11 @@ ncclResult_t execute(World *w) {
             SI_HIP(hipSetDevice(w->device[i]));
             hipStream_t s = w->slot[i].stream;
             for (int j = 0; j < n; ++j) SI_HIP(hipStreamWaitEvent(s, w->ready[j], 0));
-            for (int j = 0; j < n; ++j)
-                SI_HIP(hipMemcpyAsync((char *)w->slot[i].recv + (size_t)j * bytes, w->slot[j].send, bytes, hipMemcpyDefault, s));
+            for (int j = 0; j < n; ++j) {
+                char *dst = (char *)w->slot[i].recv + (size_t)j * bytes;
+                if (dst == (const char *)w->slot[j].send) continue;        // in-place all-gather: a rank's own slot already holds its shard
+                SI_HIP(hipMemcpyAsync(dst, w->slot[j].send, bytes, hipMemcpyDefault, s));
+            }
             SI_HIP(hipEventRecord(w->done[i], s));
         }
     } else {
@@ -171,15 +185,61 @@ ncclResult_t execute(World *w) {
     return ncclSuccess;
 }
 
+// a matched send / receive pair: the copy on the receiver's stream, ordered behind the sender's stream; the sender's stream waits for it
+ncclResult_t execute_p2p(World *w, const Op &snd, int srank, const Op &rcv, int rrank) {   // w->mu held
+    if (snd.count != rcv.count || snd.dtype != rcv.dtype) {
+        fprintf(stderr, "rccl_standin: send %d -> %d of %zu elements meets a receive of %zu\n", srank, rrank, snd.count, rcv.count);
+        return ncclInvalidArgument;
+    }
+    int dev0 = 0;
+    SI_HIP(hipGetDevice(&dev0));
+    hipEvent_t e_ready = nullptr, e_done = nullptr;
+    SI_HIP(hipSetDevice(w->device[(size_t)srank]));
+    SI_HIP(hipEventCreateWithFlags(&e_ready, hipEventDisableTiming));
+    SI_HIP(hipEventRecord(e_ready, snd.stream));
+    SI_HIP(hipSetDevice(w->device[(size_t)rrank]));
+    SI_HIP(hipEventCreateWithFlags(&e_done, hipEventDisableTiming));
+    SI_HIP(hipStreamWaitEvent(rcv.stream, e_ready, 0));
+    SI_HIP(hipMemcpyAsync(rcv.recv, snd.send, snd.count * dsize(snd.dtype), hipMemcpyDefault, rcv.stream));
+    SI_HIP(hipEventRecord(e_done, rcv.stream));
+    SI_HIP(hipSetDevice(w->device[(size_t)srank]));
+    SI_HIP(hipStreamWaitEvent(snd.stream, e_done, 0));
+    SI_HIP(hipSetDevice(dev0));
+    w->p2p_events.push_back(e_ready);
+    w->p2p_events.push_back(e_done);
+    return ncclSuccess;
+}
+
 // post the pending ops of this thread; then wait until every collective they belong to has been enqueued
 ncclResult_t flush_pending() {
     std::vector<Pending> ops;
     ops.swap(t_pending);
     std::vector<std::pair<World *, unsigned long long>> waits;
+    std::vector<std::pair<World *, unsigned long long>> p2p_waits;
     ncclResult_t res = ncclSuccess;
     for (Pending &p : ops) {
         World *w = p.w;
         std::unique_lock<std::mutex> lk(w->mu);
+        if (p.op.kind == SEND || p.op.kind == RECV) {
+            // the oldest posted counterpart of the ordered pair (FIFO, like NCCL)
+            const Kind want = p.op.kind == SEND ? RECV : SEND;
+            size_t hit = w->p2p.size();
+            for (size_t i = 0; i < w->p2p.size(); ++i)
+                if (w->p2p[i].op.kind == want && w->p2p[i].rank == p.op.peer && w->p2p[i].op.peer == p.rank) { hit = i; break; }
+            if (hit == w->p2p.size()) {
+                const unsigned long long tk = w->p2p_next++;
+                w->p2p.push_back(P2P{p.op, p.rank, tk});
+                p2p_waits.emplace_back(w, tk);
+            } else {
+                const P2P other = w->p2p[hit];
+                w->p2p.erase(w->p2p.begin() + (long)hit);
+                const ncclResult_t r = p.op.kind == SEND ? execute_p2p(w, p.op, p.rank, other.op, other.rank) : execute_p2p(w, other.op, other.rank, p.op, p.rank);
+                if (r != ncclSuccess) { res = r; w->last = r; }
+                w->p2p_matched.push_back(other.ticket);
+                w->cv.notify_all();
+            }
+            continue;
+        }
         if (w->slot[p.rank].kind != NONE) {
             fprintf(stderr, "rccl_standin: rank %d posted two collectives into one exchange\n", p.rank);
             return ncclInvalidUsage;
@@ -196,6 +256,23 @@ ncclResult_t flush_pending() {
         } else {
             waits.emplace_back(w, my_gen);
         }
+    }
+    for (auto &pw : p2p_waits) {                            // posted first: wait until the peer has matched (and enqueued) the transfer
+        World *w = pw.first;
+        std::unique_lock<std::mutex> lk(w->mu);
+        auto matched = [&] {
+            for (size_t i = 0; i < w->p2p_matched.size(); ++i)
+                if (w->p2p_matched[i] == pw.second) { w->p2p_matched.erase(w->p2p_matched.begin() + (long)i); return true; }
+            return false;
+        };
+        const bool ok = w->cv.wait_for(lk, std::chrono::duration<double>(timeout_s()), matched);
+        if (!ok) {
+            fprintf(stderr, "rccl_standin: timed out waiting for the peer of a send / receive\n");
+            for (size_t i = 0; i < w->p2p.size(); ++i)
+                if (w->p2p[i].ticket == pw.second) { w->p2p.erase(w->p2p.begin() + (long)i); break; }
+            return ncclInternalError;
+        }
+        if (w->last != ncclSuccess) res = w->last;
     }
     for (auto &wg : waits) {
         World *w = wg.first;
@@ -341,6 +418,7 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
             if (w->done[(size_t)r]) (void)hipEventDestroy(w->done[(size_t)r]);
             if (w->tmp[(size_t)r]) (void)hipFree(w->tmp[(size_t)r]);
         }
+        for (hipEvent_t e : w->p2p_events) (void)hipEventDestroy(e);
         delete w;
     }
     return ncclSuccess;
@@ -375,6 +453,20 @@ ncclResult_t ncclAllReduce(const void *sendbuff, void *recvbuff, size_t count, n
                            hipStream_t stream) {
     Op o;
     o.kind = ALLREDUCE; o.send = sendbuff; o.recv = recvbuff; o.count = count; o.dtype = datatype; o.op = op; o.stream = stream;
+    return post(o, comm);
+}
+
+ncclResult_t ncclSend(const void *sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream) {
+    if (!comm || peer < 0 || peer >= comm->w->n || peer == comm->rank) return ncclInvalidArgument;
+    Op o;
+    o.kind = SEND; o.send = sendbuff; o.count = count; o.dtype = datatype; o.stream = stream; o.peer = peer;
+    return post(o, comm);
+}
+
+ncclResult_t ncclRecv(void *recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream) {
+    if (!comm || peer < 0 || peer >= comm->w->n || peer == comm->rank) return ncclInvalidArgument;
+    Op o;
+    o.kind = RECV; o.recv = recvbuff; o.count = count; o.dtype = datatype; o.stream = stream; o.peer = peer;
     return post(o, comm);
 }
 

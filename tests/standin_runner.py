@@ -4,8 +4,9 @@
 Run in its own process by tests/test_gpu_multirank.py:  python tests/standin_runner.py <scenario>
 with PFMI_RCCL_LIB = tests/rccl_standin/librccl_standin.so (the in-process RCCL stand-in, test infrastructure) and
 PFMI_COMM_ALLOW_SHARED_GPU = 1, so that csrc/comm_rccl.hip forms a world of G ranks among contexts that all sit on GPU 0 and runs
-its real code: shard offsets rank * shard, the G-way all-gather of the log-ratio shards, replicated PSIS / index selection, the
-owner gather with zero fill, the sum all-reduce, the shard-size handshake of the process-per-GPU mode.
+its real code: the shard-size handshake, the G-way all-gather of the log-ratio shards (padded + compacted when the shards are unequal),
+replicated PSIS / index selection, and the OWNER-ONLY assembly of the result (round 6): zero-copy stores of every context's own columns into
+the caller's host array (pfmi_comm_init_all), ncclSend / ncclRecv of the owned columns to rank 0 (pfmi_comm_init_rank).
 
 Contract (reference test/multipath.jl:107-140, the `ntasks` invariance, extended to the GPU count): for the same seeds the pooled
 stage must give BIT-IDENTICAL k-hat, indices and draws for every G.
@@ -15,7 +16,9 @@ Scenarios
             (8 paths per context at G = 8 = config 4's sharding), with / without replacement, host uniforms, separate and fused calls
   c5        config 5's shape, small: d = 10^4, J = 10, K = 8, funnel; G in {2, 4}
   threads   one host THREAD per rank, pfmi_comm_init_rank with a shipped id (the process-per-GPU mode), G = 4
-  mismatch  process-per-GPU mode with unequal shards / a rank without a pool: every rank returns the error, nobody hangs
+  uneven    K = 20 runs over G in {3, 8} contexts (the reference accepts any nruns, src/multipath.jl:131-146; its own test uses 20,
+            test/multipath.jl:12-85): bit-identical to G = 1; the same in process-per-GPU mode (K = 10 over 4 threads)
+  mismatch  process-per-GPU mode with different draws per run / a rank without a pool: every rank returns the error, nobody hangs
   api       pfmi.multipathfinder(engines=[...]) at G = 2, 4 against the single-engine call, bit for bit
 """
 import os
@@ -82,6 +85,15 @@ def _compare(ref, got, tag):
             assert a == b or (a != a and b != b), (tag, key, a, b)
 
 
+def _blocks(K, G):
+    """contiguous blocks of paths, the first K % G one longer (pfmi.api._blocks)"""
+    base, rem = divmod(K, G)
+    b = [0]
+    for g in range(G):
+        b.append(b[-1] + base + (1 if g < rem else 0))
+    return b
+
+
 def _sharded(tg, K, J, N, ndraws, maxiters, scale, Gs, check_owner=True):
     run_seeds, x0 = _inputs(tg, K, scale)
     # ---- G = 1: one context, no RCCL involved at all
@@ -95,10 +107,10 @@ def _sharded(tg, K, J, N, ndraws, maxiters, scale, Gs, check_owner=True):
     c1.close()
     print(f"G=1: P={e1.P} khat={ref['k']:.6f} tail={ref['M']}", flush=True)
     for G in Gs:
-        Kl = K // G
+        bk = _blocks(K, G)
         engs = [pfmi.Engine(0) for _ in range(G)]
         for g, e in enumerate(engs):
-            sl = slice(g * Kl, (g + 1) * Kl)
+            sl = slice(bk[g], bk[g + 1])
             npts, seeds = _local_stage(e, tg, x0[sl], run_seeds[sl], J, N, maxiters)
             np.testing.assert_array_equal(npts, npts1[sl])
         comm = pfmi.Comm.init_all(engs)
@@ -109,13 +121,14 @@ def _sharded(tg, K, J, N, ndraws, maxiters, scale, Gs, check_owner=True):
         # every rank's shard is the corresponding block of the G = 1 pool, and its ELBO table the corresponding block
         for g, e in enumerate(engs):
             _, lr = e.pool_get(draws=False)
-            np.testing.assert_array_equal(lr, lr1[g * Kl * N:(g + 1) * Kl * N])
+            np.testing.assert_array_equal(lr, lr1[bk[g] * N:bk[g + 1] * N])
             el, _, bs = e.elbo_batch_wait()
-            p0 = int(e1.offsets[g * Kl])
+            p0 = int(e1.offsets[bk[g]])
             np.testing.assert_array_equal(el, elbo1[p0:p0 + e.P])
-            np.testing.assert_array_equal(bs, best1[g * Kl:(g + 1) * Kl])
+            np.testing.assert_array_equal(bs, best1[bk[g]:bk[g + 1]])
         if check_owner:                                   # the selected columns really come from different owners
-            owners = np.unique(ref["idx"] // (Kl * N))
+            owners = np.unique(np.searchsorted(np.array(bk[1:]) * N, ref["idx"], side="right"))
+            assert len(owners) > 1 or G == 1
             print(f"G={G}: bit-identical; selected columns owned by ranks {owners.tolist()}", flush=True)
         comm.close()
         for e in engs:
@@ -136,11 +149,13 @@ def scenario_c5():
     print("c5 ok")
 
 
-def scenario_threads():
+def scenario_threads(K=16, G=4):
     """process-per-GPU mode (pfmi_comm_init_rank), the ranks being threads of this process: each thread owns one context, forms the
-    group with the shipped id and makes the same sequence of pfmi_comm_* calls"""
+    group with the shipped id and makes the same sequence of pfmi_comm_* calls.  The d x ndraws result lives on rank 0 only (the owners
+    SEND their columns there); the other ranks get k-hat, the tail length and the indices (replicated) and NaN where they asked for draws."""
     tg = pfmi.t_lowrank(200, r=8, seed=2)
-    K, J, N, nd, G = 16, 6, 256, 300, 4
+    J, N, nd = 6, 256, 300
+    bk = _blocks(K, G)
     run_seeds, x0 = _inputs(tg, K, 2.0)
     e1 = pfmi.Engine(0)
     _local_stage(e1, tg, x0, run_seeds, J, N, 200)
@@ -152,9 +167,8 @@ def scenario_threads():
 
     def work(g):
         try:
-            Kl = K // G
             e = pfmi.Engine(0)
-            sl = slice(g * Kl, (g + 1) * Kl)
+            sl = slice(bk[g], bk[g + 1])
             _local_stage(e, tg, x0[sl], run_seeds[sl], J, N, 200)
             comm = pfmi.Comm.init_rank(e, G, g, uid)
             assert comm.info() == dict(world=G, nlocal=1, rccl_version=99999)
@@ -169,13 +183,31 @@ def scenario_threads():
     [t.join() for t in ths]
     assert not errs, errs
     for g in range(G):
-        _compare(ref, res[g], f"thread rank {g}")
+        if g == 0:
+            _compare(ref, res[g], f"thread rank {g}")
+        else:                                              # not the root: everything replicated is there, the draws are NaN (never stale)
+            for key in ref:
+                if key.startswith("draws"):
+                    assert np.all(np.isnan(res[g][key])), (g, key)
+                else:
+                    _compare({key: ref[key]}, {key: res[g][key]}, f"thread rank {g}")
     e1.close()
-    print("threads ok")
+    print(f"threads ok (K={K}, G={G}, blocks {bk})")
+
+
+def scenario_uneven():
+    """any nruns over any G: K = 20 over 3 and 8 contexts (blocks 7 7 6 / 3 3 3 3 2 2 2 2), pageable and page-locked destinations,
+    then the process-per-GPU mode with K = 10 over 4 threads (3 3 2 2)"""
+    tg = pfmi.t_lowrank(300, r=8, seed=2)
+    _sharded(tg, 20, 6, 256, 400, 300, 2.0, (3, 8))
+    tg2 = pfmi.t_diag(9000, seed=1)                       # 9000 x 300 x 8 B = 21.6 MB: the result array is page-locked (direct stores)
+    _sharded(tg2, 5, 6, 128, 300, 12, 2.0, (2, 4))
+    scenario_threads(K=10, G=4)
+    print("uneven ok")
 
 
 def scenario_mismatch():
-    """every rank must come back with an error (no hang) when the shards differ in size or a rank has no pool"""
+    """every rank must come back with an error (no hang) when the draws per run differ or a rank has no pool"""
     tg = pfmi.t_lowrank(64, r=8, seed=2)
     J, N, G = 6, 128, 2
     for case in ("unequal", "nopool"):
@@ -185,11 +217,11 @@ def scenario_mismatch():
         def work(g):
             e = pfmi.Engine(0)
             try:
-                Kl = 2 if (case == "unequal" and g == 1) else 3
+                Kl = 3
                 run_seeds, x0 = _inputs(tg, Kl, 2.0)
                 e.set_target(tg)
                 if not (case == "nopool" and g == 1):
-                    _local_stage(e, tg, x0, run_seeds, J, N, 50)
+                    _local_stage(e, tg, x0, run_seeds, J, N // 2 if (case == "unequal" and g == 1) else N, 50)
                 comm = pfmi.Comm.init_rank(e, G, g, uid)
                 try:
                     comm.pool_psis()
@@ -208,7 +240,7 @@ def scenario_mismatch():
         print(case, out, flush=True)
         assert all(o is not None and o != "no error" for o in out), out
         if case == "unequal":
-            assert all("differ in size" in o for o in out), out
+            assert all("differ" in o for o in out), out
         else:
             assert all("cannot take part" in o for o in out), out
     print("mismatch ok")
@@ -218,9 +250,15 @@ def scenario_api():
     """pfmi.multipathfinder(engines=[...]): ONE host thread drives G contexts (src/multipath.jl:190-225) -- result identical to the
     single-engine call for every G"""
     tg = pfmi.t_lowrank(120, r=8, seed=2)
-    kw = dict(nruns=8, ndraws_elbo=128, history_length=6, maxiters=300)
+    for nruns, Gs in ((8, (2, 4)), (10, (4,))):           # (10 runs over 4 engines: blocks 3 3 2 2)
+        _api_case(tg, nruns, Gs)
+    print("api ok")
+
+
+def _api_case(tg, nruns, Gs):
+    kw = dict(nruns=nruns, ndraws_elbo=128, history_length=6, maxiters=300)
     r1 = pfmi.multipathfinder(tg, 200, rng=pfmi.HostRNG(5), **kw)
-    for G in (2, 4):
+    for G in Gs:
         engs = [pfmi.Engine(0) for _ in range(G)]
         rg = pfmi.multipathfinder(tg, 200, rng=pfmi.HostRNG(5), engines=engs, **kw)
         np.testing.assert_array_equal(rg.draws, r1.draws)
@@ -237,12 +275,12 @@ def scenario_api():
             b = pfmi.resample(r1, 150, rng=pfmi.HostRNG(9), **rkw)
             np.testing.assert_array_equal(a.draws, b.draws)
             np.testing.assert_array_equal(a.draw_component_ids, b.draw_component_ids)
-        print(f"api G={G} ok", flush=True)
+        print(f"api nruns={nruns} G={G} ok", flush=True)
         for e in engs:
             e.close()
-    print("api ok")
 
 
 if __name__ == "__main__":
     assert os.environ.get("PFMI_RCCL_LIB"), "run through tests/test_gpu_multirank.py (PFMI_RCCL_LIB must point at the stand-in)"
-    {"c4": scenario_c4, "c5": scenario_c5, "threads": scenario_threads, "mismatch": scenario_mismatch, "api": scenario_api}[sys.argv[1]]()
+    {"c4": scenario_c4, "c5": scenario_c5, "threads": scenario_threads, "mismatch": scenario_mismatch, "api": scenario_api,
+     "uneven": scenario_uneven}[sys.argv[1]]()

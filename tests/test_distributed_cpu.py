@@ -1,9 +1,9 @@
-"""world_size-2 `gloo` test of the multi-GPU orchestration (pfmi/distributed.py) on CPU.
+"""world_size-2 `gloo` test of the multi-GPU PROTOCOL (pfmi/distributed.py = csrc/comm_rccl.hip restated over torch.distributed) on CPU.
 
-The engine-specific steps (per-path ELBO/draws, PSIS, index draw, column gather) are played by the CPU oracle,
-so what is under test is the sharding + all-gather + replicated PSIS/index selection + owner all-reduce logic
-that bench.py runs over RCCL: the 2-rank result must be IDENTICAL to the single-process result
-(extension of the reference's ntasks invariance, test/multipath.jl:107-140, to the GPU count).
+The engine-specific steps (per-path ELBO/draws, PSIS, index draw, column gather) are played by the CPU oracle, so what is under test
+is the protocol the C library runs over RCCL: uneven contiguous shards, the all-gather padded to the largest shard + compaction to
+the k-major pool order, replicated PSIS / index selection, the owners SENDING their selected columns to rank 0.  The 2-rank result
+must be IDENTICAL to the single-process result (the reference's ntasks invariance, test/multipath.jl:107-140, extended to the GPU count).
 """
 import os
 import socket
@@ -32,7 +32,7 @@ def _pipeline(rank, world, dist):
     from helpers import oracle_target
     from oracle import pf_oracle as po
 
-    K, d, N, J, ndraws = 4, 12, 40, 6, 64
+    K, d, N, J, ndraws = 5, 12, 40, 6, 64               # 5 paths over 2 ranks: blocks 3 + 2 (unequal shards)
     tg = pfmi.t_lowrank(d, r=3, seed=4)
     otg = oracle_target(tg)
     k0, k1 = shard_paths(K, world, rank)
@@ -46,8 +46,7 @@ def _pipeline(rank, world, dist):
         lrs.append(r["logp"] - r["logq"])
     pool = np.concatenate(pools, axis=1)                       # (d, K_local * N), k-major
     lr_local = torch.from_numpy(np.concatenate(lrs))
-    lr_all = torch.empty(K * N, dtype=torch.float64)
-    out = torch.zeros(d * ndraws, dtype=torch.float64)
+    shard_sizes = [(shard_paths(K, world, r)[1] - shard_paths(K, world, r)[0]) * N for r in range(world)]
     state = {}
 
     def psis_fn(t):
@@ -58,16 +57,13 @@ def _pipeline(rank, world, dist):
     def sample_fn(S):
         return po.sample_weighted(state["w"], ndraws, seed=123)
 
-    def gather_fn(idx, o):
-        col0 = k0 * N
-        buf = np.zeros((d, ndraws), order="F")
-        own = (idx >= col0) & (idx < col0 + pool.shape[1])
-        buf[:, own] = pool[:, idx[own] - col0]
-        o.copy_(torch.from_numpy(buf.T.ravel().copy()))
+    def columns_fn(cols):
+        assert np.all((cols >= k0 * N) & (cols < k1 * N)), "asked for a column this rank does not own"
+        return pool[:, cols - k0 * N]
 
-    res, idx = pooled_psis_resample(dist if world > 1 else None, lr_local, lr_all, out,
-                                    psis_fn=psis_fn, sample_fn=sample_fn, gather_fn=gather_fn)
-    return out.numpy().reshape(ndraws, d).T.copy(), idx, res["pareto_shape"]
+    res, idx, out = pooled_psis_resample(dist if world > 1 else None, lr_local, shard_sizes, d, ndraws,
+                                         psis_fn=psis_fn, sample_fn=sample_fn, columns_fn=columns_fn)
+    return out, idx, res["pareto_shape"]
 
 
 def _worker(rank, world, port, q):
@@ -95,17 +91,24 @@ def test_two_ranks_equal_single_process():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    owners = np.unique(ref_idx // (3 * 40))                    # (rank 0 owns pool columns 0 .. 119, rank 1 the rest)
+    assert len(owners) == 2, "the selection should touch both ranks' columns"
     for rank, draws, idx, k in got:
         np.testing.assert_array_equal(idx, ref_idx)            # replicated, deterministic index selection
-        np.testing.assert_array_equal(draws, ref_draws)        # owner all-reduce reassembles the same columns
+        if rank == 0:
+            np.testing.assert_array_equal(draws, ref_draws)    # the owners' columns arrive at their selection positions
+        else:
+            assert draws is None                               # the result lives on rank 0
         assert k == ref_k
 
 
 def test_shard_paths_contract():
     from pfmi.distributed import shard_paths
     assert [shard_paths(64, 8, r) for r in (0, 7)] == [(0, 8), (56, 64)]
+    assert [shard_paths(10, 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]      # any nruns: the first K % G blocks one longer
+    assert [shard_paths(20, 8, r)[1] - shard_paths(20, 8, r)[0] for r in range(8)] == [3, 3, 3, 3, 2, 2, 2, 2]
     with pytest.raises(ValueError):
-        shard_paths(10, 4, 0)
+        shard_paths(3, 4, 0)
 
 
 def _verify_worker(rank, world, port, q, tamper):

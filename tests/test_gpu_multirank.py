@@ -2,7 +2,7 @@
 
 A 1-GPU box can only form an RCCL world of one rank (RCCL refuses two ranks on a GPU), where every shard offset is 0 and every pool
 column is owned -- so until round 3 no line of the multi-rank branch had ever run.  tests/rccl_standin is an in-process stand-in
-for the 11 RCCL entry points libpfmi resolves (test infrastructure; collectives among contexts of one process, ordered across their
+for the 13 RCCL entry points libpfmi resolves (test infrastructure; collectives among contexts of one process, ordered across their
 streams with events); libpfmi loads it through PFMI_RCCL_LIB and, with PFMI_COMM_ALLOW_SHARED_GPU=1, accepts G contexts on GPU 0.
 Each scenario runs in its own process (the RCCL handle is process-global): tests/standin_runner.py.
 
@@ -48,6 +48,15 @@ def test_config5_shape_sharded():
 def test_rank_per_thread_init_rank_mode():
     """pfmi_comm_init_rank (the process-per-GPU mode bench.py uses), ranks = host threads with one context each."""
     assert "threads ok" in _run("threads", 550)
+
+
+@pytest.mark.timeout(900)
+def test_uneven_shards_any_nruns_over_any_gpu_count():
+    """the reference accepts any nruns (src/multipath.jl:131-146; its own test runs 20, test/multipath.jl:12-85): K = 20 over G = 3 and
+    G = 8, K = 5 over 2 / 4 with a page-locked destination, K = 10 over 4 threads in process-per-GPU mode -- k-hat, indices and draws
+    bit-identical to the G = 1 run; the pooled vector is compacted to the k-major order of src/resample.jl:93 before the replicated PSIS."""
+    out = _run("uneven", 850)
+    assert "uneven ok" in out and "G=8: bit-identical" in out and "G=3: bit-identical" in out
 
 
 @pytest.mark.timeout(600)

@@ -564,10 +564,10 @@ def test_pathfinder_single_path_plumbing(pfmi_mod):
 
 
 def test_torch_interop_for_the_collective_path(pfmi_mod, eng):
-    """the plumbing bench.py uses under RCCL, on one GPU: zero-copy torch view of the engine's log-ratio shard
-    (CUDA array interface), PSIS on a torch-owned device buffer, owner-gather into a torch tensor."""
+    """the `_dev` entry points of the pooled stage for hosts that keep buffers on the GPU (pfmi_pool_log_ratios_dev, pfmi_psis_dev,
+    pfmi_pool_gather_dev), on one GPU: zero-copy torch view of the engine's log-ratio shard (CUDA array interface), PSIS on a
+    torch-owned device buffer, owner-gather into a torch tensor."""
     import torch
-    from pfmi.distributed import pooled_psis_resample
 
     class DevArray:
         def __init__(self, ptr, n):
@@ -584,12 +584,10 @@ def test_torch_interop_for_the_collective_path(pfmi_mod, eng):
     np.testing.assert_array_equal(shard.cpu().numpy(), lr)
     lr_all = shard.clone()                                            # torch-owned device memory
     out = torch.zeros(tg.d * 32, dtype=torch.float64, device="cuda:0")
-    res, idx = pooled_psis_resample(
-        None, lr_all, lr_all, out,
-        psis_fn=lambda t: eng.psis_dev(t.data_ptr(), t.numel(), want_weights=True),
-        sample_fn=lambda S: eng.resample_indices(S, 32, seed=9),
-        gather_fn=lambda ix, o: eng.pool_gather_dev(ix, 0, o.data_ptr()),
-        sync_fn=torch.cuda.synchronize)
+    res = eng.psis_dev(lr_all.data_ptr(), lr_all.numel(), want_weights=True)
+    idx = eng.resample_indices(lr_all.numel(), 32, seed=9)
+    eng.pool_gather_dev(idx, 0, out.data_ptr())
+    torch.cuda.synchronize()
     ref = eng.psis(lr)
     np.testing.assert_array_equal(res["weights"], ref["weights"])
     np.testing.assert_array_equal(idx, po.sample_weighted(ref["weights"], 32, seed=9))
@@ -843,14 +841,14 @@ def test_single_pass_scan_matches_lane_kernel(pfmi_mod, eng, tname, d, K, J, N, 
 
 
 def test_rccl_collectives_on_engine_memory_world1(pfmi_mod, eng):
-    """bench.py's N > 1 data path (one RCCL all-gather of the log-ratio shard + one all-reduce of the result) with the
-    `nccl` backend at world_size 1 -- the only RCCL configuration a 1-GPU box allows: the collectives run directly on
+    """torch's `nccl` (= RCCL) collectives on ENGINE-OWNED device memory at world_size 1 -- the only RCCL configuration a 1-GPU box
+    allows (the product's own collectives are pfmi_comm_*, csrc/comm_rccl.hip; this checks the interop a torch host relies on when it
+    passes engine buffers to its own collectives): the collectives run directly on
     device memory owned by libpfmi (zero-copy view) and on torch tensors the engine writes through raw pointers, and the
     stream hand-over (engine stream -> torch stream -> engine stream) leaves the data intact.  world_size 2 is covered on
     CPU by tests/test_distributed_cpu.py (gloo)."""
     import torch
     import torch.distributed as dist
-    from pfmi.distributed import pooled_psis_resample
 
     class DevArray:
         def __init__(self, ptr, n):

@@ -576,17 +576,15 @@ def test_julia_call_sequence_in_c(tmp_path):
 
 
 # ---- bench.py contract on the GPU box ---------------------------------------------------------------------------
-@pytest.mark.parametrize("comm_mode", ["c_abi", "torch"])
+@pytest.mark.parametrize("comm_mode", ["c_abi"])
 def test_bench_force_dist_counts_its_ranks(comm_mode):
-    """bench.py --gpus 1 --force-dist: the N > 1 code path (RCCL all-gather + all-reduce) in a single-rank world; the JSON line
-    reports the ranks counted through the collective (VERDICT r1 #1)."""
+    """bench.py --gpus 1 --force-dist: the N > 1 code path (pfmi_comm_init_rank: RCCL through the C ABI) in a single-rank world; the JSON
+    line reports the ranks counted through the collective (VERDICT r1 #1).  (Round 6: the torch.distributed fallback data path is gone.)"""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    if comm_mode == "torch":
-        env["PFMI_BENCH_COMM"] = "torch"                              # the reported fallback: torch.distributed collectives
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "1", "--warmup", "1",
                         "--npaths", "8", "--dim", "100", "--target", "diag", "--no-cpu-baseline", "--verify-sharding"], capture_output=True,
                        text=True, env=env, timeout=600, cwd=root)
