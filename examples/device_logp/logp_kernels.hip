@@ -12,6 +12,9 @@
 //   pfx_gauss_create / pfx_gauss_destroy   parameters -> device-resident handle (the closure's `user`)
 //   pfx_gauss_logp                         the closure (pfmi_logp_dev_fn)
 //   pfx_funnel_logp                        the closure for the funnel (user = NULL)
+//   pfx_host_gauss_create / _destroy / pfx_host_gauss_logp    the same Gaussian family as a compiled HOST closure (pfmi_logp_fn): what a
+//                                          C / Julia caller's `logp` looks like to the library -- re-entrant, so pfmi_set_callback_threads
+//                                          (the reference's ntasks) may call it from several threads at once
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -220,3 +223,41 @@ void pfx_funnel_logp(const double *X_dev, int32_t d, int64_t n, double *out_dev,
 }
 
 }  // extern "C"
+
+
+// ---- the same target as a compiled HOST closure (include/pfmi.h: pfmi_logp_fn) ---------------------------------------------------
+// logp(x) = offset - (e' diag(a) e - |G Wd' e|^2) / 2, one column at a time like the reference calls its closure (src/elbo.jl:15);
+// plain scalar loops, no shared mutable state: thread-safe as src/multipath.jl:104-108 requires when ntasks > 1.
+namespace {
+struct HostGauss { int d, r; double offset; std::vector<double> mean, a, wd, g; };   // wd [d][r] column-major, g [r][r] column-major lower
+}
+extern "C" void *pfx_host_gauss_create(int32_t d, int32_t r, const double *mean, const double *a, const double *Wd, const double *G, double offset) {
+    if (d <= 0 || r < 0 || r > 64 || !mean || !a || (r > 0 && (!Wd || !G))) return nullptr;
+    HostGauss *h = new HostGauss();
+    h->d = d; h->r = r; h->offset = offset;
+    h->mean.assign(mean, mean + d); h->a.assign(a, a + d);
+    if (r > 0) { h->wd.assign(Wd, Wd + (size_t)d * r); h->g.assign(G, G + (size_t)r * r); }
+    return h;
+}
+extern "C" void pfx_host_gauss_destroy(void *user) { delete static_cast<HostGauss *>(user); }
+extern "C" void pfx_host_gauss_logp(const double *X, int32_t d, int64_t n, double *out, void *user) {
+    const HostGauss *h = static_cast<const HostGauss *>(user);
+    const int r = h->r;
+    for (int64_t j = 0; j < n; ++j) {
+        const double *x = X + (size_t)j * (size_t)d;
+        double q = 0.0, t[64];
+        for (int b = 0; b < r; ++b) t[b] = 0.0;
+        for (int i = 0; i < d; ++i) {
+            const double e = x[i] - h->mean[(size_t)i];
+            q += h->a[(size_t)i] * e * e;
+            for (int b = 0; b < r; ++b) t[b] += h->wd[(size_t)i + (size_t)d * b] * e;
+        }
+        double s = 0.0;
+        for (int a_ = 0; a_ < r; ++a_) {
+            double v = 0.0;
+            for (int b = 0; b <= a_; ++b) v += h->g[(size_t)a_ + (size_t)r * b] * t[b];
+            s += v * v;
+        }
+        out[j] = h->offset - 0.5 * (q - s);
+    }
+}

@@ -217,6 +217,14 @@ int32_t pfmi_elbo_batch(pfmi_ctx *ctx, int64_t N, const uint64_t *seeds, const d
 int32_t pfmi_elbo_batch_enqueue(pfmi_ctx *ctx, int64_t N, const uint64_t *seeds, const double *u_host);
 int32_t pfmi_elbo_batch_wait(pfmi_ctx *ctx, double *elbo, double *se, int64_t *best_iter);
 
+/* The reference's `ntasks` for HOST_CALLBACK targets (src/elbo.jl:3-6 and src/resample.jl:85-92 evaluate `logp` over tasks through
+ * src/utils.jl:33-49; "the log-density function must be thread-safe", src/multipath.jl:104-108): with nthreads > 1 every staged block of
+ * draws is cut into nthreads contiguous column ranges and `fn` is called on each range from its own host thread (one of them the calling
+ * thread) -- `fn` must then be re-entrant and callable from threads the library creates; `user` is shared.  The results do not depend on
+ * nthreads (same columns, one value per column; test/singlepath.jl:173-203).  Default 1.  A closure that parallelises internally (the
+ * Julia trampoline with Threads.@threads) leaves this at 1. */
+int32_t pfmi_set_callback_threads(pfmi_ctx *ctx, int32_t nthreads);
+
 /* HOST_CALLBACK targets only: wall time spent inside the user's callback and bytes of draws handed to it (device -> pinned host)
  * during the last pfmi_elbo_batch.  The draws of a block of fits are generated and downloaded while the host evaluates the
  * previous block, so elbo_batch time ~ max(callback time, generation + PCIe time). */
@@ -298,15 +306,17 @@ int32_t pfmi_resample_indices_direct(pfmi_ctx *ctx, int64_t S, int64_t ndraws, c
  * stale or out-of-range index is an error, never a silent zero column).  draws[d*ndraws]. */
 int32_t pfmi_pool_gather(pfmi_ctx *ctx, int64_t ndraws, const int64_t *idx, int64_t col_offset,
                          double *draws);
-/* multi-GPU variant into a device buffer: columns not owned are written as zeros, so that a sum all-reduce over the
- * ranks (xGMI) assembles the result */
+/* variant into a DEVICE buffer for hosts that assemble a result themselves: columns not owned are written as zeros (a sum over the
+ * ranks' buffers is then the result; pfmi_comm_* itself moves only the owned columns) */
 int32_t pfmi_pool_gather_dev(pfmi_ctx *ctx, int64_t ndraws, const int64_t *idx, int64_t col_offset,
                              void *draws_dev);
 
 /* ---- multi-GPU: the pooled stage over paths sharded across GPUs (RCCL over xGMI) ----------------------------------- */
 /* Runs are independent until pooling (src/multipath.jl:190-208); draws_per_component = stack(draws), _compute_psis_result and
  * _resample (src/multipath.jl:215-225) see every run.  Each GPU owns a contiguous block of paths (its ctx was fed only those
- * traces; pool order stays k-major, src/resample.jl:93) and has called pfmi_pool_build.  A pfmi_comm joins the contexts:
+ * traces; pool order stays k-major, src/resample.jl:93) and has called pfmi_pool_build.  The blocks may have DIFFERENT lengths (any nruns
+ * over any number of GPUs, src/multipath.jl:131-146: e.g. 20 runs over 8 GPUs = 3 3 3 3 2 2 2 2); draws per run and dimension must agree.
+ * A pfmi_comm joins the contexts:
  *   pfmi_comm_init_all   ONE host process drives G contexts, one per GPU (ncclCommInitAll) -- a single Julia / C caller;
  *   pfmi_comm_init_rank  one process per GPU: every process passes the same 128-byte id (pfmi_comm_unique_id on rank 0,
  *                        shipped by the host's launcher) -- e.g. under torch.distributed.run or MPI.
@@ -318,32 +328,42 @@ int32_t pfmi_comm_init_rank(pfmi_ctx *ctx, int32_t world, int32_t rank, const ui
 int32_t pfmi_comm_destroy(pfmi_comm *comm);
 /* world = ranks RCCL itself reports (ncclCommCount), nlocal = contexts driven by this process, rccl_version = ncclGetVersion */
 int32_t pfmi_comm_info(pfmi_comm *comm, int32_t *world, int32_t *nlocal, int32_t *rccl_version);
-/* _compute_psis_result over all runs (src/multipath.jl:221): ONE all-gather of the fp64 log-ratio shards (K/G * N_r doubles per
- * GPU), then PSIS.psis replicated on every GPU (weights stay device resident).  Shards must have equal size. */
+/* _compute_psis_result over all runs (src/multipath.jl:221): ONE all-gather of the fp64 log-ratio shards (K_r * N_r doubles from GPU r;
+ * unequal shards travel padded to the largest one and are compacted back to the pool order), then PSIS.psis replicated on every GPU
+ * (weights stay device resident). */
 int32_t pfmi_comm_pool_psis(pfmi_comm *comm, double *pareto_k, int64_t *tail_len);
 /* _resample over all runs (src/multipath.jl:225, src/resample.jl:58-72): index selection replicated on every GPU (same
- * arguments as pfmi_resample_indices; identical indices by construction, checked), every GPU gathers the columns it owns,
- * one sum all-reduce assembles draws[d * ndraws].  idx: global 0-based pool columns (component id = idx / N_r). */
+ * arguments as pfmi_resample_indices; identical indices by construction, checked); the selected columns reach the caller by
+ * OWNER-ONLY transfers -- no GPU other than the one that owns a column touches it, no rank allocates d x ndraws unless it returns it:
+ *   pfmi_comm_init_all   every GPU stores the columns it owns straight into draws[d * ndraws] (zero-copy when `draws` is page-locked
+ *                        memory from pfmi_host_alloc; through a page-locked staging block of the communicator + one host copy otherwise);
+ *   pfmi_comm_init_rank  the owners send their columns to RANK 0 (ncclSend / ncclRecv of exactly the owned columns): `draws` is filled
+ *                        on rank 0 only -- pass NULL on the other ranks (a non-NULL array there comes back all-NaN, never stale); idx,
+ *                        pareto_k, tail_len are replicated and valid on every rank.  Costs one extra host round trip (the transfers are
+ *                        sized from the indices).
+ * idx: global 0-based pool columns (component id = idx / N_r). */
 int32_t pfmi_comm_resample(pfmi_comm *comm, int64_t ndraws, int32_t importance, int32_t replace, uint64_t seed,
                            const double *uniforms, int64_t *idx, double *draws);
-/* Both stages in one call with ONE synchronisation at the end: [all-gather + PSIS when importance != 0] -> index selection -> owner
- * gather -> sum all-reduce are enqueued on every local context before the first wait, so a single host thread keeps all its GPUs
- * busy (src/multipath.jl:221-225).  A world of one context needs no RCCL at all (the single-GPU hot path takes this route too).
+/* Both stages in one call: [all-gather + PSIS when importance != 0] -> index selection -> owner-only transfer of the selected columns;
+ * under pfmi_comm_init_all everything is enqueued on every local context before the ONE wait, so a single host thread keeps all its
+ * GPUs busy (src/multipath.jl:221-225).  A world of one context needs no RCCL at all (the single-GPU hot path takes this route too).
  * pareto_k / tail_len are NaN / 0 when importance == 0.
  * One process per GPU (pfmi_comm_init_rank): every rank must make the same sequence of pfmi_comm_* calls; a PFMI_ERR_* from any of
  * them is fatal for the whole group -- the ranks first agree on their shard size and local status, so a local precondition failure
  * or a size mismatch is reported on EVERY rank instead of leaving the others blocked in a collective. */
 int32_t pfmi_comm_psis_resample(pfmi_comm *comm, int64_t ndraws, int32_t importance, int32_t replace, uint64_t seed,
                                 const double *uniforms, double *pareto_k, int64_t *tail_len, int64_t *idx, double *draws);
-/* The same in two halves: _enqueue launches everything (all-gather, PSIS, index selection, owner gather, all-reduce), _wait is the one host
- * round trip.  Between the two the caller may queue downloads on the member contexts with pfmi_defer_downloads: _wait delivers them too. */
+/* The same in two halves: _enqueue launches all-gather, PSIS and index selection; _wait adds the owner-only transfers into `draws` (known
+ * only now) and is the host round trip.  Between the two the caller may queue downloads on the member contexts with pfmi_defer_downloads:
+ * _wait delivers them too.  (The library's own staged downloads of this stage are never affected by the caller's defer mode.) */
 int32_t pfmi_comm_psis_resample_enqueue(pfmi_comm *comm, int64_t ndraws, int32_t importance, int32_t replace, uint64_t seed, const double *uniforms);
 int32_t pfmi_comm_psis_resample_wait(pfmi_comm *comm, double *pareto_k, int64_t *tail_len, int64_t *idx, double *draws);
 /* pfmi_defer_downloads(ctx, 1): from now on the download-only entry points -- pfmi_get_fit_status, pfmi_elbo_batch_wait, pfmi_psis_weights --
  * queue their copies behind whatever is enqueued and return at once; the destination arrays are filled (and a PFMI_ERR_RETRY of the scan
  * is reported) by the NEXT entry point that waits on this context (pfmi_sync, pfmi_comm_psis_resample_wait, ...): one host round trip for
  * all of them.  The arrays must stay valid until then.  (ctx, 0): back to normal, what is queued stays queued.  (ctx, -1): drop everything
- * queued (after a failure between queueing and waiting). */
+ * queued (after a failure between queueing and waiting).  A queued download delivers the values of the call it was queued for: entry
+ * points that enqueue work rewriting those results issue the pending copies first, in stream order. */
 int32_t pfmi_defer_downloads(pfmi_ctx *ctx, int32_t mode);
 
 /* ---- host utility --------------------------------------------------------------------------------------------------- */

@@ -9,6 +9,8 @@
 #include <mutex>
 #include <stdlib.h>
 #include <string>
+#include <thread>
+#include <algorithm>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -1091,9 +1093,37 @@ int32_t pfmi_get_fit(pfmi_ctx *c, int64_t p, double *alpha, double *B, double *D
 }
 
 // ---- ELBO ---------------------------------------------------------------------------------------------
+// The user's host closure on a staged block of `n` columns.  pfmi_set_callback_threads(ctx, t) with t > 1 -- the reference's `ntasks`
+// (src/elbo.jl:3-6, src/resample.jl:85-92 through src/utils.jl:33-49; the caller asserts thread safety, src/multipath.jl:104-108) --
+// cuts the block into t contiguous column ranges and calls `fn` on each from its own thread (the calling thread takes the first
+// range): same columns, same per-column results, whatever t is.  Threads live for one block: a block is milliseconds of closure
+// time, their creation tens of microseconds.
+static void host_callback_block(pfmi_ctx *c, const double *X, int d, int64_t n, double *out) {
+    const TargetDev &T = c->target;
+    int t = c->cb_threads;
+    if (t > n) t = (int)n;
+    if (t <= 1) { T.fn(X, d, n, out, T.user); return; }
+    const int64_t per = (n + t - 1) / t;
+    std::vector<std::thread> th;
+    th.reserve((size_t)t - 1);
+    for (int i = 1; i < t; ++i) {
+        const int64_t j0 = (int64_t)i * per, j1 = std::min<int64_t>(n, j0 + per);
+        if (j0 >= j1) break;
+        th.emplace_back([=, &T] { T.fn(X + (size_t)j0 * (size_t)d, d, j1 - j0, out + j0, T.user); });
+    }
+    T.fn(X, d, std::min<int64_t>(n, per), out, T.user);
+    for (std::thread &x : th) x.join();
+}
+
+int32_t pfmi_set_callback_threads(pfmi_ctx *c, int32_t nthreads) {
+    PF_CTX(c);
+    PF_CHECK(nthreads >= 1 && nthreads <= 1024, PFMI_ERR_ARG, "set_callback_threads: 1 <= nthreads <= 1024");
+    c->cb_threads = nthreads;
+    return PFMI_OK;
+}
+
 // evaluate the host-callback target on `n` columns stored at device pointer d_x; results to d_lp (pinned staging, 64 MB blocks)
 static int32_t callback_logp(pfmi_ctx *c, const double *d_x, int64_t n, double *d_lp) {
-    const TargetDev &T = c->target;
     const int d = c->d;
     int64_t chunk = (int64_t)((64ll << 20) / (sizeof(double) * (size_t)d));
     if (chunk < 1) chunk = 1;
@@ -1102,7 +1132,7 @@ static int32_t callback_logp(pfmi_ctx *c, const double *d_x, int64_t n, double *
     for (int64_t s0 = 0; s0 < n; s0 += chunk) {
         const int64_t ns = (n - s0 < chunk) ? n - s0 : chunk;
         PF_TRY(d2h(c, c->pin_x[0], d_x + (size_t)s0 * d, sizeof(double) * (size_t)ns * d));
-        T.fn(reinterpret_cast<const double *>(c->pin_x[0]), d, ns, reinterpret_cast<double *>(c->pin_lp[0]), T.user);
+        host_callback_block(c, reinterpret_cast<const double *>(c->pin_x[0]), d, ns, reinterpret_cast<double *>(c->pin_lp[0]));
         PF_TRY(h2d(c, d_lp + s0, c->pin_lp[0], sizeof(double) * (size_t)ns));
     }
     return PFMI_OK;
@@ -1236,7 +1266,7 @@ int32_t pfmi_elbo_batch_enqueue(pfmi_ctx *c, int64_t N, const uint64_t *seeds, c
             if (i + 1 < nblocks) PF_TRY(enqueue(i + 1));
             PF_HIP(hipEventSynchronize(c->cb_ev[b]));
             const auto t0 = std::chrono::steady_clock::now();
-            c->target.fn(reinterpret_cast<const double *>(c->pin_x[b]), d, ns * N, reinterpret_cast<double *>(c->pin_lp[b]), c->target.user);
+            host_callback_block(c, reinterpret_cast<const double *>(c->pin_x[b]), d, ns * N, reinterpret_cast<double *>(c->pin_lp[b]));
             c->cb_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             c->cb_bytes_d2h += (double)sizeof(double) * (double)ns * (double)per;
             PF_HIP(hipMemcpyAsync(c->cb_lp[b].p, c->pin_lp[b], sizeof(double) * (size_t)ns * N, hipMemcpyHostToDevice, c->stream));

@@ -86,6 +86,7 @@ struct pfmi_ctx {
     hipEvent_t kcur = nullptr;
     std::set<const void *> lds_attr_done;   // kernels whose dynamic-LDS limit was raised on THIS ctx's device (see pf_raise_lds_limit)
     PinArena arena;                         // staging of small uploads (pf_upload)
+    int cb_threads = 1;                     // host-closure fan-out (pfmi_set_callback_threads: the reference's ntasks)
     int hinit = 0;                          // Hinit of the history walk (PFMI_HINIT_*; pfmi_set_hinit / pfmi_fit_batch_ex)
     PinArena dl;                            // staging of small downloads (pf_download)
     std::vector<DlPending> dl_pending;

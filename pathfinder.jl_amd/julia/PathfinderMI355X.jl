@@ -124,16 +124,34 @@ struct CTarget
     fn::Ptr{Cvoid}; user::Ptr{Cvoid}
     dev_fn::Ptr{Cvoid}                                    # kind 3 (pfmi_logp_dev_fn); appended in round 3 -- same layout as pfmi_target
 end
-# logp is called one column at a time, exactly like `logp.(eachcol(phi))` (src/elbo.jl:15, src/resample.jl:90-92)
+# logp is called one column at a time, exactly like `logp.(eachcol(phi))` (src/elbo.jl:15, src/resample.jl:90-92).  `ntasks` (src/elbo.jl:3-6,
+# src/utils.jl:33-49; logp must then be thread-safe, src/multipath.jl:104-108): the columns of a staged block are spread over Julia tasks
+# HERE, inside the one callback the library makes on the calling thread (pfmi_set_callback_threads stays 1: the library's own threads are
+# foreign to the Julia runtime).  The result does not depend on ntasks: one value per column.
+const CALLBACK_NTASKS = Ref(1)
 function _logp_trampoline(X::Ptr{Float64}, d::Int32, n::Int64, out::Ptr{Float64}, user::Ptr{Cvoid})::Cvoid
     logp = unsafe_pointer_to_objref(user)[]
     Xm = unsafe_wrap(Array, X, (Int(d), Int(n)))
     o = unsafe_wrap(Array, out, Int(n))
-    @inbounds for j in 1:n
-        o[j] = logp(view(Xm, :, j))
+    nt = min(CALLBACK_NTASKS[], Int(n))
+    if nt <= 1
+        @inbounds for j in 1:n
+            o[j] = logp(view(Xm, :, j))
+        end
+    else
+        per = cld(Int(n), nt)
+        @sync for t in 1:nt
+            Threads.@spawn begin
+                @inbounds for j in ((t - 1) * per + 1):min(t * per, Int(n))
+                    o[j] = logp(view(Xm, :, j))
+                end
+            end
+        end
     end
     return nothing
 end
+"`ntasks` of the reference for host closures: columns of every staged block over `n` Julia tasks (the closure must be thread-safe)"
+set_callback_ntasks!(n::Integer) = (CALLBACK_NTASKS[] = max(1, Int(n)); nothing)
 function set_target!(eng::Engine, logp, dim::Integer)
     box = Ref{Any}(logp)
     eng.keepalive = box                                   # alive as long as the engine may call back
@@ -457,7 +475,11 @@ function multipathfinder(eng::Engine, optim_fun::SciMLBase.OptimizationFunction,
                          history_length::Int=Pathfinder.DEFAULT_HISTORY_LENGTH,
                          optimizer=Pathfinder.default_optimizer(history_length),
                          importance::Bool=true, ntries::Int=1_000, init_scale=2,
-                         init_sampler=Pathfinder.UniformSampler(init_scale), statsbase_indices::Union{Bool,Symbol}=false, kwargs...)
+                         init_sampler=Pathfinder.UniformSampler(init_scale), statsbase_indices::Union{Bool,Symbol}=false,
+                         ntasks::Int=Threads.nthreads(), ntasks_per_run::Int=1, kwargs...)
+    # the reference spreads the runs over `ntasks` tasks and each run's logp evaluations over `ntasks_per_run` (src/multipath.jl:104-108,
+    # 190-208); here all runs are one batch, so the closure sees ntasks * ntasks_per_run tasks per staged block of draws
+    set_callback_ntasks!(max(1, ntasks) * max(1, ntasks_per_run))
     if init === nothing
         nruns > 0 || throw(ArgumentError("A positive `nruns` must be set or `init` must be provided."))      # :148-150
         dim > 0 || throw(ArgumentError("An initial point `init` or dimension `dim` must be provided."))     # src/singlepath.jl:171

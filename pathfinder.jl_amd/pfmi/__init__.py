@@ -10,4 +10,4 @@ from .api import (DEFAULT_HISTORY_LENGTH, DEFAULT_NDRAWS_ELBO, ELBOEstimate, Mul
 from .core import Comm, Engine, StaleHandleError  # noqa: F401
 from .hostrng import HostRNG  # noqa: F401
 from .optimize import OptimizationTrace, optimize_with_trace  # noqa: F401
-from .targets import (CallbackTarget, DeviceCallbackTarget, TorchDeviceTarget, FunnelTarget, GaussTarget, t_diag, t_funnel, t_iso, t_lowrank)  # noqa: F401
+from .targets import (CallbackTarget, DeviceCallbackTarget, HostFnTarget, TorchDeviceTarget, FunnelTarget, GaussTarget, t_diag, t_funnel, t_iso, t_lowrank)  # noqa: F401

@@ -46,7 +46,7 @@ SYMBOLS = [
     "pfmi_callback_stats_dev", "pfmi_pool_build_best", "pfmi_pool_winners", "pfmi_psis_weights", "pfmi_comm_psis_resample", "pfmi_debug_set",
     "pfmi_host_alloc", "pfmi_host_free", "pfmi_comm_psis_resample_enqueue", "pfmi_comm_psis_resample_wait", "pfmi_defer_downloads",
     "pfmi_stream_enqueue", "pfmi_stream_seeds", "pfmi_stream_pump", "pfmi_stream_wait", "pfmi_stream_cancel",
-    "pfmi_fit_batch_ex", "pfmi_set_hinit",
+    "pfmi_fit_batch_ex", "pfmi_set_hinit", "pfmi_set_callback_threads",
 ]
 
 

@@ -337,6 +337,7 @@ def maximize_elbo(rng, target, dists, ndraws, ntasks=1):
     for dist, s in zip(dists, seeds_l):
         seeds[dist.point] = s
     eng.set_target(target)
+    eng.set_callback_threads(ntasks)                        # src/elbo.jl:3-6: logp over `ntasks` tasks (host closures; no-op for device targets)
     elbo, se, _ = eng.elbo_batch(ndraws, seeds)
     ests = [ELBOEstimate(float(elbo[d.point]), float(se[d.point]), eng, d.point, int(seeds[d.point]), ndraws,
                          token=eng.fit_token()) for d in dists]
@@ -694,6 +695,7 @@ def pathfinder(target, *, rng=None, init=None, dim=-1, init_scale=2, init_sample
         dim = len(init)
     eng = engine or Engine()
     eng.set_target(target)
+    eng.set_callback_threads(ntasks)                        # `ntasks` (src/singlepath.jl:114-117 -> src/elbo.jl:3-6): a host closure is called from ntasks threads
     rng_state = (rng.seed, rng.counter) if isinstance(rng, HostRNG) else None
     for attempt in range(_RETRIES + 1):
         try:
@@ -741,6 +743,9 @@ def multipathfinder(target, ndraws, *, init=None, nruns=-1, ndraws_elbo=DEFAULT_
     engs = list(engines) if engines else [engine or Engine()]
     for e in engs:
         e.set_target(target)
+        # the reference spreads the runs over `ntasks` tasks and each run's logp evaluations over `ntasks_per_run` (src/multipath.jl:104-108,
+        # 190-208); here the runs of an engine are ONE batch, so a host closure sees ntasks * ntasks_per_run threads per staged block
+        e.set_callback_threads(max(1, int(ntasks)) * max(1, int(ntasks_per_run)))
     resample_seed = int(rng.rand_u64(1)[0])                                                     # _resample's draw from the top-level rng (:225)
     # draws_per_component = stack(draws) (:217), _compute_psis_result (:221), _resample (:225): enqueued behind the ELBO scan
     for attempt in range(_RETRIES + 1):
@@ -809,6 +814,7 @@ def resample(result, ndraws, *, rng=None, replace=True, importance=True, ndraws_
         npr = runs[0].ndraws_per_run                                # pathfinder_results[k].draws, whatever an earlier
         seeds = [r.draw_seed for r in runs]                         # resample() drew fresh
     for eng, (k0, k1) in zip(engs, blocks):
+        eng.set_callback_threads(ntasks)                            # src/resample.jl:85-92: logp over `ntasks` tasks
         eng.pool_build(npr, [r.fit_distribution.point for r in runs[k0:k1]], seeds[k0:k1])
     S = K * npr
     # PSIS of the (re)built pool: for stored draws this reproduces result.psis_result bit for bit

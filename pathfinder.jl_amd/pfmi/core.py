@@ -271,6 +271,12 @@ class Engine:
         else:
             check(self.L.pfmi_fit_batch_ex(self.ctx, C.c_int32(history_length), C.c_double(eps), C.c_int32(HINIT[hinit])))
 
+    def set_callback_threads(self, n):
+        """the reference's `ntasks` for host closures (CallbackTarget): every staged block of draws is evaluated by n host threads on
+        contiguous column ranges (pfmi_set_callback_threads; the closure must be thread-safe, src/multipath.jl:104-108).  A closure
+        written in Python only gains where it releases the GIL (NumPy does inside its kernels)."""
+        check(self.L.pfmi_set_callback_threads(self.ctx, C.c_int32(max(1, int(n)))))
+
     def set_hinit(self, hinit):
         """the context's default Hinit (pfmi_fit_batch and the streaming pipeline use it)"""
         check(self.L.pfmi_set_hinit(self.ctx, C.c_int32(HINIT[hinit])))

@@ -158,6 +158,34 @@ class CallbackTarget:
         return t
 
 
+class HostFnTarget:
+    """A COMPILED host closure (PFMI_TARGET_HOST_CALLBACK with a raw C function pointer: what a C or Julia caller's `logp` is to the
+    library -- `fn(X, d, n, out, user)`, include/pfmi.h: pfmi_logp_fn).  Unlike CallbackTarget there is no Python in the call, so
+    Engine.set_callback_threads (the reference's ntasks) really runs it on several cores.  `host`: an object with logp / grad /
+    logp_and_grad for the host optimiser."""
+    kind = KIND_CALLBACK
+    pending_error = None
+
+    def __init__(self, d, fn, user=None, host=None, keepalive=None):
+        self.d, self._fn, self._user, self.host, self._keep = d, fn, user, host, keepalive
+
+    def _h(self):
+        if self.host is None:
+            raise ValueError("this HostFnTarget has no Python twin (logp / grad)")
+        return self.host
+
+    def logp(self, x): return self._h().logp(x)
+    def grad(self, x): return self._h().grad(x)
+    def logp_and_grad(self, x): return self._h().logp_and_grad(x)
+
+    def descriptor(self):
+        t = _lib.pfmi_target()
+        t.kind, t.d = KIND_CALLBACK, self.d
+        t.fn = self._fn if isinstance(self._fn, int) else C.cast(self._fn, C.c_void_p)
+        t.user = self._user
+        return t
+
+
 class DeviceCallbackTarget:
     """Arbitrary DEVICE closure (PFMI_TARGET_DEVICE_CALLBACK): the draws stay in HBM, `dev_fn` launches the user's kernel on the
     engine's stream.  dev_fn: a C function pointer (int address or ctypes function) with the pfmi_logp_dev_fn signature

@@ -51,6 +51,24 @@ def demo_device_target(tg):
     return pfmi.DeviceCallbackTarget(tg.d, fn, C.c_void_p(h), host=tg, keepalive=(L, h))
 
 
+def demo_host_target(tg):
+    """The compiled HOST closure of examples/device_logp for a built-in Gaussian target `tg` (same parameters): a
+    PFMI_TARGET_HOST_CALLBACK target whose function is plain C -- what a C / Julia caller hands to the library."""
+    import ctypes as C
+    import pfmi
+    pfmi.lib()
+    L = C.CDLL(DEMO_LIB)
+    dp = C.POINTER(C.c_double)
+    L.pfx_host_gauss_create.restype = C.c_void_p
+    L.pfx_host_gauss_create.argtypes = [C.c_int32, C.c_int32, dp, dp, dp, dp, C.c_double]
+    Gc = np.asfortranarray(tg.G) if tg.r else None
+    h = L.pfx_host_gauss_create(tg.d, tg.r, tg.mean.ctypes.data_as(dp), tg.a.ctypes.data_as(dp),
+                                tg.Wd.ctypes.data_as(dp) if tg.r else None, Gc.ctypes.data_as(dp) if tg.r else None, tg.offset)
+    assert h, "pfx_host_gauss_create failed"
+    fn = C.cast(L.pfx_host_gauss_logp, C.c_void_p).value
+    return pfmi.HostFnTarget(tg.d, fn, C.c_void_p(h), host=tg, keepalive=(L, h, Gc))
+
+
 def oracle_factor_from_gpu(f):
     """An oracle Factor whose arrays ARE the GPU's factor of one fit (pfmi_get_fit: U = sqrt(alpha), the Householder vectors, tau =
     diag(T), V).  x(u) = mu + U'Q[V'u_1; u_2] is a function of exactly these arrays, so the oracle's reflector-by-reflector apply
