@@ -167,7 +167,10 @@ __global__ __launch_bounds__(XW_THREADS) void pf_elbo_xw_kernel(ElboArgs A, int 
     // the priority hand-over between the two waves of a SIMD pays when the factor block is resident (config 3: 4.93 -> 4.71 ms); with a streamed
     // block every chunk ends in a barrier that re-aligns the waves anyway, and the hand-over only costs (config-5 shape: 34.1 -> 33.0 ms
     // without it; profiles/r06_experiments.md)
-    const bool fair = nchunks == 1;
+#ifndef XW_FAIR_MODE
+#define XW_FAIR_MODE 0                    // experiments: 1 = always, 2 = never
+#endif
+    const bool fair = XW_FAIR_MODE == 1 ? true : XW_FAIR_MODE == 2 ? false : nchunks == 1;
     __syncthreads();
 
     int cur = 0;

@@ -792,7 +792,18 @@ int32_t pfmi_stream_seeds(pfmi_ctx *c, const uint64_t *seeds) {
 static int32_t stream_pump_pass(pfmi_ctx *c, int32_t *finished);
 int32_t pfmi_stream_pump(pfmi_ctx *c, int32_t *finished) {
     PF_CTX_MUT(c);
+    const auto tp0 = std::chrono::steady_clock::now();
+    const int seg0 = c->sr.l_next;
+    const bool was_active = c->sr.active;
     const int32_t rc = stream_pump_pass(c, finished);
+    if (was_active && (c->sr.l_next != seg0 || !c->sr.active)) {     // this pass launched a segment (or the reduction): the scheduler's real cost
+        c->sr.host_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count();
+        c->sr.host_n += 1;
+        if (!c->sr.active && c->profile) {                            // "stream_host_schedule": host milliseconds per call spent launching segments
+            KernelStat &ks = c->kstats["stream_host_schedule"];
+            ks.ms += c->sr.host_s * 1e3; ks.launches += c->sr.host_n;
+        }
+    }
     if (rc != PFMI_OK && c->sr.active) stream_abandon(c);          // a failed pass ends the call: what is in flight is drained, the context is usable again
     return rc;
 }

@@ -137,6 +137,7 @@ struct pfmi_ctx {
         std::vector<uint64_t> seeds_pt;       // host copy of the per-point seeds (the scan's work lists are cut from it)
         std::chrono::steady_clock::time_point t_progress, t_start;
         std::vector<double> trace;            // PFMI_STREAM_TRACE: (t_us, l0, l1, fits, scan stream) per segment
+        double host_s = 0.0; int host_n = 0;   // host time of the scheduling passes that LAUNCHED something (not the idle polls), and their number
     } sr;
     bool stream_pending = false;
     bool qf_seg_mode = false;                 // scan launches of a segment that is not the last: one workgroup per fit, no tail cut (they overlap)

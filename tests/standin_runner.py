@@ -127,8 +127,8 @@ def _sharded(tg, K, J, N, ndraws, maxiters, scale, Gs, check_owner=True):
             np.testing.assert_array_equal(el, elbo1[p0:p0 + e.P])
             np.testing.assert_array_equal(bs, best1[bk[g]:bk[g + 1]])
         if check_owner:                                   # the selected columns really come from different owners
-            owners = np.unique(np.searchsorted(np.array(bk[1:]) * N, ref["idx"], side="right"))
-            assert len(owners) > 1 or G == 1
+            owners = np.unique(np.searchsorted(np.array(bk[1:]) * N, ref["idx_uni"], side="right"))
+            assert len(owners) > 1 or G == 1                # (the UNIFORM selection: the weighted one may be degenerate -- k-hat 12 at config 5's shape)
             print(f"G={G}: bit-identical; selected columns owned by ranks {owners.tolist()}", flush=True)
         comm.close()
         for e in engs:

@@ -79,13 +79,18 @@ def test_bench_single_process_drives_several_contexts():
     import json
     env = dict(os.environ, PFMI_RCCL_LIB=STANDIN_LIB, PFMI_COMM_ALLOW_SHARED_GPU="1")
     out = {}
-    for G in (1, 2):
+    for G, K in ((1, 8), (2, 8), (3, 8)):                       # (3 contexts x 8 paths: blocks 3 3 2 -- unequal shards through the bench, too)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(G), "--single-process", "--steps", "2", "--warmup", "1",
-                            "--npaths", "8", "--dim", "200", "--ndraws-elbo", "256", "--ndraws", "256"], env=env, capture_output=True,
+                            "--npaths", str(K), "--dim", "200", "--ndraws-elbo", "256", "--ndraws", "256"], env=env, capture_output=True,
                            text=True, timeout=500)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         out[G] = json.loads(r.stdout.strip().splitlines()[-1])
         assert out[G]["n_gpus"] == G and out[G]["config"]["ranks_in_collective"] == G
+        # round 6: the streamed end-to-end call of ONE host thread over G pipelines, with what that thread spends scheduling them
+        hs = out[G]["single_thread_scheduler"]
+        assert "error" not in hs, hs
+        assert hs["streamed_equals_packed"] is True and hs["host_schedule_ms_per_step"] > 0 and hs["segment_launches_per_step"] >= G
+    assert out[3]["config"]["paths_per_gpu"] == [3, 3, 2] and out[3]["pareto_k"] == out[1]["pareto_k"] and out[3]["sharded_equals_single"] is True
     assert out[2]["config"]["rccl_version"] == 99999 and out[1]["config"]["rccl_version"] == 0
     assert out[1]["pareto_k"] == out[2]["pareto_k"] and out[1]["config"]["elbo_draws_per_step"] == out[2]["config"]["elbo_draws_per_step"]
     # round 4: the sharded run verifies ITSELF -- all paths recomputed on one context, k-hat / tail length / indices / a hash of the
