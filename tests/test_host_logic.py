@@ -99,8 +99,10 @@ def test_contiguous_blocks_of_runs_per_engine():
     import pytest
     from pfmi.api import _blocks
     assert _blocks(64, 8) == [(8 * g, 8 * g + 8) for g in range(8)] and _blocks(5, 1) == [(0, 5)]
-    with pytest.raises(ValueError, match="divisible"):
-        _blocks(10, 4)
+    # uneven shards (reference: any nruns, src/multipath.jl:131-146): the first K % G engines take one more run, blocks stay contiguous
+    assert _blocks(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)] and _blocks(20, 8)[3:6] == [(9, 12), (12, 14), (14, 16)]
+    with pytest.raises(ValueError, match="at least one run"):
+        _blocks(3, 4)
 
 
 def test_host_driver_records_the_nonfinite_iterate_then_stops():
