@@ -701,6 +701,26 @@ def main():
                           "max_rel_elbo_diff_vs_builtin_target": devcb_diff,
                           "sample": f"first {Kd} paths, {e3.P - Kd} fits x {N_e} draws, d={d}; closure = examples/device_logp (HIP, same target)",
                           "note": "draws written to HBM by the library's draw kernel, read by the user's kernel on the same stream; no PCIe"}
+            # ---- the writer's own issue floor, priced like the scan's: nothing co-issues with the f64 MFMA on gfx950, so
+            # the floor is the SUM of the issue streams, with the unit times of the co-issue micro-benchmark (2 waves per SIMD:
+            # MFMA 4x4x4 7.44 ns, 16x16x4 = four times that, Philox round 10.5 ns, other VALU 2.0 ns).  Per wave and 16-row block of its TWO
+            # 16-draw groups (instruction counts read off the ISA of pf_elbo_xw_kernel<KC>, interior bodies):
+            #   pass 1  2 x 4 x KC/4 MFMA 4x4x4 (w += Vh'z), 2 Philox4x32-7, ~95 VALU (2 x 4 look-ups of 9, |u|^2, addresses)
+            #   pass 2  2 x KC/4 MFMA 16x16x4 (x~ = z - Vh tv), 2 Philox4x32-7, ~105 VALU (look-ups, x = mu + sqrt(alpha) x~, store addresses)
+            kc_w = next(o for o in (4, 8, 12, 16, 20, 32) if 2 * J <= o)
+            nt_w, nblk_w = kc_w // 4, -(-d // 16)
+            per_pair_us = ((2 * 4 * nt_w) * 7.44 + (2 * nt_w) * 4 * 7.44 + 28 * 10.5 + 200 * 2.0) * 1e-3
+            walks = (e3.P - Kd) * (-(-(-(-N_e // 16)) // 16)) * 8          # fits x batches of 16 group slots x 8 waves, each walking nblk blocks twice
+            w_floor_ms = per_pair_us * walks * nblk_w / (4.0 * 256) * 1e-3
+            tw_launch = tw                                                # kernel_time: ms of ONE scan (all its writer launches)
+            devcb_line["writer_issue_floor"] = {
+                "floor_ms": round(w_floor_ms, 3), "measured_over_floor": round(tw_launch / w_floor_ms, 3) if w_floor_ms > 0 else None,
+                "model": f"per wave and 16-row block of two 16-draw groups, both passes: {2 * 4 * nt_w} MFMA4 x 7.44 ns + {2 * nt_w} MFMA16 x 29.76 ns + "
+                         "28 Philox rounds x 10.5 ns + ~200 VALU x 2.0 ns; 2 waves per SIMD, no MFMA / VALU co-issue (profiles/r02_coissue_microbench.txt)",
+                "note": "NOT the binding constraint: ablations (profiles/r04_experiments.md 1, r06_experiments.md) -- without Philox -0.17 ms, without the "
+                        "table look-ups -0.44 ms, without the MFMAs -1.0 ms of 5.1 -- show a wave issuing ~1/3 of its cycles; what is left is LDS "
+                        "queueing of the random 16-byte table reads (the generator runs TWICE) and the dependent look-up -> cubic -> MFMA -> store chain "
+                        "with two waves per SIMD"}
             e3.close()
         except Exception as ex:  # pragma: no cover
             devcb_line = {"error": repr(ex)}

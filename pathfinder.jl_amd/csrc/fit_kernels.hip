@@ -1240,6 +1240,7 @@ static void launch_fit_t(pfmi_ctx *c, const FitArgs &a) {
 }
 
 int32_t pf_launch_fit_panel(pfmi_ctx *c, const FitArgs &a, bool *handled);   // fit_panel_kernel.hip
+int32_t pf_launch_fit_tsqr(pfmi_ctx *c, const FitArgs &a, bool *handled);    // fit_tsqr_kernel.hip
 
 int32_t pf_launch_fit(pfmi_ctx *c, int seg_l0, int seg_len) {
     FitArgs a;
@@ -1256,9 +1257,12 @@ int32_t pf_launch_fit(pfmi_ctx *c, int seg_l0, int seg_len) {
     a.big = nullptr;
     pf_kernel_begin(c);
     {
-        const char *force = pf_debug_get("PFMI_FIT_KERNEL");        // "mem": column-by-column memory-resident kernel also for d > 1024
+        // d > 1024: the TSQR + Householder-reconstruction kernel (round 6: the block crosses HBM once each way); PFMI_FIT_KERNEL (debug hook)
+        // = "panel": the left-looking panel kernel of rounds 2 - 5, "mem": the column-by-column memory-resident kernel
+        const char *force = pf_debug_get("PFMI_FIT_KERNEL");
         bool handled = false;
-        if (!(force && force[0] == 'm')) PF_TRY(pf_launch_fit_panel(c, a, &handled));
+        if (!(force && (force[0] == 'm' || force[0] == 'p'))) PF_TRY(pf_launch_fit_tsqr(c, a, &handled));
+        if (!handled && !(force && force[0] == 'm')) PF_TRY(pf_launch_fit_panel(c, a, &handled));
         if (handled) {
             pf_kernel_end(c, "fit");
             PF_HIP(hipGetLastError());
