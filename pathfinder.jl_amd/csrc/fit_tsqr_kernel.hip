@@ -32,8 +32,14 @@
 #include <stdlib.h>
 #include "fit_args.h"
 
-#define TS_NT 512
+#ifndef TS_NT
+#define TS_NT 512                      // threads per workgroup: 512 = one workgroup per CU (2 waves x 256 registers per SIMD).  256 puts TWO workgroups on a
+                                       // CU so that one fit's memory phases run under the other's reductions -- measured equal at config 5's shape (5.86 against
+                                       // 5.92 ms: the SIMDs are issue-bound in the column loop either way) and slower for a handful of fits (twice the chunks per
+                                       // fit); profiles/r06_experiments.md
+#endif
 #define TS_NW (TS_NT / 64)
+#define TS_STACK 512                   // rows of the stack of R factors (n_chunks x m <= 512): TS_STACK / TS_NT rows per thread in the stack stage
 #define TS_OPAQUE(x) asm volatile("" : "+v"(x))
 #ifndef TS_PROF
 #define TS_PROF 0                      // 1: workgroup 0 accumulates cycle counts per section and prints them (experiments only)
@@ -207,17 +213,17 @@ __device__ __noinline__ int ts_stack_stage(double *stk, const int m_, const int 
     int tid = threadIdx.x;
     TS_OPAQUE(tid);
     {
-        double Pt[1][MC], Ut[1];
+        constexpr int RCT = TS_STACK / TS_NT;                              // stack row r = tid + TS_NT i
+        double Pt[RCT][MC], Ut[RCT];
 #pragma unroll
-        for (int cc = 0; cc < MC; ++cc) Pt[0][cc] = 0.0;
-        Ut[0] = 0.0;
-        if (tid < nst) {
-            const int cr = tid % (m > 0 ? m : 1);                          // row cr of its R_i: entries left of the diagonal were never written
+        for (int i = 0; i < RCT; ++i) {
+            const int r = tid + TS_NT * i;
+            const int cr = r % (m > 0 ? m : 1);                            // row cr of its R_i: entries left of the diagonal were never written
 #pragma unroll
-            for (int cc = 0; cc < MC; ++cc) Pt[0][cc] = (cc >= cr && cc < m) ? stk[(size_t)tid * SW + cc] : 0.0;
-            Ut[0] = stk[(size_t)tid * SW + MC];
+            for (int cc = 0; cc < MC; ++cc) Pt[i][cc] = (r < nst && cc >= cr && cc < m) ? stk[(size_t)(r < nst ? r : 0) * SW + cc] : 0.0;
+            Ut[i] = (r < nst) ? stk[(size_t)r * SW + MC] : 0.0;
         }
-        ts_qr_cols<1, MC>(Pt, Ut, m, sT, srow2, red, flip, sR, MC, sHead);
+        ts_qr_cols<RCT, MC>(Pt, Ut, m, sT, srow2, red, flip, sR, MC, sHead);
         __syncthreads();
         TS_OPAQUE(tid);
         if (tid < m) {                                                     // K_t = T_t V_t[0:m, :]'  -> sM (column tid), sign D of R_in's diagonal
@@ -233,14 +239,18 @@ __device__ __noinline__ int ts_stack_stage(double *stk, const int m_, const int 
         }
         __syncthreads();
         TS_OPAQUE(tid);
-        if (tid < nst) {                                                   // W[r, c] = D_c (delta_rc - V_t[r, :] K_t[:, c])
 #pragma unroll
-            for (int c = 0; c < MC; ++c) {
-                double wv = (tid == c) ? 1.0 : 0.0;
+        for (int i = 0; i < RCT; ++i) {
+            const int r = tid + TS_NT * i;
+            if (r < nst) {                                                 // W[r, c] = D_c (delta_rc - V_t[r, :] K_t[:, c])
 #pragma unroll
-                for (int a = 0; a < MC; ++a) wv = fma(-Pt[0][a], sM[a * MC + c], wv);
-                stk[(size_t)tid * SW + c] = (c < m) ? wv * sDg[c] : 0.0;
-                __builtin_amdgcn_sched_barrier(0);
+                for (int c = 0; c < MC; ++c) {
+                    double wv = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int a = 0; a < MC; ++a) wv = fma(-Pt[i][a], sM[a * MC + c], wv);
+                    stk[(size_t)r * SW + c] = (c < m) ? wv * sDg[c] : 0.0;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         if (tid < m) {                                                     // R_in <- D R_in, head <- D head
@@ -510,14 +520,14 @@ static int ts_lds_doubles(int MC) {
 }
 
 template <int MC, int RC>
-__global__ __launch_bounds__(TS_NT, 1) void pf_fit_tsqr_kernel(FitArgs A, const int DP, const int nch_max, double *scratch_all, int *counter) {
+__global__ __launch_bounds__(TS_NT, 512 / TS_NT) void pf_fit_tsqr_kernel(FitArgs A, const int DP, const int nch_max, double *scratch_all, int *counter) {
     constexpr int NV = MC + 4, CH = TS_NT * RC, SW = MC + 4;
     int tid = threadIdx.x;                                       // re-defined (opaque) at every phase boundary: whatever is derived from it -- masks tid == c,
                                                                  // LDS row addresses, ... -- is invariant across fits and would be hoisted in front of the fit loop and spilled
     const int d = A.d, J = A.J;
-    // per-workgroup scratch: reflectors column-major [MC][DP] | stack / W rows [512][SW] | per chunk: K_i, M_i, N_i, W_i U^-1 [MC][MC], y_i, W_i Sd [MC]
+    // per-workgroup scratch: reflectors column-major [MC][DP] | stack / W rows [TS_STACK][SW] | per chunk: K_i, M_i, N_i, W_i U^-1 [MC][MC], y_i, W_i Sd [MC]
     const size_t small = (size_t)nch_max * MC * MC;
-    const size_t wg_doubles = (size_t)MC * DP + (size_t)TS_NT * SW + 4 * small + 2 * (size_t)nch_max * MC;
+    const size_t wg_doubles = (size_t)MC * DP + (size_t)TS_STACK * SW + 4 * small + 2 * (size_t)nch_max * MC;
     double *scr_wg = scratch_all + (size_t)blockIdx.x * wg_doubles;
 
     const TsLds L = ts_lds_layout<MC>();
@@ -550,7 +560,7 @@ __global__ __launch_bounds__(TS_NT, 1) void pf_fit_tsqr_kernel(FitArgs A, const 
         // fits) would otherwise be hoisted in front of the fit loop and live -- spilled -- through every phase
         double *scr = scr_wg;
         asm volatile("" : "+s"(scr));
-        double *stk = scr + (size_t)MC * DP, *Kg = stk + (size_t)TS_NT * SW, *Mg = Kg + small, *Ng = Mg + small, *Wug = Ng + small;
+        double *stk = scr + (size_t)MC * DP, *Kg = stk + (size_t)TS_STACK * SW, *Mg = Kg + small, *Ng = Mg + small, *Wug = Ng + small;
         double *Yg = Wug + small, *Wdg = Yg + (size_t)nch_max * MC;
         int64_t p;
         if (!pf_fit_point(A, sNext, p)) { if (tid == 0) A.status[p] = PFMI_FIT_ABSENT; continue; }
@@ -792,17 +802,21 @@ __global__ __launch_bounds__(TS_NT, 1) void pf_fit_tsqr_kernel(FitArgs A, const 
 
 // ---------------------------------------------------------------------------------------------------
 template <int MC, int RC>
-static int32_t launch_tsqr_t(pfmi_ctx *c, const FitArgs &a, int ncu) {
+static int32_t launch_tsqr_t(pfmi_ctx *c, const FitArgs &a, int ncu, bool *handled) {
     constexpr int CH = TS_NT * RC;
     const int lds = ts_lds_doubles(MC) * (int)sizeof(double);
     auto kern = pf_fit_tsqr_kernel<MC, RC>;
     PF_TRY(pf_raise_lds_limit(c, reinterpret_cast<const void *>(kern), lds));
     const int nch = (a.d + CH - 1) / CH, DP = nch * CH;
-    PF_CHECK(nch * MC <= TS_NT, PFMI_ERR_UNSUPPORTED, "tsqr fit: %d chunks x %d columns exceed the stack", nch, MC);
-    int64_t slots = ncu;
+    if (nch * MC > TS_STACK) { *handled = false; return PFMI_OK; }              // more chunks than the stack holds: the panel kernel takes the launch
+    int occ = 1;
+    PF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, TS_NT, lds));
+    if (occ < 1) occ = 1;
+    if (occ > 512 / TS_NT) occ = 512 / TS_NT;
+    int64_t slots = (int64_t)ncu * occ;
     if (const char *g = pf_debug_get("PFMI_FIT_PANEL_GRID")) { const int v = atoi(g); if (v > 0) slots = v; }   // experiment hook: resident workgroups
     const int grid = slots < a.P ? (int)slots : (int)a.P;
-    const size_t wg_doubles = (size_t)MC * DP + (size_t)TS_NT * (MC + 4) + 4 * (size_t)nch * MC * MC + 2 * (size_t)nch * MC;
+    const size_t wg_doubles = (size_t)MC * DP + (size_t)TS_STACK * (MC + 4) + 4 * (size_t)nch * MC * MC + 2 * (size_t)nch * MC;
     const size_t scr_bytes = (size_t)grid * wg_doubles * sizeof(double);
     PF_TRY(c->fit_scratch.ensure(scr_bytes + 256));
     int *counter = reinterpret_cast<int *>(c->fit_scratch.as<char>() + scr_bytes);
@@ -815,18 +829,18 @@ static int32_t launch_tsqr_t(pfmi_ctx *c, const FitArgs &a, int ncu) {
 int32_t pf_launch_fit_tsqr(pfmi_ctx *c, const FitArgs &a, bool *handled) {
     *handled = false;
     if (a.d <= 1024 || a.d > 16384) return PFMI_OK;
+    *handled = true;                         // (a launcher that declines resets it)
     int ncu = 0;
     PF_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device));
     switch (c->kpad) {                       // rows per thread: the chunk (RC x KPAD doubles per thread) stays inside ~130 of the 256 registers
-        case 8: PF_TRY((launch_tsqr_t<8, 8>(c, a, ncu))); break;
-        case 12: PF_TRY((launch_tsqr_t<12, 5>(c, a, ncu))); break;
-        case 16: PF_TRY((launch_tsqr_t<16, 4>(c, a, ncu))); break;
-        case 20: PF_TRY((launch_tsqr_t<20, 3>(c, a, ncu))); break;
+        case 8: PF_TRY((launch_tsqr_t<8, 8>(c, a, ncu, handled))); break;
+        case 12: PF_TRY((launch_tsqr_t<12, 5>(c, a, ncu, handled))); break;
+        case 16: PF_TRY((launch_tsqr_t<16, 4>(c, a, ncu, handled))); break;
+        case 20: PF_TRY((launch_tsqr_t<20, 3>(c, a, ncu, handled))); break;
         // KPAD = 32 (history_length 11 .. 16): 2 x 32 doubles per thread + a 36-value reduction do not fit 256 registers (the chunk loop
         // spills); the left-looking panel kernel stays the default there, "tsqr" forces this one (tests)
-        case 32: { const char *f = pf_debug_get("PFMI_FIT_KERNEL"); if (!(f && f[0] == 't')) return PFMI_OK; PF_TRY((launch_tsqr_t<32, 2>(c, a, ncu))); } break;
-        default: return PFMI_OK;
+        case 32: { const char *f = pf_debug_get("PFMI_FIT_KERNEL"); if (!(f && f[0] == 't')) { *handled = false; return PFMI_OK; } PF_TRY((launch_tsqr_t<32, 2>(c, a, ncu, handled))); } break;
+        default: *handled = false; return PFMI_OK;
     }
-    *handled = true;
     return PFMI_OK;
 }
