@@ -2,7 +2,7 @@
  * julia_sequence.c -- the exact sequence of C-ABI calls that pathfinder.jl_amd/julia/PathfinderMI355X.jl makes for
  * `multipathfinder(eng, fun, ndraws; ...)`, `resample(...)` and the multi-GPU `Comm`, replayed from plain C with the results the
  * Julia side relies on checked after every step.  No Julia toolchain exists in this repository's images, so this program is
- * the executed stand-in for the wrapper (tests/test_gpu_parity_r2.py::test_julia_call_sequence_in_c builds and runs it on the
+ * the executed stand-in for the wrapper (tests/test_gpu_abi.py::test_julia_call_sequence_in_c builds and runs it on the
  * GPU box).  Each block names the Julia function whose ccalls it replays.
  *
  *   gcc -O2 -Iinclude examples/julia_sequence.c -o julia_sequence -Lpathfinder.jl_amd/lib -lpfmi -Wl,-rpath,... -lm -ldl

@@ -2,7 +2,7 @@
 
 CPU part: with PFMI_BENCH_LAUNCH_ONLY=1 the ranks only join a `gloo` world and count themselves, which exercises the
 self-launch path (no WORLD_SIZE in the environment -> bench.py re-executes itself under torch.distributed.run on
-127.0.0.1) and the WORLD_SIZE / --gpus consistency check.  The GPU part (tests/test_gpu_parity.py::test_bench_*) runs the
+127.0.0.1) and the WORLD_SIZE / --gpus consistency check.  The GPU part (tests/test_gpu_*.py::test_bench_*) runs the
 real step through RCCL.
 """
 import json
