@@ -25,6 +25,8 @@ PINS = {
     "pf_elbo_xw_kernel<20>(": (256, 128, "draw writer at J = 10 (round 4: 264 -> 96-104 B of scratch)"),
     "pf_fit_reg_kernel<12, 4, 256>(": (168, 0, "fit at d <= 1024, J = 6: 3 workgroups per CU need <= 168 VGPRs, no spill (round 4: 163)"),
     "pf_fit_reg_kernel<12, 2, 256>(": (128, 0, "fit at d <= 512"),
+    "pf_fit_tsqr_kernel<20, 3>(": (256, 512, "large-d fit at J = 10 (round 6): 3 rows x 20 columns per thread in registers; the stage functions' few spills, nothing in the column loop"),
+    "pf_fit_tsqr_kernel<12, 5>(": (256, 512, "large-d fit at J = 6"),
     "pf_history_kernel<4, 256>(": (256, 0, "history walk at d <= 1024: four register sets of rows, nothing spilled"),
     "pf_lbfgs_kernel<4, 256, 8, true>(": (512, 0, "device L-BFGS at config 3 (rank-8 target, ring in LDS): VGPRs + AGPRs at one wave per SIMD, no scratch"),
     "pf_lbfgs_kernel<4, 256, 0, true>(": (512, 0, "device L-BFGS, diagonal / funnel target"),
