@@ -837,9 +837,14 @@ int32_t pf_launch_fit_tsqr(pfmi_ctx *c, const FitArgs &a, bool *handled) {
         case 12: PF_TRY((launch_tsqr_t<12, 5>(c, a, ncu, handled))); break;
         case 16: PF_TRY((launch_tsqr_t<16, 4>(c, a, ncu, handled))); break;
         case 20: PF_TRY((launch_tsqr_t<20, 3>(c, a, ncu, handled))); break;
-        // KPAD = 32 (history_length 11 .. 16): 2 x 32 doubles per thread + a 36-value reduction do not fit 256 registers (the chunk loop
-        // spills); the left-looking panel kernel stays the default there, "tsqr" forces this one (tests)
-        case 32: { const char *f = pf_debug_get("PFMI_FIT_KERNEL"); if (!(f && f[0] == 't')) { *handled = false; return PFMI_OK; } PF_TRY((launch_tsqr_t<32, 2>(c, a, ncu, handled))); } break;
+        // KPAD = 32 (history_length 11 .. 16): wins once the block is large (d = 8000, 968 fits: 7.5 against the panel kernel's 10.6 ms; d = 10^4:
+        // 7.7 against 9.2), loses for a short block (d = 2000, 46 fits: 0.66 against 0.54 ms -- 32 columns cost 33 block reductions per chunk):
+        // from d = 4096; "tsqr" forces it (tests, probes)
+        case 32: {
+            const char *f = pf_debug_get("PFMI_FIT_KERNEL");
+            if (a.d < 4096 && !(f && f[0] == 't')) { *handled = false; return PFMI_OK; }
+            PF_TRY((launch_tsqr_t<32, 2>(c, a, ncu, handled)));
+        } break;
         default: *handled = false; return PFMI_OK;
     }
     return PFMI_OK;

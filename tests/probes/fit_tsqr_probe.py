@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "pathfind
 import numpy as np, pfmi
 L = pfmi.lib()
 shapes = {"small": [("diag", 1500, 4, 2, 12), ("lr", 3000, 6, 2, 14), ("funnel", 6000, 10, 2, 16), ("diag", 12000, 10, 2, 14), ("diag", 2000, 16, 2, 22)],
-          "c5": [("funnel", 10000, 10, 8, 200)]}
+          "c5": [("funnel", 10000, 10, 8, 200)],
+          "j16": [("diag", 2000, 16, 2, 22), ("diag", 8000, 16, 8, 120), ("funnel", 10000, 16, 8, 100)]}
 which = [a for a in sys.argv[1:] if a in shapes] or ["small"]
 for w in which:
     for tname, d, J, K, maxit in shapes[w]:
@@ -17,7 +18,7 @@ for w in which:
         eng.optimize_batch(x0, J, maxit)
         res = {}
         for kern in ("tsqr", "panel", "mem"):
-            L.pfmi_debug_set(b"PFMI_FIT_KERNEL", None if kern == "tsqr" else kern.encode())
+            L.pfmi_debug_set(b"PFMI_FIT_KERNEL", kern.encode())               # ("tsqr" also forces the TSQR kernel where the panel kernel is the default: KPAD = 32)
             eng.fit_batch(J); eng.sync()
             eng.profile(True)
             for _ in range(3):

@@ -339,7 +339,7 @@ def test_panel_fit_kernel_variants(pfmi_mod, eng, tname, d, J, maxit):
     st, je, ld, nr = eng.fit_status()
     fits = {p: eng.get_fit(p, int(je[p])) for p in range(eng.P)}
     old = os.environ.get("PFMI_FIT_KERNEL")
-    other = "tsqr" if 2 * J > 20 else "panel"                 # the large-d kernel that is NOT the default at this history length
+    other = "tsqr" if (2 * J > 20 and d < 4096) else "panel"  # the large-d kernel that is NOT the default at this shape
     try:
         os.environ["PFMI_FIT_KERNEL"] = "mem"
         eng.fit_batch(J)
