@@ -323,7 +323,7 @@ def test_memory_resident_fit_kernel_at_large_d(pfmi_mod, eng, tname, d, J, monke
 
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("tname,d,J,maxit", [("diag", 1500, 4, 12), ("lr", 3000, 6, 14), ("funnel", 6000, 10, 16), ("diag", 12000, 10, 14),
-                                               ("diag", 2000, 16, 22), ("funnel", 10000, 10, 14), ("lr", 5000, 8, 14), ("diag", 16384, 5, 10)])
+                                               ("diag", 2000, 16, 22), ("funnel", 10000, 10, 14), ("lr", 5000, 8, 14), ("diag", 16384, 5, 10), ("diag", 5000, 12, 26)])
 def test_panel_fit_kernel_variants(pfmi_mod, eng, tname, d, J, maxit):
     """The large-d fit kernels (1024 < d <= 16384) in every instantiation.  Default since round 6: TSQR + Householder reconstruction
     (`fit_tsqr_kernel.hip`: row chunks factored in registers, the stack of their R factors, LAPACK's reflectors rebuilt from the LU of
