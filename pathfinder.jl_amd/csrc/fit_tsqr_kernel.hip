@@ -39,6 +39,9 @@
                                        // fit); profiles/r06_experiments.md
 #endif
 #define TS_NW (TS_NT / 64)
+#ifndef TS_TWAVE
+#define TS_TWAVE 1                     // wave that owns the rows of a block's compact-WY T during its factorisation: the SECOND wave (another SIMD), beside wave 0's row-c work (0: behind it; config-5 shape 5.72 against 6.05 ms)
+#endif
 #define TS_STACK 512                   // rows of the stack of R factors (n_chunks x m <= 512): TS_STACK / TS_NT rows per thread in the stack stage
 #define TS_OPAQUE(x) asm volatile("" : "+v"(x))
 #ifndef TS_PROF
@@ -137,30 +140,38 @@ __device__ __forceinline__ void ts_qr_col(double (&P)[RC][MC], double (&U)[RC], 
         const double w = tau * (srow[cc] + scal * pf_readlane_f64(tot, cc));
 #pragma unroll
         for (int i = 0; i < RC; ++i) P[i][cc] = fma(-w, vs[i], P[i][cc]);
-        if (tid == c) {                                                  // row c: the R entry out, an explicit zero in
-            if (cc < m) rdst[c * rstride + cc] = P[0][cc] - w;
-            P[0][cc] = 0.0;
-        }
     }
     {
         const double w = tau * (srow[MC] + scal * pf_readlane_f64(tot, MC));   // the extra column
 #pragma unroll
         for (int i = 0; i < RC; ++i) U[i] = fma(-w, vs[i], U[i]);
-        if (tid == c) {
-            hdst[c] = U[0] - w;
-            rdst[c * rstride + c] = beta;
-            P[0][c] = 1.0;                                               // explicit unit diagonal
-            sT[c * MC + c] = tau;
-        }
     }
-    if (tid < c) {                                                       // dlarft: T[0:c, c] = -tau T[0:c, 0:c] (V[:, 0:c]' v_c)
-        double acc = 0.0;
+    if (tid == c) {                                                      // row c (its entries were not touched above: vs = 0 there): the R entries and the
+                                                                         // transformed U out, explicit unit diagonal / zeros in -- ONE divergent region per column
 #pragma unroll
-        for (int b = 0; b < c; ++b) {
-            const double g = srow[b] + scal * pf_readlane_f64(tot, b);   // V[c, b] . 1 + sum over the rows below
-            acc += (b >= tid) ? sT[tid * MC + b] * g : 0.0;
+        for (int cc = c + 1; cc < MC; ++cc) {
+            const double w = tau * (srow[cc] + scal * pf_readlane_f64(tot, cc));
+            if (cc < m) rdst[c * rstride + cc] = P[0][cc] - w;
+            P[0][cc] = 0.0;
         }
-        sT[tid * MC + c] = -tau * acc;
+        hdst[c] = U[0] - tau * (srow[MC] + scal * pf_readlane_f64(tot, MC));
+        rdst[c * rstride + c] = beta;
+        P[0][c] = 1.0;
+    }
+    // dlarft: T[0:c, c] = -tau T[0:c, 0:c] (V[:, 0:c]' v_c), row a by thread TS_TWAVE * 64 + a (a T row is written and read by that one thread only
+    // while the loop runs).  TS_TWAVE = 1 puts the rows on the SECOND wave (another SIMD), beside wave 0's row-c work instead of behind it
+    {
+        const int ta = tid - 64 * TS_TWAVE;
+        if (ta == c) sT[c * MC + c] = tau;
+        if (ta >= 0 && ta < c) {
+            double acc = 0.0;
+#pragma unroll
+            for (int b = 0; b < c; ++b) {
+                const double g = srow[b] + scal * pf_readlane_f64(tot, b);   // V[c, b] . 1 + sum over the rows below
+                acc += (b >= ta) ? sT[ta * MC + b] * g : 0.0;
+            }
+            sT[ta * MC + c] = -tau * acc;
+        }
     }
 }
 template <int c, int RC, int MC>
