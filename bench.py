@@ -86,7 +86,7 @@ def _demo_device_target(pfmi, tg):
     materialises in HBM (the route an arbitrary device-resident `logp` takes; the built-in targets never form x)."""
     import ctypes as C
     pfmi.lib()
-    L = C.CDLL(os.path.join(ROOT, "examples", "device_logp", "liblogp_demo.so"))
+    L = C.CDLL(os.environ.get("PFMI_DEMO_CLOSURE_LIB") or os.path.join(ROOT, "examples", "device_logp", "liblogp_demo.so"))
     dp = C.POINTER(C.c_double)
     if tg.kind == 1:
         return pfmi.DeviceCallbackTarget(tg.d, C.cast(L.pfx_funnel_logp, C.c_void_p).value, None, host=tg, keepalive=L)
@@ -679,11 +679,22 @@ def main():
             elbo_d = e3.elbo_batch_wait()[0]
             dtd = (time.perf_counter() - t0) / reps
             ndr = (e3.P - Kd) * N_e
+            # the kernels' own times: one more scan on ONE stream (the timed scans above alternate their blocks between two streams, so that the
+            # closure of block i runs beside the writer of block i + 1: there a kernel's event pair also spans its neighbour's work)
+            pfmi.lib().pfmi_debug_set(b"PFMI_DEVCB_OVERLAP", b"0")
             e3.profile(2)
             e3.elbo_batch(N_e, sd)
             tw, nw = e3.kernel_time("elbo_draws_x")
             tr_, nr = e3.kernel_time("device_callback")
             e3.profile(0)
+            e3.sync()
+            t0 = time.perf_counter()
+            e3.elbo_batch_enqueue(N_e, sd)
+            elbo_1s = e3.elbo_batch_wait()[0]
+            dt1 = time.perf_counter() - t0
+            pfmi.lib().pfmi_debug_set(b"PFMI_DEVCB_OVERLAP", None)
+            if not np.array_equal(elbo_1s, elbo_d, equal_nan=True):
+                self_check_failures.append("device-closure ELBO table differs between the two-stream and the one-stream scan")
             moved = 16.0 * d * ndr
             # reference table in the PACKED layout (entry p = point p of pfmi_set_traces).  The streamed loop leaves state["elbo"] in the
             # fixed-stride slot layout k (maxiters + 1) + l, which round 5 sliced as if it were packed: the check went NaN unnoticed.
@@ -699,8 +710,12 @@ def main():
                           "writer_kernel": {"ms": round(tw, 3), "launches": int(nw), "GBps_written": round(8.0 * d * ndr / max(tw, 1e-9) / 1e6, 1)},
                           "reader_kernel": {"ms": round(tr_, 3), "launches": int(nr), "GBps_read": round(8.0 * d * ndr / max(tr_, 1e-9) / 1e6, 1)},
                           "max_rel_elbo_diff_vs_builtin_target": devcb_diff,
+                          "one_stream": {"wall_s": round(dt1, 5), "hbm_GBps": round(moved / dt1 / 1e9, 1), "frac_of_6.29TBps_measured_copy": round(moved / dt1 / 6.29e12, 4),
+                                         "identical_results": bool(np.array_equal(elbo_1s, elbo_d, equal_nan=True))},
                           "sample": f"first {Kd} paths, {e3.P - Kd} fits x {N_e} draws, d={d}; closure = examples/device_logp (HIP, same target)",
-                          "note": "draws written to HBM by the library's draw kernel, read by the user's kernel on the same stream; no PCIe"}
+                          "note": "draws written to HBM by the library's draw kernel, read by the user's kernel; no PCIe.  Round 6: the blocks of fits alternate "
+                                  "between two streams, so the closure of block i runs beside the writer of block i + 1 on the same CUs (one_stream: the "
+                                  "same scan with PFMI_DEVCB_OVERLAP=0; writer_kernel / reader_kernel are timed there)"}
             # ---- the writer's own issue floor, priced like the scan's: nothing co-issues with the f64 MFMA on gfx950, so
             # the floor is the SUM of the issue streams, with the unit times of the co-issue micro-benchmark (2 waves per SIMD:
             # MFMA 4x4x4 7.44 ns, 16x16x4 = four times that, Philox round 10.5 ns, other VALU 2.0 ns).  Per wave and 16-row block of its TWO

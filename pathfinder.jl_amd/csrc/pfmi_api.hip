@@ -311,6 +311,7 @@ int32_t pfmi_create(int32_t device, pfmi_ctx **out) {
 // staging trace -- and forget the call.  Called by whatever is about to reuse or free that memory.
 static void stream_abandon(pfmi_ctx *c) {
     for (hipStream_t s : {c->s_opt, c->s_fit, c->s_scan1}) if (s) (void)hipStreamSynchronize(s);
+    for (hipStream_t s : c->s_cb) if (s) (void)hipStreamSynchronize(s);
     c->sr.active = false;
     c->stream_pending = false;
 }
@@ -344,6 +345,9 @@ int32_t pfmi_destroy(pfmi_ctx *c) {
     for (hipEvent_t e : c->kev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : {c->sg_fit, c->sg_opt, c->sg_scan[0], c->sg_scan[1], c->sg_start}) if (e) (void)hipEventDestroy(e);
     for (hipStream_t s : {c->s_opt, c->s_fit, c->s_scan1}) if (s) (void)hipStreamDestroy(s);
+    for (hipStream_t s : c->s_cb) if (s) (void)hipStreamDestroy(s);
+    for (hipEvent_t e : c->sg_cb) if (e) (void)hipEventDestroy(e);
+    for (int b = 0; b < PF_DCB_NB; ++b) { c->dcb_x[b].release(); c->dcb_lp[b].release(); }
     if (c->h_prog) (void)hipHostFree(c->h_prog);
     if (c->h_list) (void)hipHostFree(c->h_list);
     (void)hipStreamDestroy(c->stream);
@@ -1231,19 +1235,53 @@ int32_t pfmi_elbo_batch_enqueue(pfmi_ctx *c, int64_t N, const uint64_t *seeds, c
         // (8 d bytes written per draw), the user's kernel reads them on the same stream (8 d bytes read per draw) and its log
         // densities are scattered into the point-indexed table.  Nothing crosses PCIe, nothing synchronises.
         const int64_t per = (int64_t)d * N;
-        const int64_t chunk = devcb_chunk_fits(c, per, nf, N);
-        PF_TRY(c->cb_x[0].ensure(sizeof(double) * (size_t)chunk * per));
-        PF_TRY(c->cb_lp[0].ensure(sizeof(double) * (size_t)chunk * N));
+        int64_t chunk = devcb_chunk_fits(c, per, nf, N);
+        // Round 6: the blocks alternate between SEVERAL streams (PF_DCB_NB buffers), so that the closure of block i runs beside the writer of block
+        // i + 1 ON THE SAME CUs: the writer's two waves per SIMD hold 2 x 208 of 512 registers and ~135 of 160 KB of LDS, a closure wave of
+        // <= 96 registers fits beside them, and the two kernels want different things (the writer issue / LDS time at 2.3 TB/s written, the
+        // closure HBM reads).  Measured through two engines before it was built in (tests/probes/devcb_overlap_probe.py): 2.87 -> 3.38 TB/s
+        // moved.  Same kernels on the same data: the same bits.  PFMI_DEVCB_OVERLAP = 0 | 2 | 3 (debug hook): one stream (kernel timing), two, three.
+        int nb = nf > 1 ? PF_DCB_NB : 1;
+        if (const char *ov = pf_debug_get("PFMI_DEVCB_OVERLAP")) { const int v = atoi(ov); nb = (v <= 0 || nf <= 1) ? 1 : (v < PF_DCB_NB ? (v < 2 ? 2 : v) : PF_DCB_NB); }
+        if (nb > 1) {
+            size_t free_b = 0, total_b = 0;
+            double have = 0.0;
+            for (int b = 0; b < PF_DCB_NB; ++b) have += (double)c->dcb_x[b].cap;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) have += (double)free_b;
+            // full-size buffers only when memory is plentiful and there are blocks to alternate; else the same footprint cut into nb blocks
+            if ((double)nb * (double)sizeof(double) * (double)chunk * (double)(per + N) > 0.5 * have || chunk * nb > nf) chunk = (chunk + nb - 1) / nb;
+            if (chunk < 1) chunk = 1;
+        }
+        for (int b = 0; b < nb; ++b) {
+            PF_TRY(c->dcb_x[b].ensure(sizeof(double) * (size_t)chunk * per));
+            PF_TRY(c->dcb_lp[b].ensure(sizeof(double) * (size_t)chunk * N));
+        }
+        for (int b = 1; b < nb; ++b)
+            if (!c->s_cb[b - 1]) PF_HIP(hipStreamCreateWithFlags(&c->s_cb[b - 1], hipStreamNonBlocking));
+        for (int b = 0; b < nb; ++b)
+            if (!c->sg_cb[b]) PF_HIP(hipEventCreateWithFlags(&c->sg_cb[b], hipEventDisableTiming));
+        if (nb > 1) {                                                // the side streams start behind the uploads and the fits
+            PF_HIP(hipEventRecord(c->sg_cb[0], c->stream));
+            for (int b = 1; b < nb; ++b) PF_HIP(hipStreamWaitEvent(c->s_cb[b - 1], c->sg_cb[0], 0));
+        }
         c->cb_bytes_dev = 0.0;
-        for (int64_t s0 = 0; s0 < nf; s0 += chunk) {
+        int64_t blk = 0;
+        for (int64_t s0 = 0; s0 < nf; s0 += chunk, ++blk) {
             const int64_t ns = (nf - s0 < chunk) ? nf - s0 : chunk;
-            PF_TRY(pf_launch_elbo_draws(c, d_list + s0, d_lseeds + s0, ns, 0, N, d_u, ustride, c->cb_x[0].as<double>(), per,
+            const int b = (int)(blk % nb);
+            hipStream_t ss = b ? c->s_cb[b - 1] : c->stream;
+            StreamSwap sw(c, ss);
+            PF_TRY(pf_launch_elbo_draws(c, d_list + s0, d_lseeds + s0, ns, 0, N, d_u, ustride, c->dcb_x[b].as<double>(), per,
                                         c->logp.as<double>(), c->logq.as<double>(), N, false, true));
             pf_kernel_begin(c);
-            c->target.dev_fn(c->cb_x[0].as<double>(), d, ns * N, c->cb_lp[0].as<double>(), (void *)c->stream, c->target.user);
+            c->target.dev_fn(c->dcb_x[b].as<double>(), d, ns * N, c->dcb_lp[b].as<double>(), (void *)ss, c->target.user);
             pf_kernel_end(c, "device_callback");
-            PF_TRY(pf_launch_scatter_rows(c, ns, N, d_list + s0, c->cb_lp[0].as<double>(), c->logp.as<double>()));
+            PF_TRY(pf_launch_scatter_rows(c, ns, N, d_list + s0, c->dcb_lp[b].as<double>(), c->logp.as<double>()));
             c->cb_bytes_dev += (double)sizeof(double) * (double)ns * (double)per;
+        }
+        for (int b = 1; b < nb && b < blk; ++b) {                    // the reduction waits for the side streams' blocks
+            PF_HIP(hipEventRecord(c->sg_cb[b], c->s_cb[b - 1]));
+            PF_HIP(hipStreamWaitEvent(c->stream, c->sg_cb[b], 0));
         }
     } else if (c->target.kind != PFMI_TARGET_HOST_CALLBACK) {
         PF_TRY(pf_launch_elbo_draws(c, d_list, d_lseeds, nf, 0, N, d_u, ustride, nullptr, 0, c->logp.as<double>(),

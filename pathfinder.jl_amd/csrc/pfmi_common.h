@@ -209,6 +209,11 @@ struct pfmi_ctx {
     void *pin_x[2] = {nullptr, nullptr}, *pin_lp[2] = {nullptr, nullptr};
     size_t pin_x_cap = 0, pin_lp_cap = 0;
     hipEvent_t cb_ev[2] = {nullptr, nullptr};
+    // DEVICE_CALLBACK scans: PF_DCB_NB alternating block buffers / streams (stream 0 is `stream`)
+#define PF_DCB_NB 2
+    DevBuf dcb_x[PF_DCB_NB], dcb_lp[PF_DCB_NB];
+    hipStream_t s_cb[PF_DCB_NB - 1] = {};
+    hipEvent_t sg_cb[PF_DCB_NB] = {};
     double cb_seconds = 0.0;      // wall time spent inside the user's callback during the last elbo_batch
     double cb_bytes_d2h = 0.0;    // bytes of draws handed to the callback
     double cb_bytes_dev = 0.0;    // DEVICE_CALLBACK: bytes of draws materialised in HBM for the callback

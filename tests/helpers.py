@@ -28,7 +28,7 @@ def fit_seeds(P, seed):
 
 ROOT = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
 STANDIN_LIB = __import__("os").path.join(ROOT, "tests", "rccl_standin", "librccl_standin.so")
-DEMO_LIB = __import__("os").path.join(ROOT, "examples", "device_logp", "liblogp_demo.so")
+DEMO_LIB = __import__("os").environ.get("PFMI_DEMO_CLOSURE_LIB") or __import__("os").path.join(ROOT, "examples", "device_logp", "liblogp_demo.so")   # (the override: experiment builds of the example closure)
 
 
 def demo_device_target(tg):

@@ -450,19 +450,29 @@ def test_device_callback_matches_builtin_target_and_oracle(pfmi_mod, eng, shape)
         e2.set_target(dtg)
         e2.set_traces([t[0] for t in traces], [t[2] for t in traces])
         e2.fit_batch(J)
-        for chunk_mb in (None, "0.5"):                            # one block, and many small blocks of fits
+        tables = []
+        # one block / many small blocks of fits, the blocks alternating between two streams (round 6: the closure of block i runs beside the writer
+        # of block i + 1) or all on one stream: the same bits every time
+        for chunk_mb, overlap in ((None, None), ("0.5", None), ("0.5", "0"), (None, "0")):
             if chunk_mb:
                 os.environ["PFMI_DEVCB_CHUNK_MB"] = chunk_mb
+            if overlap:
+                os.environ["PFMI_DEVCB_OVERLAP"] = overlap
             try:
                 elbo1, se1, best1 = e2.elbo_batch(N, seeds)
             finally:
                 os.environ.pop("PFMI_DEVCB_CHUNK_MB", None)
+                os.environ.pop("PFMI_DEVCB_OVERLAP", None)
+            tables.append((elbo1.copy(), se1.copy(), np.concatenate([e2.elbo_logs(p, N)[0] for p in range(1, min(e2.P, 6))])))
             assert e2.callback_stats_dev()["bytes_in_hbm"] == 8.0 * d * N * (e2.P - K)
             fin = np.isfinite(elbo0)
             np.testing.assert_array_equal(np.isfinite(elbo1), fin)
             assert np.max(np.abs(elbo1[fin] - elbo0[fin]) / (1 + np.abs(elbo0[fin]))) <= 1e-9
             assert np.max(np.abs(se1[fin] - se0[fin]) / (1 + se0[fin])) <= 1e-8
             np.testing.assert_array_equal(best1, best0)
+        for t in tables[1:]:
+            for a, b in zip(tables[0], t):
+                np.testing.assert_array_equal(a, b)
         for k in range(K):
             lp1, lq1 = e2.elbo_logs(pts[k], N)
             assert np.max(np.abs(lq1 - logs0[k][1]) / (1 + np.abs(lq1))) <= 1e-13      # same normals; |u|^2 summed in another order
