@@ -66,8 +66,9 @@ typedef void (*pfmi_logp_fn)(const double *X, int32_t d, int64_t n, double *out,
  * launch or a HIP launcher; the library orders its own work behind it on the same stream.  No PCIe traffic.  `stream` is NOT the same
  * on every call: an ELBO scan hands the blocks of fits to two streams in turn, so that the closure of one block runs beside the library's
  * draw writer of the next (round 6: 2.87 -> 3.27 TB/s of moved bytes with the example closure) -- the closure must use the stream it is
- * given and keep no per-call state in `user` that a concurrent call on the other stream could clobber.  A closure with a small footprint
- * (<= 96 vector registers per work-item, <= 24 KB of LDS per workgroup) can share a CU with the writer; a larger one still fills its tails. */
+ * given and keep no per-call state in `user` that a concurrent call on the other stream could clobber.  (The gain comes from each kernel
+ * filling the other's launch tails and idle memory pipe; a closure squeezed into the registers / LDS the writer leaves on a CU -- <= 96
+ * vector registers, <= 24 KB -- was measured and is NOT worth its slower loads: write the closure for its own bandwidth.) */
 typedef void (*pfmi_logp_dev_fn)(const double *X_dev, int32_t d, int64_t n, double *out_dev, void *stream, void *user);
 
 typedef struct {
