@@ -1236,11 +1236,11 @@ int32_t pfmi_elbo_batch_enqueue(pfmi_ctx *c, int64_t N, const uint64_t *seeds, c
         // densities are scattered into the point-indexed table.  Nothing crosses PCIe, nothing synchronises.
         const int64_t per = (int64_t)d * N;
         int64_t chunk = devcb_chunk_fits(c, per, nf, N);
-        // Round 6: the blocks alternate between SEVERAL streams (PF_DCB_NB buffers), so that the closure of block i runs beside the writer of block
-        // i + 1 ON THE SAME CUs: the writer's two waves per SIMD hold 2 x 208 of 512 registers and ~135 of 160 KB of LDS, a closure wave of
-        // <= 96 registers fits beside them, and the two kernels want different things (the writer issue / LDS time at 2.3 TB/s written, the
-        // closure HBM reads).  Measured through two engines before it was built in (tests/probes/devcb_overlap_probe.py): 2.87 -> 3.38 TB/s
-        // moved.  Same kernels on the same data: the same bits.  PFMI_DEVCB_OVERLAP = 0 | 2 | 3 (debug hook): one stream (kernel timing), two, three.
+        // Round 6: the blocks alternate between PF_DCB_NB = 2 streams (two buffers), so that the closure of block i runs beside the writer of block
+        // i + 1: the writer is bound by no single resource (SIMD issue ~70 %, LDS pipe ~50 %, HBM writes at half the link) and the closure
+        // wants what it leaves idle, HBM reads -- each kernel fills the other's launch tails and memory pipe.  7.90 -> 6.87 ms for 1 403 fits x 1000
+        // draws at d = 1000 (2.85 -> 3.27 TB/s moved); a third stream adds nothing.  Same kernels on the same data: the same bits.
+        // PFMI_DEVCB_OVERLAP = 0 | 2 (debug hook): one stream (kernel timing) / two.
         int nb = nf > 1 ? PF_DCB_NB : 1;
         if (const char *ov = pf_debug_get("PFMI_DEVCB_OVERLAP")) { const int v = atoi(ov); nb = (v <= 0 || nf <= 1) ? 1 : (v < PF_DCB_NB ? (v < 2 ? 2 : v) : PF_DCB_NB); }
         if (nb > 1) {
