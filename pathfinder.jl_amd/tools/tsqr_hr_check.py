@@ -1,5 +1,12 @@
-import numpy as np, scipy.linalg as sl
-np.set_printoptions(linewidth=200, precision=3)
+"""The data flow of csrc/fit_tsqr_kernel.hip stated in NumPy: TSQR over row chunks + Householder reconstruction (Ballard et al. 2014; LAPACK dorhr_col)
+reproduces the reflectors V, the compact-WY T and R that LAPACK's dgeqr2 / dlarft produce for the whole block, and the kernel's row-local formulas
+(N_i = -K_i W_i U^-1, the W_i U^-1 term of a chunk's first m rows, the mean through Q_in S (V_c'V_c - I) head) give Vh and mu without a sweep.
+
+    python tools/tsqr_hr_check.py        -> prints the deviations from dgeqrf / dlarft on a few shapes
+    tests/test_tsqr_hr_math.py           -> asserts them (CPU)
+"""
+import numpy as np
+import scipy.linalg as sl
 
 def geqr2(A):
     """LAPACK dgeqr2/dlarfg convention. returns V (unit lower trapezoidal explicit), tau, R"""
@@ -69,17 +76,22 @@ def tsqr_hr(B, ug, CH):
     head = S * head_in                                   # Q_out' ug
     return V, T, R, head, Qin * S[None, :]
 
-rng = np.random.default_rng(0)
-for d, m, CH in [(1000, 12, 256), (10000, 20, 2048), (3000, 8, 1024), (2500, 20, 512)]:
+def check_reconstruction(d, m, CH, seed=0, ill=True):
+    """TSQR + reconstruction against dgeqr2 / dlarft (and SciPy's dgeqrf): max deviations of V, T, R (relative), Q'(U g), Q"""
+    rng = np.random.default_rng(seed)
     B = rng.standard_normal((d, m)) * np.exp(rng.standard_normal(m))[None, :]
-    B[:, 3] = B[:, 2] * 0.7 + 1e-3 * B[:, 3]
+    if ill and m > 3:
+        B[:, 3] = B[:, 2] * 0.7 + 1e-3 * B[:, 3]              # a column of condition ~1e3
     ug = rng.standard_normal(d)
-    V0, tau0, R0 = geqr2(B); T0 = larft(V0, tau0)
+    V0, tau0, R0 = geqr2(B)
+    T0 = larft(V0, tau0)
     (qr_raw, tau_l), R_l = sl.qr(B, mode='raw')
-    assert np.allclose(np.tril(qr_raw, -1)[:, :m], np.tril(V0, -1)) and np.allclose(np.triu(qr_raw)[:m], R0[:m])
+    assert np.allclose(np.tril(qr_raw, -1)[:, :m], np.tril(V0, -1)) and np.allclose(np.triu(qr_raw)[:m], R0[:m])   # geqr2() above IS LAPACK's convention
     V, T, R, head, Qout = tsqr_hr(B, ug, CH)
     Q0 = np.eye(d, m) - V0 @ (T0 @ V0[:m].T)
-    print(d, m, CH, "V", np.abs(V - V0).max(), "T", np.abs(T - T0).max(), "R", np.abs(R - R0[:m]).max() / np.abs(R0).max(), "head", np.abs(head - Q0.T @ ug).max(), "Q", np.abs(Qout - Q0).max(), "triu(T)", np.abs(np.tril(T, -1)).max())
+    return dict(V=np.abs(V - V0).max(), T=np.abs(T - T0).max(), R=np.abs(R - R0[:m]).max() / np.abs(R0).max(), head=np.abs(head - Q0.T @ ug).max(),
+                Q=np.abs(Qout - Q0).max(), T_lower=np.abs(np.tril(T, -1)).max())
+
 
 # ---- second check: the kernel's row-local formulas (N_i, Wu_i, y_i, wd_i) and the mean
 def kernel_dataflow(B, ug, theta, sqa, Vc, CH):
@@ -124,14 +136,24 @@ def kernel_dataflow(B, ug, theta, sqa, Vc, CH):
         mu[i*CH:i*CH+n] = theta[i*CH:i*CH+n] + sqa[i*CH:i*CH+n] * (ug[i*CH:i*CH+n] + yv[:n])
     return Vout, T, R, mu
 
-for d, m, CH in [(1000, 12, 256), (10000, 20, 1536), (2500, 20, 512)]:
+def check_kernel_dataflow(d, m, CH, seed=1):
+    """the kernel's row-local formulas against the sweep-based reference: V, T, R, mu"""
+    rng = np.random.default_rng(seed)
     B = rng.standard_normal((d, m)) * np.exp(rng.standard_normal(m))[None, :]
     ug = rng.standard_normal(d); theta = rng.standard_normal(d); sqa = np.exp(rng.standard_normal(d))
     Cm = rng.standard_normal((m, m)); Vc = np.linalg.cholesky(np.eye(m) + Cm @ Cm.T).T
-    V0, tau0, R0 = geqr2(B); T0 = larft(V0, tau0)
-    # reference mean: b = Q'ug; head <- Vc'Vc head; x = Q b'
+    V0, tau0, R0 = geqr2(B)
+    T0 = larft(V0, tau0)
     def Qt(x): return x - V0 @ (T0.T @ (V0.T @ x))
     def Q(x): return x - V0 @ (T0 @ (V0.T @ x))
     b = Qt(ug); b[:m] = Vc.T @ (Vc @ b[:m]); mu0 = theta + sqa * Q(b)
     V, T, R, mu = kernel_dataflow(B, ug, theta, sqa, Vc, CH)
-    print(d, m, CH, "V", np.abs(V - V0).max(), "T", np.abs(T - T0).max(), "R", np.abs(R - R0[:m]).max() / np.abs(R0).max(), "mu", np.abs(mu - mu0).max() / np.abs(mu0).max())
+    return dict(V=np.abs(V - V0).max(), T=np.abs(T - T0).max(), R=np.abs(R - R0[:m]).max() / np.abs(R0).max(), mu=np.abs(mu - mu0).max() / np.abs(mu0).max())
+
+
+if __name__ == "__main__":
+    np.set_printoptions(linewidth=200, precision=3)
+    for d, m, CH in [(1000, 12, 256), (10000, 20, 2048), (3000, 8, 1024), (2500, 20, 512)]:
+        print("reconstruction", d, m, CH, {k: float("%.2e" % v) for k, v in check_reconstruction(d, m, CH).items()})
+    for d, m, CH in [(1000, 12, 256), (10000, 20, 1536), (2500, 20, 512)]:
+        print("kernel data flow", d, m, CH, {k: float("%.2e" % v) for k, v in check_kernel_dataflow(d, m, CH).items()})
