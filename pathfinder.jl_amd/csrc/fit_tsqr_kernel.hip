@@ -1,4 +1,4 @@
-// fit_tsqr_kernel.hip -- the Woodbury fit for large d (1024 < d <= 16384), gfx950, organised so that the d x 2J block crosses HBM ONCE
+// fit_tsqr_kernel.hip -- the Woodbury fit for large d (1024 < d <= 32768 while chunks x columns <= 512: KPAD <= 20 throughout, KPAD = 32 to 16384), gfx950, organised so that the d x 2J block crosses HBM ONCE
 // in each direction (round 6; the panel kernel of fit_panel_kernel.hip sweeps its scratch block ~12 times: 19 MB per fit at d = 10^4,
 // J = 10 against 3.6 MB of inputs + outputs).
 //
@@ -836,10 +836,11 @@ static int32_t launch_tsqr_t(pfmi_ctx *c, const FitArgs &a, int ncu, bool *handl
     return PFMI_OK;
 }
 
-// returns PFMI_OK and sets *handled when the TSQR kernel took the launch (1024 < d <= 16384, 4 <= J <= 16)
+// returns PFMI_OK and sets *handled when the TSQR kernel took the launch (1024 < d <= 32768 and the stack of R factors holds chunks x KPAD <= 512 rows:
+// a launcher declines otherwise and the panel / column-by-column kernel takes over)
 int32_t pf_launch_fit_tsqr(pfmi_ctx *c, const FitArgs &a, bool *handled) {
     *handled = false;
-    if (a.d <= 1024 || a.d > 16384) return PFMI_OK;
+    if (a.d <= 1024 || a.d > 32768) return PFMI_OK;
     *handled = true;                         // (a launcher that declines resets it)
     int ncu = 0;
     PF_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device));

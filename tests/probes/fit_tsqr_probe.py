@@ -7,6 +7,7 @@ import numpy as np, pfmi
 L = pfmi.lib()
 shapes = {"small": [("diag", 1500, 4, 2, 12), ("lr", 3000, 6, 2, 14), ("funnel", 6000, 10, 2, 16), ("diag", 12000, 10, 2, 14), ("diag", 2000, 16, 2, 22)],
           "c5": [("funnel", 10000, 10, 8, 200)],
+          "big": [("diag", 20000, 5, 4, 30), ("diag", 32768, 10, 4, 40)],
           "j16": [("diag", 2000, 16, 2, 22), ("diag", 8000, 16, 8, 120), ("funnel", 10000, 16, 8, 100)]}
 which = [a for a in sys.argv[1:] if a in shapes] or ["small"]
 for w in which:
@@ -15,7 +16,12 @@ for w in which:
         eng = pfmi.Engine(0)
         eng.set_target(tg)
         x0 = pfmi.HostRNG(4).rand(K * d).reshape(K, d) * (20 if tname == "funnel" else 4) - (10 if tname == "funnel" else 2)
-        eng.optimize_batch(x0, J, maxit)
+        if d <= 16384:
+            eng.optimize_batch(x0, J, maxit)
+        else:                                                  # the device optimiser stops at 16 384 coordinates: host driver, uploaded traces
+            from pfmi.optimize import optimize_with_trace
+            trs = [optimize_with_trace(tg, x0[k], history_length=J, maxiters=maxit) for k in range(K)]
+            eng.set_traces([t.points for t in trs], [t.gradients for t in trs])
         res = {}
         for kern in ("tsqr", "panel", "mem"):
             L.pfmi_debug_set(b"PFMI_FIT_KERNEL", kern.encode())               # ("tsqr" also forces the TSQR kernel where the panel kernel is the default: KPAD = 32)
