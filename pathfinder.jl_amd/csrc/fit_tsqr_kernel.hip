@@ -290,17 +290,29 @@ __device__ __noinline__ void ts_small_stage(const FitArgs &A, const int64_t p, c
     int tid = threadIdx.x;
     // ---- the top m x m block of Q_in = W_0 - V_0[0:m, :] (K_0 W_0), modified LU (S chosen on the fly), T = -U S V_1^-T, R = S R_in
     TS_OPAQUE(tid);
+    // (unconditional loads from clamped addresses in fully unrolled loops: all in flight at once -- as run-time loops these two were 2 m dependent
+    //  global round trips per fit)
     for (int t = tid; t < m * m; t += TS_NT) {
         const int a = t / m, c = t % m;
         double v = 0.0;
-        for (int b = 0; b < m; ++b) v += Kg[a * MC + b] * stk[(size_t)b * SW + c];
+#pragma unroll
+        for (int b = 0; b < MC; ++b) {
+            const int bb = b < m ? b : m - 1;
+            const double kb = Kg[a * MC + bb], wb = stk[(size_t)bb * SW + c];
+            v = fma(b < m ? kb : 0.0, wb, v);
+        }
         sN[a * MC + c] = v;                                                // M_0
     }
     __syncthreads();
     for (int t = tid; t < m * m; t += TS_NT) {
         const int r = t / m, c = t % m;
         double v = stk[(size_t)r * SW + c];
-        for (int a = 0; a <= r; ++a) v -= scr[(size_t)a * DP + r] * sN[a * MC + c];     // V_0[r, a]: zero for a > r
+#pragma unroll
+        for (int a = 0; a < MC; ++a) {
+            const int aa = a <= r ? a : r;
+            const double va = scr[(size_t)aa * DP + r];                        // V_0[r, a]: zero for a > r
+            v = fma(a <= r ? -va : 0.0, sN[aa * MC + c], v);
+        }
         sL[r * MC + c] = v;
     }
     __syncthreads();
