@@ -109,11 +109,17 @@ __device__ __forceinline__ void ts_qr_col(double (&P)[RC][MC], double (&U)[RC], 
         srow[MC] = U[0];
     }
     double dots[NV];
+    {
+        const double x0 = (tid > c) ? P[0][c] : 0.0;                     // rows below the diagonal (row 0 of a thread may be the diagonal row or above it)
 #pragma unroll
-    for (int v = 0; v < NV; ++v) dots[v] = 0.0;
+        for (int v = 0; v < MC; ++v) dots[v] = x0 * P[0][v];
+        dots[MC] = x0 * U[0];
 #pragma unroll
-    for (int i = 0; i < RC; ++i) {
-        const double xc = (i > 0 || tid > c) ? P[i][c] : 0.0;            // rows below the diagonal
+        for (int v = MC + 1; v < NV; ++v) dots[v] = 0.0;
+    }
+#pragma unroll
+    for (int i = 1; i < RC; ++i) {
+        const double xc = P[i][c];
 #pragma unroll
         for (int v = 0; v < MC; ++v) dots[v] = fma(xc, P[i][v], dots[v]);
         dots[MC] = fma(xc, U[i], dots[MC]);
