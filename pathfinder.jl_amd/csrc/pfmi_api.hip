@@ -1124,7 +1124,11 @@ static void host_callback_block(pfmi_ctx *c, const double *X, int d, int64_t n, 
     for (int i = 1; i < t; ++i) {
         const int64_t j0 = (int64_t)i * per, j1 = std::min<int64_t>(n, j0 + per);
         if (j0 >= j1) break;
-        th.emplace_back([=, &T] { T.fn(X + (size_t)j0 * (size_t)d, d, j1 - j0, out + j0, T.user); });
+        try {
+            th.emplace_back([=, &T] { T.fn(X + (size_t)j0 * (size_t)d, d, j1 - j0, out + j0, T.user); });
+        } catch (...) {                                        // no thread to be had (resource limits): this range runs on the calling thread
+            T.fn(X + (size_t)j0 * (size_t)d, d, j1 - j0, out + j0, T.user);
+        }
     }
     T.fn(X, d, std::min<int64_t>(n, per), out, T.user);
     for (std::thread &x : th) x.join();
